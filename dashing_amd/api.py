@@ -1,0 +1,226 @@
+"""ctypes binding of libdashing_hip.so (include/dashing_hip.h).
+
+There is deliberately no CPU fallback here: if the shared library is missing, or no gfx950
+device is visible, construction fails loudly.  (The CPU oracle lives in oracle/ and is test
+infrastructure only -- nothing in this package imports it.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ESTIM_ORIGINAL, ESTIM_ERTL_IMPROVED, ESTIM_ERTL_MLE = 0, 1, 2
+MASH_DIST, JI, FULL_MASH_DIST = 0, 1, 3  # bns::EmissionType, src/enums.h:13-23
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/dashing_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "dsh_backend_name", "dsh_device_count", "dsh_create", "dsh_destroy", "dsh_last_error",
+    "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches",
+    "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
+    "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
+    "dsh_dist_rect", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
+    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_stream",
+]
+
+
+class DshError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dashing_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdashing_hip.so")
+
+
+def load_library():
+    """Load libdashing_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dashing_amd/csrc` (there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    u64, i32, vp = C.c_uint64, C.c_int, C.c_void_p
+    lib.dsh_backend_name.restype = C.c_char_p
+    lib.dsh_device_count.restype = i32
+    lib.dsh_create.argtypes = [i32, C.POINTER(vp)]
+    lib.dsh_destroy.argtypes = [vp]
+    lib.dsh_destroy.restype = None
+    lib.dsh_last_error.argtypes = [vp]
+    lib.dsh_last_error.restype = C.c_char_p
+    lib.dsh_synchronize.argtypes = [vp]
+    lib.dsh_sketches_alloc.argtypes = [vp, u64, i32]
+    lib.dsh_upload_sketches.argtypes = [vp, vp, u64, u64]
+    lib.dsh_download_sketches.argtypes = [vp, u64, u64, vp]
+    lib.dsh_attach_device_sketches.argtypes = [vp, vp, u64, i32]
+    lib.dsh_sketch_batch.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32, vp]
+    lib.dsh_sketch_batch_device.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
+    lib.dsh_clear_sketches.argtypes = [vp, u64, u64]
+    lib.dsh_cardinalities.argtypes = [vp, i32, vp]
+    lib.dsh_dist_rows.argtypes = [vp, i32, i32, i32, u64, u64, vp]
+    lib.dsh_dist_rows_device.argtypes = [vp, i32, i32, i32, u64, u64, vp]
+    lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
+    lib.dsh_tri_span.argtypes = [u64, u64, u64]
+    lib.dsh_tri_span.restype = u64
+    lib.dsh_tri_index.argtypes = [u64, u64, u64]
+    lib.dsh_tri_index.restype = u64
+    lib.dsh_partition_rows.argtypes = [u64, C.c_uint32, C.c_uint32, vp]
+    lib.dsh_set_profiling.argtypes = [vp, i32]
+    lib.dsh_last_kernel_ms.argtypes = [vp, vp, vp, vp, vp]
+    lib.dsh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.dsh_stream.argtypes = [vp]
+    lib.dsh_stream.restype = vp
+    _LIB = lib
+    return lib
+
+
+def backend_name():
+    return load_library().dsh_backend_name().decode()
+
+
+def device_count():
+    return int(load_library().dsh_device_count())
+
+
+def tri_span(n, rb, re):
+    return int(load_library().dsh_tri_span(n, rb, re))
+
+
+def tri_index(n, i, j):
+    return int(load_library().dsh_tri_index(n, i, j))
+
+
+def partition_rows(n, nparts, align=64):
+    """Host-only helper shared with the C++ CLI: contiguous row ranges of near-equal pair count."""
+    b = np.zeros(nparts + 1, np.uint64)
+    rc = load_library().dsh_partition_rows(n, nparts, align, b.ctypes.data)
+    if rc:
+        raise DshError(rc, "dsh_partition_rows")
+    return [int(x) for x in b]
+
+
+class Context:
+    """One GPU.  Mirrors the call sequence of dist_sketch_and_cmp (src/sketch_and_cmp.h:268-417):
+    allocate N sketches, fill them (sketch_batch / upload), cardinalities, all-pairs rows."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.dsh_create(device, C.byref(h))
+        if rc:
+            raise DshError(rc, "dsh_create(device=%d) failed (no gfx950 device?)" % device)
+        self._h = h
+        self.n = 0
+        self.p = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dsh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc:
+            raise DshError(rc, self._lib.dsh_last_error(self._h).decode())
+
+    # ---- sketch matrix
+    def alloc(self, n, p):
+        self._ck(self._lib.dsh_sketches_alloc(self._h, n, p))
+        self.n, self.p = n, p
+
+    def upload(self, regs, first_slot=0):
+        regs = np.ascontiguousarray(regs, np.uint8)
+        assert regs.ndim == 2 and regs.shape[1] == (1 << self.p)
+        self._ck(self._lib.dsh_upload_sketches(self._h, regs.ctypes.data, first_slot, regs.shape[0]))
+
+    def set_sketches(self, regs):
+        regs = np.ascontiguousarray(regs, np.uint8)
+        n, m = regs.shape
+        self.alloc(n, int(m).bit_length() - 1)
+        self.upload(regs)
+
+    def attach_device(self, data_ptr, n, p):
+        self._ck(self._lib.dsh_attach_device_sketches(self._h, C.c_void_p(data_ptr), n, p))
+        self.n, self.p = n, p
+
+    def download(self, first_slot=0, n=None):
+        n = self.n - first_slot if n is None else n
+        out = np.zeros((n, 1 << self.p), np.uint8)
+        self._ck(self._lib.dsh_download_sketches(self._h, first_slot, n, out.ctypes.data))
+        return out
+
+    def clear(self, first_slot=0, n=None):
+        n = self.n - first_slot if n is None else n
+        self._ck(self._lib.dsh_clear_sketches(self._h, first_slot, n))
+
+    # ---- sketch waist
+    def sketch_batch(self, seq, genome_off, first_slot=0, k=31, canon=True, want_regs=True):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        off = np.ascontiguousarray(genome_off, np.uint64)
+        ng = off.size - 1
+        out = np.zeros((ng, 1 << self.p), np.uint8) if want_regs else None
+        self._ck(self._lib.dsh_sketch_batch(
+            self._h, seq.ctypes.data if seq.size else None, off.ctypes.data, ng, first_slot, k,
+            int(bool(canon)), out.ctypes.data if want_regs else None))
+        return out
+
+    def sketch_batch_device(self, seq_ptr, genome_off, first_slot=0, k=31, canon=True):
+        off = np.ascontiguousarray(genome_off, np.uint64)
+        self._ck(self._lib.dsh_sketch_batch_device(
+            self._h, C.c_void_p(seq_ptr), off.ctypes.data, off.size - 1, first_slot, k, int(bool(canon))))
+
+    # ---- compare waist
+    def cardinalities(self, estim=ESTIM_ERTL_MLE):
+        out = np.zeros(max(self.n, 1), np.float64)
+        self._ck(self._lib.dsh_cardinalities(self._h, estim, out.ctypes.data))
+        return out[: self.n]
+
+    def dist_rows(self, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        row_end = self.n if row_end is None else row_end
+        span = tri_span(self.n, row_begin, row_end)
+        out = np.zeros(max(span, 1), np.float32)
+        self._ck(self._lib.dsh_dist_rows(self._h, estim, result_type, k, row_begin, row_end, out.ctypes.data))
+        return out[:span]
+
+    def dist_rows_device(self, out_ptr, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        row_end = self.n if row_end is None else row_end
+        self._ck(self._lib.dsh_dist_rows_device(self._h, estim, result_type, k, row_begin, row_end, C.c_void_p(out_ptr)))
+
+    def dist_rect(self, q_begin, q_end, r_begin, r_end, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        out = np.zeros((max(q_end - q_begin, 0), max(r_end - r_begin, 0)), np.float32)
+        buf = out if out.size else np.zeros(1, np.float32)
+        self._ck(self._lib.dsh_dist_rect(self._h, estim, result_type, k, q_begin, q_end, r_begin, r_end, buf.ctypes.data))
+        return out
+
+    # ---- misc
+    def synchronize(self):
+        self._ck(self._lib.dsh_synchronize(self._h))
+
+    def set_profiling(self, on=True):
+        self._ck(self._lib.dsh_set_profiling(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        self._ck(self._lib.dsh_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return {"pair_ms": a.value, "finalize_ms": b.value, "prepare_ms": c.value, "pair_launches": n.value}
+
+    def set_option(self, name, value):
+        self._ck(self._lib.dsh_set_option(self._h, name.encode(), int(value)))
+
+    @property
+    def stream(self):
+        return self._lib.dsh_stream(self._h)

@@ -1,0 +1,714 @@
+// dsh_api.hip -- the C-ABI of libdashing_hip.so (include/dashing_hip.h) over the gfx950 kernels.
+// No CPU fallback lives here: without a HIP device dsh_create fails with DSH_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dashing_hip.h"
+#include "kernels.h"
+
+using namespace dsh;
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct dsh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // resident sketch matrix
+    DevBuf regs_own;
+    const uint8_t *regs = nullptr;  // device
+    uint64_t n = 0;
+    int p = 0;
+    bool have_sketches = false;
+    // derived state
+    bool planes_valid = false;
+    int card_estim = -1;
+    DevBuf card, vrange, planes, cum, tiles, outbuf, seqbuf, workbuf;
+    uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
+    int vlo = 0;
+    std::vector<uint2> htiles;
+    // options
+    int kc = 64;
+    uint64_t cum_budget = 2ull << 30;
+    int xcd_swizzle = 1;
+    // profiling
+    bool profiling = false;
+    double pair_ms = 0, fin_ms = 0, prep_ms = 0;
+    uint32_t pair_launches = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(dsh_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), e_ == hipErrorOutOfMemory ? DSH_ENOMEM : DSH_EIO, "%s: %s",  \
+                        #expr, hipGetErrorString(e_));                                    \
+    } while (0)
+
+int bind(dsh_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return DSH_OK;
+}
+
+hipEvent_t next_event(dsh_ctx *c)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+void invalidate(dsh_ctx *c)
+{
+    c->planes_valid = false;
+    c->card_estim = -1;
+}
+
+// cardinalities + planes for the current sketch matrix
+int prepare(dsh_ctx *c, int estim)
+{
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
+    if (c->planes_valid && c->card_estim == estim) return DSH_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = next_event(c);
+        e1 = next_event(c);
+        if (e0) (void)hipEventRecord(e0, c->stream);
+    }
+    const uint64_t n = c->n;
+    HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
+    HIPCHK(c, c->vrange.ensure(2 * sizeof(int)));
+    const int init[2] = {63, 0};
+    HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, (double *)c->card.ptr,
+                                   (int *)c->vrange.ptr));
+    c->card_estim = estim;
+    if (!c->planes_valid) {
+        int vr[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(vr, c->vrange.ptr, sizeof vr, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n == 0) vr[0] = vr[1] = 0;
+        c->vlo = vr[0];
+        c->P = (uint32_t)(vr[1] - vr[0]);
+        const uint64_t m = 1ull << c->p;
+        c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
+        c->Npad = (uint32_t)((n + kTile - 1) / kTile * kTile);
+        const uint64_t K = (uint64_t)c->P * c->W;
+        c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
+        if (c->Kpad) {
+            const size_t bytes = (size_t)c->Kpad * c->Npad * sizeof(uint32_t);
+            HIPCHK(c, c->planes.ensure(bytes));
+            if (c->Kpad > K)
+                HIPCHK(c, hipMemsetAsync((uint32_t *)c->planes.ptr + K * c->Npad, 0,
+                                         (size_t)(c->Kpad - K) * c->Npad * sizeof(uint32_t),
+                                         c->stream));
+            HIPCHK(c, launch_transform(c->stream, c->regs, n, c->p, c->vlo, c->P, c->W, c->Npad,
+                                       (uint32_t *)c->planes.ptr));
+        }
+        c->planes_valid = true;
+    }
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        c->prep_ms += ms;
+    }
+    return DSH_OK;
+}
+
+// Order the tiles of a band so that workgroups that run on the same XCD (block b -> XCD b % 8,
+// observed dispatch behaviour; speed only, never correctness) walk one tile row together and
+// share its A panel in that XCD's L2.
+void xcd_order(std::vector<uint2> &t, size_t b, size_t e)
+{
+    const size_t cnt = e - b;
+    if (cnt < 16) return;
+    std::vector<uint2> tmp(cnt);
+    const size_t nx = 8, per = (cnt + nx - 1) / nx;
+    // position q in launch order runs on XCD q % 8; give XCD x the contiguous range
+    // [x*per, (x+1)*per) of the row-major list
+    size_t q = 0;
+    for (size_t r = 0; r < per; ++r)
+        for (size_t x = 0; x < nx; ++x) {
+            const size_t src = x * per + r;
+            if (src < cnt) tmp[q++] = t[b + src];
+        }
+    std::copy(tmp.begin(), tmp.begin() + q, t.begin() + b);
+}
+
+struct PairJob {
+    int estim, result_type, k;
+    int rect;
+    uint64_t row_begin, row_end, col_begin, col_end;
+    uint64_t base_index;
+    float *d_out;
+};
+
+int run_pairs(dsh_ctx *c, const PairJob &job)
+{
+    int rc = prepare(c, job.estim);
+    if (rc) return rc;
+    if (job.result_type != DSH_JI && job.result_type != DSH_MASH_DIST &&
+        job.result_type != DSH_FULL_MASH_DIST)
+        return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
+    if (job.k < 1) return fail(c, DSH_EINVAL, "bad k %d", job.k);
+    // tile list
+    std::vector<uint2> &T = c->htiles;
+    T.clear();
+    const uint32_t NT = c->Npad / kTile;
+    std::vector<size_t> row_starts;
+    if (job.rect) {
+        if (job.row_begin >= job.row_end || job.col_begin >= job.col_end) return DSH_OK;
+        const uint32_t r0 = (uint32_t)(job.row_begin / kTile), r1 = (uint32_t)((job.row_end + kTile - 1) / kTile);
+        const uint32_t c0 = (uint32_t)(job.col_begin / kTile), c1 = (uint32_t)((job.col_end + kTile - 1) / kTile);
+        for (uint32_t ti = r0; ti < r1; ++ti) {
+            row_starts.push_back(T.size());
+            for (uint32_t tj = c0; tj < c1; ++tj) T.push_back(make_uint2(ti, tj));
+        }
+    } else {
+        if (job.row_begin >= job.row_end) return DSH_OK;
+        const uint32_t r0 = (uint32_t)(job.row_begin / kTile);
+        const uint32_t r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
+        for (uint32_t ti = r0; ti < r1; ++ti) {
+            row_starts.push_back(T.size());
+            for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(make_uint2(ti, tj));
+        }
+    }
+    row_starts.push_back(T.size());
+    if (T.empty()) return DSH_OK;
+    // bands: whole tile rows, bounded by the cum scratch budget
+    const uint64_t per_tile = (uint64_t)kTile * kTile * sizeof(uint32_t) * std::max<uint32_t>(c->P, 1);
+    const uint64_t max_tiles = std::max<uint64_t>(1, c->cum_budget / per_tile);
+    std::vector<std::pair<size_t, size_t>> bands;
+    {
+        size_t b = 0;
+        while (b < T.size()) {
+            size_t e = std::min<size_t>(T.size(), b + max_tiles);
+            bands.emplace_back(b, e);
+            b = e;
+        }
+    }
+    if (c->xcd_swizzle)
+        for (auto &bd : bands) xcd_order(T, bd.first, bd.second);
+    HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint2)));
+    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, T.data(), T.size() * sizeof(uint2),
+                             hipMemcpyHostToDevice, c->stream));
+    size_t max_band = 0;
+    for (auto &bd : bands) max_band = std::max(max_band, bd.second - bd.first);
+    HIPCHK(c, c->cum.ensure(std::max<uint64_t>(per_tile * max_band, 256)));
+
+    const float ksinv_f = (float)(1. / (double)job.k);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evp, evf;
+    for (auto &bd : bands) {
+        const uint32_t nt = (uint32_t)(bd.second - bd.first);
+        const uint64_t nslots = (uint64_t)nt * kTile * kTile;
+        const uint2 *dt = (const uint2 *)c->tiles.ptr + bd.first;
+        hipEvent_t a = nullptr, b = nullptr, d = nullptr;
+        if (c->profiling) {
+            a = next_event(c);
+            b = next_event(c);
+            d = next_event(c);
+            if (a) (void)hipEventRecord(a, c->stream);
+        }
+        HIPCHK(c, launch_pair_counts(c->stream, c->kc, (const uint32_t *)c->planes.ptr, c->Npad,
+                                     c->Kpad, c->W, c->P, dt, nt, (uint32_t *)c->cum.ptr, nslots));
+        if (b) (void)hipEventRecord(b, c->stream);
+        FinalizeLaunch f;
+        f.cum = (const uint32_t *)c->cum.ptr;
+        f.nslots = nslots;
+        f.tiles = dt;
+        f.P = c->P;
+        f.vlo = c->vlo;
+        f.p = c->p;
+        f.estim = job.estim;
+        f.result_type = job.result_type;
+        f.ksinv = (double)ksinv_f;
+        f.card = (const double *)c->card.ptr;
+        f.n = c->n;
+        f.rect = job.rect;
+        f.row_begin = job.row_begin;
+        f.row_end = job.row_end;
+        f.col_begin = job.col_begin;
+        f.col_end = job.col_end;
+        f.base_index = job.base_index;
+        f.out = job.d_out;
+        HIPCHK(c, launch_finalize(c->stream, f));
+        if (d) (void)hipEventRecord(d, c->stream);
+        if (a && b && d) {
+            evp.emplace_back(a, b);
+            evf.emplace_back(b, d);
+        }
+    }
+    if (c->profiling) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &e : evp) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            c->pair_ms += ms;
+            if (c->Kpad) c->pair_launches++;
+        }
+        for (auto &e : evf) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            c->fin_ms += ms;
+        }
+    }
+    return DSH_OK;
+}
+
+void reset_prof(dsh_ctx *c)
+{
+    c->pair_ms = c->fin_ms = c->prep_ms = 0;
+    c->pair_launches = 0;
+    c->ev_used = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dsh_backend_name(void) { return "hip:gfx950"; }
+
+int dsh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dsh_create(int device, dsh_ctx **out)
+{
+    if (!out) return DSH_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DSH_ENODEV;
+    if (device < 0 || device >= n) return DSH_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DSH_ENODEV;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DSH_ENODEV;  // gfx950-only code object
+    dsh_ctx *c = new (std::nothrow) dsh_ctx;
+    if (!c) return DSH_ENOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return DSH_EIO;
+    }
+    *out = c;
+    return DSH_OK;
+}
+
+void dsh_destroy(dsh_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    c->regs_own.release();
+    c->card.release();
+    c->vrange.release();
+    c->planes.release();
+    c->cum.release();
+    c->tiles.release();
+    c->outbuf.release();
+    c->seqbuf.release();
+    c->workbuf.release();
+    delete c;
+}
+
+const char *dsh_last_error(const dsh_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int dsh_synchronize(dsh_ctx *c)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+void *dsh_stream(dsh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int dsh_sketches_alloc(dsh_ctx *c, uint64_t n, int p)
+{
+    if (!c) return DSH_EINVAL;
+    if (p < 4 || p > 17) return fail(c, DSH_EINVAL, "p=%d outside [4,17]", p);
+    int rc = bind(c);
+    if (rc) return rc;
+    const size_t bytes = std::max<size_t>((size_t)n << p, 256);
+    HIPCHK(c, c->regs_own.ensure(bytes));
+    HIPCHK(c, hipMemsetAsync(c->regs_own.ptr, 0, bytes, c->stream));
+    c->regs = (const uint8_t *)c->regs_own.ptr;
+    c->n = n;
+    c->p = p;
+    c->have_sketches = true;
+    invalidate(c);
+    return DSH_OK;
+}
+
+int dsh_attach_device_sketches(dsh_ctx *c, const void *d_regs, uint64_t n, int p)
+{
+    if (!c || (!d_regs && n)) return DSH_EINVAL;
+    if (p < 4 || p > 17) return fail(c, DSH_EINVAL, "p=%d outside [4,17]", p);
+    if (((uintptr_t)d_regs & 15) != 0) return fail(c, DSH_EINVAL, "device sketches must be 16-byte aligned");
+    c->regs = (const uint8_t *)d_regs;
+    c->n = n;
+    c->p = p;
+    c->have_sketches = true;
+    invalidate(c);
+    return DSH_OK;
+}
+
+int dsh_upload_sketches(dsh_ctx *c, const uint8_t *regs, uint64_t first, uint64_t n)
+{
+    if (!c || (!regs && n)) return DSH_EINVAL;
+    if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
+        return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
+    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots [%llu,%llu) out of range", (unsigned long long)first, (unsigned long long)(first + n));
+    int rc = bind(c);
+    if (rc) return rc;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync((uint8_t *)c->regs_own.ptr + (first << c->p), regs, (size_t)n << c->p,
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    invalidate(c);
+    return DSH_OK;
+}
+
+int dsh_download_sketches(dsh_ctx *c, uint64_t first, uint64_t n, uint8_t *out)
+{
+    if (!c || (!out && n)) return DSH_EINVAL;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches");
+    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    int rc = bind(c);
+    if (rc) return rc;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(out, c->regs + (first << c->p), (size_t)n << c->p,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return DSH_OK;
+}
+
+int dsh_clear_sketches(dsh_ctx *c, uint64_t first, uint64_t n)
+{
+    if (!c) return DSH_EINVAL;
+    if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
+        return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
+    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    int rc = bind(c);
+    if (rc) return rc;
+    if (n) HIPCHK(c, hipMemsetAsync((uint8_t *)c->regs_own.ptr + (first << c->p), 0, (size_t)n << c->p, c->stream));
+    invalidate(c);
+    return DSH_OK;
+}
+
+static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genome_off,
+                         uint32_t n_genomes, uint64_t first_slot, int k, int canon)
+{
+    // work list: each workgroup walks up to kSubsPerWG sub-chunks of one genome
+    constexpr uint32_t kSubsPerWG = 16;
+    std::vector<SketchWork> work;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        const uint64_t gb = genome_off[g], ge = genome_off[g + 1];
+        if (ge < gb) return fail(c, DSH_EINVAL, "genome_off not monotone at %u", g);
+        if (ge - gb < (uint64_t)k) continue;
+        const uint64_t c0 = gb & ~31ull;
+        const uint64_t nsub = (ge - c0 + kSketchSub - 1) / kSketchSub;
+        for (uint64_t s = 0; s < nsub; s += kSubsPerWG) {
+            SketchWork w;
+            w.gbeg = gb;
+            w.gend = ge;
+            w.start = c0 + s * kSketchSub;
+            w.nsub = (uint32_t)std::min<uint64_t>(kSubsPerWG, nsub - s);
+            w.slot = (uint32_t)(first_slot + g);
+            work.push_back(w);
+        }
+    }
+    if (work.empty()) return DSH_OK;
+    HIPCHK(c, c->workbuf.ensure(work.size() * sizeof(SketchWork)));
+    HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, work.data(), work.size() * sizeof(SketchWork),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_sketch(c->stream, d_seq, (const SketchWork *)c->workbuf.ptr,
+                            (uint32_t)work.size(), k, c->p, canon, (uint8_t *)c->regs_own.ptr));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `work` (pageable source) must outlive the copy
+    return DSH_OK;
+}
+
+static int sketch_check(dsh_ctx *c, const uint64_t *genome_off, uint32_t n_genomes,
+                        uint64_t first_slot, int k)
+{
+    if (!c || (!genome_off && n_genomes)) return DSH_EINVAL;
+    if (k < 1 || k > 32) return fail(c, DSH_EINVAL, "k=%d outside [1,32]", k);
+    if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
+        return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
+    if (first_slot + n_genomes > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    return DSH_OK;
+}
+
+int dsh_sketch_batch(dsh_ctx *c, const uint8_t *seq, const uint64_t *genome_off, uint32_t n_genomes,
+                     uint64_t first_slot, int k, int canon, uint8_t *regs_out)
+{
+    int rc = sketch_check(c, genome_off, n_genomes, first_slot, k);
+    if (rc) return rc;
+    if ((rc = bind(c))) return rc;
+    if (n_genomes == 0) return DSH_OK;
+    const uint64_t lo = genome_off[0], hi = genome_off[n_genomes];
+    if (hi < lo) return fail(c, DSH_EINVAL, "genome_off not monotone");
+    // ship only [lo,hi), 32-aligned on the device side; pad so every lane's 64-byte read is in bounds
+    const uint64_t shift = lo & 31;
+    const size_t bytes = (size_t)(hi - lo) + shift;
+    HIPCHK(c, c->seqbuf.ensure(bytes + 256));
+    if (hi > lo) {
+        if (!seq) return DSH_EINVAL;
+        HIPCHK(c, hipMemcpyAsync((uint8_t *)c->seqbuf.ptr + shift, seq + lo, (size_t)(hi - lo),
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<uint64_t> off(n_genomes + 1);
+    for (uint32_t g = 0; g <= n_genomes; ++g) off[g] = genome_off[g] - lo + shift;
+    rc = sketch_common(c, (const uint8_t *)c->seqbuf.ptr, off.data(), n_genomes, first_slot, k, canon);
+    if (rc) return rc;
+    invalidate(c);
+    if (regs_out) return dsh_download_sketches(c, first_slot, n_genomes, regs_out);
+    return DSH_OK;
+}
+
+int dsh_sketch_batch_device(dsh_ctx *c, const void *d_seq, const uint64_t *genome_off,
+                            uint32_t n_genomes, uint64_t first_slot, int k, int canon)
+{
+    int rc = sketch_check(c, genome_off, n_genomes, first_slot, k);
+    if (rc) return rc;
+    if ((rc = bind(c))) return rc;
+    if (n_genomes == 0) return DSH_OK;
+    if (!d_seq || ((uintptr_t)d_seq & 31)) return fail(c, DSH_EINVAL, "d_seq must be 32-byte aligned and padded by 128 bytes");
+    rc = sketch_common(c, (const uint8_t *)d_seq, genome_off, n_genomes, first_slot, k, canon);
+    if (rc) return rc;
+    invalidate(c);
+    return DSH_OK;
+}
+
+int dsh_cardinalities(dsh_ctx *c, int estim, double *out)
+{
+    if (!c || !out) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
+    if (c->card_estim != estim) {
+        // cardinalities only (planes untouched)
+        HIPCHK(c, c->card.ensure(std::max<uint64_t>(c->n, 1) * sizeof(double)));
+        HIPCHK(c, c->vrange.ensure(2 * sizeof(int)));
+        const int init[2] = {63, 0};
+        HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, c->n, c->p, estim, (double *)c->card.ptr,
+                                       (int *)c->vrange.ptr));
+        c->card_estim = estim;
+    }
+    if (c->n) {
+        HIPCHK(c, hipMemcpyAsync(out, c->card.ptr, c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j) { return i * (2 * n - i - 1) / 2 + j - (i + 1); }
+
+uint64_t dsh_tri_span(uint64_t n, uint64_t rb, uint64_t re)
+{
+    if (re > n) re = n;
+    if (rb >= re) return 0;
+    // sum_{i=rb}^{re-1} (n-1-i)
+    const uint64_t cnt = re - rb;
+    return cnt * (n - 1) - (rb + re - 1) * cnt / 2;
+}
+
+int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds)
+{
+    if (!bounds || nparts == 0) return DSH_EINVAL;
+    if (align == 0) align = 1;
+    const uint64_t total = n ? n * (n - 1) / 2 : 0;
+    bounds[0] = 0;
+    uint64_t row = 0;
+    for (uint32_t r = 1; r < nparts; ++r) {
+        const long double target = (long double)total * r / nparts;
+        // advance in `align` steps to the boundary whose cumulative pair count is nearest target
+        uint64_t best = row;
+        long double bestd = -1;
+        for (uint64_t cand = row; cand <= n; cand += align) {
+            const long double cum = (long double)dsh_tri_span(n, 0, cand);
+            const long double d = cum > target ? cum - target : target - cum;
+            if (bestd < 0 || d < bestd) {
+                bestd = d;
+                best = cand;
+            }
+            if (cum > target) break;
+        }
+        row = std::min<uint64_t>(best, n);
+        bounds[r] = row;
+    }
+    bounds[nparts] = n;
+    return DSH_OK;
+}
+
+int dsh_dist_rows_device(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, void *d_out)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    reset_prof(c);
+    if (re > c->n) re = c->n;
+    if (rb >= re || c->n < 2) return DSH_OK;
+    if (!d_out) return DSH_EINVAL;
+    PairJob j;
+    j.estim = estim;
+    j.result_type = result_type;
+    j.k = k;
+    j.rect = 0;
+    j.row_begin = rb;
+    j.row_end = re;
+    j.col_begin = j.col_end = 0;
+    j.base_index = dsh_tri_span(c->n, 0, rb);
+    j.d_out = (float *)d_out;
+    return run_pairs(c, j);
+}
+
+int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, float *out)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (re > c->n) re = c->n;
+    const uint64_t span = dsh_tri_span(c->n, rb, re);
+    if (span == 0) return DSH_OK;
+    if (!out) return DSH_EINVAL;
+    HIPCHK(c, c->outbuf.ensure(span * sizeof(float)));
+    rc = dsh_dist_rows_device(c, estim, result_type, k, rb, re, c->outbuf.ptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->outbuf.ptr, span * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_dist_rect(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t qe, uint64_t rb, uint64_t re, float *out)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (qe > c->n || re > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    reset_prof(c);
+    if (qb >= qe || rb >= re) return DSH_OK;
+    if (!out) return DSH_EINVAL;
+    const uint64_t cnt = (qe - qb) * (re - rb);
+    HIPCHK(c, c->outbuf.ensure(cnt * sizeof(float)));
+    PairJob j;
+    j.estim = estim;
+    j.result_type = result_type;
+    j.k = k;
+    j.rect = 1;
+    j.row_begin = qb;
+    j.row_end = qe;
+    j.col_begin = rb;
+    j.col_end = re;
+    j.base_index = 0;
+    j.d_out = (float *)c->outbuf.ptr;
+    rc = run_pairs(c, j);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->outbuf.ptr, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_set_profiling(dsh_ctx *c, int enable)
+{
+    if (!c) return DSH_EINVAL;
+    c->profiling = enable != 0;
+    return DSH_OK;
+}
+
+int dsh_last_kernel_ms(dsh_ctx *c, double *pair_ms, double *fin_ms, double *prep_ms, uint32_t *launches)
+{
+    if (!c) return DSH_EINVAL;
+    if (pair_ms) *pair_ms = c->pair_ms;
+    if (fin_ms) *fin_ms = c->fin_ms;
+    if (prep_ms) *prep_ms = c->prep_ms;
+    if (launches) *launches = c->pair_launches;
+    return DSH_OK;
+}
+
+int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
+{
+    if (!c || !name) return DSH_EINVAL;
+    if (!std::strcmp(name, "kc")) {
+        if (v != 32 && v != 64 && v != 128) return fail(c, DSH_EINVAL, "kc must be 32, 64 or 128");
+        c->kc = (int)v;
+        c->planes_valid = false;  // Kpad depends on kc
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "cum_budget_bytes")) {
+        if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
+        c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "xcd_swizzle")) {
+        c->xcd_swizzle = v != 0;
+        return DSH_OK;
+    }
+    return fail(c, DSH_EINVAL, "unknown option %s", name);
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// estimators.h -- HLL cardinality estimators evaluated on the device, one lane per histogram.
+//
+// Product code (NOT the oracle).  Restates calculate_estimate() of the absent dnbaker/sketch
+// submodule (called through hll_t::report / union_size at src/dashing.h:139,492) from the
+// published algorithms -- SURVEY.md Appendix A.5: ORIGINAL (Flajolet et al. 2007 with small/
+// large range corrections), ERTL_IMPROVED (Ertl 2017 sigma/tau), ERTL_MLE (Ertl 2017 Alg. 8,
+// secant iteration with the relative early stop 1e-2/sqrt(m)).  All arithmetic is fp64 and the
+// translation unit is compiled with -ffp-contract=off so + - * / are IEEE-identical with a CPU
+// build of the same formulas.
+//
+// `Hist` is any callable  uint32_t c(int v)  returning the count of value v, v in [0, q+1].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsh {
+
+__device__ __forceinline__ double alpha_m(uint64_t m)
+{
+    return m == 16 ? 0.673 : m == 32 ? 0.697 : m == 64 ? 0.709 : 0.7213 / (1. + 1.079 / (double)m);
+}
+
+__device__ inline double ertl_sigma(double x)
+{
+    if (x == 1.) return __builtin_huge_val();
+    double z = x, zp = 0., y = 1.;
+    while (z != zp) {
+        x *= x;
+        zp = z;
+        z += x * y;
+        y += y;
+    }
+    return z;
+}
+
+__device__ inline double ertl_tau(double x)
+{
+    if (x == 0. || x == 1.) return 0.;
+    double z = 1. - x, y = 1., zp = x;
+    while (zp != z) {
+        x = sqrt(x);
+        zp = z;
+        y *= 0.5;
+        const double t = 1. - x;
+        z -= t * t * y;
+    }
+    return z / 3.;
+}
+
+template <class Hist>
+__device__ inline double estimate_original(const Hist &c, int p)
+{
+    const int q = 64 - p;
+    const double m = (double)(1ull << p);
+    double sum = (double)c(0);
+    for (int i = 1; i < q + 1; ++i) {
+        const uint32_t ci = c(i);
+        if (ci) sum += ldexp((double)ci, -i);
+    }
+    double value = alpha_m(1ull << p) * m * m / sum;
+    if (value < 2.5 * m) {
+        const uint32_t c0 = c(0);
+        if (c0) value = m * log(m / (double)c0);
+    } else if (value > 4294967296. / 30.) {
+        const double corr = -4294967296. * log1p(-ldexp(value, -32));
+        if (!(corr != corr)) value = corr;
+    }
+    return value;
+}
+
+template <class Hist>
+__device__ inline double estimate_improved(const Hist &c, int p)
+{
+    const int q = 64 - p;
+    const double m = (double)(1ull << p);
+    const double divinv = 0x1.71547652b82fep-1;  // 1/(2 ln 2)
+    double z = m * ertl_tau((m - (double)c(q + 1)) / m);
+    for (int i = q; i; --i) {
+        z += (double)c(i);
+        z *= 0.5;
+    }
+    z += m * ertl_sigma((double)c(0) / m);
+    return m * divinv * m / z;
+}
+
+// kmin_hint/kmax_hint: a range known to contain every non-empty bin (scan bounds only).
+template <class Hist>
+__device__ inline double estimate_mle(const Hist &c, int p, int lo_hint, int hi_hint)
+{
+    const int q = 64 - p;
+    const uint64_t m = 1ull << p;
+    const uint32_t cq1 = c(q + 1);
+    if (cq1 == m) return __builtin_huge_val();
+    int kMin = lo_hint, kMax = hi_hint;
+    while (kMin < q + 1 && c(kMin) == 0) ++kMin;
+    while (kMax > 0 && c(kMax) == 0) --kMax;
+    const int kMinPrime = kMin > 1 ? kMin : 1;
+    const int kMaxPrime = kMax < q ? kMax : q;
+    double z = 0.;
+    for (int k = kMaxPrime; k >= kMinPrime; --k) z = 0.5 * z + (double)c(k);
+    z = ldexp(z, -kMinPrime);
+    uint32_t cPrime = cq1;
+    if (q >= 1) cPrime += c(kMaxPrime);
+    const uint32_t c0 = c(0);
+    const double a = z + (double)c0;
+    const double mPrime = (double)(int)(m - c0);
+    double gprev = z + ldexp((double)cq1, -q);
+    double x = gprev <= 1.5 * a ? mPrime / (0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
+    gprev = 0.;
+    double deltaX = x;
+    const double relerr = 1e-2 / sqrt((double)m);
+    while (deltaX > x * relerr) {
+        int kappaMinus1;
+        (void)frexp(x, &kappaMinus1);
+        const int sh = kMaxPrime + 1 > kappaMinus1 + 2 ? kMaxPrime + 1 : kappaMinus1 + 2;
+        double xPrime = ldexp(x, -sh);
+        const double xPrime2 = xPrime * xPrime;
+        double h = xPrime - xPrime2 / 3. + (xPrime2 * xPrime2) * (1. / 45. - xPrime2 / 472.5);
+        for (int k = kappaMinus1; k >= kMaxPrime; --k) {
+            const double hPrime = 1. - h;
+            h = (xPrime + h * hPrime) / (xPrime + hPrime);
+            xPrime += xPrime;
+        }
+        double g = (double)cPrime * h;
+        for (int k = kMaxPrime - 1; k >= kMinPrime; --k) {
+            const double hPrime = 1. - h;
+            h = (xPrime + h * hPrime) / (xPrime + hPrime);
+            xPrime += xPrime;
+            g += (double)c(k) * h;
+        }
+        g += x * a;
+        if (gprev < g && g <= mPrime) deltaX *= (g - mPrime) / (gprev - g);
+        else deltaX = 0.;
+        x += deltaX;
+        gprev = g;
+    }
+    return x * (double)m;
+}
+
+template <class Hist>
+__device__ inline double estimate(const Hist &c, int p, int estim, int lo_hint, int hi_hint)
+{
+    switch (estim) {
+    case 0: return estimate_original(c, p);
+    case 1: return estimate_improved(c, p);
+    default: return estimate_mle(c, p, lo_hint, hi_hint);
+    }
+}
+
+// jaccard_index of hll_t: (ca + cb - us)/us clamped with std::max(0., .) -- NaN maps to 0.
+__device__ __forceinline__ double jaccard_from(double ca, double cb, double us)
+{
+    const double r = (ca + cb - us) / us;
+    return (0. < r) ? r : 0.;
+}
+
+// result_cmp (src/dashing.h:568-592) for JI / MASH_DIST / FULL_MASH_DIST;
+// dist_index :154-156, full_dist_index :172-174; ksinv = (double)(float)(1./k) (:797 of
+// src/sketch_and_cmp.h); the result is cast to float (:591).
+__device__ __forceinline__ float result_from_ji(double ji, int result_type, double ksinv)
+{
+    double ret = ji;
+    if (result_type == 0) ret = ji != 0. ? -log(2. * ji / (1. + ji)) * ksinv : 1.;
+    else if (result_type == 3) ret = 1. - pow(2. * ji / (1. + ji), ksinv);
+    return (float)ret;
+}
+
+}  // namespace dsh

@@ -1,0 +1,45 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal to libdashing_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsh {
+
+constexpr uint32_t kTile = 64;  // sketches per tile side in k_pair_counts
+
+hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
+                                double *card, int *vrange);
+hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
+                            uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes);
+hipError_t launch_pair_counts(hipStream_t st, int kc, const uint32_t *planes, uint32_t Npad,
+                              uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
+                              uint32_t ntiles, uint32_t *cum, uint64_t nslots);
+
+struct FinalizeLaunch {
+    const uint32_t *cum;
+    uint64_t nslots;
+    const uint2 *tiles;
+    uint32_t P;
+    int vlo, p, estim, result_type;
+    double ksinv;
+    const double *card;
+    uint64_t n;
+    int rect;
+    uint64_t row_begin, row_end, col_begin, col_end, base_index;
+    float *out;
+};
+hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
+
+// sketch path
+struct SketchWork {
+    uint64_t gbeg;   // absolute offset of the genome's first base in the device seq buffer
+    uint64_t gend;   // one past its last base
+    uint64_t start;  // absolute, 32-aligned offset of this workgroup's first base
+    uint32_t nsub;   // number of 8192-base sub-chunks this workgroup walks
+    uint32_t slot;   // row of the resident sketch matrix
+};
+constexpr uint32_t kSketchSub = 8192;  // bases per sub-chunk (256 threads x 32 start positions)
+hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
+                         uint32_t nwork, int k, int p, int canon, uint8_t *regs);
+
+}  // namespace dsh

@@ -1,0 +1,165 @@
+// kernels_sketch.hip -- genome bases -> HLL registers on gfx950.
+//
+// Replaces hot loop 1 of the reference: enc.for_each([&](u64 kmer){h.addh(kmer);}, ...)
+// (src/sketch_and_cmp.h:342, :515): canonical 2-bit k-mer (bonsai Encoder, unspaced,
+// unwindowed, k<=32) -> WangHash -> register rule (mirrored at src/readfilt.cpp:86-88)
+//     idx = h >> (64-p);  v = clz(((h<<1)|1) << (p-1)) + 1;  reg[idx] = max(reg[idx], v).
+//
+// Design: no sequential rolling state.  Each lane packs the 64 bases
+// at its 32-aligned position into 2-bit words -- F big-endian (first base most significant),
+// R = complement, little-endian, V = validity bits -- so the forward and reverse-complement
+// k-mer of ANY start position is a funnel-shift window of (F0:F1) / (R0:R1), and "k valid
+// bases" is a mask test on V.  Non-ACGT bytes, record separators, bases outside the genome's
+// [gbeg,gend) span are all just cleared V bits.  Registers live in LDS as packed bytes
+// (2^p B per workgroup); a plain LDS read filters out the (vast majority of) k-mers that
+// cannot raise a register, the rest do a CAS on the containing word.  At the end each
+// workgroup max-merges its LDS array into the resident matrix with 32-bit CAS (byte-wise
+// SWAR max).  max is commutative/associative/idempotent => bit-exact, order-independent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace dsh {
+
+__device__ __forceinline__ uint64_t wang64(uint64_t key)
+{
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// 0x80 in every byte of v that is zero (exact, no cross-byte borrow)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v)
+{
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+
+// 4 ASCII bases (byte 0 = first base) -> 8 bits big-endian codes, 8 bits little-endian
+// complement codes, 4 validity bits.  A0 C1 G2 T3, case-folded; anything else invalid.
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t &be8, uint32_t &le8c, uint32_t &v4)
+{
+    const uint32_t up = x & 0xDFDFDFDFu;
+    const uint32_t ok = zero_bytes(up ^ 0x41414141u) | zero_bytes(up ^ 0x43434343u) |
+                        zero_bytes(up ^ 0x47474747u) | zero_bytes(up ^ 0x54545454u);
+    v4 = ((ok >> 7) * 0x01020408u) >> 24;  // bit k = byte k valid (upper bits are junk-free)
+    const uint32_t t = (x >> 1) & 0x03030303u;                 // A0 C1 T2 G3
+    const uint32_t code = t ^ ((t >> 1) & 0x01010101u);        // A0 C1 G2 T3
+    be8 = (code * 0x40100401u) >> 24;                          // c0<<6 | c1<<4 | c2<<2 | c3
+    le8c = ((code ^ 0x03030303u) * 0x01041040u) >> 24;         // (3-c0) | (3-c1)<<2 | ...
+}
+
+__device__ __forceinline__ void pack32(const uint4 lo, const uint4 hi, uint64_t &F, uint64_t &R,
+                                       uint32_t &V)
+{
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    F = 0; R = 0; V = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t be, le, v;
+        pack4(w[k], be, le, v);
+        F |= (uint64_t)be << (56 - 8 * k);
+        R |= (uint64_t)le << (8 * k);
+        V |= (v & 0xFu) << (4 * k);
+    }
+}
+
+__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
+{
+    // bytes < 128: bit7 of (a|0x80)-b set iff a_byte >= b_byte
+    const uint32_t ge = (((a | 0x80808080u) - b) >> 7) & 0x01010101u;
+    const uint32_t mask = ge * 0xFFu;
+    return (a & mask) | (b & ~mask);
+}
+
+__global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
+                                                 const SketchWork *__restrict__ work, int k,
+                                                 int p, int canon, uint8_t *__restrict__ regs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lregs[];  // 2^p bytes
+    const int tid = threadIdx.x;
+    const SketchWork wk = work[blockIdx.x];
+    const uint32_t mwords = (1u << p) >> 2;
+    for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = 0;
+    __syncthreads();
+
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const uint64_t vk = k == 32 ? 0xFFFFFFFFull : ((1ull << k) - 1);
+    const int fshift = 64 - 2 * k;
+
+    for (uint32_t s = 0; s < wk.nsub; ++s) {
+        const uint64_t B = wk.start + (uint64_t)s * kSketchSub + (uint64_t)tid * 32;
+        if (B >= wk.gend) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(seq + B);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        uint64_t F0, R0, F1, R1;
+        uint32_t V0, V1;
+        pack32(q0, q1, F0, R0, V0);
+        pack32(q2, q3, F1, R1, V1);
+        // bases outside [gbeg,gend) are invalid
+        const uint64_t lo = wk.gbeg > B ? wk.gbeg - B : 0;
+        const uint64_t hi = wk.gend - B;  // > 0
+        uint64_t rmask = hi >= 64 ? ~0ull : ((1ull << hi) - 1);
+        rmask = lo >= 64 ? 0ull : (rmask & ~((1ull << lo) - 1));
+        const uint64_t V = ((uint64_t)V0 | ((uint64_t)V1 << 32)) & rmask;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (((V >> j) & vk) != vk) continue;
+            const uint64_t fh = j ? ((F0 << (2 * j)) | (F1 >> (64 - 2 * j))) : F0;
+            const uint64_t rl = j ? ((R0 >> (2 * j)) | (R1 << (64 - 2 * j))) : R0;
+            const uint64_t fw = fh >> fshift;
+            const uint64_t rc = rl & kmask;
+            const uint64_t km = (canon && rc < fw) ? rc : fw;
+            const uint64_t h = wang64(km);
+            const uint32_t idx = (uint32_t)(h >> (64 - p));
+            const uint64_t t = ((h << 1) | 1ull) << (p - 1);
+            const uint32_t val = (uint32_t)__builtin_clzll(t) + 1u;
+            uint32_t *wp = &lregs[idx >> 2];
+            const uint32_t sh = (idx & 3u) * 8u;
+            uint32_t old = *wp;
+            while (((old >> sh) & 0xFFu) < val) {
+                const uint32_t nw = (old & ~(0xFFu << sh)) | (val << sh);
+                const uint32_t prev = atomicCAS(wp, old, nw);
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *g = reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p));
+    for (uint32_t w = tid; w < mwords; w += 256) {
+        const uint32_t mine = lregs[w];
+        if (!mine) continue;
+        uint32_t old = g[w];
+        for (;;) {
+            const uint32_t nw = bytemax4(old, mine);
+            if (nw == old) break;
+            const uint32_t prev = atomicCAS(&g[w], old, nw);
+            if (prev == old) break;
+            old = prev;
+        }
+    }
+}
+
+hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
+                         uint32_t nwork, int k, int p, int canon, uint8_t *regs)
+{
+    if (nwork == 0) return hipSuccess;
+    const size_t lds = (size_t)1 << p;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(k_sketch, dim3(nwork), dim3(256), lds, st, seq, work, k, p, canon, regs);
+    return hipGetLastError();
+}
+
+}  // namespace dsh

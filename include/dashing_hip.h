@@ -1,0 +1,136 @@
+/*
+ * dashing_hip.h -- C-ABI of libdashing_hip.so: dashing's HLL sketch-and-compare hot path on
+ * MI355X (gfx950).  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * dashing (the reference, /root/reference) has no plugin/FFI interface for this path: it is
+ * C++ templates instantiated per sketch type.  Each entry point below replaces one of the two
+ * loop bodies ("waists") of the reference, cited file:line; INTEGRATION.md shows the
+ * reference-side glue a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns DSH_OK (0) or a negative errno-style code; no exceptions cross
+ *     the boundary; dsh_last_error(ctx) gives a human-readable message for the last failure.
+ *   - the caller owns all host memory; the library owns device memory behind dsh_ctx.
+ *   - one dsh_ctx per GPU; a ctx is not thread-safe, different ctxs are independent.
+ *   - there is NO CPU fallback: with no gfx950 device dsh_create fails with DSH_ENODEV.
+ *   - register arrays are dashing's: uint8_t[2^p] per sketch, row-major [n][2^p].
+ *   - distances are float32 in the packed upper-triangular order of
+ *     distmat/distmat.h:260-264: index(i,j) = i*(2n-i-1)/2 + j-(i+1), i<j.
+ */
+#ifndef DASHING_HIP_H_
+#define DASHING_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSH_OK 0
+#define DSH_EINVAL (-22)  /* bad argument */
+#define DSH_ENOMEM (-12)  /* host or device allocation failed */
+#define DSH_ENODEV (-19)  /* no usable gfx950 device */
+#define DSH_EIO (-5)      /* HIP runtime error / file error */
+#define DSH_ESTATE (-11)  /* call sequence error (e.g. dist before sketches are loaded) */
+
+/* sketch::hll::EstimationMethod values selected by dist_main, src/distmain.cpp:37,59-62
+ * (-E ORIGINAL, -I ERTL_IMPROVED, default/-m ERTL_MLE). */
+#define DSH_ESTIM_ORIGINAL 0
+#define DSH_ESTIM_ERTL_IMPROVED 1
+#define DSH_ESTIM_ERTL_MLE 2
+
+/* bns::EmissionType values, src/enums.h:13-23.  Symmetric measures handled by result_cmp's
+ * first switch arm, src/dashing.h:571-576. */
+#define DSH_MASH_DIST 0
+#define DSH_JI 1
+#define DSH_FULL_MASH_DIST 3
+
+typedef struct dsh_ctx dsh_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+const char *dsh_backend_name(void);       /* "hip:gfx950" */
+int dsh_device_count(void);               /* number of visible HIP devices (0 if none) */
+int dsh_create(int device, dsh_ctx **out);
+void dsh_destroy(dsh_ctx *ctx);
+const char *dsh_last_error(const dsh_ctx *ctx);
+int dsh_synchronize(dsh_ctx *ctx);
+
+/* ---- the resident sketch matrix ----------------------------------------------------------
+ * Replaces `std::vector<hll_t> sketches` (src/sketch_and_cmp.h:282-288): n register arrays
+ * of 2^p bytes, resident in HBM for the lifetime of the ctx (or until re-allocated). */
+int dsh_sketches_alloc(dsh_ctx *ctx, uint64_t n, int p);
+/* sketch.read(path) path (src/sketch_and_cmp.h:318-324, --presketched): host rows -> slots. */
+int dsh_upload_sketches(dsh_ctx *ctx, const uint8_t *regs, uint64_t first_slot, uint64_t n);
+int dsh_download_sketches(dsh_ctx *ctx, uint64_t first_slot, uint64_t n, uint8_t *regs_out);
+/* Use a caller-owned DEVICE buffer [n][2^p] as the sketch matrix (no copy; the caller keeps it
+ * alive).  This is how bench.py hands over inputs already resident in HBM. */
+int dsh_attach_device_sketches(dsh_ctx *ctx, const void *d_regs, uint64_t n, int p);
+
+/* ---- sketch waist -------------------------------------------------------------------------
+ * Replaces the body of hot loop 1, `enc.for_each([&](u64 kmer){h.addh(kmer);}, file, ksp)`
+ * (src/sketch_and_cmp.h:342 and :515; register rule mirrored at src/readfilt.cpp:86-88), for a
+ * batch of genomes.  `seq` is host ASCII: genome g occupies seq[genome_off[g] .. genome_off[g+1]);
+ * FASTA records inside a genome are separated by at least one non-ACGT byte (so k-mers never
+ * span records, like kseq records); case is folded; any non-ACGT byte resets the window.
+ * Canonical k-mers iff canon != 0 (-C clears it, src/distmain.cpp:65).  k in [1,32].
+ * Registers go to slots [first_slot, first_slot+n_genomes) of the resident matrix (max-merged
+ * into what is there, so a genome may be fed in several calls) and, if regs_out != NULL, are
+ * also copied to the host.  Bit-exact with the CPU definition (max is order-independent). */
+int dsh_sketch_batch(dsh_ctx *ctx, const uint8_t *seq, const uint64_t *genome_off,
+                     uint32_t n_genomes, uint64_t first_slot, int k, int canon,
+                     uint8_t *regs_out);
+/* Same with `seq` already on the device (d_seq device pointer; genome_off stays on the host). */
+int dsh_sketch_batch_device(dsh_ctx *ctx, const void *d_seq, const uint64_t *genome_off,
+                            uint32_t n_genomes, uint64_t first_slot, int k, int canon);
+int dsh_clear_sketches(dsh_ctx *ctx, uint64_t first_slot, uint64_t n);
+
+/* ---- cardinalities ------------------------------------------------------------------------
+ * Replaces cardinality_estimate(hll_t&) = h.report() (src/dashing.h:492, used at
+ * src/sketch_and_cmp.h:377-382): one double per sketch. */
+int dsh_cardinalities(dsh_ctx *ctx, int estim, double *card_out);
+
+/* ---- compare waist ------------------------------------------------------------------------
+ * Replaces hot loop 2: perform_core_op (src/sketch_and_cmp.h:699-710) / the oracle(i,j) of
+ * dm::parallel_fill (distmat/distmat.h:459-512) with func = result_cmp (src/dashing.h:568-592):
+ * for rows i in [row_begin,row_end) and all j>i, out[index(i,j) - index(row_begin,row_begin+1)]
+ * = float(result_cmp(sketch_j, sketch_i, result_type, 1/k)).  The rows of a range are one
+ * contiguous span of the packed triangle, dsh_tri_span() elements long.
+ * result_type in {DSH_JI, DSH_MASH_DIST, DSH_FULL_MASH_DIST}; k only matters for the Mash forms. */
+int dsh_dist_rows(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
+                  uint64_t row_end, float *out);
+/* Same, result left in a caller-owned DEVICE buffer (no D2H); asynchronous on the ctx stream --
+ * call dsh_synchronize (or use the stream) before reading d_out. */
+int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
+                         uint64_t row_end, void *d_out);
+/* Query x reference rectangle (partdist_loop, src/dashing.h:660-712): queries are slots
+ * [q_begin,q_end), references slots [r_begin,r_end); out[(qi-q_begin)*(r_end-r_begin)+(rj-r_begin)]. */
+int dsh_dist_rect(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin,
+                  uint64_t q_end, uint64_t r_begin, uint64_t r_end, float *out);
+
+/* ---- helpers shared by every host (C++ CLI, Python, a patched dashing) -------------------- */
+/* number of packed elements of rows [row_begin,row_end) of an n x n upper triangle */
+uint64_t dsh_tri_span(uint64_t n, uint64_t row_begin, uint64_t row_end);
+/* index(i,j) of distmat/distmat.h:260-264 */
+uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j);
+/* Split rows [0,n) into nparts contiguous ranges of near-equal pair count, boundaries aligned
+ * to `align` rows (the kernel tile, 64, keeps every rank on whole tile rows).
+ * bounds_out[0..nparts] receives the boundaries (bounds_out[0]=0, bounds_out[nparts]=n). */
+int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds_out);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+/* Milliseconds spent in the dominant kernel (all-pairs AND+popcount) during the last
+ * dsh_dist_* call on this ctx, measured with HIP events on the ctx stream; launches = number
+ * of launches of that kernel in the call.  Enabled by dsh_set_profiling(ctx, 1) (adds event
+ * records + one sync at the end of the call). */
+int dsh_set_profiling(dsh_ctx *ctx, int enable);
+int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
+                       double *prepare_ms, uint32_t *pair_kernel_launches);
+/* Tunables (tile shape variant etc.); returns DSH_EINVAL for unknown names. */
+int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
+/* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work. */
+void *dsh_stream(dsh_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASHING_HIP_H_ */

@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dashing_hip.h declares, and its
+host-only helpers behave.  No GPU compute here (dsh_create must fail loudly without a device)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dashing_amd
+from dashing_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "dashing_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsh_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    lib = ctypes.CDLL(dashing_amd.lib_path())
+    decl = _declared_symbols()
+    assert len(decl) >= 20
+    for s in decl:
+        assert hasattr(lib, s), "libdashing_hip.so does not export %s" % s
+    assert sorted(api.SYMBOLS) == decl, "python binding out of sync with the header"
+
+
+def test_backend_name():
+    assert dashing_amd.backend_name() == "hip:gfx950"
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device context creation must fail (never silently compute on the CPU)."""
+    if dashing_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(dashing_amd.DshError) as e:
+        dashing_amd.Context(0)
+    assert e.value.code == -19
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dashing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_c" not in txt and "oracle_py" not in txt and "liboracle" not in txt and "dsho_" not in txt, f
+
+
+def test_tri_index_and_span():
+    n = 37
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert dashing_amd.tri_index(n, i, j) == k  # distmat/distmat.h:260-264 is row-major
+            k += 1
+    assert dashing_amd.tri_span(n, 0, n) == n * (n - 1) // 2
+    assert dashing_amd.tri_span(n, 5, 9) == sum(n - 1 - i for i in range(5, 9))
+    assert dashing_amd.tri_span(n, 9, 5) == 0
+    assert dashing_amd.tri_span(n, 30, 99) == sum(n - 1 - i for i in range(30, n))
+
+
+@pytest.mark.parametrize("n,parts", [(10000, 8), (10000, 2), (1000, 4), (65, 8), (1, 2), (0, 3), (100000, 8)])
+def test_partition_rows(n, parts):
+    b = dashing_amd.partition_rows(n, parts, 64)
+    assert b[0] == 0 and b[-1] == n and len(b) == parts + 1
+    assert all(b[i] <= b[i + 1] for i in range(parts))
+    assert all(x % 64 == 0 for x in b[1:-1] if x != n)
+    if n >= 10000:
+        spans = [dashing_amd.tri_span(n, b[i], b[i + 1]) for i in range(parts)]
+        assert max(spans) / (sum(spans) / parts) < 1.05  # balanced within 5 %
+        assert sum(spans) == n * (n - 1) // 2

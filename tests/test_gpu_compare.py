@@ -1,0 +1,171 @@
+"""GPU parity: the HIP compare path (through the C-ABI) vs the CPU oracle on the same inputs.
+Bar: distances within 1e-6 relative (|d| <= 1e-6*max(|ref|,1e-9)), the J==0 -> Mash==1 branch
+exact, cardinalities within 1e-12 relative (only libm log/log1p/pow ulps may differ)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import dashing_amd
+from dashing_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-6
+
+
+def close(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all()
+    err = np.abs(got[fin] - ref[fin])
+    tol = RTOL * np.maximum(np.abs(ref[fin]), 1e-9)
+    bad = err > tol
+    assert not bad.any(), "max rel err %.3g at %d of %d" % (
+        (err / np.maximum(np.abs(ref[fin]), 1e-9)).max(), int(bad.sum()), err.size)
+
+
+def test_backend_is_hip(ctx):
+    assert dashing_amd.backend_name() == "hip:gfx950"
+    assert dashing_amd.device_count() >= 1
+
+
+def test_golden_pairs(ctx):
+    with open(os.path.join(GOLD, "kat.json")) as f:
+        kat = json.load(f)
+    for row in kat["pairs"]:
+        regs = np.load(os.path.join(GOLD, "regs_p%d.npy" % row["p"]))
+        ctx.set_sketches(regs)
+        want = np.frombuffer(bytes.fromhex(row["tri_hex"]), np.float32)
+        got = ctx.dist_rows(estim=row["estim"], result_type=row["result_type"], k=row["k"])
+        close(got, want)
+        wc = np.frombuffer(bytes.fromhex(row["card_hex"]), np.float64)
+        gc = ctx.cardinalities(row["estim"])
+        assert np.allclose(gc, wc, rtol=1e-12, atol=0)
+        if row["result_type"] == dashing_amd.MASH_DIST:
+            assert ((got == 1.0) == (want == 1.0)).all()  # J==0 branch agrees exactly
+
+
+@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 63), (10, 64), (10, 65), (10, 200), (14, 130), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20)])
+@pytest.mark.parametrize("estim", [0, 1, 2])
+def test_tri_vs_oracle(ctx, oracle, p, n, estim):
+    regs = synth.synthetic_sketches(n, p, seed=0x1234 + p * 131 + n)
+    if n > 3:
+        regs[n // 2] = regs[0]      # identical pair -> J == 1
+        regs[n - 1] = 0             # empty sketch -> J == 0, Mash == 1
+    ctx.set_sketches(regs)
+    for rt in (dashing_amd.JI, dashing_amd.MASH_DIST, dashing_amd.FULL_MASH_DIST):
+        want = oracle.dist_tri(regs, estim, rt, 31)
+        got = ctx.dist_rows(estim=estim, result_type=rt, k=31)
+        close(got, want)
+        if rt == dashing_amd.MASH_DIST:
+            assert ((got == 1.0) == (want == 1.0)).all()
+    if n > 3:
+        ji = ctx.dist_rows(estim=estim, result_type=dashing_amd.JI)
+        assert ji[dashing_amd.tri_index(n, 0, n // 2)] == 1.0
+
+
+def test_cardinalities_vs_oracle(ctx, oracle):
+    for p in (4, 10, 14):
+        regs = synth.synthetic_sketches(50, p, seed=p)
+        regs[7] = 0
+        regs[8] = 64 - p + 1  # saturated
+        ctx.set_sketches(regs)
+        for e in (0, 1, 2):
+            want = oracle.cardinalities(regs, e)
+            got = ctx.cardinalities(e)
+            fin = np.isfinite(want)
+            assert (np.isfinite(got) == fin).all()
+            assert np.allclose(got[fin], want[fin], rtol=1e-12, atol=0)
+
+
+def test_row_ranges_concatenate(ctx):
+    """Sharding primitive: any split of the rows gives byte-identical spans (multi-GPU by construction)."""
+    n, p = 333, 10
+    regs = synth.synthetic_sketches(n, p, seed=42)
+    ctx.set_sketches(regs)
+    full = ctx.dist_rows()
+    for parts in (2, 3, 8):
+        b = dashing_amd.partition_rows(n, parts, 64)
+        cat = np.concatenate([ctx.dist_rows(b[i], b[i + 1]) for i in range(parts)])
+        assert cat.tobytes() == full.tobytes()
+    odd = np.concatenate([ctx.dist_rows(0, 1), ctx.dist_rows(1, 70), ctx.dist_rows(70, 71), ctx.dist_rows(71, n)])
+    assert odd.tobytes() == full.tobytes()
+
+
+def test_rect_matches_tri(ctx, oracle):
+    n, p = 150, 10
+    regs = synth.synthetic_sketches(n, p, seed=43)
+    ctx.set_sketches(regs)
+    tri = ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=21)
+    rect = ctx.dist_rect(3, 70, 60, 150, result_type=dashing_amd.MASH_DIST, k=21)
+    for i in (3, 10, 64, 69):
+        for j in (70, 100, 128, 149):
+            assert rect[i - 3, j - 60] == tri[dashing_amd.tri_index(n, i, j)]
+    want = oracle.dist_rect(regs[3:70], regs[60:150], 2, oracle.MASH_DIST, 21)
+    # diagonal (i == j) is computed too in a rectangle: identical sketches -> J = 1 -> Mash 0
+    close(rect, want)
+
+
+def test_options_do_not_change_results(ctx):
+    n, p = 140, 14
+    regs = synth.synthetic_sketches(n, p, seed=44)
+    ctx.set_sketches(regs)
+    base = ctx.dist_rows()
+    try:
+        for kc in (32, 128, 64):
+            ctx.set_option("kc", kc)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+        ctx.set_option("xcd_swizzle", 0)
+        assert ctx.dist_rows().tobytes() == base.tobytes()
+        ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
+        assert ctx.dist_rows().tobytes() == base.tobytes()
+    finally:
+        ctx.set_option("kc", 64)
+        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("cum_budget_bytes", 2 << 30)
+
+
+def test_properties_at_scale(ctx, oracle):
+    """Size-independent properties at a size the oracle cannot sweep: symmetry under
+    permutation, identical rows -> J == 1, sampled rows agree with the oracle."""
+    n, p = 2000, 14
+    regs = synth.synthetic_sketches(n, p, seed=45)
+    regs[1500] = regs[3]
+    ctx.set_sketches(regs)
+    tri = ctx.dist_rows()
+    assert tri.size == n * (n - 1) // 2
+    assert np.isfinite(tri).all() and tri.min() >= 0 and tri.max() <= 1
+    assert tri[dashing_amd.tri_index(n, 3, 1500)] == 1.0
+    # permutation: reversing the sketch order must give the same values at the mirrored index
+    ctx.set_sketches(regs[::-1])
+    rev = ctx.dist_rows()
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        assert tri[dashing_amd.tri_index(n, i, j)] == rev[dashing_amd.tri_index(n, n - 1 - j, n - 1 - i)]
+    # a few full rows against the oracle
+    for r in (0, 777, 1998):
+        want = oracle.dist_rows(regs, r, r + 1)
+        lo = dashing_amd.tri_index(n, r, r + 1)
+        close(tri[lo : lo + want.size], want)
+
+
+def test_errors(ctx):
+    with pytest.raises(dashing_amd.DshError):
+        ctx.alloc(10, 3)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.alloc(10, 30)
+    ctx.alloc(4, 10)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.dist_rows(result_type=5)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.set_option("nope", 1)
+    # empty / degenerate
+    ctx.alloc(0, 10)
+    assert ctx.dist_rows().size == 0
+    ctx.alloc(1, 10)
+    assert ctx.dist_rows().size == 0

@@ -1,0 +1,97 @@
+"""GPU parity: HIP sketch kernel (through the C-ABI) vs the CPU oracle -- register arrays BIT-EXACT."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from dashing_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run(ctx, oracle, genomes, k, p, canon=True):
+    seq, off = synth.concat_for_device(genomes)
+    ctx.alloc(len(genomes), p)
+    got = ctx.sketch_batch(seq, off, 0, k, canon)
+    want = oracle.sketch_batch(seq, off, k, p, canon)
+    assert got.shape == want.shape
+    assert (got == want).all(), "registers differ in %d places" % int((got != want).sum())
+    return got
+
+
+def test_golden_small_genome(ctx):
+    with open(os.path.join(GOLD, "kat.json")) as f:
+        s = json.load(f)["sketch_small"]
+    g = np.frombuffer(s["seq"].encode(), np.uint8)
+    seq, off = synth.concat_for_device([g])
+    ctx.alloc(1, s["p"])
+    got = ctx.sketch_batch(seq, off, 0, s["k"], s["canon"])
+    assert got[0].tobytes().hex() == s["regs_hex"]
+
+
+@pytest.mark.parametrize("k", [31, 32, 21, 5, 1])
+@pytest.mark.parametrize("canon", [True, False])
+def test_k_and_canon(ctx, oracle, k, canon):
+    gs = synth.synthetic_genomes(5, 20011, seed=k * 7 + canon, decorate=True)
+    run(ctx, oracle, gs, k, 10, canon)
+
+
+@pytest.mark.parametrize("p", [4, 8, 10, 12, 14, 16, 17])
+def test_precisions(ctx, oracle, p):
+    gs = synth.synthetic_genomes(3, 50021, seed=p)
+    run(ctx, oracle, gs, 31, p)
+
+
+def test_ragged_and_edge_genomes(ctx, oracle):
+    """empty genome, shorter than k, exactly k, all-N, N every 31 bases, separators between records,
+    lengths that straddle the 32/8192/131072-base chunk boundaries, unaligned offsets."""
+    base = synth.synthetic_genomes(1, 300000, seed=99, decorate=False)[0]
+    gs = [
+        base[:0], base[:30], base[:31], base[:32], base[:33], np.full(500, ord("N"), np.uint8),
+        base[:8191], base[:8192], base[:8193], base[:8222], base[:131071], base[:131073],
+        base[:262147], base[5:70001], base[17:100], base.copy(),
+    ]
+    withn = base[:40000].copy()
+    withn[::31] = ord("N")         # never 31 valid bases in a row -> no k-mers at k=31
+    gs.append(withn)
+    rec = base[:30000].copy()
+    rec[10000] = ord(">")          # record separators (any non-ACGT byte)
+    rec[20000:20003] = 0
+    gs.append(rec)
+    low = base[:25000].copy()
+    low |= 0x20                    # all lowercase
+    gs.append(low)
+    got = run(ctx, oracle, gs, 31, 12)
+    assert not got[0].any() and not got[1].any() and not got[5].any() and not got[16].any()
+    assert got[2].any()
+    assert (got[18] == run(ctx, oracle, [base[:25000]], 31, 12)[0]).all()
+
+
+def test_merge_across_calls(ctx, oracle):
+    """A genome fed in two calls (same slot) max-merges: equals sketching both record sets at once."""
+    a, b = synth.synthetic_genomes(2, 40000, seed=5, decorate=False)
+    ctx.alloc(1, 10)
+    s1, o1 = synth.concat_for_device([a])
+    s2, o2 = synth.concat_for_device([b])
+    ctx.sketch_batch(s1, o1, 0, 31, True)
+    got = ctx.sketch_batch(s2, o2, 0, 31, True)[0]
+    both = np.concatenate([a, np.array([ord("N")], np.uint8), b])
+    s3, o3 = synth.concat_for_device([both])
+    want = oracle.sketch_batch(s3, o3, 31, 10, True)[0]
+    assert (got == want).all()
+
+
+def test_sketch_then_dist_c1_like(ctx, oracle):
+    """BASELINE configs[0] in miniature: synthetic related genomes -> sketch -> all-pairs, vs oracle."""
+    gs = synth.synthetic_genomes(24, 100000, seed=0xDA5410)
+    seq, off = synth.concat_for_device(gs)
+    ctx.alloc(len(gs), 10)
+    regs = ctx.sketch_batch(seq, off, 0, 31, True)
+    want_regs = oracle.sketch_batch(seq, off, 31, 10, True)
+    assert (regs == want_regs).all()
+    got = ctx.dist_rows()
+    want = oracle.dist_tri(want_regs)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-15)
+    assert got.max() > 0.5 and got.min() < 0.05  # related and unrelated pairs both present
