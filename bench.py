@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- all-pairs HLL distance throughput on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted
+on: 10 000 synthetic sketches, p=14 (16 KiB register arrays), all-pairs Jaccard with dashing's
+default estimator (Ertl MLE), packed float32 upper triangle.  One "step" = one full pass of the
+hot path over register arrays already resident in HBM: cardinalities + bit-plane transform +
+all-pairs AND/popcount + per-pair estimator -> distances in HBM (+ for N>1 the RCCL gather of
+the per-rank row spans to rank 0).  Strong scaling: the matrix is fixed, rows are sharded.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_pair_counts), timed
+with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement
+of the reference algorithm and row schedule -- the reference itself is not buildable: its
+bonsai/sketch submodules are absent) timed on this host on a bounded sample of the same rows.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_SKETCH = int(os.environ.get("DSH_BENCH_N", "10000"))
+P = int(os.environ.get("DSH_BENCH_P", "14"))
+K = 31
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import dashing_amd
+    from dashing_amd import multigpu, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n, p, m = N_SKETCH, P, 1 << P
+    regs_h = synth.synthetic_sketches(n, p, seed=0x5EED0000)  # identical bytes on every rank
+    regs_d = torch.from_numpy(regs_h).to(dev)                 # resident in HBM before timing
+    bounds = multigpu.row_bounds(n, world)
+    rb, re = bounds[rank], bounds[rank + 1]
+    span = dashing_amd.tri_span(n, rb, re)
+    mx = multigpu.max_span(n, bounds)
+    out_d = torch.empty(max(mx, 1), dtype=torch.float32, device=dev)
+    staging = [torch.empty(mx, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    total_pairs = n * (n - 1) // 2
+
+    ctx = dashing_amd.Context(local_rank)
+
+    def step():
+        # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        ctx.dist_rows_device(out_d.data_ptr(), rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        if world > 1:
+            return multigpu.gather_spans(out_d, n, bounds, rank, world, 0, staging)
+        return out_d[:span]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = total_pairs * args.steps / dt
+
+    # ---- roofline of the dominant kernel: HIP events on the library stream, outside the timed region
+    ctx.set_profiling(True)
+    pair_ms, launches, fin_ms, prep_ms = 0.0, 0, 0.0, 0.0
+    reps = 3
+    for _ in range(reps):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        ctx.dist_rows_device(out_d.data_ptr(), rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        k = ctx.last_kernel_ms()
+        pair_ms += k["pair_ms"]
+        fin_ms += k["finalize_ms"]
+        prep_ms += k["prepare_ms"]
+        launches += k["pair_launches"]
+    ctx.set_profiling(False)
+    b_pair = 2 * m + 4                                   # algorithmic bytes per pair
+    my_pairs = span
+    achieved = my_pairs * reps * b_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "k_pair_counts", "launches_per_step": launches // reps,
+        "avg_launch_ms": round(pair_ms / max(launches, 1), 4),
+        "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
+        "finalize_ms_per_step": round(fin_ms / reps, 4), "prepare_ms_per_step": round(prep_ms / reps, 4),
+        "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
+    }
+
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "genome-pairs/sec, all-pairs HLL Jaccard (Ertl-MLE), N=%d p=%d" % (n, p),
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8/u32 popcount + f64 estimator",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
+                       "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
+                       "sharding": "rows->ranks by pair count, RCCL gather to rank 0" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity_vs_cpu": parity,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(regs_h, gpu_full, n, p, seconds):
+    """Time the CPU oracle (reference algorithm + row schedule) on a bounded sample of rows.
+    The oracle is only the checker/baseline here -- never the thing measured as `value`."""
+    import subprocess
+
+    from oracle import oracle_c
+
+    cores = oracle_c.effective_cpus()
+    native = "/tmp/liboracle_native_%d.so" % os.getpid()
+    kind_lib = None
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "OUT=" + native],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        kind_lib = oracle_c.load(native, threads=cores)
+        isa = "-march=native"
+    except Exception:
+        kind_lib = oracle_c.load(threads=cores)
+        isa = "-march=x86-64-v3 (prebuilt)"
+    # calibrate on a few rows, then size the sample for ~`seconds`
+    t0 = time.perf_counter()
+    r0 = oracle_c.dist_rows(regs_h, 0, 8, lib=kind_lib)
+    t_cal = time.perf_counter() - t0
+    rate = r0.size / max(t_cal, 1e-6)
+    rows = int(min(n - 1, max(16, seconds * rate / n)))
+    t0 = time.perf_counter()
+    ref = oracle_c.dist_rows(regs_h, 0, rows, lib=kind_lib)
+    t = time.perf_counter() - t0
+    got = gpu_full[: ref.size].cpu().numpy()
+    rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
+    cpu = {"value": ref.size / t, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": "rows [0,%d) of the same %d-sketch p=%d matrix = %d pairs in %.1f s; oracle/dsh_oracle.c (%s, OpenMP dynamic over j per row as src/sketch_and_cmp.h:699-710)" % (rows, n, p, ref.size, t, isa),
+           "note": "CPU restatement; reference not buildable (bonsai/sketch submodules absent)"}
+    parity = {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6,
+              "exact_float32_matches": int((got == ref).sum())}
+    try:
+        os.unlink(native)
+    except OSError:
+        pass
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""Row-block sharding of the packed upper triangle across ranks + gather of the distance rows
+(torch.distributed: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+Every pair is independent, so there is no data-path collective inside the compare itself: rank r
+computes the contiguous row range [bounds[r], bounds[r+1]) (near-equal pair counts, boundaries on
+whole 64-row tile rows) and the only exchange is the gather of the per-rank spans of the packed
+triangle to rank 0 -- the writer, as in dashing where one process emits the matrix
+(src/sketch_and_cmp.h:838-849)."""
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+def row_bounds(n, world):
+    return api.partition_rows(n, world, 64)
+
+
+def span_sizes(n, bounds):
+    return [api.tri_span(n, bounds[r], bounds[r + 1]) for r in range(len(bounds) - 1)]
+
+
+def gather_spans(local, n, bounds, rank, world, dst=0, staging=None):
+    """local: 1-D float32 tensor holding this rank's span (may be longer than the span: padded).
+    Returns the full packed triangle on `dst` (a 1-D tensor of n(n-1)/2 floats), None elsewhere.
+    Spans are padded to the largest span so one dist.gather moves everything."""
+    sizes = span_sizes(n, bounds)
+    if world == 1:
+        return local[: sizes[0]]
+    mx = max(sizes)
+    assert local.numel() >= mx, "allocate the local span with max_span(n, bounds) elements"
+    send = local[:mx]
+    if rank == dst:
+        if staging is None:
+            staging = [torch.empty(mx, dtype=local.dtype, device=local.device) for _ in range(world)]
+        dist.gather(send, gather_list=staging, dst=dst)
+        return torch.cat([staging[r][: sizes[r]] for r in range(world)])
+    dist.gather(send, gather_list=None, dst=dst)
+    return None
+
+
+def max_span(n, bounds):
+    return max(span_sizes(n, bounds))

@@ -46,6 +46,20 @@
 #define DSHO_JI 1
 #define DSHO_FULL_MASH_DIST 3
 
+/* Thread count for every parallel region below.  0 = OpenMP default.  Tests keep this small:
+ * a GPU box may report far more logical CPUs than its cgroup quota lets us run, and a team of
+ * spinning threads starves itself there. */
+static int g_threads = 0;
+void dsho_set_threads(int n) { g_threads = n > 0 ? n : 0; }
+static int nthreads_(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* ---- A.2  Thomas Wang 64-bit integer hash (sketch::WangHash) ------------------------ */
 uint64_t dsho_wang(uint64_t key)
 {
@@ -123,7 +137,7 @@ void dsho_sketch_batch(const uint8_t *seq, const uint64_t *genome_off, uint32_t 
 {
     const uint64_t m = UINT64_C(1) << p;
     memset(regs_out, 0, (size_t)n_genomes * m);
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
     for (int64_t g = 0; g < (int64_t)n_genomes; ++g)
         dsho_walk(seq + genome_off[g], genome_off[g + 1] - genome_off[g], k, canon, p,
                   regs_out + (uint64_t)g * m, NULL, 0);
@@ -301,7 +315,7 @@ double dsho_cardinality(const uint8_t *regs, int p, int estim)
 void dsho_cardinalities(const uint8_t *regs, uint64_t n, int p, int estim, double *out)
 {
     const uint64_t m = UINT64_C(1) << p;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads_())
     for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = dsho_cardinality(regs + (uint64_t)i * m, p, estim);
 }
 
@@ -354,7 +368,7 @@ void dsho_dist_tri(const uint8_t *regs, uint64_t n, int p, int estim, int result
     for (uint64_t i = 0; i + 1 < n; ++i) {
         const uint8_t *hi = regs + i * m;
         float *row = out_packed + tri_index(n, i, i + 1);
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
         for (int64_t j = (int64_t)i + 1; j < (int64_t)n; ++j)
             row[j - (int64_t)i - 1] =
                 dsho_pair(regs + (uint64_t)j * m, hi, card[j], card[i], p, estim, result_type, k);
@@ -374,7 +388,7 @@ uint64_t dsho_dist_rows(const uint8_t *regs, uint64_t n, int p, int estim, int r
     for (uint64_t i = row_begin; i < row_end && i + 1 < n; ++i) {
         const uint8_t *hi = regs + i * m;
         float *row = out + done;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
         for (int64_t j = (int64_t)i + 1; j < (int64_t)n; ++j)
             row[j - (int64_t)i - 1] =
                 dsho_pair(regs + (uint64_t)j * m, hi, card[j], card[i], p, estim, result_type, k);
@@ -394,7 +408,7 @@ void dsho_dist_rect(const uint8_t *qregs, uint64_t nq, const uint8_t *rregs, uin
     dsho_cardinalities(qregs, nq, p, estim, cq);
     dsho_cardinalities(rregs, nr, p, estim, cr);
     for (uint64_t i = 0; i < nq; ++i) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
         for (int64_t j = 0; j < (int64_t)nr; ++j)
             out[i * nr + (uint64_t)j] = dsho_pair(rregs + (uint64_t)j * m, qregs + i * m, cr[j],
                                                   cq[i], p, estim, result_type, k);
@@ -403,11 +417,4 @@ void dsho_dist_rect(const uint8_t *qregs, uint64_t nq, const uint8_t *rregs, uin
     free(cr);
 }
 
-int dsho_num_threads(void)
-{
-#ifdef _OPENMP
-    return omp_get_max_threads();
-#else
-    return 1;
-#endif
-}
+int dsho_num_threads(void) { return nthreads_(); }

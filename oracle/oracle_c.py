@@ -29,7 +29,28 @@ def build(native_out=None):
     return os.path.join(_HERE, "liboracle.so")
 
 
+def effective_cpus():
+    """CPUs we can really run on: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def _bind(lib):
+    lib.dsho_set_threads.restype = None
+    lib.dsho_set_threads.argtypes = [C.c_int]
     lib.dsho_wang.restype = C.c_uint64
     lib.dsho_wang.argtypes = [C.c_uint64]
     lib.dsho_reg_rule.restype = None
@@ -65,15 +86,23 @@ def _bind(lib):
 _LIB = None
 
 
-def load(path=None):
+def load(path=None, threads=None):
+    """Load the oracle.  By default it runs on at most 8 threads with passive waiting (tests);
+    bench.py's cpu_baseline leg passes threads=effective_cpus()."""
     global _LIB
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     if path is not None:
-        return _bind(C.CDLL(path))
+        lib = _bind(C.CDLL(path))
+        lib.dsho_set_threads(threads or min(8, effective_cpus()))
+        return lib
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
         _LIB = _bind(C.CDLL(so))
+        _LIB.dsho_set_threads(threads or min(8, effective_cpus()))
+    elif threads:
+        _LIB.dsho_set_threads(threads)
     return _LIB
 
 
