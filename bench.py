@@ -59,7 +59,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n, p, m = N_SKETCH, P, 1 << P
-    regs_h = synth.synthetic_sketches(n, p, seed=0x5EED0000)  # identical bytes on every rank
+    regs_h = synth.survey_sketches(n, p, seed=0x5EED0000)[0]  # SURVEY 8d; identical bytes on every rank
     regs_d = torch.from_numpy(regs_h).to(dev)                 # resident in HBM before timing
     bounds = multigpu.row_bounds(n, world)
     rb, re = bounds[rank], bounds[rank + 1]
@@ -123,6 +123,8 @@ def main():
         "kernel": "k_pair_counts", "launches_per_step": launches // reps,
         "avg_launch_ms": round(pair_ms / max(launches, 1), 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
+        "dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
+        "exception_list_cap": ctx.info("emax"),
         "finalize_ms_per_step": round(fin_ms / reps, 4), "prepare_ms_per_step": round(prep_ms / reps, 4),
         "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
     }

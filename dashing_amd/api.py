@@ -22,7 +22,7 @@ SYMBOLS = [
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rect", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
-    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_stream",
+    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
 
@@ -75,6 +75,7 @@ def load_library():
     lib.dsh_set_profiling.argtypes = [vp, i32]
     lib.dsh_last_kernel_ms.argtypes = [vp, vp, vp, vp, vp]
     lib.dsh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.dsh_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     lib.dsh_stream.argtypes = [vp]
     lib.dsh_stream.restype = vp
     _LIB = lib
@@ -97,7 +98,7 @@ def tri_index(n, i, j):
     return int(load_library().dsh_tri_index(n, i, j))
 
 
-def partition_rows(n, nparts, align=64):
+def partition_rows(n, nparts, align=128):
     """Host-only helper shared with the C++ CLI: contiguous row ranges of near-equal pair count."""
     b = np.zeros(nparts + 1, np.uint64)
     rc = load_library().dsh_partition_rows(n, nparts, align, b.ctypes.data)
@@ -220,6 +221,11 @@ class Context:
 
     def set_option(self, name, value):
         self._ck(self._lib.dsh_set_option(self._h, name.encode(), int(value)))
+
+    def info(self, name):
+        v = C.c_int64()
+        self._ck(self._lib.dsh_get_info(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     @property
     def stream(self):

@@ -49,12 +49,14 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
-    DevBuf card, vrange, planes, cum, tiles, outbuf, seqbuf, workbuf;
+    DevBuf card, vrange, planes, cum, tiles, outbuf, seqbuf, workbuf, exc, exc_n;
     uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
-    int vlo = 0;
+    int vlo = 0, vhi = 0;
+    int emax = 0, cum_bytes = 4;
     std::vector<uint2> htiles;
     // options
-    int kc = 64;
+    int kc = 32;
+    int emax_opt = -1;  // -1: min(64, 2^p / 256)
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     // profiling
@@ -123,20 +125,29 @@ int prepare(dsh_ctx *c, int estim)
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
     const uint64_t n = c->n;
+    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap)
+                                          : (int)std::min<uint64_t>(kExcCap, (1ull << c->p) >> 8);
+    if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
+    c->emax = emax_new;
     HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
-    HIPCHK(c, c->vrange.ensure(2 * sizeof(int)));
-    const int init[2] = {63, 0};
+    HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
+    HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+    HIPCHK(c, c->vrange.ensure(3 * sizeof(int)));
+    const int init[3] = {63, 0, 0};
     HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, (double *)c->card.ptr,
-                                   (int *)c->vrange.ptr));
+    HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
+                                   (double *)c->card.ptr, (int *)c->vrange.ptr,
+                                   (uint32_t *)c->exc.ptr, (uint32_t *)c->exc_n.ptr));
     c->card_estim = estim;
     if (!c->planes_valid) {
-        int vr[2] = {0, 0};
+        int vr[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(vr, c->vrange.ptr, sizeof vr, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (n == 0) vr[0] = vr[1] = 0;
+        if (n == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
-        c->P = (uint32_t)(vr[1] - vr[0]);
+        c->vhi = vr[1];
+        c->P = (uint32_t)(vr[2] - vr[0]);  // dense planes cover v in (lo, Tmax]
+        c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
         c->Npad = (uint32_t)((n + kTile - 1) / kTile * kTile);
@@ -225,7 +236,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     row_starts.push_back(T.size());
     if (T.empty()) return DSH_OK;
     // bands: whole tile rows, bounded by the cum scratch budget
-    const uint64_t per_tile = (uint64_t)kTile * kTile * sizeof(uint32_t) * std::max<uint32_t>(c->P, 1);
+    const uint64_t per_tile = (uint64_t)kTile * kTile * c->cum_bytes * std::max<uint32_t>(c->P, 1);
     const uint64_t max_tiles = std::max<uint64_t>(1, c->cum_budget / per_tile);
     std::vector<std::pair<size_t, size_t>> bands;
     {
@@ -258,11 +269,15 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             d = next_event(c);
             if (a) (void)hipEventRecord(a, c->stream);
         }
-        HIPCHK(c, launch_pair_counts(c->stream, c->kc, (const uint32_t *)c->planes.ptr, c->Npad,
-                                     c->Kpad, c->W, c->P, dt, nt, (uint32_t *)c->cum.ptr, nslots));
+        HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                     c->Npad, c->Kpad, c->W, c->P, dt, nt, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
         FinalizeLaunch f;
-        f.cum = (const uint32_t *)c->cum.ptr;
+        f.cum = c->cum.ptr;
+        f.cum_bytes = c->cum_bytes;
+        f.vhi = c->vhi;
+        f.exc = (const uint32_t *)c->exc.ptr;
+        f.exc_n = (const uint32_t *)c->exc_n.ptr;
         f.nslots = nslots;
         f.tiles = dt;
         f.P = c->P;
@@ -359,6 +374,8 @@ void dsh_destroy(dsh_ctx *c)
     c->card.release();
     c->vrange.release();
     c->planes.release();
+    c->exc.release();
+    c->exc_n.release();
     c->cum.release();
     c->tiles.release();
     c->outbuf.release();
@@ -547,14 +564,12 @@ int dsh_cardinalities(dsh_ctx *c, int estim, double *out)
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
     if (c->card_estim != estim) {
-        // cardinalities only (planes untouched)
-        HIPCHK(c, c->card.ensure(std::max<uint64_t>(c->n, 1) * sizeof(double)));
-        HIPCHK(c, c->vrange.ensure(2 * sizeof(int)));
-        const int init[2] = {63, 0};
-        HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, c->n, c->p, estim, (double *)c->card.ptr,
-                                       (int *)c->vrange.ptr));
-        c->card_estim = estim;
+        // same per-sketch pass as prepare() (thresholds/exception lists come out identical)
+        const bool pv = c->planes_valid;
+        c->planes_valid = true;  // do not rebuild planes for a cardinality query
+        rc = prepare(c, estim);
+        c->planes_valid = pv && c->planes_valid;
+        if (rc) return rc;
     }
     if (c->n) {
         HIPCHK(c, hipMemcpyAsync(out, c->card.ptr, c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -690,11 +705,28 @@ int dsh_last_kernel_ms(dsh_ctx *c, double *pair_ms, double *fin_ms, double *prep
     return DSH_OK;
 }
 
+int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
+{
+    if (!c || !name || !out) return DSH_EINVAL;
+    if (!std::strcmp(name, "planes")) *out = c->P;
+    else if (!std::strcmp(name, "vlo")) *out = c->vlo;
+    else if (!std::strcmp(name, "vhi")) *out = c->vhi;
+    else if (!std::strcmp(name, "threshold")) *out = c->vlo + (int64_t)c->P;
+    else if (!std::strcmp(name, "emax")) *out = c->emax;
+    else if (!std::strcmp(name, "kc")) *out = c->kc;
+    else if (!std::strcmp(name, "tile")) *out = kTile;
+    else if (!std::strcmp(name, "npad")) *out = c->Npad;
+    else if (!std::strcmp(name, "kpad")) *out = c->Kpad;
+    else if (!std::strcmp(name, "cum_bytes")) *out = c->cum_bytes;
+    else return fail(c, DSH_EINVAL, "unknown info %s", name);
+    return DSH_OK;
+}
+
 int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
 {
     if (!c || !name) return DSH_EINVAL;
     if (!std::strcmp(name, "kc")) {
-        if (v != 32 && v != 64 && v != 128) return fail(c, DSH_EINVAL, "kc must be 32, 64 or 128");
+        if (v != 16 && v != 32 && v != 64) return fail(c, DSH_EINVAL, "kc must be 16, 32 or 64");
         c->kc = (int)v;
         c->planes_valid = false;  // Kpad depends on kc
         return DSH_OK;
@@ -702,6 +734,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "emax")) {
+        if (v < -1 || v > (int64_t)kExcCap) return fail(c, DSH_EINVAL, "emax must be in [-1,%u]", kExcCap);
+        c->emax_opt = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "xcd_swizzle")) {

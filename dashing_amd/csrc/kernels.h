@@ -5,24 +5,28 @@
 
 namespace dsh {
 
-constexpr uint32_t kTile = 64;  // sketches per tile side in k_pair_counts
+constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
+constexpr uint32_t kExcCap = 64;  // capacity of a sketch's exception list (entries)
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                double *card, int *vrange);
+                                int emax, double *card, int *vrange, uint32_t *exc,
+                                uint32_t *exc_n);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes);
-hipError_t launch_pair_counts(hipStream_t st, int kc, const uint32_t *planes, uint32_t Npad,
-                              uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
-                              uint32_t ntiles, uint32_t *cum, uint64_t nslots);
+hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
+                              uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
+                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots);
 
 struct FinalizeLaunch {
-    const uint32_t *cum;
+    const void *cum;
+    int cum_bytes;  // 2 or 4
     uint64_t nslots;
     const uint2 *tiles;
     uint32_t P;
-    int vlo, p, estim, result_type;
+    int vlo, vhi, p, estim, result_type;
     double ksinv;
     const double *card;
+    const uint32_t *exc, *exc_n;
     uint64_t n;
     int rect;
     uint64_t row_begin, row_end, col_begin, col_end, base_index;

@@ -4,21 +4,28 @@
 // dm::parallel_fill (distmat/distmat.h:459-512) calling result_cmp (src/dashing.h:568-592)
 // -> hll_t::jaccard_index -> union_size = estimate(histogram(max(a,b))).
 //
-// Formulation.  Per pair the reference needs the histogram
-// c[v] = #{t : max(a_t,b_t) = v}.  With thermometer bit-planes  A_v[t] = (a_t < v)
-//     C(v) = #{t : max(a_t,b_t) < v} = popcount(A_v & B_v),   c[v] = C(v+1) - C(v),
-// exact integers.  So the O(N^2 * 2^p) part is AND + popcount over LDS-staged bit-planes
-// (v_and_b32 + v_bcnt_u32_b32, no MFMA: integer work), and the estimator runs once per pair
-// in fp64 in a second kernel.
+// Formulation.  Per pair the reference needs the exact histogram
+// c[x] = #{t : max(a_t,b_t) = x}.  It is assembled from two exact pieces:
+//  (1) dense part, x < T: thermometer bit-planes A_v[t] = (a_t < v), v in (lo, T]:
+//        C(v) = #{t : max(a_t,b_t) < v} = popcount(A_v & B_v),   c[x] = C(x+1) - C(x)
+//      -- the O(N^2 * 2^p) work: v_and_b32 + v_bcnt_u32_b32 over LDS-staged planes (integer
+//      work, no MFMA);
+//  (2) sparse tail, x > T: every sketch keeps the (position,value) list of its <= emax
+//      registers above its own threshold T_i <= T (the geometric tail of the register law);
+//      max(a_t,b_t) > T iff t is in one of the two lists, so the union of the two lists
+//      (LDS hash of list i, walk of list j) gives c[x] for x > T and |union| = m - C(T+1),
+//      hence c[T] as well.
+// The estimator then runs once per pair in fp64.
 //
 // Kernels:
-//   k_selfhist_card  per-sketch 64-bin histogram (LDS atomics) -> cardinality + value range
+//   k_selfhist_card  per sketch: 64-bin histogram (LDS atomics) -> cardinality, value range,
+//                    threshold T_i, sorted exception list
 //   k_transform      uint8 registers [N][m] -> bit-plane matrix planes[K][Npad] (u32 words,
 //                    row kk = plane*W + word, sketch index fastest)
-//   k_pair_counts    64x64-sketch tiles: stage planes rows through double-buffered LDS,
-//                    each lane owns a 4x4 block of pairs, AND+popcount; writes C(v) per pair
-//   k_finalize       one lane per pair: differences -> histogram (LDS column) -> estimator
-//                    -> J -> Mash transform -> float at the packed-triangle index
+//   k_pair_counts    128x128-sketch tiles: plane rows streamed through double-buffered LDS by
+//                    LDS-DMA, each lane owns an 8x8 block of pairs; writes C(v) per pair
+//   k_finalize       one lane per pair: C(v) differences + exception union -> histogram (LDS
+//                    column) -> estimator -> J -> Mash transform -> float at the packed index
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,21 +35,24 @@
 namespace dsh {
 
 // ------------------------------------------------------------------------------------------
-// per-sketch histogram, cardinality, global min/max register value
-// block = 256 threads = 4 waves, one sketch per wave.
+// per-sketch pass.  block = 256 threads = 4 waves, one sketch per wave.
+// vrange[0] = min register value over all sketches, [1] = max, [2] = max threshold T_i.
 __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs,
-                                                        uint64_t n, int p, int estim,
+                                                        uint64_t n, int p, int estim, int emax,
                                                         double *__restrict__ card,
-                                                        int *__restrict__ vrange)
+                                                        int *__restrict__ vrange,
+                                                        uint32_t *__restrict__ exc,
+                                                        uint32_t *__restrict__ exc_n)
 {
     __shared__ uint32_t hist[4][64];
+    __shared__ int thr[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
     hist[wave][lane] = 0;
     __syncthreads();
     const uint64_t m = 1ull << p;
+    const uint4 *src = reinterpret_cast<const uint4 *>(regs + (s < n ? s : 0) * m);
     if (s < n) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(regs + s * m);
         for (uint64_t c = lane; c < (m >> 4); c += 64) {
             const uint4 x = src[c];
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -63,21 +73,69 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         while (lo < 63 && h[lo] == 0) ++lo;
         while (hi > 0 && h[hi] == 0) --hi;
         card[s] = estimate(c, p, estim, 0, 64 - p + 1);
+        // threshold: the largest tail that fits the exception list
+        int T = hi;
+        uint32_t cnt = 0;
+        while (T > lo && cnt + h[T] <= (uint32_t)emax) {
+            cnt += h[T];
+            --T;
+        }
+        thr[wave] = T;
+        exc_n[s] = cnt;
         atomicMin(&vrange[0], lo);
         atomicMax(&vrange[1], hi);
+        atomicMax(&vrange[2], T);
+    }
+    __syncthreads();
+    if (s >= n || emax == 0) return;
+    // second pass: registers above T_i, in position order (iteration-major, lane, byte)
+    const uint32_t T = (uint32_t)thr[wave];
+    uint32_t *dst = exc + s * kExcCap;
+    uint32_t base = 0;
+    for (uint64_t c0 = 0; c0 < (m >> 4); c0 += 64) {
+        const uint64_t c = c0 + lane;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (c < (m >> 4)) {
+            const uint4 x = src[c];
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mine += ((w[k] >> (8 * b)) & 0xFFu) > T;
+        // inclusive prefix sum over the wave
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (mine) {
+            uint32_t off = base + incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t v = (w[k] >> (8 * b)) & 0xFFu;
+                    if (v > T) dst[off++] = ((uint32_t)(c * 16 + k * 4 + b) << 8) | v;
+                }
+        }
+        base += total;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // registers -> thermometer bit-planes.  Thread (i, w) reads 32 registers of sketch i and emits
 // one 32-bit word per plane: bit r of planes[(pl*W + w)*Npad + i] = (reg[i][32w + r] < vlo+1+pl).
-// Padding sketches (i >= N) and padding rows get zeros (they never count).
+// Padding sketches (i >= N) get zeros (they never count).
 __device__ __forceinline__ uint32_t lt_nibble(uint32_t x, uint32_t vrep)
 {
     // bytes of x are < 128 (or 0xFF fillers); bit7 of (x|0x80)-v is set iff byte >= v
     const uint32_t ge = ((x | 0x80808080u) - vrep) & 0x80808080u;
     const uint32_t lt = (ge ^ 0x80808080u) >> 7;  // 0/1 per byte
-    return (lt * 0x01020408u) >> 24;              // bit k = byte k (no carries: see DESIGN.md)
+    return (lt * 0x01020408u) >> 24;              // bit k = byte k (partial products never collide)
 }
 
 __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ regs, uint64_t n,
@@ -111,17 +169,18 @@ __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------
-// all-pairs AND+popcount.  One 256-thread workgroup per 64x64 tile of sketches.
-//   waves: 2x2, each covers 32x32 pairs; lane (ly,lx) in 8x8 owns a 4x4 block of pairs.
-//   per k-row: one ds_read_b128 of 4 A-words (broadcast over lx), one of 4 B-words (broadcast
-//   over ly), 16 x (v_and_b32 + v_bcnt_u32_b32 with accumulate).  LDS rows are 256 B
-//   (64 sketches x 4 B); the 8 distinct 16-B slots a wave touches per read are contiguous ->
-//   conflict-free.
+// all-pairs AND+popcount.  One 256-thread workgroup per 128x128 tile of sketches.
+//   waves 2x2, each covers 64x64 pairs; lane (ly,lx) of the 8x8 lane grid owns an 8x8 block.
+//   per k-row: two ds_read_b128 of A-words (broadcast over lx), two of B-words (broadcast over
+//   ly), 64 x (v_and_b32 + v_bcnt_u32_b32 with accumulate) -> 128 VALU per 4 LDS reads.
+//   LDS rows are 512 B (128 sketches x 4 B) per operand; the 16-B slots a lane group touches
+//   are distinct banks -> conflict-free.
 //   K (= planes x words) is streamed in chunks of KC rows through two LDS buffers with
-//   direct global->LDS DMA (global_load_lds_dwordx4: lane-linear LDS image == our row-major
-//   [row][64] layout, 4 rows per wave-instruction), one barrier per chunk: the DMA of chunk
-//   c+1 is in flight while chunk c is consumed.
-//   At each plane boundary the 16 counters C(v) are written to cum[pl][tile*4096 + r*64 + c].
+//   direct global->LDS DMA (global_load_lds_dwordx4: the lane-linear LDS image IS our
+//   row-major [row][128] layout, 2 rows per wave-instruction), one barrier per chunk: the DMA
+//   of chunk c+1 is in flight while chunk c is consumed.
+//   At each plane boundary the 64 counters C(v) go to cum[pl][tile*16384 + r*128 + c]
+//   (CT = uint16_t when 2^p < 65536, else uint32_t).
 __device__ __forceinline__ void popc_acc(uint32_t &acc, uint32_t x)
 {
     // v_bcnt_u32_b32 d, s0, s1 : d = popcount(s0) + s1  (hipcc splits this into bcnt + add3)
@@ -145,32 +204,43 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_byte_addr)
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int KC, int U>
+__device__ __forceinline__ void store8(uint16_t *dst, const uint32_t *a)
+{
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16),
+                                                 a[4] | (a[5] << 16), a[6] | (a[7] << 16));
+}
+__device__ __forceinline__ void store8(uint32_t *dst, const uint32_t *a)
+{
+    reinterpret_cast<uint4 *>(dst)[0] = make_uint4(a[0], a[1], a[2], a[3]);
+    reinterpret_cast<uint4 *>(dst)[1] = make_uint4(a[4], a[5], a[6], a[7]);
+}
+
+template <int KC, int U, typename CT>
 __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict__ planes,
                                                       uint32_t Npad, uint32_t Kpad, uint32_t W,
                                                       uint32_t P, const uint2 *__restrict__ tiles,
-                                                      uint32_t *__restrict__ cum, uint64_t nslots)
+                                                      CT *__restrict__ cum, uint64_t nslots)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][64]
-    constexpr int NPASS = KC / 16;  // wave-instructions per operand per chunk (4 rows each)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128]
+    constexpr int NPASS = KC / 8;  // wave-instructions per operand per chunk (2 rows each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ii = (wave >> 1) * 32 + (lane >> 3) * 4;
-    const int jj = (wave & 1) * 32 + (lane & 7) * 4;
+    const int ii = (wave >> 1) * 64 + (lane >> 3) * 8;
+    const int jj = (wave & 1) * 64 + (lane & 7) * 8;
     const uint2 tile = tiles[blockIdx.x];
-    // DMA source of this lane: row (4*wave + lane/16) of each 16-row pass, 16 B at column lane%16
-    const uint64_t lrow = (uint64_t)(wave * 4 + (lane >> 4));
-    const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * 64 + (lane & 15) * 4;
-    const uint32_t *gB = planes + lrow * Npad + (uint64_t)tile.y * 64 + (lane & 15) * 4;
-    const uint64_t pass_stride = (uint64_t)16 * Npad;
+    // DMA source of this lane: row (2*wave + lane/32) of each 8-row pass, 16 B at column lane%32
+    const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
+    const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
+    const uint32_t *gB = planes + lrow * Npad + (uint64_t)tile.y * kTile + (lane & 31) * 4;
+    const uint64_t pass_stride = (uint64_t)8 * Npad;
 
     // LDS-DMA issued from inline asm so that hipcc does not count it: the compiler would
     // otherwise drain it with vmcnt(0) before the first ds_read of the chunk being consumed.
     // We wait for it ourselves (vmcnt(0) right before the barrier that publishes the chunk).
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem + wave * 1024;  // bytes
     auto stage = [&](uint32_t chunk, int buf) {
-        const uint32_t la = lds_base + buf * (2 * KC * 256);
-        const uint32_t lb = la + KC * 256;
+        const uint32_t la = lds_base + buf * (2 * KC * 512);
+        const uint32_t lb = la + KC * 512;
         const uint32_t *a = gA + (uint64_t)chunk * KC * Npad;
         const uint32_t *b = gB + (uint64_t)chunk * KC * Npad;
 #pragma unroll
@@ -180,68 +250,71 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
         }
     };
 
-    uint32_t acc[4][4];
+    uint32_t acc[8][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0;
 
     const uint32_t nchunks = Kpad / KC;
-    uint32_t *cum_tile = cum + (uint64_t)blockIdx.x * 4096 + (uint64_t)ii * 64 + jj;
+    CT *cum_tile = cum + (uint64_t)blockIdx.x * (kTile * kTile) + (uint64_t)ii * kTile + jj;
 
     stage(0, 0);
     for (uint32_t ch = 0; ch < nchunks; ++ch) {
         dma_wait();       // this wave's DMA pieces of chunk ch have landed ...
         __syncthreads();  // ... and so have everyone's; buffer (ch+1)&1 is no longer being read
         if (ch + 1 < nchunks) stage(ch + 1, (ch + 1) & 1);
-        const uint32_t *As = smem + (ch & 1) * (2 * KC * 64) + ii;
-        const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 64) + KC * 64 + jj;
+        const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + ii;
+        const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 128) + KC * 128 + jj;
         // U rows (U = min(W, 8), compile time) per step, then a plane-boundary check
         for (uint32_t s0 = 0; s0 < (uint32_t)KC; s0 += U) {
 #pragma unroll
             for (uint32_t kk = 0; kk < (uint32_t)U; ++kk) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(As + (s0 + kk) * 64);
-                const uint4 b = *reinterpret_cast<const uint4 *>(Bs + (s0 + kk) * 64);
-                const uint32_t av[4] = {a.x, a.y, a.z, a.w};
-                const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(As + (s0 + kk) * 128);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(As + (s0 + kk) * 128 + 4);
+                const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + (s0 + kk) * 128);
+                const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + (s0 + kk) * 128 + 4);
+                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 8; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) popc_acc(acc[r][c], av[r] & bv[c]);
+                    for (int c = 0; c < 8; ++c) popc_acc(acc[r][c], av[r] & bv[c]);
             }
             const uint32_t row_end = ch * KC + s0 + U;
             if ((row_end & (W - 1)) == 0) {
                 const uint32_t pl = row_end / W - 1;
                 if (pl < P) {
-                    uint32_t *dst = cum_tile + (uint64_t)pl * nslots;
+                    CT *dst = cum_tile + (uint64_t)pl * nslots;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        *reinterpret_cast<uint4 *>(dst + r * 64) =
-                            make_uint4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-                    }
+                    for (int r = 0; r < 8; ++r) store8(dst + r * kTile, acc[r]);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 8; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+                    for (int c = 0; c < 8; ++c) acc[r][c] = 0;
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// finalize: one lane per pair slot of a band of tiles.
+// finalize: one lane per pair slot of a band of tiles.  128 threads per block = one tile row
+// (consecutive lanes = consecutive j: coalesced cum reads and output writes).
 struct FinalizeArgs {
-    const uint32_t *cum;
+    const void *cum;
     uint64_t nslots;
     const uint2 *tiles;
     uint32_t P;
-    int vlo;
+    int vlo;    // planes cover v in (vlo, vlo+P]; T = vlo+P is the dense/sparse threshold
+    int vhi;    // largest register value present anywhere
     int p;
     int estim;
     int result_type;
     double ksinv;
     const double *card;
+    const uint32_t *exc;
+    const uint32_t *exc_n;
     uint64_t n;
     // triangle mode: rows [row_begin,row_end), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
@@ -251,33 +324,108 @@ struct FinalizeArgs {
     float *out;
 };
 
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a)
+// Exception handling without a sequential merge: the block's 128 lanes share sketch i (one
+// tile row), so i's tail entries (value > T) go into a 128-slot open-addressing LDS hash keyed
+// by position, and their value histogram histA is the starting point of every lane's tail
+// bins.  A lane then walks only its own sketch j's list (independent iterations, 16-B loads):
+// for an entry (pos,vb) it looks up va = A's value at pos (0 if absent); if va > T that
+// position was counted in histA under va and is re-filed under max(va,vb); otherwise it is a
+// new union position iff vb > T.  Exact, order-independent.
+constexpr uint32_t kHashSlots = 128;  // 2 x kExcCap
+
+template <typename CT>
+__global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hs[];  // [(P+1)][256]
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs[];  // [(vhi-vlo+1)][128]
+    __shared__ uint32_t hashA[kHashSlots];
+    __shared__ uint32_t histA[64];
     const int tid = threadIdx.x;
-    const uint64_t slot = (uint64_t)blockIdx.x * 256 + tid;
-    if (slot >= a.nslots) return;
-    const uint2 tile = a.tiles[slot >> 12];
-    const uint64_t i = (uint64_t)tile.x * 64 + ((slot >> 6) & 63);
-    const uint64_t j = (uint64_t)tile.y * 64 + (slot & 63);
+    const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
+    const uint2 tile = a.tiles[slot >> 14];
+    const uint64_t i = (uint64_t)tile.x * kTile + ((slot >> 7) & 127);  // block-uniform
+    const uint64_t j = (uint64_t)tile.y * kTile + (slot & 127);
+    const int vlo = a.vlo, T = a.vlo + (int)a.P, vhi = a.vhi;
+    // block-level skip (uniform): row outside the requested range / beyond n
+    bool row_ok;
+    if (a.rect) row_ok = i >= a.row_begin && i < a.row_end;
+    else row_ok = i < a.n && i >= a.row_begin && i < a.row_end;
+    if (!row_ok) return;
+    hashA[tid] = 0xFFFFFFFFu;
+    if (tid < 64) histA[tid] = 0;
+    __syncthreads();
+    const uint32_t na = a.exc_n[i];
+    if ((uint32_t)tid < na) {
+        const uint32_t e = a.exc[i * kExcCap + tid];
+        if ((int)(e & 0xFFu) > T) {
+            atomicAdd(&histA[e & 63u], 1u);
+            uint32_t h = (e >> 8) & (kHashSlots - 1);
+            while (atomicCAS(&hashA[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1) & (kHashSlots - 1);
+        }
+    }
+    __syncthreads();
     bool active;
-    if (a.rect) active = i >= a.row_begin && i < a.row_end && j >= a.col_begin && j < a.col_end;
-    else active = i < j && j < a.n && i >= a.row_begin && i < a.row_end;
+    if (a.rect) active = j >= a.col_begin && j < a.col_end;
+    else active = i < j && j < a.n;
     if (!active) return;
     const uint32_t m = 1u << a.p;
+    uint32_t *col = hs + tid;
+    // dense part: c[x] = C(x+1) - C(x), x in [vlo, T)
+    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
     uint32_t prev = 0;
     for (uint32_t pl = 0; pl < a.P; ++pl) {
-        const uint32_t cv = a.cum[(uint64_t)pl * a.nslots + slot];
-        hs[pl * 256 + tid] = cv - prev;
+        const uint32_t cv = cum[(uint64_t)pl * a.nslots];
+        col[pl * 128] = cv - prev;
         prev = cv;
     }
-    hs[a.P * 256 + tid] = m - prev;
-    const int vlo = a.vlo, vhi = a.vlo + (int)a.P;
-    const uint32_t *col = hs + tid;
+    // tail bins start from A's own tail histogram
+    uint32_t ucnt = 0;
+    int maxv = T;
+    for (int x = T + 1; x <= vhi; ++x) {
+        const uint32_t h = histA[x];
+        col[(x - vlo) * 128] = h;
+        ucnt += h;
+        if (h) maxv = x;
+    }
+    const uint32_t nb = a.exc_n[j];
+    const uint4 *eb = reinterpret_cast<const uint4 *>(a.exc + j * kExcCap);
+    for (uint32_t q = 0; q * 4 < nb; ++q) {
+        const uint4 e4 = eb[q];
+        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (q * 4 + t >= nb) break;
+            const uint32_t e = ev[t];
+            const int vb = (int)(e & 0xFFu);
+            const uint32_t pos = e >> 8;
+            int va = 0;
+            uint32_t h = pos & (kHashSlots - 1);
+            for (;;) {
+                const uint32_t s = hashA[h];
+                if (s == 0xFFFFFFFFu) break;
+                if ((s >> 8) == pos) {
+                    va = (int)(s & 0xFFu);
+                    break;
+                }
+                h = (h + 1) & (kHashSlots - 1);
+            }
+            if (va > T) {  // already counted under va: re-file under the max
+                if (vb > va) {
+                    col[(va - vlo) * 128] -= 1;
+                    col[(vb - vlo) * 128] += 1;
+                    if (vb > maxv) maxv = vb;
+                }
+            } else if (vb > T) {
+                col[(vb - vlo) * 128] += 1;
+                ++ucnt;
+                if (vb > maxv) maxv = vb;
+            }
+        }
+    }
+    col[(T - vlo) * 128] = m - ucnt - prev;  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
     auto c = [col, vlo, vhi](int v) -> uint32_t {
-        return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 256];
+        return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
-    const double us = estimate(c, a.p, a.estim, vlo, vhi);
+    const double us = estimate(c, a.p, a.estim, vlo, maxv);
     const double ji = jaccard_from(a.card[j], a.card[i], us);
     const float res = result_from_ji(ji, a.result_type, a.ksinv);
     uint64_t oidx;
@@ -289,12 +437,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a)
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                double *card, int *vrange)
+                                int emax, double *card, int *vrange, uint32_t *exc,
+                                uint32_t *exc_n)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
-    hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, card,
-                       vrange);
+    hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
+                       card, vrange, exc, exc_n);
     return hipGetLastError();
 }
 
@@ -309,44 +458,53 @@ hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int
     return hipGetLastError();
 }
 
-template <int KC, int U>
+template <int KC, int U, typename CT>
 static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad,
                             uint32_t W, uint32_t P, const uint2 *tiles, uint32_t ntiles,
-                            uint32_t *cum, uint64_t nslots)
+                            void *cum, uint64_t nslots)
 {
     static bool attr_set = false;
-    const size_t lds = (size_t)KC * 1024;
+    const size_t lds = (size_t)KC * 2048;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts<KC, U>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e =
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts<KC, U, CT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_pair_counts<KC, U>), dim3(ntiles), dim3(256), lds, st, planes, Npad,
-                       Kpad, W, P, tiles, cum, nslots);
+    hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(ntiles), dim3(256), lds, st, planes, Npad,
+                       Kpad, W, P, tiles, reinterpret_cast<CT *>(cum), nslots);
     return hipGetLastError();
 }
 
-template <int KC>
+template <int KC, typename CT>
 static hipError_t launch_pc_u(hipStream_t st, const uint32_t *planes, uint32_t Npad,
                               uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
-                              uint32_t ntiles, uint32_t *cum, uint64_t nslots)
+                              uint32_t ntiles, void *cum, uint64_t nslots)
 {
-    if (W >= 8) return launch_pc<KC, 8>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    if (W == 4) return launch_pc<KC, 4>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    if (W == 2) return launch_pc<KC, 2>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    return launch_pc<KC, 1>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    if (W >= 8) return launch_pc<KC, 8, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    if (W == 4) return launch_pc<KC, 4, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    if (W == 2) return launch_pc<KC, 2, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    return launch_pc<KC, 1, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
 }
 
-hipError_t launch_pair_counts(hipStream_t st, int kc, const uint32_t *planes, uint32_t Npad,
-                              uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
-                              uint32_t ntiles, uint32_t *cum, uint64_t nslots)
+hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
+                              uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
+                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots)
 {
     if (ntiles == 0 || Kpad == 0) return hipSuccess;
+    if (cum_bytes == 2) {
+        switch (kc) {
+        case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+        case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (kc) {
-    case 32: return launch_pc_u<32>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    case 64: return launch_pc_u<64>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    case 128: return launch_pc_u<128>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
     default: return hipErrorInvalidValue;
     }
 }
@@ -355,20 +513,15 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
-    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.P = f.P; a.vlo = f.vlo; a.p = f.p;
-    a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv; a.card = f.card;
-    a.n = f.n; a.rect = f.rect; a.row_begin = f.row_begin; a.row_end = f.row_end;
-    a.col_begin = f.col_begin; a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
-    const size_t lds = (size_t)(f.P + 1) * 256 * sizeof(uint32_t);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
-    }
-    const uint32_t blocks = (uint32_t)((f.nslots + 255) / 256);
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), lds, st, a);
+    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.P = f.P; a.vlo = f.vlo; a.vhi = f.vhi;
+    a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
+    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect;
+    a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
+    a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
+    const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * sizeof(uint32_t);
+    const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
+    if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@
 
 Every pair is independent, so there is no data-path collective inside the compare itself: rank r
 computes the contiguous row range [bounds[r], bounds[r+1]) (near-equal pair counts, boundaries on
-whole 64-row tile rows) and the only exchange is the gather of the per-rank spans of the packed
+whole 128-row tile rows) and the only exchange is the gather of the per-rank spans of the packed
 triangle to rank 0 -- the writer, as in dashing where one process emits the matrix
 (src/sketch_and_cmp.h:838-849)."""
 import torch
@@ -13,7 +13,7 @@ from . import api
 
 
 def row_bounds(n, world):
-    return api.partition_rows(n, world, 64)
+    return api.partition_rows(n, world, 128)
 
 
 def span_sizes(n, bounds):

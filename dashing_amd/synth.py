@@ -64,6 +64,35 @@ def related_sketches(n, p, seed=0x5EED0000, cluster=10, card_lo=2_000_000, card_
     return regs, core_card, priv_card, cid
 
 
+def survey_sketches(n, p, seed=0x5EED0000, cluster=10):
+    """Benchmark register arrays per SURVEY.md section 8d: every sketch has a cardinality in
+    [2e6, 8e6] (bacterial scale); sketch(g) = max(core_c(g), private_g).  A cluster has a size
+    S_c in [2.4e6, 6.6e6]; its shared core is phi_c * S_c with phi cycling through
+    {0.95, 0.67, 0.18, 0.02, 0} and each member adds (1 - phi_c) * S_c * U(0.8, 1.2) private
+    elements, so the true within-cluster J is ~ {0.9, 0.5, 0.1, 0.01, 0} and 0 across clusters.
+    Returns (regs, core_card[n], priv_card[n], cluster_id[n])."""
+    m = 1 << p
+    phi = (0.95, 0.67, 0.18, 0.02, 0.0)
+    regs = np.zeros((n, m), np.uint8)
+    core_card = np.zeros(n, np.float64)
+    priv_card = np.zeros(n, np.float64)
+    cid = np.zeros(n, np.int64)
+    ncl = (n + cluster - 1) // cluster
+    size = 2_400_000 + (splitmix64(seed ^ 0x8D, ncl) % np.uint64(4_200_001)).astype(np.int64)
+    jit = 0.8 + 0.4 * _uniform(seed ^ 0x77, n)
+    for c in range(ncl):
+        lo, hi = c * cluster, min(n, (c + 1) * cluster)
+        f = phi[c % len(phi)]
+        n_core = int(f * size[c])
+        core = hll_registers(seed + 7919 * (c + 1), n_core, p)
+        for g in range(lo, hi):
+            n_priv = int((1.0 - f) * size[c] * jit[g])
+            priv = hll_registers(seed + 0x10000000 + g, n_priv, p)
+            regs[g] = np.maximum(core, priv)
+            core_card[g], priv_card[g], cid[g] = n_core, n_priv, c
+    return regs, core_card, priv_card, cid
+
+
 _ACGT = np.frombuffer(b"ACGT", np.uint8)
 
 

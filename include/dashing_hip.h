@@ -113,7 +113,7 @@ uint64_t dsh_tri_span(uint64_t n, uint64_t row_begin, uint64_t row_end);
 /* index(i,j) of distmat/distmat.h:260-264 */
 uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j);
 /* Split rows [0,n) into nparts contiguous ranges of near-equal pair count, boundaries aligned
- * to `align` rows (the kernel tile, 64, keeps every rank on whole tile rows).
+ * to `align` rows (the kernel tile, 128, keeps every rank on whole tile rows).
  * bounds_out[0..nparts] receives the boundaries (bounds_out[0]=0, bounds_out[nparts]=n). */
 int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds_out);
 
@@ -127,6 +127,9 @@ int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_ke
                        double *prepare_ms, uint32_t *pair_kernel_launches);
 /* Tunables (tile shape variant etc.); returns DSH_EINVAL for unknown names. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
+/* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
+ * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes". */
+int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work. */
 void *dsh_stream(dsh_ctx *ctx);
 

@@ -49,7 +49,7 @@ def test_golden_pairs(ctx):
             assert ((got == 1.0) == (want == 1.0)).all()  # J==0 branch agrees exactly
 
 
-@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 63), (10, 64), (10, 65), (10, 200), (14, 130), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20)])
+@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 127), (10, 128), (10, 129), (10, 300), (14, 130), (14, 260), (15, 40), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20)])
 @pytest.mark.parametrize("estim", [0, 1, 2])
 def test_tri_vs_oracle(ctx, oracle, p, n, estim):
     regs = synth.synthetic_sketches(n, p, seed=0x1234 + p * 131 + n)
@@ -89,7 +89,7 @@ def test_row_ranges_concatenate(ctx):
     ctx.set_sketches(regs)
     full = ctx.dist_rows()
     for parts in (2, 3, 8):
-        b = dashing_amd.partition_rows(n, parts, 64)
+        b = dashing_amd.partition_rows(n, parts, 128)
         cat = np.concatenate([ctx.dist_rows(b[i], b[i + 1]) for i in range(parts)])
         assert cat.tobytes() == full.tobytes()
     odd = np.concatenate([ctx.dist_rows(0, 1), ctx.dist_rows(1, 70), ctx.dist_rows(70, 71), ctx.dist_rows(71, n)])
@@ -116,15 +116,19 @@ def test_options_do_not_change_results(ctx):
     ctx.set_sketches(regs)
     base = ctx.dist_rows()
     try:
-        for kc in (32, 128, 64):
+        for kc in (16, 64, 32):
             ctx.set_option("kc", kc)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+        for emax in (0, 1, 8, 64, -1):   # dense-only .. full exception lists: same exact histogram
+            ctx.set_option("emax", emax)
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("xcd_swizzle", 0)
         assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
     finally:
-        ctx.set_option("kc", 64)
+        ctx.set_option("kc", 32)
+        ctx.set_option("emax", -1)
         ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("cum_budget_bytes", 2 << 30)
 
