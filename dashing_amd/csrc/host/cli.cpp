@@ -1,0 +1,327 @@
+// cli.cpp -- `dashing-amd`: dashing's `sketch` and `dist` (= `cmp` = `setdist`) subcommands
+// (src/main.cpp:22-44) with the two hot loops running on MI355X through the C-ABI
+// (include/dashing_hip.h).  Flags keep dashing's spellings (src/dashing.h:35-104,
+// src/distmain.cpp:47-100, src/dashing.cpp:253-337): NB -S is log2(sketch bytes) = HLL precision
+// and -p is host threads.  HLL sketches only; flags selecting other sketch types / encoders are
+// rejected.  There is no CPU compute path: without a gfx950 device the program exits non-zero.
+#include <getopt.h>
+#include <omp.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/dashing_hip.h"
+#include "host.h"
+
+using namespace dshh;
+
+static const char *kVersion = "dashing-amd 0.1 (gfx950; HLL sketch/dist hot path of dashing v1)";
+
+[[noreturn]] static void die(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    std::vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    std::fputc('\n', stderr);
+    std::exit(EXIT_FAILURE);
+}
+
+#define DSH(ctx, call)                                                             \
+    do {                                                                           \
+        int rc_ = (call);                                                          \
+        if (rc_) die("[dashing-amd] %s failed (%d): %s", #call, rc_, dsh_last_error(ctx)); \
+    } while (0)
+
+static bool isfile(const std::string &p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+static void usage(const char *sub)
+{
+    std::fprintf(stderr,
+        "%s\nUsage: dashing-amd %s [options] genome1 genome2 ... | -F paths.txt\n"
+        "  -k, --kmer-length INT    k (<=32) [31]\n"
+        "  -S, --sketch-size INT    log2 sketch size in bytes = HLL precision p [10]\n"
+        "  -p, --nthreads INT       host threads for FASTA parsing [1]\n"
+        "  -F, --paths FILE         file with one genome path per line\n"
+        "  -P, --prefix DIR / -x, --suffix STR   sketch cache location / name suffix\n"
+        "  -C, --no-canon           do not canonicalise k-mers\n"
+        "  --device INT             GPU ordinal [0]\n", kVersion, sub);
+    if (!std::strcmp(sub, "sketch")) {
+        std::fprintf(stderr, "  -c, --skip-cached        skip genomes whose .hll already exists\n");
+    } else {
+        std::fprintf(stderr,
+            "  -o, --out-sizes FILE     cardinalities [stdout]\n"
+            "  -O, --out-dists FILE     distances [stdout]\n"
+            "  -b/-U/-T                 emit binary / PHYLIP upper-triangular / full TSV [upper-triangular TSV]\n"
+            "  -M/-l                    Mash distance / full Mash distance [Jaccard index]\n"
+            "  -E/-I/-m                 ORIGINAL / ERTL_IMPROVED / ERTL_MLE estimator [ERTL_MLE]\n"
+            "  -W, --cache-sketches     read/write <genome>.w.<k>.spacing.<S>.hll next to the input (or in -P)\n"
+            "  -H, --presketched        inputs are .hll files\n"
+            "  --avoid-sorting          keep input order (default: largest file first)\n");
+    }
+    std::exit(EXIT_FAILURE);
+}
+
+struct Opts {
+    int k = 31, S = 10, nthreads = 1, canon = 1, device = 0;
+    int estim = ERTL_MLE, result_type = JI, fmt = UT_TSV;
+    int cache = 0, presketched = 0, avoid_sorting = 0, skip_cached = 0;
+    std::string paths_file, prefix, suffix, spacing, out_sizes, out_dists;
+    std::vector<std::string> inpaths;
+};
+
+enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_UNSUPPORTED };
+
+static Opts parse(int argc, char **argv, bool is_dist)
+{
+    Opts o;
+    static const option longopts[] = {
+        {"kmer-length", required_argument, nullptr, 'k'}, {"sketch-size", required_argument, nullptr, 'S'},
+        {"nthreads", required_argument, nullptr, 'p'}, {"paths", required_argument, nullptr, 'F'},
+        {"prefix", required_argument, nullptr, 'P'}, {"suffix", required_argument, nullptr, 'x'},
+        {"no-canon", no_argument, nullptr, 'C'}, {"out-sizes", required_argument, nullptr, 'o'},
+        {"out-dists", required_argument, nullptr, 'O'}, {"emit-binary", no_argument, nullptr, 'b'},
+        {"phylip", no_argument, nullptr, 'U'}, {"full-tsv", no_argument, nullptr, 'T'},
+        {"mash-dist", no_argument, nullptr, 'M'}, {"full-mash-dist", no_argument, nullptr, 'l'},
+        // dashing declares these long forms with required_argument (LO_ARG, src/dashing.h:62-64);
+        // that is a quirk, scripts use the short forms.  We take them without an argument.
+        {"original", no_argument, nullptr, 'E'}, {"improved", no_argument, nullptr, 'I'},
+        {"ertl-mle", no_argument, nullptr, 'm'}, {"cache-sketches", no_argument, nullptr, 'W'},
+        {"presketched", no_argument, nullptr, OPT_PRESKETCHED}, {"avoid-sorting", no_argument, nullptr, OPT_AVOID_SORT},
+        {"skip-cached", no_argument, nullptr, 'c'}, {"device", required_argument, nullptr, OPT_DEVICE},
+        {"nperbatch", required_argument, nullptr, OPT_NPERBATCH}, {"spacing", required_argument, nullptr, 's'},
+        {"window-size", required_argument, nullptr, 'w'}, {"help", no_argument, nullptr, 'h'},
+        {"use-bb-minhash", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-range-minhash", no_argument, nullptr, OPT_UNSUPPORTED},
+        {"use-bloom-filter", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-nthash", no_argument, nullptr, OPT_UNSUPPORTED},
+        {"use-cyclic-hash", no_argument, nullptr, OPT_UNSUPPORTED}, {"countmin", no_argument, nullptr, OPT_UNSUPPORTED},
+        {"nearest-neighbors", required_argument, nullptr, OPT_UNSUPPORTED}, {"containment-index", no_argument, nullptr, OPT_UNSUPPORTED},
+        {"containment-dist", no_argument, nullptr, OPT_UNSUPPORTED}, {"sizes", no_argument, nullptr, OPT_UNSUPPORTED},
+        {nullptr, 0, nullptr, 0}};
+    int co;
+    optind = 1;
+    while ((co = getopt_long(argc, argv, "k:S:p:F:P:x:Co:O:bUTMlEImWHcs:w:eh?8yJQ:", longopts, nullptr)) >= 0) {
+        switch (co) {
+        case 'k': o.k = std::atoi(optarg); break;
+        case 'S': o.S = std::atoi(optarg); break;
+        case 'p': o.nthreads = std::max(1, std::atoi(optarg)); break;
+        case 'F': o.paths_file = optarg; break;
+        case 'P': o.prefix = optarg; break;
+        case 'x': o.suffix = optarg; break;
+        case 'C': o.canon = 0; break;
+        case 'o': o.out_sizes = optarg; break;
+        case 'O': o.out_dists = optarg; break;
+        case 'b': o.fmt = BINARY; break;
+        case 'U': o.fmt = UPPER_TRIANGULAR; break;
+        case 'T': o.fmt = FULL_TSV; break;
+        case 'M': o.result_type = MASH_DIST; break;
+        case 'l': o.result_type = FULL_MASH_DIST; break;
+        case 'E': o.estim = ORIGINAL; break;
+        case 'I': o.estim = ERTL_IMPROVED; break;
+        case 'm': o.estim = ERTL_MLE; break;
+        case 'W': o.cache = 1; break;
+        case 'H': case OPT_PRESKETCHED: o.presketched = 1; break;  // dashing ignores short -H; we honour it
+        case OPT_AVOID_SORT: o.avoid_sorting = 1; break;
+        case 'c': o.skip_cached = 1; break;
+        case OPT_DEVICE: o.device = std::atoi(optarg); break;
+        case OPT_NPERBATCH: case 'e': break;  // accepted, no effect here
+        case 's': if (optarg && *optarg) die("spaced seeds are out of scope (HLL hot path only)"); break;
+        case 'w': if (std::atoi(optarg) > 0) die("minimizer windows are out of scope (HLL hot path only)"); break;
+        case '8': case 'y': case 'J': case 'Q': case OPT_UNSUPPORTED:
+            die("this option selects a sketch type / emitter outside the HLL sketch+dist hot path");
+        default: usage(is_dist ? "dist" : "sketch");
+        }
+    }
+    if (o.k < 1 || o.k > 32) die("k must be in [1,32] for 2-bit encoded k-mers (src/distmain.cpp:101)");
+    if (o.S < 4 || o.S > 17) die("-S (log2 sketch bytes) must be in [4,17]");
+    o.inpaths = o.paths_file.empty() ? std::vector<std::string>(argv + optind, argv + argc) : read_paths_file(o.paths_file);
+    if (o.inpaths.empty()) {
+        std::fprintf(stderr, "No paths. See usage.\n");
+        usage(is_dist ? "dist" : "sketch");
+    }
+    return o;
+}
+
+// Hot loop 1 for genomes [g0,g1): cache hit -> read .hll; else parse FASTA on host threads and
+// sketch on the GPU in batches of <= batch_bytes of sequence.
+static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool skip_cached)
+{
+    const size_t n = o.inpaths.size();
+    const size_t m = (size_t)1 << o.S;
+    const size_t batch_bytes = (size_t)512 << 20;
+    std::vector<uint8_t> row(m);
+    size_t g = 0;
+    while (g < n) {
+        // decide the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
+        size_t e = g, bytes = 0;
+        while (e < n && (e == g || bytes + genome_file_size(o.inpaths[e]) <= batch_bytes)) bytes += genome_file_size(o.inpaths[e++]);
+        const size_t nb = e - g;
+        std::vector<std::vector<uint8_t>> seqs(nb);
+        std::vector<int> cached(nb, 0);
+        std::vector<std::string> fnames(nb);
+#pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
+        for (long i = 0; i < (long)nb; ++i) {
+            const std::string &entry = o.inpaths[g + i];
+            fnames[i] = make_fname(entry, (unsigned)o.S, o.k, o.spacing, o.suffix, o.prefix);
+            if ((o.cache || skip_cached) && isfile(fnames[i])) {
+                cached[i] = 1;
+                continue;
+            }
+            for (const auto &f : split_genome_paths(entry)) {
+                if (!seqs[i].empty()) seqs[i].push_back('N');
+                if (append_fastx(f, seqs[i]) < 0) die("Could not open %s", f.c_str());
+            }
+        }
+        // upload cached sketches, sketch the rest
+        std::vector<uint8_t> seq;
+        std::vector<uint64_t> off;
+        std::vector<size_t> slot_of;
+        for (size_t i = 0; i < nb; ++i) {
+            if (cached[i]) {
+                if (skip_cached) continue;  // `sketch -c`: nothing to do for this genome
+                int p = 0;
+                std::vector<uint8_t> r;
+                if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
+                DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
+            } else {
+                off.push_back(seq.size());
+                seq.insert(seq.end(), seqs[i].begin(), seqs[i].end());
+                seq.push_back('N');
+                slot_of.push_back(g + i);
+                std::vector<uint8_t>().swap(seqs[i]);
+            }
+        }
+        if (!slot_of.empty()) {
+            // consecutive runs of slots go in one call each
+            size_t r0 = 0;
+            while (r0 < slot_of.size()) {
+                size_t r1 = r0 + 1;
+                while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
+                std::vector<uint64_t> o2(off.begin() + r0, off.begin() + r1);
+                o2.push_back(r1 < off.size() ? off[r1] : seq.size());
+                // (each span ends with its 'N' separator: an invalid base, harmless)
+                DSH(ctx, dsh_sketch_batch(ctx, seq.data(), o2.data(), (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon, nullptr));
+                r0 = r1;
+            }
+            if (write_files) {
+                for (size_t t = 0; t < slot_of.size(); ++t) {
+                    DSH(ctx, dsh_download_sketches(ctx, slot_of[t], 1, row.data()));
+                    const std::string &fn = fnames[slot_of[t] - g];
+                    if (write_hll(fn, row.data(), o.S, o.estim, o.estim, false, 0.0)) die("Could not write %s", fn.c_str());
+                }
+            }
+        }
+        g = e;
+    }
+}
+
+static int sketch_main(int argc, char **argv)
+{
+    Opts o = parse(argc, argv, false);
+    if (!o.avoid_sorting) sort_paths_by_fsize(o.inpaths);  // src/dashing.cpp:356-357
+    dsh_ctx *ctx = nullptr;
+    if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
+    DSH(ctx, dsh_sketches_alloc(ctx, o.inpaths.size(), o.S));
+    fill_sketches(ctx, o, /*write_files=*/true, /*skip_cached=*/o.skip_cached != 0);
+    dsh_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+static int dist_main(int argc, char **argv)
+{
+    Opts o = parse(argc, argv, true);
+    std::FILE *ofp = stdout, *pairofp = stdout;
+    if (!o.out_sizes.empty() && !(ofp = std::fopen(o.out_sizes.c_str(), "w"))) die("Could not open file at %s for writing.", o.out_sizes.c_str());
+    if (!o.out_dists.empty() && !(pairofp = std::fopen(o.out_dists.c_str(), "wb"))) die("Could not open file at %s for writing.", o.out_dists.c_str());
+    if (!o.presketched && !o.avoid_sorting) sort_paths_by_fsize(o.inpaths);  // src/distmain.cpp:126-129
+    const size_t n = o.inpaths.size();
+    dsh_ctx *ctx = nullptr;
+    if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
+    DSH(ctx, dsh_sketches_alloc(ctx, n, o.S));
+    if (o.presketched) {  // sketch.read(path), src/sketch_and_cmp.h:318-324
+        std::vector<uint8_t> r;
+        for (size_t i = 0; i < n; ++i) {
+            int p = 0;
+            if (read_hll(o.inpaths[i], r, p)) die("Could not read sketch %s", o.inpaths[i].c_str());
+            if (p != o.S) die("Sketch %s has p=%d but -S is %d", o.inpaths[i].c_str(), p, o.S);
+            DSH(ctx, dsh_upload_sketches(ctx, r.data(), i, 1));
+        }
+    } else {
+        fill_sketches(ctx, o, /*write_files=*/o.cache != 0, false);
+    }
+    // sizes (src/sketch_and_cmp.h:372-385)
+    std::vector<double> card(std::max<size_t>(n, 1));
+    DSH(ctx, dsh_cardinalities(ctx, o.estim, card.data()));
+    emit_sizes(ofp, o.inpaths, card.data());
+    if (ofp != stdout) std::fclose(ofp);
+    // distances (dist_loop, src/sketch_and_cmp.h:785-880)
+    const uint64_t total = n ? (uint64_t)n * (n - 1) / 2 : 0;
+    if (o.fmt == FULL_TSV) {
+        std::vector<float> tri(std::max<uint64_t>(total, 1));
+        DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, 0, n, tri.data()));
+        emit_full_header(pairofp, o.inpaths);
+        for (size_t i = 0; i < n; ++i) emit_full_row(pairofp, o.inpaths, i, tri.data());
+    } else {
+        if (o.fmt == BINARY) {
+            if (write_binary_header(pairofp, n)) die("Failure");
+        } else {
+            emit_header(pairofp, o.fmt, o.inpaths);
+        }
+        // row blocks of <= 64 Mi values; the GPU computes block b+1 while the host emits block b
+        const uint64_t block_vals = (uint64_t)64 << 20;
+        std::vector<float> buf;
+        uint64_t rb = 0;
+        while (rb < n) {
+            uint64_t re = rb + 1;
+            while (re < n && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
+            const uint64_t span = dsh_tri_span(n, rb, re);
+            buf.resize(std::max<uint64_t>(span, 1));
+            DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, rb, re, buf.data()));
+            if (o.fmt == BINARY) {
+                if (span && std::fwrite(buf.data(), sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
+            } else {
+                uint64_t off = 0;
+                for (uint64_t i = rb; i < re; ++i) {
+                    emit_ut_row(pairofp, o.fmt, o.inpaths, i, buf.data() + off);
+                    off += n - i - 1;
+                }
+            }
+            rb = re;
+        }
+    }
+    std::fflush(pairofp);
+    if (pairofp != stdout) std::fclose(pairofp);
+    if (o.fmt == BINARY) {  // src/distmain.cpp:191-200
+        const std::string labels = o.out_dists.empty() ? "unspecified" : o.out_dists + ".labels";
+        if (write_labels(labels, o.inpaths)) die("Could not open file at '%s' for writing", labels.c_str());
+    }
+    dsh_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
+        std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n", kVersion);
+        return EXIT_FAILURE;
+    }
+    const std::string sub(argv[1]);
+    if (sub == "sketch") return sketch_main(argc - 1, argv + 1);
+    if (sub == "dist" || sub == "cmp" || sub == "setdist") return dist_main(argc - 1, argv + 1);
+    if (sub == "version" || sub == "--version") {
+        std::printf("%s\nbackend: %s\n", kVersion, dsh_backend_name());
+        return EXIT_SUCCESS;
+    }
+    std::fprintf(stderr, "subcommand '%s' is outside the HLL sketch+dist hot path this build covers\n", sub.c_str());
+    return EXIT_FAILURE;
+}

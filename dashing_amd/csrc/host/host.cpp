@@ -1,0 +1,269 @@
+// host.cpp -- see host.h.  No GPU code; links zlib.
+#include "host.h"
+
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+
+namespace dshh {
+
+std::vector<std::string> read_paths_file(const std::string &path)
+{
+    std::vector<std::string> out;
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return out;
+    std::string line;
+    char buf[65536];
+    while (gzgets(fp, buf, sizeof buf)) {
+        line += buf;
+        if (!line.empty() && line.back() == '\n') {
+            while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+            if (!line.empty()) out.push_back(line);
+            line.clear();
+        }
+    }
+    if (!line.empty()) out.push_back(line);
+    gzclose(fp);
+    return out;
+}
+
+std::vector<std::string> split_genome_paths(const std::string &s, char sep)
+{
+    std::vector<std::string> out;
+    size_t b = 0;
+    while (b <= s.size()) {
+        size_t e = s.find(sep, b);
+        if (e == std::string::npos) e = s.size();
+        if (e > b) out.emplace_back(s.substr(b, e - b));
+        b = e + 1;
+    }
+    return out;
+}
+
+uint64_t genome_file_size(const std::string &entry)
+{
+    uint64_t tot = 0;
+    for (const auto &f : split_genome_paths(entry)) {
+        struct stat st;
+        if (::stat(f.c_str(), &st) == 0) tot += (uint64_t)st.st_size;
+    }
+    return tot;
+}
+
+void sort_paths_by_fsize(std::vector<std::string> &paths)
+{
+    if (paths.size() < 2) return;
+    std::vector<std::pair<uint32_t, std::string>> ps;
+    ps.reserve(paths.size());
+    for (auto &p : paths) ps.emplace_back((uint32_t)genome_file_size(p), std::move(p));
+    std::stable_sort(ps.begin(), ps.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+    paths.clear();
+    for (auto &p : ps) paths.emplace_back(std::move(p.second));
+}
+
+long append_fastx(const std::string &path, std::vector<uint8_t> &out)
+{
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return -1;
+    gzbuffer(fp, 1 << 20);
+    std::vector<char> buf(1 << 20);
+    long nrec = 0;
+    // line-oriented state machine: 0 = expect header, 1 = sequence lines, 2 = quality lines
+    int state = 0;
+    bool at_line_start = true, skipping_line = false;
+    size_t seq_len = 0, qual_len = 0;
+    int n;
+    while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+        for (int i = 0; i < n; ++i) {
+            const char c = buf[i];
+            if (c == '\n') {
+                at_line_start = true;
+                skipping_line = false;
+                if (state == 2 && qual_len >= seq_len) state = 0;
+                continue;
+            }
+            if (c == '\r') continue;
+            if (at_line_start) {
+                at_line_start = false;
+                if (state != 2 && (c == '>' || c == '@')) {  // new record header
+                    if (nrec) out.push_back('N');
+                    ++nrec;
+                    state = 1;
+                    seq_len = qual_len = 0;
+                    skipping_line = true;
+                    continue;
+                }
+                if (state == 1 && c == '+') {  // FASTQ separator line
+                    state = 2;
+                    skipping_line = true;
+                    continue;
+                }
+            }
+            if (skipping_line) continue;
+            if (state == 1) {
+                out.push_back((uint8_t)c);
+                ++seq_len;
+            } else if (state == 2) {
+                ++qual_len;
+            }
+        }
+    }
+    gzclose(fp);
+    return nrec;
+}
+
+std::string make_fname(const std::string &path, unsigned sketch_p, int k, const std::string &spacing,
+                       const std::string &suffix, const std::string &prefix)
+{
+    std::string ret(prefix);
+    if (!ret.empty()) ret += '/';
+    {
+        const char *p = std::strchr(path.c_str(), ' ');
+        p = p ? p + 1 : path.c_str();
+        const char *p2;
+        if (!ret.empty() && (p2 = std::strrchr(p, '/'))) ret += std::string(p2 + 1);
+        else ret += p;
+    }
+    ret += ".w";
+    ret += ".";
+    ret += std::to_string(k);
+    ret += ".spacing";
+    ret += spacing;
+    ret += '.';
+    if (!suffix.empty()) {
+        ret += "suf";
+        ret += suffix;
+        ret += '.';
+    }
+    ret += std::to_string(sketch_p);
+    ret += ".hll";
+    return ret;
+}
+
+int write_hll(const std::string &path, const uint8_t *regs, int p, int estim, int jestim,
+              bool is_calculated, double value)
+{
+    gzFile fp = gzopen(path.c_str(), "wb");
+    if (!fp) return -EIO;
+    const uint32_t bf[4] = {(uint32_t)is_calculated, (uint32_t)estim, (uint32_t)jestim, 1u};
+    const uint32_t np = (uint32_t)p;
+    int ok = gzwrite(fp, bf, sizeof bf) == (int)sizeof bf;
+    ok = ok && gzwrite(fp, &np, sizeof np) == (int)sizeof np;
+    ok = ok && gzwrite(fp, &value, sizeof value) == (int)sizeof value;
+    const size_t m = (size_t)1 << p;
+    ok = ok && gzwrite(fp, regs, (unsigned)m) == (int)m;
+    gzclose(fp);
+    return ok ? 0 : -EIO;
+}
+
+int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
+{
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return -ENOENT;
+    std::vector<uint8_t> all;
+    uint8_t buf[1 << 16];
+    int n;
+    while ((n = gzread(fp, buf, sizeof buf)) > 0) all.insert(all.end(), buf, buf + n);
+    gzclose(fp);
+    auto try_layout = [&](size_t hdr, size_t np_off) -> bool {
+        if (all.size() <= hdr) return false;
+        const size_t m = all.size() - hdr;
+        if (m & (m - 1)) return false;
+        uint32_t np;
+        std::memcpy(&np, all.data() + np_off, 4);
+        if (np < 4 || np > 30 || ((size_t)1 << np) != m) return false;
+        p = (int)np;
+        regs.assign(all.begin() + hdr, all.end());
+        return true;
+    };
+    if (try_layout(28, 16)) return 0;  // uint32[4] flags, uint32 p, double value
+    if (try_layout(16, 4)) return 0;   // uint8[4] flags, uint32 p, double value
+    return -EINVAL;
+}
+
+void emit_sizes(std::FILE *fp, const std::vector<std::string> &paths, const double *card)
+{
+    std::fputs("#Path\tSize (est.)\n", fp);
+    for (size_t i = 0; i < paths.size(); ++i) std::fprintf(fp, "%s\t%zu\n", paths[i].c_str(), (size_t)card[i]);
+    std::fflush(fp);
+}
+
+void emit_header(std::FILE *fp, int fmt, const std::vector<std::string> &paths)
+{
+    if (fmt == UT_TSV) {
+        std::string s("##Names\t");
+        for (const auto &p : paths) {
+            s += p;
+            s += '\t';
+        }
+        s.back() = '\n';
+        std::fwrite(s.data(), 1, s.size(), fp);
+    } else if (fmt == UPPER_TRIANGULAR) {
+        std::fprintf(fp, "%zu\n", paths.size());
+    }
+    std::fflush(fp);
+}
+
+void emit_ut_row(std::FILE *fp, int fmt, const std::vector<std::string> &paths, size_t i, const float *row)
+{
+    const size_t n = paths.size();
+    std::string s(paths[i]);
+    if (fmt == UT_TSV) {
+        for (size_t k = 0; k < i + 1; ++k) s += "\t-";
+    } else if (s.size() < 9) {
+        s.append(9 - s.size(), ' ');
+    }
+    char num[64];
+    for (size_t k = 0; k + i + 1 < n; ++k) {
+        const int len = std::snprintf(num, sizeof num, "\t%.6g", (double)row[k]);
+        s.append(num, (size_t)len);
+    }
+    s += '\n';
+    std::fwrite(s.data(), 1, s.size(), fp);
+}
+
+void emit_full_header(std::FILE *fp, const std::vector<std::string> &paths)
+{
+    std::fputs("#Names", fp);
+    for (size_t i = 0; i < paths.size(); ++i) {
+        std::fputs(paths[i].c_str(), fp);
+        std::fputc(i == paths.size() - 1 ? '\n' : '\t', fp);
+    }
+}
+
+void emit_full_row(std::FILE *fp, const std::vector<std::string> &paths, size_t i, const float *tri)
+{
+    const size_t n = paths.size();
+    auto at = [&](size_t r, size_t c) -> float {
+        if (r == c) return 0.f;
+        if (r > c) std::swap(r, c);
+        return tri[r * (2 * n - r - 1) / 2 + c - (r + 1)];
+    };
+    std::fprintf(fp, "%s\t", paths[i].c_str());
+    size_t j;
+    for (j = 0; j + 1 < n; ++j) std::fprintf(fp, "%0.6g\t", (double)at(i, j));
+    std::fprintf(fp, "%0.6g\n", (double)at(i, j));
+}
+
+int write_binary_header(std::FILE *fp, uint64_t n)
+{
+    if (std::fputc('\0', fp) == EOF) return -EIO;
+    return std::fwrite(&n, sizeof n, 1, fp) == 1 ? 0 : -EIO;
+}
+
+int write_labels(const std::string &path, const std::vector<std::string> &paths)
+{
+    std::FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp) return -EIO;
+    for (const auto &p : paths) {
+        std::fwrite(p.data(), p.size(), 1, fp);
+        std::fputc('\n', fp);
+    }
+    std::fclose(fp);
+    return 0;
+}
+
+}  // namespace dshh

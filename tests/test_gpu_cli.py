@@ -1,0 +1,163 @@
+"""GPU: the dashing-amd CLI end to end (FASTA -> sketch -> dist -> emitters) against the oracle.
+BASELINE configs[0] in miniature: synthetic related genomes, k=31, `dist` with dashing's flags."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from dashing_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+
+
+def run(*args, cwd=None):
+    r = subprocess.run([CLI] + [str(a) for a in args], cwd=cwd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    return r
+
+
+@pytest.fixture(scope="module")
+def genomes(tmp_path_factory):
+    d = tmp_path_factory.mktemp("genomes")
+    lens = [60000, 52000, 71000, 45000, 66000, 58000, 49000, 64000]
+    base = synth.synthetic_genomes(len(lens), 80000, seed=0xC11)
+    paths, seqs = [], []
+    for i, (g, L) in enumerate(zip(base, lens)):
+        s = g[:L].copy()
+        p = d / ("g%d.fna" % i)
+        if i == 2:  # two records
+            fa = synth.to_fasta(s[:30000], "g2a") + synth.to_fasta(s[30000:], "g2b")
+            s = np.concatenate([s[:30000], np.array([ord("N")], np.uint8), s[30000:]])
+        else:
+            fa = synth.to_fasta(s, "g%d" % i)
+        if i == 5:
+            p = d / "g5.fna.gz"
+            with gzip.open(p, "wb") as f:
+                f.write(fa)
+        else:
+            p.write_bytes(fa)
+        paths.append(str(p))
+        seqs.append(s)
+    return d, paths, seqs
+
+
+def oracle_regs(oracle, seqs, k, p, canon=True):
+    seq, off = synth.concat_for_device(seqs)
+    return oracle.sketch_batch(seq, off, k, p, canon)
+
+
+def parse_ut(text, n):
+    lines = text.decode().split("\n")
+    assert lines[0].startswith("##Names\t")
+    names = lines[0].split("\t")[1:]
+    vals = []
+    for i in range(n):
+        f = lines[1 + i].split("\t")
+        assert f[0] == names[i]
+        assert f[1 : 2 + i] == ["-"] * (i + 1)
+        vals += [float(x) for x in f[2 + i :]]
+    return names, np.array(vals)
+
+
+def test_dist_default_ut_tsv(genomes, oracle, tmp_path):
+    d, paths, seqs = genomes
+    out, sizes = tmp_path / "d.tsv", tmp_path / "s.tsv"
+    run("dist", "-k", 31, "-S", 10, "-p", 4, "--avoid-sorting", "-O", out, "-o", sizes, *paths)
+    regs = oracle_regs(oracle, seqs, 31, 10)
+    want = oracle.dist_tri(regs)
+    names, got = parse_ut(out.read_bytes(), len(paths))
+    assert names == paths
+    exp = np.array([float("%.6g" % x) for x in want])
+    assert np.allclose(got, exp, rtol=2e-6, atol=1e-12)
+    card = oracle.cardinalities(regs)
+    lines = sizes.read_text().split("\n")
+    assert lines[0] == "#Path\tSize (est.)"
+    for i, pth in enumerate(paths):
+        nm, v = lines[1 + i].split("\t")
+        assert nm == pth and abs(int(v) - int(card[i])) <= 1
+
+
+def test_size_sorted_order(genomes, tmp_path):
+    d, paths, seqs = genomes
+    out = tmp_path / "d.tsv"
+    run("dist", "-O", out, "-o", os.devnull, *paths)
+    names, _ = parse_ut(out.read_bytes(), len(paths))
+    sizes = [os.path.getsize(p) for p in names]
+    assert sizes == sorted(sizes, reverse=True)  # largest file first (src/distmain.cpp:126-129)
+
+
+@pytest.mark.parametrize("flags,estim,rt", [(["-M"], 2, 0), (["-l", "-E"], 0, 3), (["-I"], 1, 1)])
+def test_binary_and_measures(genomes, oracle, tmp_path, flags, estim, rt):
+    d, paths, seqs = genomes
+    out = tmp_path / "d.bin"
+    run("dist", "-k", 21, "-S", 12, "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, *flags, *paths)
+    raw = out.read_bytes()
+    n = len(paths)
+    assert raw[0] == 0 and struct.unpack("<Q", raw[1:9])[0] == n and len(raw) == 9 + 4 * n * (n - 1) // 2
+    got = np.frombuffer(raw[9:], np.float32)
+    want = oracle.dist_tri(oracle_regs(oracle, seqs, 21, 12), estim, rt, 21)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-12)
+    assert (tmp_path / "d.bin.labels").read_text().split("\n")[:-1] == paths
+
+
+def test_phylip_full_tsv_and_nocanon(genomes, oracle, tmp_path):
+    d, paths, seqs = genomes
+    sub = paths[:4]
+    want = oracle.dist_tri(oracle_regs(oracle, seqs[:4], 31, 10, canon=False))
+    ph = tmp_path / "p.txt"
+    run("dist", "-U", "-C", "--avoid-sorting", "-O", ph, "-o", os.devnull, *sub)
+    lines = ph.read_text().split("\n")
+    assert lines[0] == "4"
+    k = 0
+    for i in range(4):
+        f = lines[1 + i].split("\t")
+        assert f[0].rstrip(" ") == sub[i] and len(f[0]) >= 9
+        for x in f[1:]:
+            assert abs(float(x) - float("%.6g" % want[k])) <= 2e-6 * max(want[k], 1e-9)
+            k += 1
+    full = tmp_path / "f.txt"
+    run("dist", "-T", "-C", "--avoid-sorting", "-O", full, "-o", os.devnull, *sub)
+    lines = full.read_text().split("\n")
+    assert lines[0] == "#Names" + "\t".join(sub)
+    row1 = lines[2].split("\t")
+    assert row1[0] == sub[1] and row1[2] == "0" and abs(float(row1[1]) - want[0]) < 1e-5
+
+
+def test_cache_presketched_and_sketch_subcommand(genomes, oracle, tmp_path):
+    d, paths, seqs = genomes
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    a = tmp_path / "a.bin"
+    run("dist", "-b", "-W", "-P", cache, "--avoid-sorting", "-O", a, "-o", os.devnull, *paths)
+    hlls = [str(cache / (os.path.basename(p) + ".w.31.spacing.10.hll")) for p in paths]
+    assert all(os.path.exists(h) for h in hlls)
+    regs = oracle_regs(oracle, seqs, 31, 10)
+    for i, h in enumerate(hlls):  # .hll payload = registers, bit-exact
+        raw = gzip.open(h).read()
+        assert raw[28:] == regs[i].tobytes() and struct.unpack("<I", raw[16:20])[0] == 10
+    b = tmp_path / "b.bin"
+    run("dist", "-b", "--presketched", "-O", b, "-o", os.devnull, *hlls)
+    assert a.read_bytes() == b.read_bytes()
+    c = tmp_path / "c.bin"  # second -W run takes the cache-hit path
+    run("dist", "-b", "-W", "-P", cache, "--avoid-sorting", "-O", c, "-o", os.devnull, *paths)
+    assert a.read_bytes() == c.read_bytes()
+    sk = tmp_path / "sk"
+    sk.mkdir()
+    lst = tmp_path / "paths.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    run("sketch", "-k", 31, "-S", 10, "-P", sk, "-F", lst)
+    for p, h in zip(paths, hlls):
+        assert gzip.open(str(sk / os.path.basename(h))).read() == gzip.open(h).read()
+
+
+def test_cli_rejects_out_of_scope(genomes):
+    d, paths, seqs = genomes
+    r = subprocess.run([CLI, "dist", "--use-bb-minhash", *paths], capture_output=True)
+    assert r.returncode != 0
+    r = subprocess.run([CLI, "union", *paths], capture_output=True)
+    assert r.returncode != 0

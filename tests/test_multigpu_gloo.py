@@ -1,0 +1,71 @@
+"""CPU, world_size 2 (and 3), gloo: the N>1 path of bench.py -- row partition by pair count,
+per-rank contiguous span of the packed triangle, padded gather to rank 0 -- assembles a matrix
+byte-identical to the single-rank one.  The per-rank compute is stood in by the CPU oracle here
+(no GPU in this container); on the GPU box the same multigpu.gather_spans runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, p, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dashing_amd import multigpu, synth
+    from oracle import oracle_c
+
+    oracle_c.load(threads=2)
+    regs = synth.synthetic_sketches(n, p, seed=123)
+    bounds = multigpu.row_bounds(n, world)
+    mx = multigpu.max_span(n, bounds)
+    local = torch.zeros(max(mx, 1), dtype=torch.float32)
+    rows = oracle_c.dist_rows(regs, bounds[rank], bounds[rank + 1])
+    local[: rows.size] = torch.from_numpy(rows)
+    full = multigpu.gather_spans(local, n, bounds, rank, world, 0)
+    if rank == 0:
+        np.save(os.path.join(outdir, "full_%d.npy" % world), full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_spans_gloo(tmp_path, world):
+    n, p = 300, 8
+    mp.spawn(_worker, args=(world, _free_port(), n, p, str(tmp_path)), nprocs=world, join=True)
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    regs = synth.synthetic_sketches(n, p, seed=123)
+    want = oracle_c.dist_tri(regs)
+    got = np.load(os.path.join(str(tmp_path), "full_%d.npy" % world))
+    assert got.tobytes() == want.tobytes()
+
+
+def test_bounds_cover_and_align():
+    from dashing_amd import multigpu
+
+    for n in (10000, 300, 129, 5):
+        for w in (1, 2, 4, 8):
+            b = multigpu.row_bounds(n, w)
+            assert b[0] == 0 and b[-1] == n
+            assert sum(multigpu.span_sizes(n, b)) == n * (n - 1) // 2
+            assert all(x % 128 == 0 or x == n for x in b)
