@@ -70,6 +70,9 @@ def main():
     total_pairs = n * (n - 1) // 2
 
     ctx = dashing_amd.Context(local_rank)
+    for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # tuning sweeps, e.g. "kc=64,emax=32"
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
 
     def step():
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
@@ -114,12 +117,20 @@ def main():
         prep_ms += k["prepare_ms"]
         launches += k["pair_launches"]
     ctx.set_profiling(False)
+    traffic = None  # HBM bytes per launch from the committed PMC passes of the same workload
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pair_kernel.json")))
+        if pm["workload"]["n_sketches"] == n and pm["workload"]["p"] == p and world == 1:
+            traffic = pm["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     b_pair = 2 * m + 4                                   # algorithmic bytes per pair
     my_pairs = span
     achieved = my_pairs * reps * b_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_note": "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/pmc_pair_kernel.json; collected in separate --pmc passes, not in this run",
         "kernel": "k_pair_counts", "launches_per_step": launches // reps,
         "avg_launch_ms": round(pair_ms / max(launches, 1), 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),

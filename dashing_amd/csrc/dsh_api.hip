@@ -56,9 +56,10 @@ struct dsh_ctx {
     std::vector<uint2> htiles;
     // options
     int kc = 32;
-    int emax_opt = -1;  // -1: min(64, 2^p / 256)
+    int emax_opt = -1;  // -1: min(32, 2^p / 512) -- sweep in profiles/r1e: 32 beats 16 and 64 at p=14
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
+    int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
     bool profiling = false;
     double pair_ms = 0, fin_ms = 0, prep_ms = 0;
@@ -126,7 +127,7 @@ int prepare(dsh_ctx *c, int estim)
     }
     const uint64_t n = c->n;
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap)
-                                          : (int)std::min<uint64_t>(kExcCap, (1ull << c->p) >> 8);
+                                          : (int)std::min<uint64_t>(32, (1ull << c->p) >> 9);
     if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
     c->emax = emax_new;
     HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
@@ -270,7 +271,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             if (a) (void)hipEventRecord(a, c->stream);
         }
         HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
-                                     c->Npad, c->Kpad, c->W, c->P, dt, nt, c->cum.ptr, nslots));
+                                     c->Npad, c->Kpad, c->W, c->P, dt, nt, c->cum.ptr, nslots,
+                                     c->nsplit > 0 ? (uint32_t)c->nsplit
+                                                   : (uint32_t)((16 * 512 + nt - 1) / nt)));
         if (b) (void)hipEventRecord(b, c->stream);
         FinalizeLaunch f;
         f.cum = c->cum.ptr;
@@ -734,6 +737,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "nsplit")) {
+        if (v < 0 || v > 64) return fail(c, DSH_EINVAL, "nsplit must be in [0,64]");
+        c->nsplit = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "emax")) {

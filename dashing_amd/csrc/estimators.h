@@ -83,21 +83,24 @@ __device__ inline double estimate_improved(const Hist &c, int p)
     return m * divinv * m / z;
 }
 
-// kmin_hint/kmax_hint: a range known to contain every non-empty bin (scan bounds only).
-template <class Hist>
-__device__ inline double estimate_mle(const Hist &c, int p, int lo_hint, int hi_hint)
+// lo_hint/hi_hint: a range known to contain every non-empty bin; `raw(v)` may be called only for
+// v in [lo_hint, hi_hint] and skips the bounds test that `c(v)` performs (the iteration's
+// count reads all fall in that range).  The next count is fetched one step ahead so the LDS
+// read overlaps the dependent fp64 divide chain.
+template <class Hist, class Raw>
+__device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint)
 {
     const int q = 64 - p;
     const uint64_t m = 1ull << p;
     const uint32_t cq1 = c(q + 1);
     if (cq1 == m) return __builtin_huge_val();
     int kMin = lo_hint, kMax = hi_hint;
-    while (kMin < q + 1 && c(kMin) == 0) ++kMin;
-    while (kMax > 0 && c(kMax) == 0) --kMax;
+    while (kMin < hi_hint && raw(kMin) == 0) ++kMin;
+    while (kMax > lo_hint && raw(kMax) == 0) --kMax;
     const int kMinPrime = kMin > 1 ? kMin : 1;
     const int kMaxPrime = kMax < q ? kMax : q;
     double z = 0.;
-    for (int k = kMaxPrime; k >= kMinPrime; --k) z = 0.5 * z + (double)c(k);
+    for (int k = kMaxPrime; k >= kMinPrime; --k) z = 0.5 * z + (double)raw(k);
     z = ldexp(z, -kMinPrime);
     uint32_t cPrime = cq1;
     if (q >= 1) cPrime += c(kMaxPrime);
@@ -122,11 +125,14 @@ __device__ inline double estimate_mle(const Hist &c, int p, int lo_hint, int hi_
             xPrime += xPrime;
         }
         double g = (double)cPrime * h;
+        uint32_t cnext = kMaxPrime - 1 >= kMinPrime ? raw(kMaxPrime - 1) : 0u;
         for (int k = kMaxPrime - 1; k >= kMinPrime; --k) {
+            const double ck = (double)cnext;
+            if (k > kMinPrime) cnext = raw(k - 1);
             const double hPrime = 1. - h;
             h = (xPrime + h * hPrime) / (xPrime + hPrime);
             xPrime += xPrime;
-            g += (double)c(k) * h;
+            g += ck * h;
         }
         g += x * a;
         if (gprev < g && g <= mPrime) deltaX *= (g - mPrime) / (gprev - g);
@@ -137,13 +143,14 @@ __device__ inline double estimate_mle(const Hist &c, int p, int lo_hint, int hi_
     return x * (double)m;
 }
 
-template <class Hist>
-__device__ inline double estimate(const Hist &c, int p, int estim, int lo_hint, int hi_hint)
+template <class Hist, class Raw>
+__device__ inline double estimate(const Hist &c, const Raw &raw, int p, int estim, int lo_hint,
+                                  int hi_hint)
 {
     switch (estim) {
     case 0: return estimate_original(c, p);
     case 1: return estimate_improved(c, p);
-    default: return estimate_mle(c, p, lo_hint, hi_hint);
+    default: return estimate_mle(c, raw, p, lo_hint, hi_hint);
     }
 }
 

@@ -15,7 +15,8 @@ hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes);
 hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
                               uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
-                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots);
+                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots,
+                              uint32_t nsplit);
 
 struct FinalizeLaunch {
     const void *cum;

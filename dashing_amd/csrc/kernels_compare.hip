@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         int lo = 0, hi = 63;
         while (lo < 63 && h[lo] == 0) ++lo;
         while (hi > 0 && h[hi] == 0) --hi;
-        card[s] = estimate(c, p, estim, 0, 64 - p + 1);
+        card[s] = estimate(c, c, p, estim, lo, hi);
         // threshold: the largest tail that fits the exception list
         int T = hi;
         uint32_t cnt = 0;
@@ -219,15 +219,20 @@ template <int KC, int U, typename CT>
 __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict__ planes,
                                                       uint32_t Npad, uint32_t Kpad, uint32_t W,
                                                       uint32_t P, const uint2 *__restrict__ tiles,
-                                                      CT *__restrict__ cum, uint64_t nslots)
+                                                      CT *__restrict__ cum, uint64_t nslots,
+                                                      uint32_t ntiles, uint32_t chunks_per_item)
 {
+    // work item = (tile, contiguous range of K-chunks): blockIdx = split * ntiles + tile.  Every
+    // plane's count is independent, so splitting the plane range over workgroups needs no
+    // reduction; it only shortens the items so the last round of the grid wastes less.
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128]
     constexpr int NPASS = KC / 8;  // wave-instructions per operand per chunk (2 rows each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ii = (wave >> 1) * 64 + (lane >> 3) * 8;
     const int jj = (wave & 1) * 64 + (lane & 7) * 8;
-    const uint2 tile = tiles[blockIdx.x];
+    const uint32_t tile_id = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const uint2 tile = tiles[tile_id];
     // DMA source of this lane: row (2*wave + lane/32) of each 8-row pass, 16 B at column lane%32
     const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
     const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
@@ -256,14 +261,17 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[r][c] = 0;
 
-    const uint32_t nchunks = Kpad / KC;
-    CT *cum_tile = cum + (uint64_t)blockIdx.x * (kTile * kTile) + (uint64_t)ii * kTile + jj;
+    const uint32_t nchunks_all = Kpad / KC;
+    const uint32_t ch_begin = split * chunks_per_item;
+    const uint32_t ch_end = ch_begin + chunks_per_item < nchunks_all ? ch_begin + chunks_per_item : nchunks_all;
+    CT *cum_tile = cum + (uint64_t)tile_id * (kTile * kTile) + (uint64_t)ii * kTile + jj;
+    if (ch_begin >= ch_end) return;
 
-    stage(0, 0);
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    stage(ch_begin, ch_begin & 1);
+    for (uint32_t ch = ch_begin; ch < ch_end; ++ch) {
         dma_wait();       // this wave's DMA pieces of chunk ch have landed ...
         __syncthreads();  // ... and so have everyone's; buffer (ch+1)&1 is no longer being read
-        if (ch + 1 < nchunks) stage(ch + 1, (ch + 1) & 1);
+        if (ch + 1 < ch_end) stage(ch + 1, (ch + 1) & 1);
         const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + ii;
         const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 128) + KC * 128 + jj;
         // U rows (U = min(W, 8), compile time) per step, then a plane-boundary check
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
             if (q * 4 + t >= nb) break;
             const uint32_t e = ev[t];
             const int vb = (int)(e & 0xFFu);
+            if (vb <= T) continue;  // cannot change anything: either already filed under va > T, or no tail
             const uint32_t pos = e >> 8;
             int va = 0;
             uint32_t h = pos & (kHashSlots - 1);
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
                     col[(vb - vlo) * 128] += 1;
                     if (vb > maxv) maxv = vb;
                 }
-            } else if (vb > T) {
+            } else {
                 col[(vb - vlo) * 128] += 1;
                 ++ucnt;
                 if (vb > maxv) maxv = vb;
@@ -425,7 +434,8 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
-    const double us = estimate(c, a.p, a.estim, vlo, maxv);
+    auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
+    const double us = estimate(c, raw, a.p, a.estim, vlo, maxv);
     const double ji = jaccard_from(a.card[j], a.card[i], us);
     const float res = result_from_ji(ji, a.result_type, a.ksinv);
     uint64_t oidx;
@@ -461,7 +471,7 @@ hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int
 template <int KC, int U, typename CT>
 static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad,
                             uint32_t W, uint32_t P, const uint2 *tiles, uint32_t ntiles,
-                            void *cum, uint64_t nslots)
+                            void *cum, uint64_t nslots, uint32_t nsplit)
 {
     static bool attr_set = false;
     const size_t lds = (size_t)KC * 2048;
@@ -472,39 +482,49 @@ static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npa
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(ntiles), dim3(256), lds, st, planes, Npad,
-                       Kpad, W, P, tiles, reinterpret_cast<CT *>(cum), nslots);
+    // items must hold whole planes: chunks_per_item is a multiple of the chunks of one plane
+    const uint32_t nchunks = Kpad / KC;
+    const uint32_t cpp = W >= (uint32_t)KC ? W / KC : 1;  // chunks per plane (>= 1)
+    const uint32_t planes_chunks = (nchunks + cpp - 1) / cpp;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > planes_chunks) nsplit = planes_chunks;
+    const uint32_t per = (planes_chunks + nsplit - 1) / nsplit * cpp;
+    nsplit = (nchunks + per - 1) / per;
+    hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(ntiles * nsplit), dim3(256), lds, st,
+                       planes, Npad, Kpad, W, P, tiles, reinterpret_cast<CT *>(cum), nslots, ntiles,
+                       per);
     return hipGetLastError();
 }
 
 template <int KC, typename CT>
 static hipError_t launch_pc_u(hipStream_t st, const uint32_t *planes, uint32_t Npad,
                               uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
-                              uint32_t ntiles, void *cum, uint64_t nslots)
+                              uint32_t ntiles, void *cum, uint64_t nslots, uint32_t nsplit)
 {
-    if (W >= 8) return launch_pc<KC, 8, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    if (W == 4) return launch_pc<KC, 4, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    if (W == 2) return launch_pc<KC, 2, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    return launch_pc<KC, 1, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    if (W >= 8) return launch_pc<KC, 8, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    if (W == 4) return launch_pc<KC, 4, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    if (W == 2) return launch_pc<KC, 2, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    return launch_pc<KC, 1, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
 }
 
 hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
                               uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
-                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots)
+                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots,
+                              uint32_t nsplit)
 {
     if (ntiles == 0 || Kpad == 0) return hipSuccess;
     if (cum_bytes == 2) {
         switch (kc) {
-        case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-        case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+        case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+        case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
         default: return hipErrorInvalidValue;
         }
     }
     switch (kc) {
-    case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
-    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots);
+    case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
     default: return hipErrorInvalidValue;
     }
 }

@@ -124,6 +124,9 @@ def test_options_do_not_change_results(ctx):
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("xcd_swizzle", 0)
         assert ctx.dist_rows().tobytes() == base.tobytes()
+        for ns in (1, 2, 7, 64, 0):
+            ctx.set_option("nsplit", ns)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
     finally:
