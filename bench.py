@@ -135,7 +135,8 @@ def main():
         "avg_launch_ms": round(pair_ms / max(launches, 1), 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
         "dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
-        "exception_list_cap": ctx.info("emax"),
+        "exception_list_cap": ctx.info("emax"), "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
+        "sorted_columns": bool(ctx.info("sorted")),
         "finalize_ms_per_step": round(fin_ms / reps, 4), "prepare_ms_per_step": round(prep_ms / reps, 4),
         "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
     }

@@ -49,16 +49,22 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
-    DevBuf card, vrange, planes, cum, tiles, outbuf, seqbuf, workbuf, exc, exc_n;
+    DevBuf card, vrange, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm;
+    int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
+    std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
+    std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
+    std::vector<uint8_t> blk_T, blk_lo; // per 128-column block: max threshold, min register value
+    std::vector<uint4> hitems;
     uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
     int vlo = 0, vhi = 0;
     int emax = 0, cum_bytes = 4;
-    std::vector<uint2> htiles;
+    std::vector<uint4> htiles;
     // options
     int kc = 32;
     int emax_opt = -1;  // -1: min(32, 2^p / 512) -- sweep in profiles/r1e: 32 beats 16 and 64 at p=14
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
+    int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
     bool profiling = false;
@@ -113,12 +119,15 @@ void invalidate(dsh_ctx *c)
     c->card_estim = -1;
 }
 
-// cardinalities + planes for the current sketch matrix
-int prepare(dsh_ctx *c, int estim)
+// cardinalities + thresholds/exception lists + planes for the current sketch matrix.
+// want_sorted: lay the plane-matrix columns out in (threshold, min value) order so that the
+// 128-column blocks are homogeneous and every tile can use its own narrow plane range.
+int prepare(dsh_ctx *c, int estim, int want_sorted)
 {
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
-    if (c->planes_valid && c->card_estim == estim) return DSH_OK;
+    if (want_sorted < 0) want_sorted = c->planes_sorted;  // "whatever is cached"
+    if (c->planes_valid && c->card_estim == estim && c->planes_sorted == want_sorted) return DSH_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
@@ -130,19 +139,25 @@ int prepare(dsh_ctx *c, int estim)
                                           : (int)std::min<uint64_t>(32, (1ull << c->p) >> 9);
     if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
     c->emax = emax_new;
-    HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
-    HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
-    HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
-    HIPCHK(c, c->vrange.ensure(3 * sizeof(int)));
-    const int init[3] = {63, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
-                                   (double *)c->card.ptr, (int *)c->vrange.ptr,
-                                   (uint32_t *)c->exc.ptr, (uint32_t *)c->exc_n.ptr));
-    c->card_estim = estim;
-    if (!c->planes_valid) {
+    if (!c->planes_valid || c->card_estim != estim) {
+        HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
+        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
+        HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint16_t)));
+        HIPCHK(c, c->vrange.ensure(3 * sizeof(int)));
+        const int init[3] = {63, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
+                                       (double *)c->card.ptr, (int *)c->vrange.ptr,
+                                       (uint32_t *)c->exc.ptr, (uint32_t *)c->exc_n.ptr,
+                                       (uint16_t *)c->keys.ptr));
+        c->card_estim = estim;
+    }
+    if (!c->planes_valid || c->planes_sorted != want_sorted) {
         int vr[3] = {0, 0, 0};
+        c->hkeys.resize(n);
         HIPCHK(c, hipMemcpyAsync(vr, c->vrange.ptr, sizeof vr, hipMemcpyDeviceToHost, c->stream));
+        if (n) HIPCHK(c, hipMemcpyAsync(c->hkeys.data(), c->keys.ptr, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
@@ -152,6 +167,27 @@ int prepare(dsh_ctx *c, int estim)
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
         c->Npad = (uint32_t)((n + kTile - 1) / kTile * kTile);
+        // column order: identity, or a counting sort by key (threshold major, min value minor)
+        c->hperm.resize(n);
+        if (want_sorted) {
+            std::vector<uint32_t> cnt(65537, 0);
+            for (uint64_t i = 0; i < n; ++i) cnt[c->hkeys[i] + 1u]++;
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            for (uint64_t i = 0; i < n; ++i) c->hperm[cnt[c->hkeys[i]]++] = (uint32_t)i;
+            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+            if (n) HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->hperm.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        } else {
+            for (uint64_t i = 0; i < n; ++i) c->hperm[i] = (uint32_t)i;
+        }
+        const uint32_t NT = c->Npad / kTile;
+        c->blk_T.assign(NT, 0);
+        c->blk_lo.assign(NT, 255);
+        for (uint64_t s = 0; s < n; ++s) {
+            const uint16_t key = c->hkeys[c->hperm[s]];
+            const uint32_t b = (uint32_t)(s / kTile);
+            c->blk_T[b] = std::max<uint8_t>(c->blk_T[b], (uint8_t)(key >> 8));
+            c->blk_lo[b] = std::min<uint8_t>(c->blk_lo[b], (uint8_t)(key & 0xFF));
+        }
         const uint64_t K = (uint64_t)c->P * c->W;
         c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
         if (c->Kpad) {
@@ -162,8 +198,11 @@ int prepare(dsh_ctx *c, int estim)
                                          (size_t)(c->Kpad - K) * c->Npad * sizeof(uint32_t),
                                          c->stream));
             HIPCHK(c, launch_transform(c->stream, c->regs, n, c->p, c->vlo, c->P, c->W, c->Npad,
-                                       (uint32_t *)c->planes.ptr));
+                                       (uint32_t *)c->planes.ptr,
+                                       want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
+            if (want_sorted) HIPCHK(c, hipStreamSynchronize(c->stream));  // hperm (pageable) upload done
         }
+        c->planes_sorted = want_sorted;
         c->planes_valid = true;
     }
     if (e0 && e1) {
@@ -179,11 +218,11 @@ int prepare(dsh_ctx *c, int estim)
 // Order the tiles of a band so that workgroups that run on the same XCD (block b -> XCD b % 8,
 // observed dispatch behaviour; speed only, never correctness) walk one tile row together and
 // share its A panel in that XCD's L2.
-void xcd_order(std::vector<uint2> &t, size_t b, size_t e)
+void xcd_order(std::vector<uint4> &t, size_t b, size_t e)
 {
     const size_t cnt = e - b;
     if (cnt < 16) return;
-    std::vector<uint2> tmp(cnt);
+    std::vector<uint4> tmp(cnt);
     const size_t nx = 8, per = (cnt + nx - 1) / nx;
     // position q in launch order runs on XCD q % 8; give XCD x the contiguous range
     // [x*per, (x+1)*per) of the row-major list
@@ -206,63 +245,113 @@ struct PairJob {
 
 int run_pairs(dsh_ctx *c, const PairJob &job)
 {
-    int rc = prepare(c, job.estim);
+    // sorted columns pay off only when (nearly) all tiles are wanted: full-triangle calls
+    const bool full_tri = !job.rect && job.row_begin == 0 && job.row_end >= c->n;
+    const int want_sorted = c->sort_mode == 0 ? 0 : (full_tri ? 1 : 0);
+    int rc = prepare(c, job.estim, want_sorted);
     if (rc) return rc;
     if (job.result_type != DSH_JI && job.result_type != DSH_MASH_DIST &&
         job.result_type != DSH_FULL_MASH_DIST)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
     if (job.k < 1) return fail(c, DSH_EINVAL, "bad k %d", job.k);
-    // tile list
-    std::vector<uint2> &T = c->htiles;
+    // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes
+    // v in (max(min lo of its two blocks), max threshold of its two blocks]
+    std::vector<uint4> &T = c->htiles;
     T.clear();
     const uint32_t NT = c->Npad / kTile;
-    std::vector<size_t> row_starts;
+    auto tile_of = [&](uint32_t ti, uint32_t tj) {
+        const int lo_t = std::max<int>(c->blk_lo[ti], c->blk_lo[tj]);
+        const int T_t = std::max<int>(c->blk_T[ti], c->blk_T[tj]);
+        int pb = lo_t - c->vlo, pe = T_t - c->vlo;
+        if (pb < 0) pb = 0;
+        if (pe < pb) pe = pb;
+        return make_uint4(ti, tj, (uint32_t)pb, (uint32_t)pe);
+    };
     if (job.rect) {
         if (job.row_begin >= job.row_end || job.col_begin >= job.col_end) return DSH_OK;
         const uint32_t r0 = (uint32_t)(job.row_begin / kTile), r1 = (uint32_t)((job.row_end + kTile - 1) / kTile);
         const uint32_t c0 = (uint32_t)(job.col_begin / kTile), c1 = (uint32_t)((job.col_end + kTile - 1) / kTile);
-        for (uint32_t ti = r0; ti < r1; ++ti) {
-            row_starts.push_back(T.size());
-            for (uint32_t tj = c0; tj < c1; ++tj) T.push_back(make_uint2(ti, tj));
-        }
+        for (uint32_t ti = r0; ti < r1; ++ti)
+            for (uint32_t tj = c0; tj < c1; ++tj) T.push_back(tile_of(ti, tj));
     } else {
         if (job.row_begin >= job.row_end) return DSH_OK;
-        const uint32_t r0 = (uint32_t)(job.row_begin / kTile);
-        const uint32_t r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
-        for (uint32_t ti = r0; ti < r1; ++ti) {
-            row_starts.push_back(T.size());
-            for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(make_uint2(ti, tj));
+        uint32_t r0 = 0, r1 = NT;
+        if (!c->planes_sorted) {  // identity columns: only the tile rows that hold wanted rows
+            r0 = (uint32_t)(job.row_begin / kTile);
+            r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
         }
+        for (uint32_t ti = r0; ti < r1; ++ti)
+            for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(tile_of(ti, tj));
     }
-    row_starts.push_back(T.size());
     if (T.empty()) return DSH_OK;
-    // bands: whole tile rows, bounded by the cum scratch budget
+    // bands bounded by the cum scratch budget
     const uint64_t per_tile = (uint64_t)kTile * kTile * c->cum_bytes * std::max<uint32_t>(c->P, 1);
     const uint64_t max_tiles = std::max<uint64_t>(1, c->cum_budget / per_tile);
     std::vector<std::pair<size_t, size_t>> bands;
-    {
-        size_t b = 0;
-        while (b < T.size()) {
-            size_t e = std::min<size_t>(T.size(), b + max_tiles);
-            bands.emplace_back(b, e);
-            b = e;
-        }
+    for (size_t b = 0; b < T.size();) {
+        const size_t e = std::min<size_t>(T.size(), b + max_tiles);
+        bands.emplace_back(b, e);
+        b = e;
     }
     if (c->xcd_swizzle)
         for (auto &bd : bands) xcd_order(T, bd.first, bd.second);
-    HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint2)));
-    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, T.data(), T.size() * sizeof(uint2),
-                             hipMemcpyHostToDevice, c->stream));
+    // work items per band: {tile index in band, chunk begin, chunk end}
+    const uint32_t KC = (uint32_t)c->kc;
+    auto chunk_range = [&](const uint4 &t, uint32_t &cb, uint32_t &ce) {
+        cb = (uint32_t)(((uint64_t)t.z * c->W) / KC);
+        ce = (uint32_t)(((uint64_t)t.w * c->W + KC - 1) / KC);
+    };
+    std::vector<uint4> &I = c->hitems;
+    I.clear();
+    std::vector<std::pair<size_t, size_t>> band_items;
+    const uint32_t cpp = c->W >= KC ? c->W / KC : 1;  // chunks per plane when a plane spans chunks
+    for (auto &bd : bands) {
+        const size_t nt = bd.second - bd.first;
+        uint64_t tot = 0;
+        for (size_t t = bd.first; t < bd.second; ++t) {
+            uint32_t cb, ce;
+            chunk_range(T[t], cb, ce);
+            tot += ce - cb;
+        }
+        // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
+        uint64_t piece = c->nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + c->nsplit - 1) / c->nsplit)
+                                       : std::max<uint64_t>(1, tot / (16 * 512));
+        piece = (piece + cpp - 1) / cpp * cpp;
+        const size_t i0 = I.size();
+        uint32_t maxpieces = 0;
+        for (size_t t = bd.first; t < bd.second; ++t) {
+            uint32_t cb, ce;
+            chunk_range(T[t], cb, ce);
+            maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((ce - cb + piece - 1) / piece));
+        }
+        for (uint32_t s = 0; s < maxpieces; ++s)  // piece-major so neighbours in launch order share planes
+            for (size_t t = bd.first; t < bd.second; ++t) {
+                uint32_t cb, ce;
+                chunk_range(T[t], cb, ce);
+                const uint64_t b0 = cb + (uint64_t)s * piece;
+                if (b0 >= ce) continue;
+                I.push_back(make_uint4((uint32_t)(t - bd.first), (uint32_t)b0, (uint32_t)std::min<uint64_t>(ce, b0 + piece), 0));
+            }
+        band_items.emplace_back(i0, I.size());
+    }
+    HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
+    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, T.data(), T.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
+    if (!I.empty())
+        HIPCHK(c, hipMemcpyAsync(c->items.ptr, I.data(), I.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     size_t max_band = 0;
     for (auto &bd : bands) max_band = std::max(max_band, bd.second - bd.first);
     HIPCHK(c, c->cum.ensure(std::max<uint64_t>(per_tile * max_band, 256)));
 
     const float ksinv_f = (float)(1. / (double)job.k);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evp, evf;
-    for (auto &bd : bands) {
+    for (size_t bi = 0; bi < bands.size(); ++bi) {
+        const auto &bd = bands[bi];
         const uint32_t nt = (uint32_t)(bd.second - bd.first);
         const uint64_t nslots = (uint64_t)nt * kTile * kTile;
-        const uint2 *dt = (const uint2 *)c->tiles.ptr + bd.first;
+        const uint4 *dt = (const uint4 *)c->tiles.ptr + bd.first;
+        const uint4 *di = (const uint4 *)c->items.ptr + band_items[bi].first;
+        const uint32_t ni = (uint32_t)(band_items[bi].second - band_items[bi].first);
         hipEvent_t a = nullptr, b = nullptr, d = nullptr;
         if (c->profiling) {
             a = next_event(c);
@@ -271,9 +360,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             if (a) (void)hipEventRecord(a, c->stream);
         }
         HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
-                                     c->Npad, c->Kpad, c->W, c->P, dt, nt, c->cum.ptr, nslots,
-                                     c->nsplit > 0 ? (uint32_t)c->nsplit
-                                                   : (uint32_t)((16 * 512 + nt - 1) / nt)));
+                                     c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
         FinalizeLaunch f;
         f.cum = c->cum.ptr;
@@ -283,7 +370,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.exc_n = (const uint32_t *)c->exc_n.ptr;
         f.nslots = nslots;
         f.tiles = dt;
-        f.P = c->P;
+        f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
         f.vlo = c->vlo;
         f.p = c->p;
         f.estim = job.estim;
@@ -305,8 +392,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             evf.emplace_back(b, d);
         }
     }
+    // T and I are pageable sources of async copies: make sure they were consumed before reuse
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->profiling) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         for (auto &e : evp) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e.first, e.second);
@@ -379,6 +467,9 @@ void dsh_destroy(dsh_ctx *c)
     c->planes.release();
     c->exc.release();
     c->exc_n.release();
+    c->keys.release();
+    c->perm.release();
+    c->items.release();
     c->cum.release();
     c->tiles.release();
     c->outbuf.release();
@@ -570,7 +661,7 @@ int dsh_cardinalities(dsh_ctx *c, int estim, double *out)
         // same per-sketch pass as prepare() (thresholds/exception lists come out identical)
         const bool pv = c->planes_valid;
         c->planes_valid = true;  // do not rebuild planes for a cardinality query
-        rc = prepare(c, estim);
+        rc = prepare(c, estim, -1);
         c->planes_valid = pv && c->planes_valid;
         if (rc) return rc;
     }
@@ -721,6 +812,12 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "npad")) *out = c->Npad;
     else if (!std::strcmp(name, "kpad")) *out = c->Kpad;
     else if (!std::strcmp(name, "cum_bytes")) *out = c->cum_bytes;
+    else if (!std::strcmp(name, "sorted")) *out = c->planes_sorted;
+    else if (!std::strcmp(name, "avg_tile_planes_x100")) {
+        uint64_t tot = 0;
+        for (const auto &t : c->htiles) tot += t.w - t.z;
+        *out = c->htiles.empty() ? 0 : (int64_t)(tot * 100 / c->htiles.size());
+    }
     else return fail(c, DSH_EINVAL, "unknown info %s", name);
     return DSH_OK;
 }
@@ -737,6 +834,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "sort")) {
+        if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "sort must be -1, 0 or 1");
+        c->sort_mode = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "nsplit")) {

@@ -10,20 +10,21 @@ constexpr uint32_t kExcCap = 64;  // capacity of a sketch's exception list (entr
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, double *card, int *vrange, uint32_t *exc,
-                                uint32_t *exc_n);
+                                uint32_t *exc_n, uint16_t *keys);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
-                            uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes);
+                            uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
+                            const uint32_t *perm);
 hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
                               uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
-                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots,
-                              uint32_t nsplit);
+                              const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
+                              uint64_t nslots);
 
 struct FinalizeLaunch {
     const void *cum;
     int cum_bytes;  // 2 or 4
     uint64_t nslots;
-    const uint2 *tiles;
-    uint32_t P;
+    const uint4 *tiles;
+    const uint32_t *perm;
     int vlo, vhi, p, estim, result_type;
     double ksinv;
     const double *card;

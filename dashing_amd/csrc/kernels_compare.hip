@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                                                         double *__restrict__ card,
                                                         int *__restrict__ vrange,
                                                         uint32_t *__restrict__ exc,
-                                                        uint32_t *__restrict__ exc_n)
+                                                        uint32_t *__restrict__ exc_n,
+                                                        uint16_t *__restrict__ keys)
 {
     __shared__ uint32_t hist[4][64];
     __shared__ int thr[4];
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         }
         thr[wave] = T;
         exc_n[s] = cnt;
+        keys[s] = (uint16_t)((T << 8) | lo);  // sort key / per-block plane range: (threshold, min value)
         atomicMin(&vrange[0], lo);
         atomicMax(&vrange[1], hi);
         atomicMax(&vrange[2], T);
@@ -140,8 +142,10 @@ __device__ __forceinline__ uint32_t lt_nibble(uint32_t x, uint32_t vrep)
 
 __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ regs, uint64_t n,
                                                     int p, int vlo, uint32_t P, uint32_t W,
-                                                    uint32_t Npad, uint32_t *__restrict__ planes)
+                                                    uint32_t Npad, uint32_t *__restrict__ planes,
+                                                    const uint32_t *__restrict__ perm)
 {
+    // column i of the plane matrix holds sketch perm[i] (perm == nullptr: identity)
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t i = (uint32_t)(gid % Npad);
     const uint32_t w = (uint32_t)(gid / Npad);
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ r
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = 0xFFFFFFFFu;
     if (i < n) {
-        const uint8_t *src = regs + (uint64_t)i * m + (uint64_t)w * 32;
+        const uint8_t *src = regs + (uint64_t)(perm ? perm[i] : i) * m + (uint64_t)w * 32;
         const uint4 a = *reinterpret_cast<const uint4 *>(src);
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
         if (m >= 32) {
@@ -218,21 +222,22 @@ __device__ __forceinline__ void store8(uint32_t *dst, const uint32_t *a)
 template <int KC, int U, typename CT>
 __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict__ planes,
                                                       uint32_t Npad, uint32_t Kpad, uint32_t W,
-                                                      uint32_t P, const uint2 *__restrict__ tiles,
-                                                      CT *__restrict__ cum, uint64_t nslots,
-                                                      uint32_t ntiles, uint32_t chunks_per_item)
+                                                      uint32_t P, const uint4 *__restrict__ tiles,
+                                                      const uint4 *__restrict__ items,
+                                                      CT *__restrict__ cum, uint64_t nslots)
 {
-    // work item = (tile, contiguous range of K-chunks): blockIdx = split * ntiles + tile.  Every
-    // plane's count is independent, so splitting the plane range over workgroups needs no
-    // reduction; it only shortens the items so the last round of the grid wastes less.
+    // work item = (tile, contiguous range of K-chunks inside the tile's own plane range).  Every
+    // plane's count is independent, so splitting a tile's planes over workgroups needs no
+    // reduction; it shortens the items so the last round of the grid wastes less.
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128]
     constexpr int NPASS = KC / 8;  // wave-instructions per operand per chunk (2 rows each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ii = (wave >> 1) * 64 + (lane >> 3) * 8;
     const int jj = (wave & 1) * 64 + (lane & 7) * 8;
-    const uint32_t tile_id = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
-    const uint2 tile = tiles[tile_id];
+    const uint4 item = items[blockIdx.x];  // {tile index in band, chunk begin, chunk end, -}
+    const uint32_t tile_id = item.x;
+    const uint4 tile = tiles[tile_id];     // {row block, col block, plane begin, plane end}
     // DMA source of this lane: row (2*wave + lane/32) of each 8-row pass, 16 B at column lane%32
     const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
     const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
@@ -261,9 +266,7 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[r][c] = 0;
 
-    const uint32_t nchunks_all = Kpad / KC;
-    const uint32_t ch_begin = split * chunks_per_item;
-    const uint32_t ch_end = ch_begin + chunks_per_item < nchunks_all ? ch_begin + chunks_per_item : nchunks_all;
+    const uint32_t ch_begin = item.y, ch_end = item.z;
     CT *cum_tile = cum + (uint64_t)tile_id * (kTile * kTile) + (uint64_t)ii * kTile + jj;
     if (ch_begin >= ch_end) return;
 
@@ -312,9 +315,9 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 struct FinalizeArgs {
     const void *cum;
     uint64_t nslots;
-    const uint2 *tiles;
-    uint32_t P;
-    int vlo;    // planes cover v in (vlo, vlo+P]; T = vlo+P is the dense/sparse threshold
+    const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile of the band
+    const uint32_t *perm;  // plane-matrix column -> sketch index (nullptr: identity)
+    int vlo;    // global: plane pl is threshold v = vlo+1+pl; histogram columns start at vlo
     int vhi;    // largest register value present anywhere
     int p;
     int estim;
@@ -324,7 +327,7 @@ struct FinalizeArgs {
     const uint32_t *exc;
     const uint32_t *exc_n;
     uint64_t n;
-    // triangle mode: rows [row_begin,row_end), out index = tri(i,j) - base_index
+    // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
     int rect;
     uint64_t row_begin, row_end, col_begin, col_end;
@@ -349,15 +352,16 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     __shared__ uint32_t histA[64];
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
-    const uint2 tile = a.tiles[slot >> 14];
-    const uint64_t i = (uint64_t)tile.x * kTile + ((slot >> 7) & 127);  // block-uniform
-    const uint64_t j = (uint64_t)tile.y * kTile + (slot & 127);
-    const int vlo = a.vlo, T = a.vlo + (int)a.P, vhi = a.vhi;
-    // block-level skip (uniform): row outside the requested range / beyond n
-    bool row_ok;
-    if (a.rect) row_ok = i >= a.row_begin && i < a.row_end;
-    else row_ok = i < a.n && i >= a.row_begin && i < a.row_end;
-    if (!row_ok) return;
+    const uint4 tile = a.tiles[slot >> 14];
+    const uint64_t si = (uint64_t)tile.x * kTile + ((slot >> 7) & 127);  // block-uniform
+    const uint64_t sj = (uint64_t)tile.y * kTile + (slot & 127);
+    if (si >= a.n) return;  // padding row (uniform)
+    const uint64_t i = a.perm ? a.perm[si] : si;
+    // this tile's own plane range: C(v) = 0 for v <= vlo_t, exceptions above T
+    const int vlo = a.vlo, vhi = a.vhi;
+    const int vlo_t = vlo + (int)tile.z, T = vlo + (int)tile.w;
+    // block-level skip (uniform) when the row sketch cannot be wanted
+    if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
     hashA[tid] = 0xFFFFFFFFu;
     if (tid < 64) histA[tid] = 0;
     __syncthreads();
@@ -371,16 +375,28 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         }
     }
     __syncthreads();
+    if (sj >= a.n) return;
+    const uint64_t j = a.perm ? a.perm[sj] : sj;
+    uint64_t oi = i, oj = j;
     bool active;
-    if (a.rect) active = j >= a.col_begin && j < a.col_end;
-    else active = i < j && j < a.n;
+    if (a.rect) {
+        active = j >= a.col_begin && j < a.col_end;
+    } else {
+        if (oi > oj) {
+            const uint64_t t = oi;
+            oi = oj;
+            oj = t;
+        }
+        active = si < sj && oi >= a.row_begin && oi < a.row_end;
+    }
     if (!active) return;
     const uint32_t m = 1u << a.p;
     uint32_t *col = hs + tid;
-    // dense part: c[x] = C(x+1) - C(x), x in [vlo, T)
+    // bins below the tile's range are empty; dense part: c[x] = C(x+1) - C(x), x in [vlo_t, T)
+    for (int x = vlo; x < vlo_t; ++x) col[(x - vlo) * 128] = 0;
     const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
     uint32_t prev = 0;
-    for (uint32_t pl = 0; pl < a.P; ++pl) {
+    for (uint32_t pl = tile.z; pl < tile.w; ++pl) {
         const uint32_t cv = cum[(uint64_t)pl * a.nslots];
         col[pl * 128] = cv - prev;
         prev = cv;
@@ -435,12 +451,12 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
-    const double us = estimate(c, raw, a.p, a.estim, vlo, maxv);
+    const double us = estimate(c, raw, a.p, a.estim, vlo_t, maxv);
     const double ji = jaccard_from(a.card[j], a.card[i], us);
     const float res = result_from_ji(ji, a.result_type, a.ksinv);
     uint64_t oidx;
     if (a.rect) oidx = (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin);
-    else oidx = i * (2 * a.n - i - 1) / 2 + j - (i + 1) - a.base_index;
+    else oidx = oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     a.out[oidx] = res;
 }
 
@@ -448,30 +464,31 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, double *card, int *vrange, uint32_t *exc,
-                                uint32_t *exc_n)
+                                uint32_t *exc_n, uint16_t *keys)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
     hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                       card, vrange, exc, exc_n);
+                       card, vrange, exc, exc_n, keys);
     return hipGetLastError();
 }
 
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
-                            uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes)
+                            uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
+                            const uint32_t *perm)
 {
     if (P == 0) return hipSuccess;
     const uint64_t threads = (uint64_t)Npad * W;
     const uint32_t blocks = (uint32_t)((threads + 255) / 256);
     hipLaunchKernelGGL(k_transform, dim3(blocks), dim3(256), 0, st, regs, n, p, vlo, P, W, Npad,
-                       planes);
+                       planes, perm);
     return hipGetLastError();
 }
 
 template <int KC, int U, typename CT>
 static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad,
-                            uint32_t W, uint32_t P, const uint2 *tiles, uint32_t ntiles,
-                            void *cum, uint64_t nslots, uint32_t nsplit)
+                            uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
+                            uint32_t nitems, void *cum, uint64_t nslots)
 {
     static bool attr_set = false;
     const size_t lds = (size_t)KC * 2048;
@@ -482,49 +499,40 @@ static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npa
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // items must hold whole planes: chunks_per_item is a multiple of the chunks of one plane
-    const uint32_t nchunks = Kpad / KC;
-    const uint32_t cpp = W >= (uint32_t)KC ? W / KC : 1;  // chunks per plane (>= 1)
-    const uint32_t planes_chunks = (nchunks + cpp - 1) / cpp;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > planes_chunks) nsplit = planes_chunks;
-    const uint32_t per = (planes_chunks + nsplit - 1) / nsplit * cpp;
-    nsplit = (nchunks + per - 1) / per;
-    hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(ntiles * nsplit), dim3(256), lds, st,
-                       planes, Npad, Kpad, W, P, tiles, reinterpret_cast<CT *>(cum), nslots, ntiles,
-                       per);
+    hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(nitems), dim3(256), lds, st, planes, Npad,
+                       Kpad, W, P, tiles, items, reinterpret_cast<CT *>(cum), nslots);
     return hipGetLastError();
 }
 
 template <int KC, typename CT>
 static hipError_t launch_pc_u(hipStream_t st, const uint32_t *planes, uint32_t Npad,
-                              uint32_t Kpad, uint32_t W, uint32_t P, const uint2 *tiles,
-                              uint32_t ntiles, void *cum, uint64_t nslots, uint32_t nsplit)
+                              uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles,
+                              const uint4 *items, uint32_t nitems, void *cum, uint64_t nslots)
 {
-    if (W >= 8) return launch_pc<KC, 8, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-    if (W == 4) return launch_pc<KC, 4, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-    if (W == 2) return launch_pc<KC, 2, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-    return launch_pc<KC, 1, CT>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    if (W >= 8) return launch_pc<KC, 8, CT>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    if (W == 4) return launch_pc<KC, 4, CT>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    if (W == 2) return launch_pc<KC, 2, CT>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    return launch_pc<KC, 1, CT>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
 }
 
 hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
                               uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
-                              const uint2 *tiles, uint32_t ntiles, void *cum, uint64_t nslots,
-                              uint32_t nsplit)
+                              const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
+                              uint64_t nslots)
 {
-    if (ntiles == 0 || Kpad == 0) return hipSuccess;
+    if (nitems == 0 || Kpad == 0) return hipSuccess;
     if (cum_bytes == 2) {
         switch (kc) {
-        case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-        case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+        case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
         default: return hipErrorInvalidValue;
         }
     }
     switch (kc) {
-    case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-    case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
-    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, ntiles, cum, nslots, nsplit);
+    case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     default: return hipErrorInvalidValue;
     }
 }
@@ -533,7 +541,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
-    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.P = f.P; a.vlo = f.vlo; a.vhi = f.vhi;
+    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
     a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;

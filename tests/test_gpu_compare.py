@@ -124,6 +124,10 @@ def test_options_do_not_change_results(ctx):
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("xcd_swizzle", 0)
         assert ctx.dist_rows().tobytes() == base.tobytes()
+        for sm in (0, 1, -1):   # identity vs (threshold,min)-sorted plane columns
+            ctx.set_option("sort", sm)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+            assert ctx.info("sorted") == (0 if sm == 0 else 1)
         for ns in (1, 2, 7, 64, 0):
             ctx.set_option("nsplit", ns)
             assert ctx.dist_rows().tobytes() == base.tobytes()
@@ -132,6 +136,8 @@ def test_options_do_not_change_results(ctx):
     finally:
         ctx.set_option("kc", 32)
         ctx.set_option("emax", -1)
+        ctx.set_option("sort", -1)
+        ctx.set_option("nsplit", 0)
         ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("cum_budget_bytes", 2 << 30)
 
@@ -159,6 +165,30 @@ def test_properties_at_scale(ctx, oracle):
         want = oracle.dist_rows(regs, r, r + 1)
         lo = dashing_amd.tri_index(n, r, r + 1)
         close(tri[lo : lo + want.size], want)
+
+
+def test_heterogeneous_collection(ctx, oracle):
+    """Cardinalities spread over 3 decades (thresholds and minima differ a lot between sketches):
+    exercises per-tile plane ranges, empty dense ranges and the sorted column order."""
+    p, m = 12, 1 << 12
+    parts = []
+    for k, card in enumerate((3_000, 40_000, 600_000, 9_000_000, 150_000_000)):
+        parts += [synth.hll_registers(1000 * k + g, card * (1 + g % 3), p) for g in range(60)]
+    regs = np.stack(parts)
+    rng = np.random.default_rng(7)
+    regs = regs[rng.permutation(len(regs))]
+    regs[5] = 0
+    regs[6] = regs[7]
+    ctx.set_sketches(regs)
+    for estim in (0, 2):
+        want = oracle.dist_tri(regs, estim, oracle.JI, 31)
+        try:
+            for sm in (1, 0):
+                ctx.set_option("sort", sm)
+                close(ctx.dist_rows(estim=estim), want)
+        finally:
+            ctx.set_option("sort", -1)
+    assert ctx.dist_rows()[dashing_amd.tri_index(len(regs), 6, 7)] == 1.0
 
 
 def test_errors(ctx):
