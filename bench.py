@@ -48,12 +48,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DSH_BENCH_BACKEND=gloo is a dry-run of the N>1 code path on a box with ONE GPU: all ranks share
+    # cuda:0 and the gather is staged through host memory.  Never used for reported numbers.
+    backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -61,27 +69,45 @@ def main():
     n, p, m = N_SKETCH, P, 1 << P
     regs_h = synth.survey_sketches(n, p, seed=0x5EED0000)[0]  # SURVEY 8d; identical bytes on every rank
     regs_d = torch.from_numpy(regs_h).to(dev)                 # resident in HBM before timing
-    bounds = multigpu.row_bounds(n, world)
-    rb, re = bounds[rank], bounds[rank + 1]
-    span = dashing_amd.tri_span(n, rb, re)
-    mx = multigpu.max_span(n, bounds)
-    out_d = torch.empty(max(mx, 1), dtype=torch.float32, device=dev)
-    staging = [torch.empty(mx, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     total_pairs = n * (n - 1) // 2
-
     ctx = dashing_amd.Context(local_rank)
     for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # tuning sweeps, e.g. "kc=64,emax=32"
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
+    ctx.attach_device(regs_d.data_ptr(), n, p)
+    # N>1: every rank holds all sketches and computes one cost-balanced shard (a contiguous span
+    # of the sorted-order triangle); the only exchange is the RCCL gather of the spans to rank 0,
+    # which un-permutes them once into dashing's packed order.
+    span_off = ctx.shard_plan(world) if world > 1 else [0, total_pairs]
+    span = span_off[rank + 1] - span_off[rank]
+    mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
+    out_d = torch.empty(mx, dtype=torch.float32, device=dev)
+    stage = sorted_full = final = None
+    if world > 1 and rank == 0:
+        stage = torch.empty(world * mx, dtype=torch.float32, device=dev)
+        sorted_full = torch.empty(total_pairs, dtype=torch.float32, device=dev)
+        final = torch.empty(total_pairs, dtype=torch.float32, device=dev)
 
     def step():
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        ctx.dist_rows_device(out_d.data_ptr(), rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        if world == 1:
+            ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            return out_d[:span]
+        ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
-        if world > 1:
-            return multigpu.gather_spans(out_d, n, bounds, rank, world, 0, staging)
-        return out_d[:span]
+        if backend == "gloo":  # dry-run only: stage through the host
+            h = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
+            full = sorted_full.copy_(h) if rank == 0 else None
+        else:
+            full = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, sorted_full, 0)
+        if rank == 0:
+            torch.cuda.current_stream().synchronize()
+            ctx.unpermute_device(full.data_ptr(), final.data_ptr())
+            ctx.synchronize()
+            return final
+        return None
 
     def fence():
         if world > 1:
@@ -97,7 +123,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -109,7 +135,10 @@ def main():
     reps = 3
     for _ in range(reps):
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        ctx.dist_rows_device(out_d.data_ptr(), rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        if world == 1:
+            ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        else:
+            ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
         k = ctx.last_kernel_ms()
         pair_ms += k["pair_ms"]
@@ -143,6 +172,13 @@ def main():
 
     cpu = None
     parity = None
+    if rank == 0 and world > 1:
+        # assembled multi-rank matrix vs one single-GPU call on rank 0 (outside the timed region)
+        ref = torch.empty(total_pairs, dtype=torch.float32, device=dev)
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        ctx.dist_rows_device(ref.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full)), "pairs_checked": total_pairs}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
 
@@ -155,7 +191,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
                        "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                       "sharding": "rows->ranks by pair count, RCCL gather to rank 0" if world > 1 else "single GPU"},
+                       "sharding": "cost-balanced row shards of the sorted-order triangle, RCCL gather to rank 0 + un-permute" if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,

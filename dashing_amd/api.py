@@ -21,7 +21,7 @@ SYMBOLS = [
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
-    "dsh_dist_rect", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
+    "dsh_dist_rect", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -67,6 +67,9 @@ def load_library():
     lib.dsh_dist_rows.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_dist_rows_device.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
+    lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
+    lib.dsh_dist_shard_device.argtypes = [vp, i32, i32, i32, C.c_uint32, C.c_uint32, vp]
+    lib.dsh_unpermute_device.argtypes = [vp, vp, vp]
     lib.dsh_tri_span.argtypes = [u64, u64, u64]
     lib.dsh_tri_span.restype = u64
     lib.dsh_tri_index.argtypes = [u64, u64, u64]
@@ -206,6 +209,18 @@ class Context:
         buf = out if out.size else np.zeros(1, np.float32)
         self._ck(self._lib.dsh_dist_rect(self._h, estim, result_type, k, q_begin, q_end, r_begin, r_end, buf.ctypes.data))
         return out
+
+    # ---- multi-GPU shards (sorted-order spans + one un-permute)
+    def shard_plan(self, nshards, estim=ESTIM_ERTL_MLE):
+        off = np.zeros(nshards + 1, np.uint64)
+        self._ck(self._lib.dsh_shard_plan(self._h, estim, nshards, off.ctypes.data))
+        return [int(x) for x in off]
+
+    def dist_shard_device(self, out_ptr, shard, nshards, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        self._ck(self._lib.dsh_dist_shard_device(self._h, estim, result_type, k, shard, nshards, C.c_void_p(out_ptr)))
+
+    def unpermute_device(self, sorted_ptr, out_ptr):
+        self._ck(self._lib.dsh_unpermute_device(self._h, C.c_void_p(sorted_ptr), C.c_void_p(out_ptr)))
 
     # ---- misc
     def synchronize(self):

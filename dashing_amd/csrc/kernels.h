@@ -30,11 +30,13 @@ struct FinalizeLaunch {
     const double *card;
     const uint32_t *exc, *exc_n;
     uint64_t n;
-    int rect;
+    int rect, sorted_out;
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, uint64_t n,
+                            float *out);
 
 // sketch path
 struct SketchWork {

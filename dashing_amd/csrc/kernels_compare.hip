@@ -46,25 +46,36 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                                                         uint16_t *__restrict__ keys)
 {
     __shared__ uint32_t hist[4][64];
+    __shared__ uint32_t sub[4][8][64];  // 8 privatised copies per wave: the register values pile up
+                                        // in ~8 bins, so one copy would serialise its LDS atomics
     __shared__ int thr[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
-    hist[wave][lane] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sub[wave][k][lane] = 0;
     __syncthreads();
     const uint64_t m = 1ull << p;
     const uint4 *src = reinterpret_cast<const uint4 *>(regs + (s < n ? s : 0) * m);
     if (s < n) {
+        uint32_t *mysub = sub[wave][lane & 7];
         for (uint64_t c = lane; c < (m >> 4); c += 64) {
             const uint4 x = src[c];
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                atomicAdd(&hist[wave][w[k] & 63], 1u);
-                atomicAdd(&hist[wave][(w[k] >> 8) & 63], 1u);
-                atomicAdd(&hist[wave][(w[k] >> 16) & 63], 1u);
-                atomicAdd(&hist[wave][(w[k] >> 24) & 63], 1u);
+                atomicAdd(&mysub[w[k] & 63], 1u);
+                atomicAdd(&mysub[(w[k] >> 8) & 63], 1u);
+                atomicAdd(&mysub[(w[k] >> 16) & 63], 1u);
+                atomicAdd(&mysub[(w[k] >> 24) & 63], 1u);
             }
         }
+    }
+    __syncthreads();
+    {
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sub[wave][k][lane];
+        hist[wave][lane] = t;
     }
     __syncthreads();
     if (s < n && lane == 0) {
@@ -330,6 +341,10 @@ struct FinalizeArgs {
     // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
     int rect;
+    // sorted_out != 0 (triangle mode only): rows and the output index are in plane-column
+    // (sorted) order instead of original sketch order -- used for multi-GPU shards, whose spans
+    // are gathered first and un-permuted once (k_unpermute)
+    int sorted_out;
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
@@ -381,6 +396,10 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     bool active;
     if (a.rect) {
         active = j >= a.col_begin && j < a.col_end;
+    } else if (a.sorted_out) {
+        oi = si;
+        oj = sj;
+        active = si < sj && si >= a.row_begin && si < a.row_end;
     } else {
         if (oi > oj) {
             const uint64_t t = oi;
@@ -458,6 +477,29 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     if (a.rect) oidx = (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin);
     else oidx = oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     a.out[oidx] = res;
+}
+
+// sorted packed triangle -> packed triangle in original sketch order (one block per sorted row)
+__global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ in,
+                                                    const uint32_t *__restrict__ perm, uint64_t n,
+                                                    float *__restrict__ out)
+{
+    const uint64_t si = blockIdx.x;
+    const uint64_t i = perm[si];
+    const float *row = in + si * (2 * n - si - 1) / 2 - (si + 1);
+    for (uint64_t sj = si + 1 + threadIdx.x; sj < n; sj += 256) {
+        const uint64_t j = perm[sj];
+        const uint64_t a = i < j ? i : j, b = i < j ? j : i;
+        out[a * (2 * n - a - 1) / 2 + b - (a + 1)] = row[sj];
+    }
+}
+
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, uint64_t n,
+                            float *out)
+{
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_unpermute, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, perm, n, out);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -543,7 +585,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect;
+    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * sizeof(uint32_t);

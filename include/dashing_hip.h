@@ -107,6 +107,23 @@ int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64
 int dsh_dist_rect(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin,
                   uint64_t q_end, uint64_t r_begin, uint64_t r_end, float *out);
 
+/* ---- multi-GPU shards of the full triangle ------------------------------------------------
+ * Every rank holds all sketches (dsh_upload/attach) and computes one shard; no collective is
+ * needed inside the compare.  Internally the plane matrix is laid out in (threshold, min value)
+ * order so that tiles need few planes; shards are contiguous row ranges of THAT order, balanced
+ * by cost, so a shard's result is one contiguous span of the packed triangle of the sorted order.
+ *   dsh_shard_plan        span_off[0..nshards] = element offsets of the shards' spans (identical
+ *                         on every rank: it depends only on the sketches)
+ *   dsh_dist_shard_device compute shard `shard` into d_span (span_off[shard+1]-span_off[shard]
+ *                         floats, device memory)
+ *   dsh_unpermute_device  after the spans were gathered back to back (e.g. RCCL gather):
+ *                         sorted-order packed triangle -> packed triangle in the original sketch
+ *                         order (distmat/distmat.h:260-264), device to device. */
+int dsh_shard_plan(dsh_ctx *ctx, int estim, uint32_t nshards, uint64_t *span_off);
+int dsh_dist_shard_device(dsh_ctx *ctx, int estim, int result_type, int k, uint32_t shard,
+                          uint32_t nshards, void *d_span);
+int dsh_unpermute_device(dsh_ctx *ctx, const void *d_sorted_tri, void *d_out_tri);
+
 /* ---- helpers shared by every host (C++ CLI, Python, a patched dashing) -------------------- */
 /* number of packed elements of rows [row_begin,row_end) of an n x n upper triangle */
 uint64_t dsh_tri_span(uint64_t n, uint64_t row_begin, uint64_t row_end);

@@ -191,6 +191,32 @@ def test_heterogeneous_collection(ctx, oracle):
     assert ctx.dist_rows()[dashing_amd.tri_index(len(regs), 6, 7)] == 1.0
 
 
+@pytest.mark.parametrize("nshards", [1, 2, 3, 8])
+def test_virtual_shards_assemble(ctx, nshards):
+    """Multi-GPU path with G virtual ranks on one device: cost-balanced shards of the sorted-order
+    triangle, spans laid back to back, one un-permute == the single-call matrix, byte for byte."""
+    import torch
+
+    n, p = 700, 12
+    regs = synth.synthetic_sketches(n, p, seed=77)
+    ctx.set_sketches(regs)
+    want = ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=21)
+    off = ctx.shard_plan(nshards)
+    assert off[0] == 0 and off[-1] == n * (n - 1) // 2 and all(off[i] <= off[i + 1] for i in range(nshards))
+    dev = torch.device("cuda", 0)
+    sorted_full = torch.full((off[-1],), -1.0, dtype=torch.float32, device=dev)
+    for r in range(nshards):
+        span = torch.full((max(off[r + 1] - off[r], 1),), -2.0, dtype=torch.float32, device=dev)
+        ctx.dist_shard_device(span.data_ptr(), r, nshards, result_type=dashing_amd.MASH_DIST, k=21)
+        ctx.synchronize()
+        sorted_full[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
+    torch.cuda.synchronize()
+    final = torch.full((off[-1],), -3.0, dtype=torch.float32, device=dev)
+    ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
+    ctx.synchronize()
+    assert final.cpu().numpy().tobytes() == want.tobytes()
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)

@@ -60,6 +60,35 @@ def test_gather_spans_gloo(tmp_path, world):
     assert got.tobytes() == want.tobytes()
 
 
+def _worker_spans(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dashing_amd import multigpu
+
+    span_off = [0, 1000, 1700, 4000][: world + 1]  # unequal spans, as a cost-balanced plan gives
+    mx = max(span_off[r + 1] - span_off[r] for r in range(world))
+    local = torch.full((mx,), -1.0)
+    local[: span_off[rank + 1] - span_off[rank]] = torch.arange(span_off[rank], span_off[rank + 1], dtype=torch.float32)
+    full = multigpu.gather_shard_spans(local, span_off, rank, world)
+    if rank == 0:
+        np.save(os.path.join(outdir, "spans_%d.npy" % world), full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_shard_spans_gloo(tmp_path, world):
+    """bench.py's N>1 exchange: padded gather of unequal sorted-order spans, laid back to back."""
+    mp.spawn(_worker_spans, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "spans_%d.npy" % world))
+    end = [0, 1000, 1700, 4000][world]
+    assert (got == np.arange(end, dtype=np.float32)).all()
+
+
 def test_bounds_cover_and_align():
     from dashing_amd import multigpu
 
