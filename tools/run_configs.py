@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""End-to-end checks of BASELINE.json configs on a GPU box (not part of the test suite: minutes).
+  c1: configs[0] 100 synthetic 1 Mbp genomes, k=31, p=10: FASTA files -> `dashing-amd dist` vs the CPU oracle
+  c4: configs[3]-shaped 100 000 sketches, p=10, full matrix on one GPU: timing + sampled rows vs the oracle
+Prints one JSON line per config."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dashing_amd  # noqa: E402
+from dashing_amd import synth  # noqa: E402
+from oracle import oracle_c  # noqa: E402
+
+
+def c1():
+    n, L, k, p = 100, 1_000_000, 31, 10
+    gs = synth.synthetic_genomes(n, L, seed=0xDA5410)
+    d = tempfile.mkdtemp(prefix="c1_")
+    paths = []
+    for i, g in enumerate(gs):
+        pth = os.path.join(d, "g%03d.fna" % i)
+        open(pth, "wb").write(synth.to_fasta(g, "g%d" % i))
+        paths.append(pth)
+    lst = os.path.join(d, "paths.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    out = os.path.join(d, "dist.bin")
+    cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+    t0 = time.perf_counter()
+    subprocess.check_call([cli, "dist", "-k", str(k), "-S", str(p), "-p", "8", "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst])
+    t_cli = time.perf_counter() - t0
+    got = np.frombuffer(open(out, "rb").read()[9:], np.float32)
+    seq, off = synth.concat_for_device(gs)
+    oracle_c.load(threads=oracle_c.effective_cpus())
+    t0 = time.perf_counter()
+    regs = oracle_c.sketch_batch(seq, off, k, p, True)
+    want = oracle_c.dist_tri(regs)
+    t_cpu = time.perf_counter() - t0
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-9)
+    print(json.dumps({"config": "C1: 100 x 1 Mbp FASTA, k=31, p=10, dashing-amd dist -b (end to end incl. FASTA parsing and process start)",
+                      "cli_seconds": t_cli, "cpu_oracle_seconds_sketch_plus_dist": t_cpu, "cores": oracle_c.effective_cpus(),
+                      "pairs": int(got.size), "max_rel_diff": float(rel.max()), "exact_matches": int((got == want).sum()),
+                      "j_range": [float(want.min()), float(want.max())]}))
+
+
+def c4(n=100_000, p=10):
+    import torch
+
+    t0 = time.perf_counter()
+    regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
+    t_gen = time.perf_counter() - t0
+    dev = torch.device("cuda", 0)
+    regs_d = torch.from_numpy(regs).to(dev)
+    total = n * (n - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    ctx = dashing_amd.Context(0)
+    ctx.set_profiling(True)
+    times = []
+    for _ in range(2):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.dist_rows_device(out.data_ptr(), 0, n)
+        ctx.synchronize()
+        times.append(time.perf_counter() - t0)
+    k = ctx.last_kernel_ms()
+    oracle_c.load(threads=oracle_c.effective_cpus())
+    worst, checked = 0.0, 0
+    for r in (0, 1, 4999, 50_000, 99_000, 99_998):
+        want = oracle_c.dist_rows(regs, r, r + 1)
+        lo = dashing_amd.tri_index(n, r, r + 1)
+        got = out[lo : lo + want.size].cpu().numpy()
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-9)
+        worst = max(worst, float(rel.max()) if rel.size else 0.0)
+        checked += want.size
+    fin = bool(torch.isfinite(out).all().item())
+    print(json.dumps({"config": "C4-shaped: %d sketches, p=%d, full triangle on one MI355X (output left in HBM: %.1f GB)" % (n, p, total * 4 / 1e9),
+                      "seconds": min(times), "pairs_per_s": total / min(times), "kernel_ms": k,
+                      "planes": ctx.info("planes"), "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100,
+                      "rows_checked_vs_oracle_pairs": checked, "max_rel_diff": worst, "all_finite": fin, "gen_seconds": t_gen}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c1", "c4"]
+    if "c1" in which:
+        c1()
+    if "c4" in which:
+        c4()
