@@ -170,6 +170,13 @@ def main():
         "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
     }
 
+    # what actually bounds the kernel: integer VALU issue (v_and_b32 + v_bcnt_u32_b32 per 32 pair-bits,
+    # 4 cycles per wave64 instruction => 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 3.93e13 lane-ops/s)
+    lane_ops = 2.0 * ctx.info("avg_tile_planes_x100") / 100.0 * ctx.info("words_per_plane") * ctx.info("tiles") * 128 * 128
+    roofline["valu_int"] = {"achieved_lane_ops_per_s": lane_ops * reps / (pair_ms * 1e-3) if pair_ms > 0 else 0.0,
+                            "peak_lane_ops_per_s": 3.93e13,
+                            "frac": round(lane_ops * reps / (pair_ms * 1e-3) / 3.93e13, 4) if pair_ms > 0 else 0.0,
+                            "note": "the binding resource of k_pair_counts (DESIGN.md 3.2); PMC SQ_INSTS_VALU in profiles/r1g agrees"}
     cpu = None
     parity = None
     if rank == 0 and world > 1:

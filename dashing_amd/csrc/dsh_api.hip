@@ -893,6 +893,8 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "kpad")) *out = c->Kpad;
     else if (!std::strcmp(name, "cum_bytes")) *out = c->cum_bytes;
     else if (!std::strcmp(name, "sorted")) *out = c->planes_sorted;
+    else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->htiles.size();
+    else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
         uint64_t tot = 0;
         for (const auto &t : c->htiles) tot += t.w - t.z;

@@ -98,8 +98,8 @@ int dsh_cardinalities(dsh_ctx *ctx, int estim, double *card_out);
  * result_type in {DSH_JI, DSH_MASH_DIST, DSH_FULL_MASH_DIST}; k only matters for the Mash forms. */
 int dsh_dist_rows(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
                   uint64_t row_end, float *out);
-/* Same, result left in a caller-owned DEVICE buffer (no D2H); asynchronous on the ctx stream --
- * call dsh_synchronize (or use the stream) before reading d_out. */
+/* Same, result left in a caller-owned DEVICE buffer (no D2H).  The work runs on the ctx stream
+ * (dsh_stream); the call returns after it has completed. */
 int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
                          uint64_t row_end, void *d_out);
 /* Query x reference rectangle (partdist_loop, src/dashing.h:660-712): queries are slots
@@ -145,7 +145,8 @@ int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_ke
 /* Tunables (tile shape variant etc.); returns DSH_EINVAL for unknown names. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
- * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes". */
+ * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "tiles",
+ * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work. */
 void *dsh_stream(dsh_ctx *ctx);
