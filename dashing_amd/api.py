@@ -11,6 +11,8 @@ import numpy as np
 
 ESTIM_ORIGINAL, ESTIM_ERTL_IMPROVED, ESTIM_ERTL_MLE = 0, 1, 2
 MASH_DIST, JI, FULL_MASH_DIST = 0, 1, 3  # bns::EmissionType, src/enums.h:13-23
+SIZES, FULL_CONTAINMENT_DIST, CONTAINMENT_INDEX, CONTAINMENT_DIST = 2, 4, 5, 6
+SYMMETRIC_CONTAINMENT_INDEX, SYMMETRIC_CONTAINMENT_DIST = 7, 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None

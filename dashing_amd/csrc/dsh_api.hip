@@ -251,8 +251,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     const int want_sorted = job.sorted_rows ? 1 : (c->sort_mode == 0 ? 0 : (full_tri ? 1 : 0));
     int rc = prepare(c, job.estim, want_sorted);
     if (rc) return rc;
-    if (job.result_type != DSH_JI && job.result_type != DSH_MASH_DIST &&
-        job.result_type != DSH_FULL_MASH_DIST)
+    if (job.result_type < 0 || job.result_type > 8)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
     if (job.k < 1) return fail(c, DSH_EINVAL, "bad k %d", job.k);
     // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes

@@ -172,4 +172,34 @@ __device__ __forceinline__ float result_from_ji(double ji, int result_type, doub
     return (float)ret;
 }
 
+// Second arm of result_cmp (src/dashing.h:577-588): measures on set_triple(lhs, rhs) =
+// lhs.full_set_comparison(rhs) = {max(mys-is,0), max(os-is,0), is}, is = max(mys+os-us, 0)
+// (the triple is restated from the absent sketch submodule, SURVEY.md A.6, medium confidence;
+// the formulas on it are in-tree).  EmissionType values: SIZES 2, FULL_CONTAINMENT_DIST 4,
+// CONTAINMENT_INDEX 5, CONTAINMENT_DIST 6, SYMMETRIC_CONTAINMENT_INDEX 7, _DIST 8.
+__device__ __forceinline__ double max0(double x) { return x < 0. ? 0. : x; }
+__device__ inline float result_from_triple(double mys, double os, double us, int result_type, double ksinv)
+{
+    const double is = max0(mys + os - us);
+    const double t0 = max0(mys - is), t1 = max0(os - is), t2 = is;
+    double ret = t2;
+    if (result_type == 7 || result_type == 8) {
+        ret /= ((t1 < t0 ? t1 : t0) + t2);
+        if (result_type == 8) ret = ret != 0. ? -log(ret) * ksinv : 1.;
+    } else if (result_type == 4 || result_type == 5 || result_type == 6) {
+        ret /= (t0 + t1 + t2);
+        if (result_type == 6) ret = ret != 0. ? -log(ret) * ksinv : 1.;
+        else if (result_type == 4) ret = 1. - pow(ret, ksinv);
+    }
+    return (float)ret;
+}
+
+// result_cmp(lhs, rhs): mys/os = cardinalities of lhs/rhs, us = union size
+__device__ inline float result_cmp_from(double mys, double os, double us, int result_type, double ksinv)
+{
+    if (result_type == 0 || result_type == 1 || result_type == 3)
+        return result_from_ji(jaccard_from(mys, os, us), result_type, ksinv);
+    return result_from_triple(mys, os, us, result_type, ksinv);
+}
+
 }  // namespace dsh

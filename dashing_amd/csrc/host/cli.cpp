@@ -78,7 +78,7 @@ struct Opts {
     int estim = ERTL_MLE, result_type = JI, fmt = UT_TSV;
     int cache = 0, presketched = 0, avoid_sorting = 0, skip_cached = 0;
     std::string paths_file, prefix, suffix, spacing, out_sizes, out_dists;
-    std::vector<std::string> inpaths;
+    std::vector<std::string> inpaths, querypaths;
 };
 
 enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_UNSUPPORTED };
@@ -105,12 +105,16 @@ static Opts parse(int argc, char **argv, bool is_dist)
         {"use-bb-minhash", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-range-minhash", no_argument, nullptr, OPT_UNSUPPORTED},
         {"use-bloom-filter", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-nthash", no_argument, nullptr, OPT_UNSUPPORTED},
         {"use-cyclic-hash", no_argument, nullptr, OPT_UNSUPPORTED}, {"countmin", no_argument, nullptr, OPT_UNSUPPORTED},
-        {"nearest-neighbors", required_argument, nullptr, OPT_UNSUPPORTED}, {"containment-index", no_argument, nullptr, OPT_UNSUPPORTED},
-        {"containment-dist", no_argument, nullptr, OPT_UNSUPPORTED}, {"sizes", no_argument, nullptr, OPT_UNSUPPORTED},
+        {"nearest-neighbors", required_argument, nullptr, OPT_UNSUPPORTED},
+        // second arm of result_cmp (src/dashing.h:577-588); flag numbers as in DIST_LONG_OPTS
+        {"sizes", no_argument, nullptr, 'Z'}, {"containment-index", no_argument, nullptr, 131},
+        {"containment-dist", no_argument, nullptr, 132}, {"full-containment-dist", no_argument, nullptr, 133},
+        {"symmetric-containment-index", no_argument, nullptr, 137}, {"symmetric-containment-dist", no_argument, nullptr, 138},
+        {"query-paths", required_argument, nullptr, 'Q'},
         {nullptr, 0, nullptr, 0}};
     int co;
     optind = 1;
-    while ((co = getopt_long(argc, argv, "k:S:p:F:P:x:Co:O:bUTMlEImWHcs:w:eh?8yJQ:", longopts, nullptr)) >= 0) {
+    while ((co = getopt_long(argc, argv, "k:S:p:F:P:x:Co:O:bUTMlEImWHcs:w:eh?8yJQ:Z", longopts, nullptr)) >= 0) {
         switch (co) {
         case 'k': o.k = std::atoi(optarg); break;
         case 'S': o.S = std::atoi(optarg); break;
@@ -137,7 +141,14 @@ static Opts parse(int argc, char **argv, bool is_dist)
         case OPT_NPERBATCH: case 'e': break;  // accepted, no effect here
         case 's': if (optarg && *optarg) die("spaced seeds are out of scope (HLL hot path only)"); break;
         case 'w': if (std::atoi(optarg) > 0) die("minimizer windows are out of scope (HLL hot path only)"); break;
-        case '8': case 'y': case 'J': case 'Q': case OPT_UNSUPPORTED:
+        case 'Z': o.result_type = 2; break;
+        case 131: o.result_type = 5; break;
+        case 132: o.result_type = 6; break;
+        case 133: o.result_type = 4; break;
+        case 137: o.result_type = 7; break;
+        case 138: o.result_type = 8; break;
+        case 'Q': o.querypaths = read_paths_file(optarg); break;
+        case '8': case 'y': case 'J': case OPT_UNSUPPORTED:
             die("this option selects a sketch type / emitter outside the HLL sketch+dist hot path");
         default: usage(is_dist ? "dist" : "sketch");
         }
@@ -243,7 +254,18 @@ static int dist_main(int argc, char **argv)
     std::FILE *ofp = stdout, *pairofp = stdout;
     if (!o.out_sizes.empty() && !(ofp = std::fopen(o.out_sizes.c_str(), "w"))) die("Could not open file at %s for writing.", o.out_sizes.c_str());
     if (!o.out_dists.empty() && !(pairofp = std::fopen(o.out_dists.c_str(), "wb"))) die("Could not open file at %s for writing.", o.out_dists.c_str());
-    if (!o.presketched && !o.avoid_sorting) sort_paths_by_fsize(o.inpaths);  // src/distmain.cpp:126-129
+    // asymmetric measure without -Q: all references are also the queries (src/distmain.cpp:120-125)
+    const bool symmetric = !(o.result_type == 4 || o.result_type == 5 || o.result_type == 6);  // src/dashing.h:389-399
+    if (o.querypaths.empty() && !symmetric) {
+        o.querypaths = o.inpaths;
+        std::fprintf(stderr, "Note: No query files provided, but an asymmetric distance was requested. Switching to a query/reference format with all references as queries.\n");
+    }
+    if (!o.presketched && !o.avoid_sorting) {  // src/distmain.cpp:126-129
+        sort_paths_by_fsize(o.inpaths);
+        sort_paths_by_fsize(o.querypaths);
+    }
+    const size_t nq = o.querypaths.size();
+    for (auto &q : o.querypaths) o.inpaths.push_back(q);  // queries follow the references (src/distmain.cpp:130-133)
     const size_t n = o.inpaths.size();
     dsh_ctx *ctx = nullptr;
     if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
@@ -266,7 +288,30 @@ static int dist_main(int argc, char **argv)
     if (ofp != stdout) std::fclose(ofp);
     // distances (dist_loop, src/sketch_and_cmp.h:785-880)
     const uint64_t total = n ? (uint64_t)n * (n - 1) / 2 : 0;
-    if (o.fmt == FULL_TSV) {
+    if (nq) {  // partdist_loop (src/dashing.h:660-712): one row per query over all references
+        if (nq >= n) die("Wrong number of query/references. (ip size: %zu, nq: %zu", n, nq);
+        const size_t nr = n - nq;
+        if (o.fmt == UPPER_TRIANGULAR) std::fprintf(pairofp, "%zu\n", n);  // src/sketch_and_cmp.h:394-396
+        const size_t qblock = std::max<size_t>(1, ((size_t)64 << 20) / nr);
+        std::vector<float> buf;
+        for (size_t q0 = nr; q0 < n; q0 += qblock) {
+            const size_t q1 = std::min(n, q0 + qblock);
+            buf.resize((q1 - q0) * nr);
+            DSH(ctx, dsh_dist_rect(ctx, o.estim, o.result_type, o.k, q0, q1, 0, nr, buf.data()));
+            for (size_t qi = q0; qi < q1; ++qi) {
+                const float *row = buf.data() + (qi - q0) * nr;
+                if (o.fmt == BINARY) {
+                    if (std::fwrite(row, sizeof(float), nr, pairofp) != nr) die("Error writing to binary file");
+                } else {
+                    std::string s(o.inpaths[qi]);
+                    char num[64];
+                    for (size_t j = 0; j < nr; ++j) s.append(num, (size_t)std::snprintf(num, sizeof num, "\t%g", (double)row[j]));
+                    s += '\n';
+                    std::fwrite(s.data(), 1, s.size(), pairofp);
+                }
+            }
+        }
+    } else if (o.fmt == FULL_TSV) {
         std::vector<float> tri(std::max<uint64_t>(total, 1));
         DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, 0, n, tri.data()));
         emit_full_header(pairofp, o.inpaths);

@@ -471,8 +471,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
     const double us = estimate(c, raw, a.p, a.estim, vlo_t, maxv);
-    const double ji = jaccard_from(a.card[j], a.card[i], us);
-    const float res = result_from_ji(ji, a.result_type, a.ksinv);
+    const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
     uint64_t oidx;
     if (a.rect) oidx = (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin);
     else oidx = oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;

@@ -44,6 +44,13 @@ extern "C" {
 #define DSH_MASH_DIST 0
 #define DSH_JI 1
 #define DSH_FULL_MASH_DIST 3
+/* second arm of result_cmp (src/dashing.h:577-588), built on set_triple = full_set_comparison */
+#define DSH_SIZES 2
+#define DSH_FULL_CONTAINMENT_DIST 4
+#define DSH_CONTAINMENT_INDEX 5
+#define DSH_CONTAINMENT_DIST 6
+#define DSH_SYMMETRIC_CONTAINMENT_INDEX 7
+#define DSH_SYMMETRIC_CONTAINMENT_DIST 8
 
 typedef struct dsh_ctx dsh_ctx;
 
@@ -95,7 +102,8 @@ int dsh_cardinalities(dsh_ctx *ctx, int estim, double *card_out);
  * for rows i in [row_begin,row_end) and all j>i, out[index(i,j) - index(row_begin,row_begin+1)]
  * = float(result_cmp(sketch_j, sketch_i, result_type, 1/k)).  The rows of a range are one
  * contiguous span of the packed triangle, dsh_tri_span() elements long.
- * result_type in {DSH_JI, DSH_MASH_DIST, DSH_FULL_MASH_DIST}; k only matters for the Mash forms. */
+ * result_type: any bns::EmissionType above; k only matters for the *_DIST forms.  In every pair the
+ * reference calls result_cmp(lhs = sketch_j, rhs = sketch_i). */
 int dsh_dist_rows(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
                   uint64_t row_end, float *out);
 /* Same, result left in a caller-owned DEVICE buffer (no D2H).  The work runs on the ctx stream

@@ -45,6 +45,12 @@
 #define DSHO_MASH_DIST 0
 #define DSHO_JI 1
 #define DSHO_FULL_MASH_DIST 3
+#define DSHO_SIZES 2
+#define DSHO_FULL_CONTAINMENT_DIST 4
+#define DSHO_CONTAINMENT_INDEX 5
+#define DSHO_CONTAINMENT_DIST 6
+#define DSHO_SYMMETRIC_CONTAINMENT_INDEX 7
+#define DSHO_SYMMETRIC_CONTAINMENT_DIST 8
 
 /* Thread count for every parallel region below.  0 = OpenMP default.  Tests keep this small:
  * a GPU box may report far more logical CPUs than its cgroup quota lets us run, and a team of
@@ -347,10 +353,39 @@ float dsho_result(double ji, int result_type, int k)
     return (float)ret;
 }
 
+/* Second arm of result_cmp (src/dashing.h:577-588): measures built on set_triple(lhs, rhs) =
+ * lhs.full_set_comparison(rhs).  The triple itself lives in the absent sketch submodule; restated
+ * (medium confidence) as  is = max(mys + os - us, 0), {max(mys-is,0), max(os-is,0), is}
+ * with std::max(x, 0.) semantics (NaN in the first argument propagates).  The formulas applied to
+ * the triple are in-tree. */
+static double max0(double x) { return x < 0. ? 0. : x; }
+float dsho_result_triple(double mys, double os, double us, int result_type, int k)
+{
+    const float ksinv_f = (float)(1. / (double)k);
+    const double ksinv = (double)ksinv_f;
+    const double is = max0(mys + os - us);
+    const double t0 = max0(mys - is), t1 = max0(os - is), t2 = is;
+    double ret = t2;
+    if (result_type == DSHO_SYMMETRIC_CONTAINMENT_INDEX || result_type == DSHO_SYMMETRIC_CONTAINMENT_DIST) {
+        ret /= ((t1 < t0 ? t1 : t0) + t2);
+        if (result_type == DSHO_SYMMETRIC_CONTAINMENT_DIST) ret = ret ? -log(ret) * ksinv : 1.;
+    } else if (result_type == DSHO_FULL_CONTAINMENT_DIST || result_type == DSHO_CONTAINMENT_DIST ||
+               result_type == DSHO_CONTAINMENT_INDEX) {
+        ret /= (t0 + t1 + t2);
+        if (result_type == DSHO_CONTAINMENT_DIST) ret = ret ? -log(ret) * ksinv : 1.;
+        else if (result_type == DSHO_FULL_CONTAINMENT_DIST) ret = 1. - pow(ret, ksinv);
+    }
+    return (float)ret;
+}
+
+/* result_cmp(lhs = a, rhs = b): ca, cb are their cardinalities */
 float dsho_pair(const uint8_t *a, const uint8_t *b, double ca, double cb, int p, int estim,
                 int result_type, int k)
 {
-    return dsho_result(dsho_jaccard_from(ca, cb, dsho_union_size(a, b, p, estim)), result_type, k);
+    const double us = dsho_union_size(a, b, p, estim);
+    if (result_type == DSHO_MASH_DIST || result_type == DSHO_JI || result_type == DSHO_FULL_MASH_DIST)
+        return dsho_result(dsho_jaccard_from(ca, cb, us), result_type, k);
+    return dsho_result_triple(ca, cb, us, result_type, k);
 }
 
 /* ---- a7-a9: all-pairs, reference schedule (row i serial, dynamic over j > i) ---------- */

@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORIGINAL, ERTL_IMPROVED, ERTL_MLE = 0, 1, 2
 MASH_DIST, JI, FULL_MASH_DIST = 0, 1, 3
+SIZES, FULL_CONTAINMENT_DIST, CONTAINMENT_INDEX, CONTAINMENT_DIST = 2, 4, 5, 6
+SYMMETRIC_CONTAINMENT_INDEX, SYMMETRIC_CONTAINMENT_DIST = 7, 8
 
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
@@ -73,6 +75,8 @@ def _bind(lib):
     lib.dsho_jaccard_from.argtypes = [C.c_double, C.c_double, C.c_double]
     lib.dsho_result.restype = C.c_float
     lib.dsho_result.argtypes = [C.c_double, C.c_int, C.c_int]
+    lib.dsho_result_triple.restype = C.c_float
+    lib.dsho_result_triple.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.dsho_dist_tri.restype = None
     lib.dsho_dist_tri.argtypes = [_u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
     lib.dsho_dist_rows.restype = C.c_uint64
@@ -170,6 +174,10 @@ def jaccard_from(ca, cb, us):
 
 def result(ji, result_type, k):
     return float(load().dsho_result(ji, result_type, k))
+
+
+def result_triple(mys, os_, us, result_type, k):
+    return float(load().dsho_result_triple(mys, os_, us, result_type, k))
 
 
 def dist_tri(regs, estim=ERTL_MLE, result_type=JI, k=31, lib=None):

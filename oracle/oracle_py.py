@@ -14,6 +14,8 @@ import numpy as np
 M64 = (1 << 64) - 1
 ORIGINAL, ERTL_IMPROVED, ERTL_MLE = 0, 1, 2
 MASH_DIST, JI, FULL_MASH_DIST = 0, 1, 3
+SIZES, FULL_CONTAINMENT_DIST, CONTAINMENT_INDEX, CONTAINMENT_DIST = 2, 4, 5, 6
+SYMMETRIC_CONTAINMENT_INDEX, SYMMETRIC_CONTAINMENT_DIST = 7, 8
 _CODE = {ord("A"): 0, ord("a"): 0, ord("C"): 1, ord("c"): 1, ord("G"): 2, ord("g"): 2, ord("T"): 3, ord("t"): 3}
 
 
@@ -212,6 +214,26 @@ def result(ji, result_type, k):
         ret = 1.0 - math.pow(2.0 * ji / (1.0 + ji), ksinv)
     else:
         ret = ji
+    return float(np.float32(ret))
+
+
+def result_triple(mys, os_, us, result_type, k):
+    """second arm of result_cmp (src/dashing.h:577-588) on {max(mys-is,0), max(os-is,0), is}"""
+    ksinv = float(np.float32(1.0 / k))
+    mx0 = lambda x: 0.0 if x < 0.0 else x  # noqa: E731  (std::max(x, 0.): NaN propagates)
+    is_ = mx0(mys + os_ - us)
+    t0, t1, t2 = mx0(mys - is_), mx0(os_ - is_), is_
+    ret = t2
+    if result_type in (SYMMETRIC_CONTAINMENT_INDEX, SYMMETRIC_CONTAINMENT_DIST):
+        ret = _div(ret, min(t0, t1) + t2)
+        if result_type == SYMMETRIC_CONTAINMENT_DIST:
+            ret = -math.log(ret) * ksinv if ret else 1.0
+    elif result_type in (FULL_CONTAINMENT_DIST, CONTAINMENT_DIST, CONTAINMENT_INDEX):
+        ret = _div(ret, t0 + t1 + t2)
+        if result_type == CONTAINMENT_DIST:
+            ret = -math.log(ret) * ksinv if ret else 1.0
+        elif result_type == FULL_CONTAINMENT_DIST:
+            ret = 1.0 - math.pow(ret, ksinv)
     return float(np.float32(ret))
 
 

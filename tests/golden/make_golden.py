@@ -104,6 +104,14 @@ def main():
                               "tri_hex": tri.tobytes().hex(), "card_hex": card.tobytes().hex()})
         np.save(os.path.join(ROOT, "tests", "golden", "regs_p%d.npy" % p), regs)
     kat["pairs"] = pairs
+    # second arm of result_cmp: set_triple measures on fixed (mys, os, us) triples
+    tri = []
+    for rt in (2, 4, 5, 6, 7, 8):
+        for (a, b, u) in [(1000.0, 2000.0, 2500.0), (5e6, 5e6, 5e6), (100.0, 200.0, 400.0), (10.0, 20.0, 30.0), (3e6, 4e6, 6.5e6)]:
+            x, y = op.result_triple(a, b, u, rt, 31), oc.result_triple(a, b, u, rt, 31)
+            assert x == y, (rt, a, b, u)
+            tri.append([rt, a, b, u, float(x).hex()])
+    kat["set_triple"] = tri
     with open(os.path.join(ROOT, "tests", "golden", "kat.json"), "w") as f:
         json.dump(kat, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in kat.items()})

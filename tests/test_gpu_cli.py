@@ -155,6 +155,35 @@ def test_cache_presketched_and_sketch_subcommand(genomes, oracle, tmp_path):
         assert gzip.open(str(sk / os.path.basename(h))).read() == gzip.open(h).read()
 
 
+def test_query_reference_and_containment(genomes, oracle, tmp_path):
+    """-Q queries x -F references (partdist_loop format: name, then "\\t%g" per reference) and the
+    containment family; an asymmetric measure without -Q switches to all-vs-all rectangle."""
+    d, paths, seqs = genomes
+    refs, qs = paths[:5], paths[5:]
+    (tmp_path / "r.txt").write_text("\n".join(refs) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(qs) + "\n")
+    out = tmp_path / "qr.tsv"
+    run("dist", "--avoid-sorting", "--containment-index", "-F", tmp_path / "r.txt", "-Q", tmp_path / "q.txt", "-O", out, "-o", os.devnull)
+    regs = oracle_regs(oracle, seqs, 31, 10)
+    want = oracle.dist_rect(regs[5:], regs[:5], 2, oracle.CONTAINMENT_INDEX, 31)
+    lines = out.read_text().split("\n")[:-1]
+    assert len(lines) == len(qs)
+    for qi, ln in enumerate(lines):
+        f = ln.split("\t")
+        assert f[0] == qs[qi] and len(f) == 1 + len(refs)
+        for j, x in enumerate(f[1:]):
+            assert abs(float(x) - float("%g" % want[qi, j])) <= 2e-6 * max(abs(want[qi, j]), 1e-9)
+    b = tmp_path / "all.bin"
+    run("dist", "--avoid-sorting", "--containment-dist", "-b", "-O", b, "-o", os.devnull, *paths[:4])
+    got = np.frombuffer(b.read_bytes(), np.float32).reshape(4, 4)  # partdist binary: raw rows, no header
+    w2 = oracle.dist_rect(regs[:4], regs[:4], 2, oracle.CONTAINMENT_DIST, 31)
+    assert np.allclose(got, w2, rtol=1e-6, atol=1e-9)
+    s = tmp_path / "sizes.bin"
+    run("dist", "--avoid-sorting", "--sizes", "-b", "-O", s, "-o", os.devnull, *paths[:4])
+    raw = s.read_bytes()
+    assert np.allclose(np.frombuffer(raw[9:], np.float32), oracle.dist_tri(regs[:4], 2, oracle.SIZES, 31), rtol=1e-6)
+
+
 def test_cli_rejects_out_of_scope(genomes):
     d, paths, seqs = genomes
     r = subprocess.run([CLI, "dist", "--use-bb-minhash", *paths], capture_output=True)

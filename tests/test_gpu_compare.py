@@ -217,6 +217,25 @@ def test_virtual_shards_assemble(ctx, nshards):
     assert final.cpu().numpy().tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("rt", [2, 4, 5, 6, 7, 8])
+def test_set_triple_measures(ctx, oracle, rt):
+    """Second arm of result_cmp (SIZES, containment family): triangle and rectangle vs the oracle."""
+    n, p = 150, 12
+    regs = synth.synthetic_sketches(n, p, seed=91)
+    regs[10] = 0
+    regs[11] = regs[12]
+    ctx.set_sketches(regs)
+    want = oracle.dist_tri(regs, 2, rt, 31)
+    got = ctx.dist_rows(result_type=rt, k=31)
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all()
+    assert np.allclose(got[fin], want[fin], rtol=1e-6, atol=1e-9)
+    rect = ctx.dist_rect(100, 150, 0, 100, result_type=rt, k=31)
+    wr = oracle.dist_rect(regs[100:150], regs[:100], 2, rt, 31)
+    f2 = np.isfinite(wr)
+    assert np.allclose(rect[f2], wr[f2], rtol=1e-6, atol=1e-9)
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)
@@ -224,7 +243,7 @@ def test_errors(ctx):
         ctx.alloc(10, 30)
     ctx.alloc(4, 10)
     with pytest.raises(dashing_amd.DshError):
-        ctx.dist_rows(result_type=5)
+        ctx.dist_rows(result_type=9)
     with pytest.raises(dashing_amd.DshError):
         ctx.set_option("nope", 1)
     # empty / degenerate
