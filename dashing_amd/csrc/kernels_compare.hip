@@ -362,7 +362,10 @@ constexpr uint32_t kHashSlots = 128;  // 2 x kExcCap
 template <typename CT>
 __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hs[];  // [(vhi-vlo+1)][128]
+    // histogram columns hold counts <= 2^p: CT (uint16 when p <= 15) halves the LDS footprint and
+    // doubles the resident waves of this latency-sensitive kernel
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
+    CT *hs = reinterpret_cast<CT *>(hs_raw);  // [(vhi-vlo+1)][128]
     __shared__ uint32_t hashA[kHashSlots];
     __shared__ uint32_t histA[64];
     const int tid = threadIdx.x;
@@ -410,14 +413,14 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     }
     if (!active) return;
     const uint32_t m = 1u << a.p;
-    uint32_t *col = hs + tid;
+    CT *col = hs + tid;
     // bins below the tile's range are empty; dense part: c[x] = C(x+1) - C(x), x in [vlo_t, T)
     for (int x = vlo; x < vlo_t; ++x) col[(x - vlo) * 128] = 0;
     const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
     uint32_t prev = 0;
     for (uint32_t pl = tile.z; pl < tile.w; ++pl) {
         const uint32_t cv = cum[(uint64_t)pl * a.nslots];
-        col[pl * 128] = cv - prev;
+        col[pl * 128] = (CT)(cv - prev);
         prev = cv;
     }
     // tail bins start from A's own tail histogram
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     int maxv = T;
     for (int x = T + 1; x <= vhi; ++x) {
         const uint32_t h = histA[x];
-        col[(x - vlo) * 128] = h;
+        col[(x - vlo) * 128] = (CT)h;
         ucnt += h;
         if (h) maxv = x;
     }
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
             }
         }
     }
-    col[(T - vlo) * 128] = m - ucnt - prev;  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
+    col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
@@ -587,7 +590,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
-    const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * sizeof(uint32_t);
+    const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);
