@@ -236,6 +236,36 @@ def test_set_triple_measures(ctx, oracle, rt):
     assert np.allclose(rect[f2], wr[f2], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("p", [8, 11, 15])
+def test_adversarial_registers(ctx, oracle, p):
+    """Register arrays that do NOT follow the HLL law: uniform random over the whole value range
+    (no sparse tail: thresholds collapse to the maximum, ~50 dense planes), saturated and constant
+    sketches, a sketch with a single non-zero register.  Every estimator, sorted and identity columns."""
+    q = 64 - p
+    rng = np.random.default_rng(p)
+    n, m = 140, 1 << p
+    regs = rng.integers(0, q + 2, size=(n, m)).astype(np.uint8)
+    regs[0] = q + 1                 # saturated: MLE -> inf, J -> 0
+    regs[1] = 7                     # constant
+    regs[2] = 0
+    regs[2, 5] = 9                  # one non-zero register
+    regs[3] = rng.integers(0, 3, size=m)          # tiny values
+    regs[4] = rng.integers(q - 2, q + 2, size=m)  # huge values
+    ctx.set_sketches(regs)
+    try:
+        for sm in (1, 0):
+            ctx.set_option("sort", sm)
+            for estim in (0, 1, 2):
+                want = oracle.dist_tri(regs, estim, oracle.JI, 31)
+                got = ctx.dist_rows(estim=estim)
+                fin = np.isfinite(want)
+                assert (np.isfinite(got) == fin).all()
+                err = np.abs(got[fin].astype(np.float64) - want[fin])
+                assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9)).all(), (p, sm, estim, err.max())
+    finally:
+        ctx.set_option("sort", -1)
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)
