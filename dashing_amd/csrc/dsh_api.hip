@@ -65,6 +65,8 @@ struct dsh_ctx {
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
+    int assembler_permille = 24;  // un-permute + span copies on rank 0 ~ 0.53 ms of a 22 ms pass (profiles/r1h)
+    double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
     bool profiling = false;
@@ -794,17 +796,25 @@ static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb
         for (uint32_t tj = ti; tj < NT; ++tj) {
             const int lo_t = std::max<int>(c->blk_lo[ti], c->blk_lo[tj]);
             const int T_t = std::max<int>(c->blk_T[ti], c->blk_T[tj]);
-            rowcost[ti] += std::max(0, T_t - lo_t) + 5.0;
+            rowcost[ti] += std::max(0, T_t - lo_t) + c->shard_c0;
         }
         total += rowcost[ti];
     }
+    // boundary r = the tile row whose cumulative cost is nearest to r/nshards of the total
+    std::vector<double> cum(NT + 1, 0.);
+    for (uint32_t ti = 0; ti < NT; ++ti) cum[ti + 1] = cum[ti] + rowcost[ti];
     tb.assign(nshards + 1, NT);
     tb[0] = 0;
-    double acc = 0;
-    uint32_t r = 1;
-    for (uint32_t ti = 0; ti < NT && r < nshards; ++ti) {
-        acc += rowcost[ti];
-        while (r < nshards && acc >= total * r / nshards) tb[r++] = ti + 1;
+    uint32_t ti = 0;
+    for (uint32_t r = 1; r < nshards; ++r) {
+        // shard 0 belongs to the rank that also assembles the result (copies + un-permute, about
+        // assembler_permille/1000 of a single-GPU pass): give it that much less work
+        const double f0 = std::max(0.0, 1.0 / nshards - c->assembler_permille / 1000.0 * (nshards - 1) / nshards);
+        const double target = total * (f0 + (1.0 - f0) * (r - 1) / (nshards - 1));
+        while (ti < NT && cum[ti + 1] <= target) ++ti;
+        uint32_t b = ti;  // cum[b] <= target < cum[b+1]
+        if (b < NT && target - cum[b] > cum[b + 1] - target) ++b;
+        tb[r] = std::max(b, tb[r - 1]);
     }
 }
 
@@ -915,6 +925,16 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "assembler_permille")) {
+        if (v < 0 || v > 500) return fail(c, DSH_EINVAL, "assembler_permille out of range");
+        c->assembler_permille = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "shard_c0_x10")) {
+        if (v < 0 || v > 10000) return fail(c, DSH_EINVAL, "shard_c0_x10 out of range");
+        c->shard_c0 = (double)v / 10.0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "sort")) {

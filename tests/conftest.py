@@ -26,6 +26,12 @@ def ctx():
     """A GPU context; fails loudly if the HIP library or the device is missing."""
     import dashing_amd
 
+    try:  # bring torch's HIP runtime up first: some tests hand torch device buffers to the library
+        import torch
+
+        torch.cuda.init()
+    except Exception:
+        pass
     c = dashing_amd.Context(0)
     yield c
     c.close()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Times every shard of a G-way plan sequentially on ONE GPU (what each rank of a G-GPU run would
+spend in compute, incl. its own prepare): shows shard balance and the fixed per-rank overhead."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import dashing_amd  # noqa: E402
+from dashing_amd import synth  # noqa: E402
+
+n, p = 10000, 14
+regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
+ctx = dashing_amd.Context(0)
+if os.environ.get("C0"):
+    ctx.set_option("shard_c0_x10", int(os.environ["C0"]))
+for G in (8,):
+    ctx.attach_device(regs.data_ptr(), n, p)
+    off = ctx.shard_plan(G)
+    mx = max(off[r + 1] - off[r] for r in range(G))
+    out = torch.empty(mx, dtype=torch.float32, device="cuda")
+    rows = []
+    for r in range(G):
+        best = 1e9
+        for _ in range(3):
+            ctx.attach_device(regs.data_ptr(), n, p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.dist_shard_device(out.data_ptr(), r, G)
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        rows.append(round(best * 1e3, 3))
+    print(json.dumps({"G": G, "shard_ms": rows, "max_ms": max(rows), "pairs_share": [round((off[r + 1] - off[r]) / off[-1], 3) for r in range(G)]}))
+# unpermute cost
+full = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device="cuda")
+fin = torch.empty_like(full)
+ctx.attach_device(regs.data_ptr(), n, p)
+ctx.shard_plan(8)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ctx.unpermute_device(full.data_ptr(), fin.data_ptr())
+ctx.synchronize()
+print(json.dumps({"unpermute_ms": (time.perf_counter() - t0) * 100}))
