@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/dashing_hip.h"
@@ -322,27 +323,36 @@ static int dist_main(int argc, char **argv)
         } else {
             emit_header(pairofp, o.fmt, o.inpaths);
         }
-        // row blocks of <= 64 Mi values; the GPU computes block b+1 while the host emits block b
+        // row blocks of <= 64 Mi values, two ping-pong buffers: the GPU computes block b+1 while a
+        // writer thread emits block b (as dist_loop does with dps[i & 1], src/sketch_and_cmp.h:804-816)
         const uint64_t block_vals = (uint64_t)64 << 20;
-        std::vector<float> buf;
+        std::vector<float> bufs[2];
+        std::thread writer;
+        int which = 0;
         uint64_t rb = 0;
         while (rb < n) {
             uint64_t re = rb + 1;
             while (re < n && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
             const uint64_t span = dsh_tri_span(n, rb, re);
+            std::vector<float> &buf = bufs[which];
             buf.resize(std::max<uint64_t>(span, 1));
             DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, rb, re, buf.data()));
-            if (o.fmt == BINARY) {
-                if (span && std::fwrite(buf.data(), sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
-            } else {
-                uint64_t off = 0;
-                for (uint64_t i = rb; i < re; ++i) {
-                    emit_ut_row(pairofp, o.fmt, o.inpaths, i, buf.data() + off);
-                    off += n - i - 1;
+            if (writer.joinable()) writer.join();
+            writer = std::thread([&o, &buf, pairofp, rb, re, n, span]() {
+                if (o.fmt == BINARY) {
+                    if (span && std::fwrite(buf.data(), sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
+                } else {
+                    uint64_t off = 0;
+                    for (uint64_t i = rb; i < re; ++i) {
+                        emit_ut_row(pairofp, o.fmt, o.inpaths, i, buf.data() + off);
+                        off += n - i - 1;
+                    }
                 }
-            }
+            });
+            which ^= 1;
             rb = re;
         }
+        if (writer.joinable()) writer.join();
     }
     std::fflush(pairofp);
     if (pairofp != stdout) std::fclose(pairofp);

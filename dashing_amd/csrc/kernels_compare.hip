@@ -534,15 +534,11 @@ static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npa
                             uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
                             uint32_t nitems, void *cum, uint64_t nslots)
 {
-    static bool attr_set = false;
     const size_t lds = (size_t)KC * 2048;
-    if (!attr_set) {
-        hipError_t e =
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts<KC, U, CT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // per launch, not cached in a static: the attribute is per device and a process may own several
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts<KC, U, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(nitems), dim3(256), lds, st, planes, Npad,
                        Kpad, W, P, tiles, items, reinterpret_cast<CT *>(cum), nslots);
     return hipGetLastError();

@@ -151,12 +151,10 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
 {
     if (nwork == 0) return hipSuccess;
     const size_t lds = (size_t)1 << p;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    if (lds > (48u << 10)) {  // per launch: the attribute is per device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_lds = lds;
     }
     hipLaunchKernelGGL(k_sketch, dim3(nwork), dim3(256), lds, st, seq, work, k, p, canon, regs);
     return hipGetLastError();

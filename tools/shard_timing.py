@@ -18,7 +18,7 @@ regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
 ctx = dashing_amd.Context(0)
 if os.environ.get("C0"):
     ctx.set_option("shard_c0_x10", int(os.environ["C0"]))
-for G in (8,):
+for G in (1, 2, 4, 8):
     ctx.attach_device(regs.data_ptr(), n, p)
     off = ctx.shard_plan(G)
     mx = max(off[r + 1] - off[r] for r in range(G))
