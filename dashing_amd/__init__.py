@@ -10,6 +10,12 @@ from .api import (  # noqa: F401
     MASH_DIST,
     JI,
     FULL_MASH_DIST,
+    SIZES,
+    FULL_CONTAINMENT_DIST,
+    CONTAINMENT_INDEX,
+    CONTAINMENT_DIST,
+    SYMMETRIC_CONTAINMENT_INDEX,
+    SYMMETRIC_CONTAINMENT_DIST,
     device_count,
     backend_name,
     lib_path,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
-    "dsh_dist_rect", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
+    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -69,6 +69,7 @@ def load_library():
     lib.dsh_dist_rows.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_dist_rows_device.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
+    lib.dsh_knn.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, C.c_uint32, vp, vp]
     lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
     lib.dsh_dist_shard_device.argtypes = [vp, i32, i32, i32, C.c_uint32, C.c_uint32, vp]
     lib.dsh_unpermute_device.argtypes = [vp, vp, vp]
@@ -211,6 +212,17 @@ class Context:
         buf = out if out.size else np.zeros(1, np.float32)
         self._ck(self._lib.dsh_dist_rect(self._h, estim, result_type, k, q_begin, q_end, r_begin, r_end, buf.ctypes.data))
         return out
+
+    def knn(self, nn, q_begin=0, q_end=None, r_begin=0, r_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        q_end = self.n if q_end is None else q_end
+        r_end = self.n if r_end is None else r_end
+        nq = max(q_end - q_begin, 0)
+        idx = np.zeros((nq, nn), np.uint32)
+        val = np.zeros((nq, nn), np.float32)
+        if nq and nn:
+            self._ck(self._lib.dsh_knn(self._h, estim, result_type, k, q_begin, q_end, r_begin, r_end, nn,
+                                       idx.ctypes.data, val.ctypes.data))
+        return idx, val
 
     # ---- multi-GPU shards (sorted-order spans + one un-permute)
     def shard_plan(self, nshards, estim=ESTIM_ERTL_MLE):

@@ -785,6 +785,66 @@ int dsh_dist_rect(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, ui
     return DSH_OK;
 }
 
+int dsh_knn(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t qe, uint64_t rb,
+            uint64_t re, uint32_t nn, uint32_t *idx_out, float *val_out)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (qe > c->n || re > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    reset_prof(c);
+    if (qb >= qe || nn == 0) return DSH_OK;
+    if (!idx_out || !val_out) return DSH_EINVAL;
+    // similarity measures rank descending, distances ascending (emt2nntype, src/dashing.h:268-280)
+    const int descending = !(result_type == DSH_MASH_DIST || result_type == DSH_FULL_MASH_DIST ||
+                             result_type == DSH_CONTAINMENT_DIST || result_type == DSH_FULL_CONTAINMENT_DIST ||
+                             result_type == DSH_SYMMETRIC_CONTAINMENT_DIST);
+    const uint64_t nq = qe - qb, nr = re > rb ? re - rb : 0;
+    const bool overlap = qb < re && rb < qe;
+    DevBuf &rect = c->outbuf;
+    const uint64_t qblock = std::max<uint64_t>(1, std::min<uint64_t>(nq, ((uint64_t)256 << 20) / std::max<uint64_t>(nr, 1)));
+    HIPCHK(c, rect.ensure(std::max<uint64_t>(qblock * nr, 1) * sizeof(float)));
+    DevBuf didx, dval;
+    rc = DSH_OK;
+    do {
+        if (didx.ensure(nq * nn * sizeof(uint32_t)) != hipSuccess || dval.ensure(nq * nn * sizeof(float)) != hipSuccess) {
+            rc = fail(c, DSH_ENOMEM, "device allocation failed");
+            break;
+        }
+        for (uint64_t q0 = qb; q0 < qe && rc == DSH_OK; q0 += qblock) {
+            const uint64_t q1 = std::min(qe, q0 + qblock);
+            if (nr) {
+                PairJob j;
+                j.estim = estim;
+                j.result_type = result_type;
+                j.k = k;
+                j.rect = 1;
+                j.row_begin = q0;
+                j.row_end = q1;
+                j.col_begin = rb;
+                j.col_end = re;
+                j.base_index = 0;
+                j.d_out = (float *)rect.ptr;
+                rc = run_pairs(c, j);
+                if (rc) break;
+            }
+            hipError_t e = launch_topk(c->stream, (const float *)rect.ptr, q1 - q0, nr, q0, rb, descending, nn,
+                                       overlap ? 1 : 0, (uint32_t *)didx.ptr + (q0 - qb) * nn,
+                                       (float *)dval.ptr + (q0 - qb) * nn);
+            if (e != hipSuccess) rc = fail(c, DSH_EIO, "k_topk: %s", hipGetErrorString(e));
+        }
+        if (rc) break;
+        if (hipMemcpyAsync(idx_out, didx.ptr, nq * nn * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(val_out, dval.ptr, nq * nn * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = fail(c, DSH_EIO, "copy of neighbours failed");
+    } while (0);
+    didx.release();
+    dval.release();
+    return rc;
+}
+
 // cost model for balancing shards: a tile costs its dense planes plus ~5 plane-equivalents of
 // finalize work (6.6 ms finalize vs 1.4 ms per plane on the C3 workload, profiles/r1f)
 static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb)

@@ -78,11 +78,12 @@ struct Opts {
     int k = 31, S = 10, nthreads = 1, canon = 1, device = 0;
     int estim = ERTL_MLE, result_type = JI, fmt = UT_TSV;
     int cache = 0, presketched = 0, avoid_sorting = 0, skip_cached = 0;
+    unsigned nneighbors = 0;  // --nearest-neighbors
     std::string paths_file, prefix, suffix, spacing, out_sizes, out_dists;
     std::vector<std::string> inpaths, querypaths;
 };
 
-enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_UNSUPPORTED };
+enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_NN, OPT_UNSUPPORTED };
 
 static Opts parse(int argc, char **argv, bool is_dist)
 {
@@ -106,7 +107,7 @@ static Opts parse(int argc, char **argv, bool is_dist)
         {"use-bb-minhash", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-range-minhash", no_argument, nullptr, OPT_UNSUPPORTED},
         {"use-bloom-filter", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-nthash", no_argument, nullptr, OPT_UNSUPPORTED},
         {"use-cyclic-hash", no_argument, nullptr, OPT_UNSUPPORTED}, {"countmin", no_argument, nullptr, OPT_UNSUPPORTED},
-        {"nearest-neighbors", required_argument, nullptr, OPT_UNSUPPORTED},
+        {"nearest-neighbors", required_argument, nullptr, OPT_NN},
         // second arm of result_cmp (src/dashing.h:577-588); flag numbers as in DIST_LONG_OPTS
         {"sizes", no_argument, nullptr, 'Z'}, {"containment-index", no_argument, nullptr, 131},
         {"containment-dist", no_argument, nullptr, 132}, {"full-containment-dist", no_argument, nullptr, 133},
@@ -149,6 +150,10 @@ static Opts parse(int argc, char **argv, bool is_dist)
         case 137: o.result_type = 7; break;
         case 138: o.result_type = 8; break;
         case 'Q': o.querypaths = read_paths_file(optarg); break;
+        case OPT_NN:
+            if (std::atoi(optarg) <= 0) die("--nearest-neighbors needs a positive count");
+            o.nneighbors = (unsigned)std::atoi(optarg);
+            break;
         case '8': case 'y': case 'J': case OPT_UNSUPPORTED:
             die("this option selects a sketch type / emitter outside the HLL sketch+dist hot path");
         default: usage(is_dist ? "dist" : "sketch");
@@ -289,7 +294,36 @@ static int dist_main(int argc, char **argv)
     if (ofp != stdout) std::fclose(ofp);
     // distances (dist_loop, src/sketch_and_cmp.h:785-880)
     const uint64_t total = n ? (uint64_t)n * (n - 1) / 2 : 0;
-    if (nq) {  // partdist_loop (src/dashing.h:660-712): one row per query over all references
+    if (o.nneighbors) {  // nndist_loop (src/sketch_and_cmp.h:712-783)
+        const size_t nr = nq ? n - nq : n, npairs = nq ? nq : n;
+        unsigned nn = o.nneighbors;
+        const size_t possible = nq ? nr : (n ? n - 1 : 0);
+        if (nn > possible) {
+            std::fprintf(stderr, "Only reporting %zu rather than %u neighbors due to their being only that many sets.\n", possible, nn);
+            nn = (unsigned)possible;
+        }
+        std::vector<uint32_t> idx(std::max<size_t>(npairs * nn, 1));
+        std::vector<float> val(std::max<size_t>(npairs * nn, 1));
+        if (nn) DSH(ctx, dsh_knn(ctx, o.estim, o.result_type, o.k, nq ? nr : 0, n, 0, nr, nn, idx.data(), val.data()));
+        if (o.fmt == BINARY) {  // u32 n, u32 nn, then {float value, u32 id} pairs (validx_t, :605)
+            uint32_t hdr[2] = {(uint32_t)n, nn};
+            std::fwrite(hdr, sizeof(uint32_t), 2, pairofp);
+            for (size_t t = 0; t < npairs * nn; ++t) {
+                std::fwrite(&val[t], sizeof(float), 1, pairofp);
+                std::fwrite(&idx[t], sizeof(uint32_t), 1, pairofp);
+            }
+        } else {  // rows in input order (the reference's row order depends on its thread schedule)
+            std::fputs("#File\tNeighbor ID:distance\t...\n", pairofp);
+            for (size_t i = 0; i < npairs; ++i) {
+                std::string s(o.inpaths[i + (nq ? nr : 0)]);
+                char num[64];
+                for (unsigned j = 0; j < nn; ++j)
+                    s.append(num, (size_t)std::snprintf(num, sizeof num, "\t%u:%g", idx[i * nn + j], (double)val[i * nn + j]));
+                s += '\n';
+                std::fwrite(s.data(), 1, s.size(), pairofp);
+            }
+        }
+    } else if (nq) {  // partdist_loop (src/dashing.h:660-712): one row per query over all references
         if (nq >= n) die("Wrong number of query/references. (ip size: %zu, nq: %zu", n, nq);
         const size_t nr = n - nq;
         if (o.fmt == UPPER_TRIANGULAR) std::fprintf(pairofp, "%zu\n", n);  // src/sketch_and_cmp.h:394-396
@@ -356,7 +390,7 @@ static int dist_main(int argc, char **argv)
     }
     std::fflush(pairofp);
     if (pairofp != stdout) std::fclose(pairofp);
-    if (o.fmt == BINARY) {  // src/distmain.cpp:191-200
+    if (o.fmt == BINARY && !o.nneighbors) {  // src/distmain.cpp:191-200 (emit_fmt == BINARY exactly)
         const std::string labels = o.out_dists.empty() ? "unspecified" : o.out_dists + ".labels";
         if (write_labels(labels, o.inpaths)) die("Could not open file at '%s' for writing", labels.c_str());
     }

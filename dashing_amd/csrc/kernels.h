@@ -38,6 +38,10 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
 hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, uint64_t n,
                             float *out);
 
+hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
+                       uint64_t row0, uint64_t col0, int descending, uint32_t nn,
+                       int exclude_self, uint32_t *idx_out, float *val_out);
+
 // sketch path
 struct SketchWork {
     uint64_t gbeg;   // absolute offset of the genome's first base in the device seq buffer

@@ -505,6 +505,83 @@ hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *per
 }
 
 // ------------------------------------------------------------------------------------------
+// k best columns of every row of a row-major [rows][ncols] block (perform_nns,
+// src/sketch_and_cmp.h:642-697, without its heaps and mutexes): one wave per row, nn selection
+// passes; pass t takes the best element that comes strictly after pass t-1's pick in the total
+// order (value best-first, then column index ascending), so nothing is mutated and ties are
+// deterministic.  NaN ranks last.  self_col (or ~0) is skipped.
+__global__ __launch_bounds__(256) void k_topk(const float *__restrict__ vals, uint64_t rows,
+                                               uint64_t ncols, uint64_t row0, uint64_t col0,
+                                               int descending, uint32_t nn, int exclude_self,
+                                               uint32_t *__restrict__ idx_out,
+                                               float *__restrict__ val_out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float *v = vals + r * ncols;
+    const float worst = descending ? -__builtin_huge_valf() : __builtin_huge_valf();
+    const uint64_t self = exclude_self ? row0 + r - col0 : ~0ull;  // column of the row's own sketch
+    // order: a before b  <=>  a.val better than b.val, or equal and a.idx < b.idx
+    auto before = [descending](float av, uint32_t ai, float bv, uint32_t bi) {
+        if (av != bv) return descending ? av > bv : av < bv;
+        return ai < bi;
+    };
+    float pv = descending ? __builtin_huge_valf() : -__builtin_huge_valf();  // "before everything"
+    uint32_t pi = 0;
+    bool first = true;
+    for (uint32_t t = 0; t < nn; ++t) {
+        float bv = worst;
+        uint32_t bi = 0xFFFFFFFFu;
+        for (uint64_t j = lane; j < ncols; j += 64) {
+            if (j == self) continue;
+            float x = v[j];
+            if (x != x) x = worst;
+            const uint32_t ji = (uint32_t)j;
+            if (!first && !before(pv, pi, x, ji)) continue;  // not after the previous pick
+            if (bi == 0xFFFFFFFFu || before(x, ji, bv, bi)) {
+                bv = x;
+                bi = ji;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const uint32_t oi = __shfl_xor(bi, d, 64);
+            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || before(ov, oi, bv, bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            idx_out[r * nn + t] = bi == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)(bi + col0);
+            val_out[r * nn + t] = bi == 0xFFFFFFFFu ? worst : v[bi];
+        }
+        pv = bv;
+        pi = bi;
+        first = false;
+        if (bi == 0xFFFFFFFFu) {  // fewer candidates than nn: fill the rest
+            for (uint32_t u = t + 1; u < nn; ++u)
+                if (lane == 0) {
+                    idx_out[r * nn + u] = 0xFFFFFFFFu;
+                    val_out[r * nn + u] = worst;
+                }
+            break;
+        }
+    }
+}
+
+hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
+                       uint64_t row0, uint64_t col0, int descending, uint32_t nn,
+                       int exclude_self, uint32_t *idx_out, float *val_out)
+{
+    if (rows == 0 || nn == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_topk, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, st, vals, rows,
+                       ncols, row0, col0, descending, nn, exclude_self, idx_out, val_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, double *card, int *vrange, uint32_t *exc,

@@ -115,6 +115,17 @@ int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64
 int dsh_dist_rect(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin,
                   uint64_t q_end, uint64_t r_begin, uint64_t r_end, float *out);
 
+/* ---- k nearest neighbours -------------------------------------------------------------------
+ * Replaces perform_nns / nndist_loop (src/sketch_and_cmp.h:642-783, --nearest-neighbors): for
+ * every query slot in [q_begin,q_end) the nn best reference slots in [r_begin,r_end) under
+ * result_type -- similarity measures best = largest, distances best = smallest (emt2nntype,
+ * src/dashing.h:268-280) -- best first; a query is never its own neighbour.  Ties are broken by the
+ * lower slot index (the reference's heap/thread order is unspecified).  idx_out/val_out: host
+ * arrays [q_end-q_begin][nn]; missing neighbours (nn larger than the candidates) get idx 0xFFFFFFFF.
+ * All-vs-all (nq == 0 in dashing): q = r = [0,n). */
+int dsh_knn(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin, uint64_t q_end,
+            uint64_t r_begin, uint64_t r_end, uint32_t nn, uint32_t *idx_out, float *val_out);
+
 /* ---- multi-GPU shards of the full triangle ------------------------------------------------
  * Every rank holds all sketches (dsh_upload/attach) and computes one shard; no collective is
  * needed inside the compare.  Internally the plane matrix is laid out in (threshold, min value)

@@ -452,4 +452,49 @@ void dsho_dist_rect(const uint8_t *qregs, uint64_t nq, const uint8_t *rregs, uin
     free(cr);
 }
 
+/* perform_nns (src/sketch_and_cmp.h:642-697) by brute force: for query i the nn best references
+ * j != i, best first; similarity measures descending, distances ascending (emt2nntype,
+ * src/dashing.h:268-280); ties by lower index (the reference's heap order is unspecified), NaN last. */
+void dsho_knn(const uint8_t *regs, uint64_t n, int p, int estim, int result_type, int k, uint64_t qb,
+              uint64_t qe, uint64_t rb, uint64_t re, uint32_t nn, uint32_t *idx_out, float *val_out)
+{
+    const uint64_t m = UINT64_C(1) << p;
+    const int descending = !(result_type == DSHO_MASH_DIST || result_type == DSHO_FULL_MASH_DIST ||
+                             result_type == DSHO_CONTAINMENT_DIST || result_type == DSHO_FULL_CONTAINMENT_DIST ||
+                             result_type == DSHO_SYMMETRIC_CONTAINMENT_DIST);
+    const float worst = descending ? -INFINITY : INFINITY;
+    double *card = (double *)malloc(sizeof(double) * (n ? n : 1));
+    dsho_cardinalities(regs, n, p, estim, card);
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
+    for (int64_t qi = (int64_t)qb; qi < (int64_t)qe; ++qi) {
+        const uint64_t nr = re > rb ? re - rb : 0;
+        float *row = (float *)malloc(sizeof(float) * (nr ? nr : 1));
+        uint8_t *used = (uint8_t *)calloc(nr ? nr : 1, 1);
+        for (uint64_t j = rb; j < re; ++j) {
+            float x = dsho_pair(regs + j * m, regs + (uint64_t)qi * m, card[j], card[qi], p, estim, result_type, k);
+            row[j - rb] = (x != x) ? worst : x;
+        }
+        for (uint32_t t = 0; t < nn; ++t) {
+            int64_t best = -1;
+            for (uint64_t j = 0; j < nr; ++j) {
+                if (used[j] || j + rb == (uint64_t)qi) continue;
+                if (best < 0 || (descending ? row[j] > row[best] : row[j] < row[best])) best = (int64_t)j;
+            }
+            uint32_t *io = idx_out + ((uint64_t)qi - qb) * nn + t;
+            float *vo = val_out + ((uint64_t)qi - qb) * nn + t;
+            if (best < 0) {
+                *io = 0xFFFFFFFFu;
+                *vo = worst;
+            } else {
+                used[best] = 1;
+                *io = (uint32_t)(best + rb);
+                *vo = dsho_pair(regs + ((uint64_t)best + rb) * m, regs + (uint64_t)qi * m, card[best + rb], card[qi], p, estim, result_type, k);
+            }
+        }
+        free(row);
+        free(used);
+    }
+    free(card);
+}
+
 int dsho_num_threads(void) { return nthreads_(); }

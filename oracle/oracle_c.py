@@ -83,6 +83,9 @@ def _bind(lib):
     lib.dsho_dist_rows.argtypes = [_u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _f32p]
     lib.dsho_dist_rect.restype = None
     lib.dsho_dist_rect.argtypes = [_u8p, C.c_uint64, _u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.dsho_knn.restype = None
+    lib.dsho_knn.argtypes = [_u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                             C.c_uint64, C.c_uint64, C.c_uint32, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), _f32p]
     lib.dsho_num_threads.restype = C.c_int
     return lib
 
@@ -204,6 +207,18 @@ def dist_rect(qregs, rregs, estim=ERTL_MLE, result_type=JI, k=31):
     out = np.zeros((q.shape[0], r.shape[0]), np.float32)
     load().dsho_dist_rect(q, q.shape[0], r, r.shape[0], int(q.shape[1]).bit_length() - 1, estim, result_type, k, out)
     return out
+
+
+def knn(regs, nn, qb=0, qe=None, rb=0, re=None, estim=ERTL_MLE, result_type=JI, k=31):
+    regs = np.ascontiguousarray(regs, np.uint8)
+    n, m = regs.shape
+    qe = n if qe is None else qe
+    re = n if re is None else re
+    idx = np.zeros((max(qe - qb, 0), nn), np.uint32)
+    val = np.zeros((max(qe - qb, 0), nn), np.float32)
+    if idx.size:
+        load().dsho_knn(regs, n, int(m).bit_length() - 1, estim, result_type, k, qb, qe, rb, re, nn, idx, val)
+    return idx, val
 
 
 def num_threads():

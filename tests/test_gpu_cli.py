@@ -184,6 +184,26 @@ def test_query_reference_and_containment(genomes, oracle, tmp_path):
     assert np.allclose(np.frombuffer(raw[9:], np.float32), oracle.dist_tri(regs[:4], 2, oracle.SIZES, 31), rtol=1e-6)
 
 
+def test_nearest_neighbors_cli(genomes, oracle, tmp_path):
+    d, paths, seqs = genomes
+    out = tmp_path / "nn.tsv"
+    run("dist", "--avoid-sorting", "--nearest-neighbors", 3, "-M", "-O", out, "-o", os.devnull, *paths)
+    regs = oracle_regs(oracle, seqs, 31, 10)
+    wi, wv = oracle.knn(regs, 3, result_type=oracle.MASH_DIST, k=31)
+    lines = out.read_text().split("\n")
+    assert lines[0] == "#File\tNeighbor ID:distance\t..."
+    for i, pth in enumerate(paths):
+        f = lines[1 + i].split("\t")
+        assert f[0] == pth and len(f) == 4
+        for j, cell in enumerate(f[1:]):
+            a, b = cell.split(":")
+            assert int(a) == wi[i, j] and abs(float(b) - float("%g" % wv[i, j])) <= 2e-6 * max(wv[i, j], 1e-9)
+    b = tmp_path / "nn.bin"
+    run("dist", "--avoid-sorting", "--nearest-neighbors", 2, "-b", "-O", b, "-o", os.devnull, *paths)
+    raw = b.read_bytes()
+    assert struct.unpack("<II", raw[:8]) == (len(paths), 2) and len(raw) == 8 + 8 * 2 * len(paths)
+
+
 def test_cli_rejects_out_of_scope(genomes):
     d, paths, seqs = genomes
     r = subprocess.run([CLI, "dist", "--use-bb-minhash", *paths], capture_output=True)

@@ -266,6 +266,30 @@ def test_adversarial_registers(ctx, oracle, p):
         ctx.set_option("sort", -1)
 
 
+@pytest.mark.parametrize("rt", [dashing_amd.JI, dashing_amd.MASH_DIST, dashing_amd.SYMMETRIC_CONTAINMENT_INDEX])
+def test_knn_vs_oracle(ctx, oracle, rt):
+    """--nearest-neighbors: k best per sketch, similarity descending / distance ascending, ties by
+    lower index (identical sketches and the empty sketch create exact ties)."""
+    n, p = 300, 10
+    regs = synth.synthetic_sketches(n, p, seed=55)
+    regs[7] = regs[8] = regs[9]
+    regs[20] = 0
+    ctx.set_sketches(regs)
+    for nn in (1, 5, 64):
+        wi, wv = oracle.knn(regs, nn, result_type=rt, k=21)
+        gi, gv = ctx.knn(nn, result_type=rt, k=21)
+        assert (gi == wi).all(), (rt, nn, np.argwhere(gi != wi)[:5])
+        assert np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
+    # all neighbours (nn = n-1) and more than exist
+    gi, gv = ctx.knn(n + 5, result_type=rt, k=21)
+    assert (gi[:, n - 1 :] == 0xFFFFFFFF).all() and (gi[:, : n - 1] != 0xFFFFFFFF).all()
+    assert all(sorted(row[: n - 1].tolist()) == [j for j in range(n) if j != i] for i, row in enumerate(gi[:10]))
+    # queries x references
+    wi, wv = oracle.knn(regs, 3, qb=200, qe=300, rb=0, re=200, result_type=rt, k=21)
+    gi, gv = ctx.knn(3, 200, 300, 0, 200, result_type=rt, k=21)
+    assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)
