@@ -3,6 +3,7 @@ hot path.  The product is libdashing_hip.so (C-ABI in include/dashing_hip.h) and
 dashing-amd CLI; this package is the thin ctypes binding used by tests and bench.py."""
 from .api import (  # noqa: F401
     Context,
+    PinnedArray,
     DshError,
     ESTIM_ORIGINAL,
     ESTIM_ERTL_IMPROVED,

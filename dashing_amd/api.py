@@ -23,7 +23,7 @@ SYMBOLS = [
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
-    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows",
+    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -78,6 +78,10 @@ def load_library():
     lib.dsh_tri_index.argtypes = [u64, u64, u64]
     lib.dsh_tri_index.restype = u64
     lib.dsh_partition_rows.argtypes = [u64, C.c_uint32, C.c_uint32, vp]
+    lib.dsh_alloc_host.argtypes = [C.c_size_t]
+    lib.dsh_alloc_host.restype = vp
+    lib.dsh_free_host.argtypes = [vp]
+    lib.dsh_free_host.restype = None
     lib.dsh_set_profiling.argtypes = [vp, i32]
     lib.dsh_last_kernel_ms.argtypes = [vp, vp, vp, vp, vp]
     lib.dsh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -111,6 +115,24 @@ def partition_rows(n, nparts, align=128):
     if rc:
         raise DshError(rc, "dsh_partition_rows")
     return [int(x) for x in b]
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (dsh_alloc_host); keep the object alive while in use."""
+
+    def __init__(self, n, dtype=np.float32):
+        self._lib = load_library()
+        nbytes = max(int(n), 1) * np.dtype(dtype).itemsize
+        self._p = self._lib.dsh_alloc_host(nbytes)
+        if not self._p:
+            raise MemoryError("dsh_alloc_host(%d) failed" % nbytes)
+        buf = (C.c_char * nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=max(int(n), 1))
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._lib.dsh_free_host(self._p)
+            self._p = None
 
 
 class Context:
@@ -196,10 +218,11 @@ class Context:
         self._ck(self._lib.dsh_cardinalities(self._h, estim, out.ctypes.data))
         return out[: self.n]
 
-    def dist_rows(self, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+    def dist_rows(self, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31, out=None):
         row_end = self.n if row_end is None else row_end
         span = tri_span(self.n, row_begin, row_end)
-        out = np.zeros(max(span, 1), np.float32)
+        if out is None:
+            out = np.zeros(max(span, 1), np.float32)
         self._ck(self._lib.dsh_dist_rows(self._h, estim, result_type, k, row_begin, row_end, out.ctypes.data))
         return out[:span]
 

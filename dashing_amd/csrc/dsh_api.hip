@@ -931,6 +931,18 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     return DSH_OK;
 }
 
+void *dsh_alloc_host(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void dsh_free_host(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int dsh_set_profiling(dsh_ctx *c, int enable)
 {
     if (!c) return DSH_EINVAL;

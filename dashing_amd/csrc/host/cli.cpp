@@ -277,12 +277,20 @@ static int dist_main(int argc, char **argv)
     if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
     DSH(ctx, dsh_sketches_alloc(ctx, n, o.S));
     if (o.presketched) {  // sketch.read(path), src/sketch_and_cmp.h:318-324
-        std::vector<uint8_t> r;
-        for (size_t i = 0; i < n; ++i) {
-            int p = 0;
-            if (read_hll(o.inpaths[i], r, p)) die("Could not read sketch %s", o.inpaths[i].c_str());
-            if (p != o.S) die("Sketch %s has p=%d but -S is %d", o.inpaths[i].c_str(), p, o.S);
-            DSH(ctx, dsh_upload_sketches(ctx, r.data(), i, 1));
+        // read on all host threads into a staging matrix, upload in batches
+        const size_t m = (size_t)1 << o.S, batch = std::max<size_t>(1, ((size_t)256 << 20) / m);
+        std::vector<uint8_t> stage(std::min(n, batch) * m);
+        for (size_t b0 = 0; b0 < n; b0 += batch) {
+            const size_t b1 = std::min(n, b0 + batch);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(o.nthreads)
+            for (int64_t i = (int64_t)b0; i < (int64_t)b1; ++i) {
+                int p = 0;
+                std::vector<uint8_t> r;
+                if (read_hll(o.inpaths[i], r, p)) die("Could not read sketch %s", o.inpaths[i].c_str());
+                if (p != o.S) die("Sketch %s has p=%d but -S is %d", o.inpaths[i].c_str(), p, o.S);
+                std::memcpy(stage.data() + (size_t)(i - (int64_t)b0) * m, r.data(), m);
+            }
+            DSH(ctx, dsh_upload_sketches(ctx, stage.data(), b0, b1 - b0));
         }
     } else {
         fill_sketches(ctx, o, /*write_files=*/o.cache != 0, false);
@@ -360,7 +368,11 @@ static int dist_main(int argc, char **argv)
         // row blocks of <= 64 Mi values, two ping-pong buffers: the GPU computes block b+1 while a
         // writer thread emits block b (as dist_loop does with dps[i & 1], src/sketch_and_cmp.h:804-816)
         const uint64_t block_vals = (uint64_t)64 << 20;
-        std::vector<float> bufs[2];
+        // page-locked ping-pong buffers: the D2H copy of a block is then a direct DMA
+        float *bufs[2] = {nullptr, nullptr};
+        const uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(block_vals + n, std::max<uint64_t>(total, 1)), 1);
+        for (auto &b : bufs)
+            if (!(b = (float *)dsh_alloc_host(cap * sizeof(float)))) die("could not allocate %llu bytes of pinned host memory", (unsigned long long)(cap * sizeof(float)));
         std::thread writer;
         int which = 0;
         uint64_t rb = 0;
@@ -368,25 +380,32 @@ static int dist_main(int argc, char **argv)
             uint64_t re = rb + 1;
             while (re < n && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
             const uint64_t span = dsh_tri_span(n, rb, re);
-            std::vector<float> &buf = bufs[which];
-            buf.resize(std::max<uint64_t>(span, 1));
-            DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, rb, re, buf.data()));
+            float *buf = bufs[which];
+            DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, rb, re, buf));
             if (writer.joinable()) writer.join();
-            writer = std::thread([&o, &buf, pairofp, rb, re, n, span]() {
+            writer = std::thread([&o, buf, pairofp, rb, re, n, span]() {
                 if (o.fmt == BINARY) {
-                    if (span && std::fwrite(buf.data(), sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
-                } else {
-                    uint64_t off = 0;
-                    for (uint64_t i = rb; i < re; ++i) {
-                        emit_ut_row(pairofp, o.fmt, o.inpaths, i, buf.data() + off);
-                        off += n - i - 1;
-                    }
+                    if (span && std::fwrite(buf, sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
+                    return;
+                }
+                // format rows on all host threads (snprintf dominates text output), write in order
+                std::vector<uint64_t> off(re - rb + 1, 0);
+                for (uint64_t i = rb; i < re; ++i) off[i - rb + 1] = off[i - rb] + (n - i - 1);
+                const uint64_t group = 64;
+                for (uint64_t g0 = rb; g0 < re; g0 += group * (uint64_t)o.nthreads) {
+                    const uint64_t g1 = std::min<uint64_t>(re, g0 + group * (uint64_t)o.nthreads);
+                    std::vector<std::string> rows(g1 - g0);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads)
+                    for (int64_t i = (int64_t)g0; i < (int64_t)g1; ++i)
+                        format_ut_row(rows[i - g0], o.fmt, o.inpaths, (size_t)i, buf + off[i - rb]);
+                    for (auto &r : rows) std::fwrite(r.data(), 1, r.size(), pairofp);
                 }
             });
             which ^= 1;
             rb = re;
         }
         if (writer.joinable()) writer.join();
+        for (auto &b : bufs) dsh_free_host(b);
     }
     std::fflush(pairofp);
     if (pairofp != stdout) std::fclose(pairofp);

@@ -209,8 +209,15 @@ void emit_header(std::FILE *fp, int fmt, const std::vector<std::string> &paths)
 
 void emit_ut_row(std::FILE *fp, int fmt, const std::vector<std::string> &paths, size_t i, const float *row)
 {
+    std::string s;
+    format_ut_row(s, fmt, paths, i, row);
+    std::fwrite(s.data(), 1, s.size(), fp);
+}
+
+void format_ut_row(std::string &s, int fmt, const std::vector<std::string> &paths, size_t i, const float *row)
+{
     const size_t n = paths.size();
-    std::string s(paths[i]);
+    s = paths[i];
     if (fmt == UT_TSV) {
         for (size_t k = 0; k < i + 1; ++k) s += "\t-";
     } else if (s.size() < 9) {
@@ -222,7 +229,6 @@ void emit_ut_row(std::FILE *fp, int fmt, const std::vector<std::string> &paths, 
         s.append(num, (size_t)len);
     }
     s += '\n';
-    std::fwrite(s.data(), 1, s.size(), fp);
 }
 
 void emit_full_header(std::FILE *fp, const std::vector<std::string> &paths)

@@ -52,6 +52,9 @@ void emit_header(std::FILE *fp, int fmt, const std::vector<std::string> &paths);
 // name, then (i+1) x "\t-" (UT_TSV) or padding to 9 chars (PHYLIP), then "\t%.6g" per value.
 void emit_ut_row(std::FILE *fp, int fmt, const std::vector<std::string> &paths, size_t i,
                  const float *row /* n-i-1 values */);
+// same row rendered into a string (lets the CLI format many rows on parallel host threads)
+void format_ut_row(std::string &out, int fmt, const std::vector<std::string> &paths, size_t i,
+                   const float *row);
 // FULL_TSV (src/sketch_and_cmp.h:851-877): "#Names" + names; rows "<name>\t" + n x "%0.6g".
 void emit_full_header(std::FILE *fp, const std::vector<std::string> &paths);
 void emit_full_row(std::FILE *fp, const std::vector<std::string> &paths, size_t i,

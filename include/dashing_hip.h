@@ -153,6 +153,12 @@ uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j);
  * bounds_out[0..nparts] receives the boundaries (bounds_out[0]=0, bounds_out[nparts]=n). */
 int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds_out);
 
+/* Page-locked host memory for the host-buffer entry points (dsh_dist_rows, dsh_upload_sketches,
+ * dsh_sketch_batch): with such buffers the copies are direct DMA at PCIe rate instead of going
+ * through the runtime's staging of pageable memory.  Optional -- any host pointer works. */
+void *dsh_alloc_host(size_t bytes);
+void dsh_free_host(void *p);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 /* Milliseconds spent in the dominant kernel (all-pairs AND+popcount) during the last
  * dsh_dist_* call on this ctx, measured with HIP events on the ctx stream; launches = number
