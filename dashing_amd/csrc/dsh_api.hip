@@ -49,7 +49,7 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
-    DevBuf card, vrange, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm;
+    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm;
     int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
     std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
@@ -145,22 +145,25 @@ int prepare(dsh_ctx *c, int estim, int want_sorted)
         HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
         HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
         HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
-        HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint16_t)));
-        HIPCHK(c, c->vrange.ensure(3 * sizeof(int)));
-        const int init[3] = {63, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(c->vrange.ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
-                                       (double *)c->card.ptr, (int *)c->vrange.ptr,
-                                       (uint32_t *)c->exc.ptr, (uint32_t *)c->exc_n.ptr,
-                                       (uint16_t *)c->keys.ptr));
+                                       (double *)c->card.ptr, (uint32_t *)c->exc.ptr,
+                                       (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr));
         c->card_estim = estim;
     }
     if (!c->planes_valid || c->planes_sorted != want_sorted) {
-        int vr[3] = {0, 0, 0};
+        int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
+        std::vector<uint32_t> k32(n);
         c->hkeys.resize(n);
-        HIPCHK(c, hipMemcpyAsync(vr, c->vrange.ptr, sizeof vr, hipMemcpyDeviceToHost, c->stream));
-        if (n) HIPCHK(c, hipMemcpyAsync(c->hkeys.data(), c->keys.ptr, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+        if (n) HIPCHK(c, hipMemcpyAsync(k32.data(), c->keys.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t key = k32[i];
+            vr[0] = std::min<int>(vr[0], (int)(key & 0xFF));
+            vr[1] = std::max<int>(vr[1], (int)(key >> 16));
+            vr[2] = std::max<int>(vr[2], (int)((key >> 8) & 0xFF));
+            c->hkeys[i] = (uint16_t)(key & 0xFFFF);
+        }
         if (n == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
         c->vhi = vr[1];
@@ -466,7 +469,6 @@ void dsh_destroy(dsh_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->regs_own.release();
     c->card.release();
-    c->vrange.release();
     c->planes.release();
     c->exc.release();
     c->exc_n.release();

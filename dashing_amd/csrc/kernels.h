@@ -9,8 +9,8 @@ constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
 constexpr uint32_t kExcCap = 64;  // capacity of a sketch's exception list (entries)
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, int *vrange, uint32_t *exc,
-                                uint32_t *exc_n, uint16_t *keys);
+                                int emax, double *card, uint32_t *exc, uint32_t *exc_n,
+                                uint32_t *keys);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
                             const uint32_t *perm);

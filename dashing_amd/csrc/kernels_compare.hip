@@ -36,14 +36,12 @@ namespace dsh {
 
 // ------------------------------------------------------------------------------------------
 // per-sketch pass.  block = 256 threads = 4 waves, one sketch per wave.
-// vrange[0] = min register value over all sketches, [1] = max, [2] = max threshold T_i.
 __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs,
                                                         uint64_t n, int p, int estim, int emax,
                                                         double *__restrict__ card,
-                                                        int *__restrict__ vrange,
                                                         uint32_t *__restrict__ exc,
                                                         uint32_t *__restrict__ exc_n,
-                                                        uint16_t *__restrict__ keys)
+                                                        uint32_t *__restrict__ keys)
 {
     __shared__ uint32_t hist[4][64];
     __shared__ uint32_t sub[4][8][64];  // 8 privatised copies per wave: the register values pile up
@@ -56,10 +54,19 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     __syncthreads();
     const uint64_t m = 1ull << p;
     const uint4 *src = reinterpret_cast<const uint4 *>(regs + (s < n ? s : 0) * m);
+    const uint64_t nch = m >> 4;  // 16-byte chunks of this sketch
+    // the first kRegCache*64 chunks (the whole sketch for p <= 14) are loaded once, all loads in
+    // flight together, and reused by the second pass; larger sketches re-read the remainder
+    constexpr int kRegCache = 16;
+    uint4 cache[kRegCache];
+#pragma unroll
+    for (int k = 0; k < kRegCache; ++k) {
+        const uint64_t c = (uint64_t)k * 64 + lane;
+        cache[k] = (s < n && c < nch) ? src[c] : make_uint4(0, 0, 0, 0);
+    }
     if (s < n) {
         uint32_t *mysub = sub[wave][lane & 7];
-        for (uint64_t c = lane; c < (m >> 4); c += 64) {
-            const uint4 x = src[c];
+        auto count16 = [mysub](const uint4 x) {
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -68,7 +75,11 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                 atomicAdd(&mysub[(w[k] >> 16) & 63], 1u);
                 atomicAdd(&mysub[(w[k] >> 24) & 63], 1u);
             }
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < kRegCache; ++k)
+            if ((uint64_t)k * 64 + lane < nch) count16(cache[k]);
+        for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) count16(src[c]);
     }
     __syncthreads();
     {
@@ -94,10 +105,9 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         }
         thr[wave] = T;
         exc_n[s] = cnt;
-        keys[s] = (uint16_t)((T << 8) | lo);  // sort key / per-block plane range: (threshold, min value)
-        atomicMin(&vrange[0], lo);
-        atomicMax(&vrange[1], hi);
-        atomicMax(&vrange[2], T);
+        // (max value, threshold, min value): the host derives the global value range from these (no
+        // same-address global atomics: 3 x N of them cost ~12 ns each) and sorts columns by the low 16 bits
+        keys[s] = ((uint32_t)hi << 16) | ((uint32_t)T << 8) | (uint32_t)lo;
     }
     __syncthreads();
     if (s >= n || emax == 0) return;
@@ -105,18 +115,15 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     const uint32_t T = (uint32_t)thr[wave];
     uint32_t *dst = exc + s * kExcCap;
     uint32_t base = 0;
-    for (uint64_t c0 = 0; c0 < (m >> 4); c0 += 64) {
-        const uint64_t c = c0 + lane;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (c < (m >> 4)) {
-            const uint4 x = src[c];
-            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
-        }
+    auto emit16 = [&](const uint4 x, uint64_t c, bool inrange) {
+        uint32_t w[4] = {x.x, x.y, x.z, x.w};
         uint32_t mine = 0;
+        if (inrange) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) mine += ((w[k] >> (8 * b)) & 0xFFu) > T;
+                for (int b = 0; b < 4; ++b) mine += ((w[k] >> (8 * b)) & 0xFFu) > T;
+        }
         // inclusive prefix sum over the wave
         uint32_t incl = mine;
 #pragma unroll
@@ -136,6 +143,16 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                 }
         }
         base += total;
+    };
+#pragma unroll
+    for (int k = 0; k < kRegCache; ++k) {
+        if ((uint64_t)k * 64 >= nch) break;  // uniform
+        const uint64_t c = (uint64_t)k * 64 + lane;
+        emit16(cache[k], c, c < nch);
+    }
+    for (uint64_t c0 = (uint64_t)kRegCache * 64; c0 < nch; c0 += 64) {
+        const uint64_t c = c0 + lane;
+        emit16(c < nch ? src[c] : make_uint4(0, 0, 0, 0), c, c < nch);
     }
 }
 
@@ -584,13 +601,13 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, int *vrange, uint32_t *exc,
-                                uint32_t *exc_n, uint16_t *keys)
+                                int emax, double *card, uint32_t *exc, uint32_t *exc_n,
+                                uint32_t *keys)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
     hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                       card, vrange, exc, exc_n, keys);
+                       card, exc, exc_n, keys);
     return hipGetLastError();
 }
 
