@@ -77,39 +77,78 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
     return (a & mask) | (b & ~mask);
 }
 
+// windows of k consecutive valid bases: bit j of the result is set iff bits j..j+k-1 of V are set
+// (binary decomposition of k: log2(k) doubling steps + one AND per set bit of k)
+__device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
+{
+    uint64_t run = V;      // runs of length `len`
+    uint64_t acc = ~0ull;  // AND of the pieces taken so far
+    int len = 1, off = 0;
+    for (int bit = 0; bit < 6; ++bit) {
+        if (k & (1 << bit)) {
+            acc &= run >> off;
+            off += len;
+        }
+        run &= run >> len;
+        len <<= 1;
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, int canon, uint8_t *__restrict__ regs)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lregs[];  // 2^p bytes
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // [0, 2^p/4): registers as packed bytes; then the packed words of the current sub-chunk, one
+    // slot per lane plus one for the 32 bases that follow it (each lane needs its right neighbour)
     const int tid = threadIdx.x;
-    const SketchWork wk = work[blockIdx.x];
     const uint32_t mwords = (1u << p) >> 2;
+    uint32_t *lregs = lds;
+    uint64_t *xF = reinterpret_cast<uint64_t *>(lds + ((mwords + 3) & ~3u));
+    uint64_t *xR = xF + 260;
+    uint32_t *xV = reinterpret_cast<uint32_t *>(xR + 260);
+    const SketchWork wk = work[blockIdx.x];
     for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = 0;
-    __syncthreads();
 
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    const uint64_t vk = k == 32 ? 0xFFFFFFFFull : ((1ull << k) - 1);
     const int fshift = 64 - 2 * k;
 
-    for (uint32_t s = 0; s < wk.nsub; ++s) {
-        const uint64_t B = wk.start + (uint64_t)s * kSketchSub + (uint64_t)tid * 32;
-        if (B >= wk.gend) continue;
+    // pack the 32 bases at absolute offset B (bases outside [gbeg,gend) are invalid)
+    auto pack_at = [&](uint64_t B, uint64_t &F, uint64_t &R, uint32_t &V) {
+        F = 0; R = 0; V = 0;
+        if (B >= wk.gend) return;
         const uint4 *src = reinterpret_cast<const uint4 *>(seq + B);
-        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-        uint64_t F0, R0, F1, R1;
-        uint32_t V0, V1;
-        pack32(q0, q1, F0, R0, V0);
-        pack32(q2, q3, F1, R1, V1);
-        // bases outside [gbeg,gend) are invalid
+        pack32(src[0], src[1], F, R, V);
         const uint64_t lo = wk.gbeg > B ? wk.gbeg - B : 0;
         const uint64_t hi = wk.gend - B;  // > 0
-        uint64_t rmask = hi >= 64 ? ~0ull : ((1ull << hi) - 1);
-        rmask = lo >= 64 ? 0ull : (rmask & ~((1ull << lo) - 1));
-        const uint64_t V = ((uint64_t)V0 | ((uint64_t)V1 << 32)) & rmask;
+        uint32_t rmask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1);
+        rmask = lo >= 32 ? 0u : (rmask & ~((1u << lo) - 1));
+        V &= rmask;
+    };
+
+    for (uint32_t s = 0; s < wk.nsub; ++s) {
+        const uint64_t B0 = wk.start + (uint64_t)s * kSketchSub;
+        const uint64_t B = B0 + (uint64_t)tid * 32;
+        uint64_t F0, R0;
+        uint32_t V0;
+        pack_at(B, F0, R0, V0);
+        __syncthreads();  // previous sub-chunk's neighbour reads (and the register clear) are done
+        xF[tid] = F0; xR[tid] = R0; xV[tid] = V0;
+        if (tid < 64) {  // one extra slot: the 32 bases after this sub-chunk (lane 0 of wave 0)
+            uint64_t Fe, Re;
+            uint32_t Ve;
+            pack_at(B0 + kSketchSub, Fe, Re, Ve);
+            if (tid == 0) { xF[256] = Fe; xR[256] = Re; xV[256] = Ve; }
+        }
+        __syncthreads();
+        const uint64_t F1 = xF[tid + 1], R1 = xR[tid + 1];
+        const uint64_t V = (uint64_t)V0 | ((uint64_t)xV[tid + 1] << 32);
+        const uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
+        if (ok == 0) continue;  // (barriers are at the top of the loop body: safe to skip the rest)
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            if (((V >> j) & vk) != vk) continue;
+            if (!(ok & (1u << j))) continue;
             const uint64_t fh = j ? ((F0 << (2 * j)) | (F1 >> (64 - 2 * j))) : F0;
             const uint64_t rl = j ? ((R0 >> (2 * j)) | (R1 << (64 - 2 * j))) : R0;
             const uint64_t fw = fh >> fshift;
@@ -150,7 +189,8 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs)
 {
     if (nwork == 0) return hipSuccess;
-    const size_t lds = (size_t)1 << p;
+    // registers (2^p bytes, 16-byte aligned) + 260 x (F, R) + 260 x V exchange slots
+    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + 260 * 16 + 260 * 4 + 16;
     if (lds > (48u << 10)) {  // per launch: the attribute is per device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
