@@ -57,7 +57,8 @@ static void usage(const char *sub)
         "  -F, --paths FILE         file with one genome path per line\n"
         "  -P, --prefix DIR / -x, --suffix STR   sketch cache location / name suffix\n"
         "  -C, --no-canon           do not canonicalise k-mers\n"
-        "  --device INT             GPU ordinal [0]\n", kVersion, sub);
+        "  --device INT             GPU ordinal [0]\n"
+        "  --ngpus INT | --devices a,b,..  (dist, -b only) share the rows of the matrix between several GPUs\n", kVersion, sub);
     if (!std::strcmp(sub, "sketch")) {
         std::fprintf(stderr, "  -c, --skip-cached        skip genomes whose .hll already exists\n");
     } else {
@@ -79,11 +80,12 @@ struct Opts {
     int estim = ERTL_MLE, result_type = JI, fmt = UT_TSV;
     int cache = 0, presketched = 0, avoid_sorting = 0, skip_cached = 0;
     unsigned nneighbors = 0;  // --nearest-neighbors
+    std::vector<int> devices;  // --devices a,b,... / --ngpus G: GPUs sharing the all-pairs rows (binary output)
     std::string paths_file, prefix, suffix, spacing, out_sizes, out_dists;
     std::vector<std::string> inpaths, querypaths;
 };
 
-enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_NN, OPT_UNSUPPORTED };
+enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_NN, OPT_NGPUS, OPT_DEVICES, OPT_UNSUPPORTED };
 
 static Opts parse(int argc, char **argv, bool is_dist)
 {
@@ -102,6 +104,7 @@ static Opts parse(int argc, char **argv, bool is_dist)
         {"ertl-mle", no_argument, nullptr, 'm'}, {"cache-sketches", no_argument, nullptr, 'W'},
         {"presketched", no_argument, nullptr, OPT_PRESKETCHED}, {"avoid-sorting", no_argument, nullptr, OPT_AVOID_SORT},
         {"skip-cached", no_argument, nullptr, 'c'}, {"device", required_argument, nullptr, OPT_DEVICE},
+        {"ngpus", required_argument, nullptr, OPT_NGPUS}, {"devices", required_argument, nullptr, OPT_DEVICES},
         {"nperbatch", required_argument, nullptr, OPT_NPERBATCH}, {"spacing", required_argument, nullptr, 's'},
         {"window-size", required_argument, nullptr, 'w'}, {"help", no_argument, nullptr, 'h'},
         {"use-bb-minhash", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-range-minhash", no_argument, nullptr, OPT_UNSUPPORTED},
@@ -140,6 +143,22 @@ static Opts parse(int argc, char **argv, bool is_dist)
         case OPT_AVOID_SORT: o.avoid_sorting = 1; break;
         case 'c': o.skip_cached = 1; break;
         case OPT_DEVICE: o.device = std::atoi(optarg); break;
+        case OPT_NGPUS: {
+            const int g = std::atoi(optarg);
+            if (g < 1) die("--ngpus needs a positive count");
+            o.devices.clear();
+            for (int d = 0; d < g; ++d) o.devices.push_back(o.device + d);
+            break;
+        }
+        case OPT_DEVICES: {  // explicit list; a device may repeat (used to test the sharding on one GPU)
+            o.devices.clear();
+            for (const char *q = optarg; *q;) {
+                o.devices.push_back(std::atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            break;
+        }
         case OPT_NPERBATCH: case 'e': break;  // accepted, no effect here
         case 's': if (optarg && *optarg) die("spaced seeds are out of scope (HLL hot path only)"); break;
         case 'w': if (std::atoi(optarg) > 0) die("minimizer windows are out of scope (HLL hot path only)"); break;
@@ -354,6 +373,49 @@ static int dist_main(int argc, char **argv)
                 }
             }
         }
+    } else if (o.fmt == BINARY && o.devices.size() > 1 && !o.out_dists.empty()) {
+        // Several GPUs of one node: every device holds all sketches, device d computes the row range
+        // dsh_partition_rows gives it (near-equal pair counts, 128-row boundaries) and writes its
+        // contiguous span of the packed matrix straight into the output file.
+        if (write_binary_header(pairofp, n)) die("Failure");
+        std::fflush(pairofp);
+        const int fd = ::fileno(pairofp);
+        if (::ftruncate(fd, (off_t)(9 + total * sizeof(float)))) die("could not size %s", o.out_dists.c_str());
+        const size_t G = o.devices.size(), m = (size_t)1 << o.S;
+        std::vector<uint8_t> all(n * m);
+        DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
+        std::vector<uint64_t> bounds(G + 1);
+        if (dsh_partition_rows(n, (uint32_t)G, 128, bounds.data())) die("dsh_partition_rows failed");
+        std::vector<std::thread> workers;
+        for (size_t d = 0; d < G; ++d)
+            workers.emplace_back([&, d]() {
+                dsh_ctx *c = ctx;
+                if (d > 0) {
+                    if (int rc = dsh_create(o.devices[d], &c)) die("[dashing-amd] dsh_create(device %d) = %d", o.devices[d], rc);
+                    DSH(c, dsh_sketches_alloc(c, n, o.S));
+                    DSH(c, dsh_upload_sketches(c, all.data(), 0, n));
+                }
+                const uint64_t block_vals = (uint64_t)64 << 20;
+                float *buf = (float *)dsh_alloc_host((block_vals + n) * sizeof(float));
+                if (!buf) die("could not allocate pinned host memory");
+                for (uint64_t rb = bounds[d]; rb < bounds[d + 1];) {
+                    uint64_t re = rb + 1;
+                    while (re < bounds[d + 1] && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
+                    const uint64_t span = dsh_tri_span(n, rb, re);
+                    DSH(c, dsh_dist_rows(c, o.estim, o.result_type, o.k, rb, re, buf));
+                    const off_t pos = (off_t)(9 + dsh_tri_span(n, 0, rb) * sizeof(float));
+                    size_t done = 0;
+                    while (done < span * sizeof(float)) {
+                        const ssize_t w = ::pwrite(fd, (const char *)buf + done, span * sizeof(float) - done, pos + (off_t)done);
+                        if (w <= 0) die("Failed to write rows to disk");
+                        done += (size_t)w;
+                    }
+                    rb = re;
+                }
+                dsh_free_host(buf);
+                if (d > 0) dsh_destroy(c);
+            });
+        for (auto &w : workers) w.join();
     } else if (o.fmt == FULL_TSV) {
         std::vector<float> tri(std::max<uint64_t>(total, 1));
         DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, 0, n, tri.data()));

@@ -204,6 +204,41 @@ def test_nearest_neighbors_cli(genomes, oracle, tmp_path):
     assert struct.unpack("<II", raw[:8]) == (len(paths), 2) and len(raw) == 8 + 8 * 2 * len(paths)
 
 
+def test_multi_device_binary_matches_single(genomes, tmp_path):
+    """--devices shares the rows between contexts (here two contexts on GPU 0, as on a box with one
+    GPU): the file must be byte-identical to the single-device one."""
+    d, paths, seqs = genomes
+    a, b, c = tmp_path / "one.bin", tmp_path / "two.bin", tmp_path / "three.bin"
+    run("dist", "-b", "--avoid-sorting", "-O", a, "-o", os.devnull, *paths)
+    run("dist", "-b", "--avoid-sorting", "--devices", "0,0", "-O", b, "-o", os.devnull, *paths)
+    run("dist", "-b", "--avoid-sorting", "--devices", "0,0,0", "-M", "-O", c, "-o", os.devnull, *paths)
+    assert a.read_bytes() == b.read_bytes()
+    assert len(c.read_bytes()) == len(a.read_bytes())
+
+
+def test_multi_device_presketched_large(oracle, tmp_path):
+    """700 presketched sketches (several 128-row tile rows per device): 3 contexts vs 1, and vs the oracle."""
+    import ctypes as C
+
+    n, p = 700, 11
+    regs = synth.synthetic_sketches(n, p, seed=2024)
+    host = C.CDLL(os.path.join(ROOT, "dashing_amd", "libdashing_host.so"))
+    host.dshh_write_hll.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    paths = []
+    for i in range(n):
+        pth = str(tmp_path / ("s%04d.hll" % i))
+        assert host.dshh_write_hll(pth.encode(), regs[i].ctypes.data, p, 2) == 0
+        paths.append(pth)
+    lst = tmp_path / "l.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    one, three = tmp_path / "1.bin", tmp_path / "3.bin"
+    run("dist", "--presketched", "-S", p, "-b", "-p", 8, "-O", one, "-o", os.devnull, "-F", lst)
+    run("dist", "--presketched", "-S", p, "-b", "-p", 8, "--devices", "0,0,0", "-O", three, "-o", os.devnull, "-F", lst)
+    assert one.read_bytes() == three.read_bytes()
+    got = np.frombuffer(one.read_bytes()[9:], np.float32)
+    assert np.allclose(got, oracle.dist_tri(regs), rtol=1e-6, atol=1e-12)
+
+
 def test_cli_rejects_out_of_scope(genomes):
     d, paths, seqs = genomes
     r = subprocess.run([CLI, "dist", "--use-bb-minhash", *paths], capture_output=True)
