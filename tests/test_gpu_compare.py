@@ -134,7 +134,7 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
     finally:
-        ctx.set_option("kc", 32)
+        ctx.set_option("kc", 16)
         ctx.set_option("emax", -1)
         ctx.set_option("sort", -1)
         ctx.set_option("nsplit", 0)
