@@ -196,6 +196,8 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
     const size_t m = (size_t)1 << o.S;
     const size_t batch_bytes = (size_t)512 << 20;
     std::vector<uint8_t> row(m);
+    uint8_t *pin = nullptr;  // page-locked staging buffer for a batch of sequence, reused
+    size_t pin_cap = 0;
     size_t g = 0;
     while (g < n) {
         // decide the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
@@ -218,10 +220,11 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
                 if (append_fastx(f, seqs[i]) < 0) die("Could not open %s", f.c_str());
             }
         }
-        // upload cached sketches, sketch the rest
-        std::vector<uint8_t> seq;
+        // upload cached sketches; lay the parsed genomes out back to back ('N' after each) in one
+        // page-locked buffer (parallel copies) so the host->device transfer is a single direct DMA
         std::vector<uint64_t> off;
-        std::vector<size_t> slot_of;
+        std::vector<size_t> slot_of, src_of;
+        uint64_t tot = 0;
         for (size_t i = 0; i < nb; ++i) {
             if (cached[i]) {
                 if (skip_cached) continue;  // `sketch -c`: nothing to do for this genome
@@ -230,23 +233,32 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
                 if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
                 DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
             } else {
-                off.push_back(seq.size());
-                seq.insert(seq.end(), seqs[i].begin(), seqs[i].end());
-                seq.push_back('N');
+                off.push_back(tot);
+                tot += seqs[i].size() + 1;
                 slot_of.push_back(g + i);
-                std::vector<uint8_t>().swap(seqs[i]);
+                src_of.push_back(i);
             }
         }
+        off.push_back(tot);
         if (!slot_of.empty()) {
+            if (tot > pin_cap) {
+                dsh_free_host(pin);
+                pin_cap = tot + (tot >> 3);
+                if (!(pin = (uint8_t *)dsh_alloc_host(pin_cap))) die("could not allocate %zu bytes of pinned host memory", pin_cap);
+            }
+#pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
+            for (long t = 0; t < (long)slot_of.size(); ++t) {
+                std::vector<uint8_t> &sv = seqs[src_of[t]];
+                if (!sv.empty()) std::memcpy(pin + off[t], sv.data(), sv.size());
+                pin[off[t] + sv.size()] = 'N';  // an invalid base closes every span: harmless
+                std::vector<uint8_t>().swap(sv);
+            }
             // consecutive runs of slots go in one call each
             size_t r0 = 0;
             while (r0 < slot_of.size()) {
                 size_t r1 = r0 + 1;
                 while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
-                std::vector<uint64_t> o2(off.begin() + r0, off.begin() + r1);
-                o2.push_back(r1 < off.size() ? off[r1] : seq.size());
-                // (each span ends with its 'N' separator: an invalid base, harmless)
-                DSH(ctx, dsh_sketch_batch(ctx, seq.data(), o2.data(), (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon, nullptr));
+                DSH(ctx, dsh_sketch_batch(ctx, pin, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon, nullptr));
                 r0 = r1;
             }
             if (write_files) {
@@ -259,6 +271,7 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
         }
         g = e;
     }
+    dsh_free_host(pin);
 }
 
 static int sketch_main(int argc, char **argv)

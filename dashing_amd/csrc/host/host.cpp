@@ -71,22 +71,40 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out)
     gzbuffer(fp, 1 << 20);
     std::vector<char> buf(1 << 20);
     long nrec = 0;
-    // line-oriented state machine: 0 = expect header, 1 = sequence lines, 2 = quality lines
+    // line-oriented state machine: 0 = expect header, 1 = sequence lines, 2 = quality lines;
+    // whole line pieces are appended at once (memchr for the newline), not byte by byte
     int state = 0;
     bool at_line_start = true, skipping_line = false;
     size_t seq_len = 0, qual_len = 0;
+    auto take = [&](const char *p, size_t len) {  // a piece of a line's content
+        if (skipping_line || len == 0) return;
+        if (std::memchr(p, '\r', len)) {  // rare: strip carriage returns the slow way
+            for (size_t t = 0; t < len; ++t) {
+                if (p[t] == '\r') continue;
+                if (state == 1) { out.push_back((uint8_t)p[t]); ++seq_len; }
+                else if (state == 2) ++qual_len;
+            }
+            return;
+        }
+        if (state == 1) {
+            out.insert(out.end(), (const uint8_t *)p, (const uint8_t *)p + len);
+            seq_len += len;
+        } else if (state == 2) {
+            qual_len += len;
+        }
+    };
     int n;
     while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
-        for (int i = 0; i < n; ++i) {
-            const char c = buf[i];
-            if (c == '\n') {
-                at_line_start = true;
-                skipping_line = false;
-                if (state == 2 && qual_len >= seq_len) state = 0;
-                continue;
-            }
-            if (c == '\r') continue;
+        size_t i = 0;
+        const size_t N = (size_t)n;
+        while (i < N) {
             if (at_line_start) {
+                const char c = buf[i];
+                if (c == '\n') {  // empty line
+                    if (state == 2 && qual_len >= seq_len) state = 0;
+                    ++i;
+                    continue;
+                }
                 at_line_start = false;
                 if (state != 2 && (c == '>' || c == '@')) {  // new record header
                     if (nrec) out.push_back('N');
@@ -94,20 +112,21 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out)
                     state = 1;
                     seq_len = qual_len = 0;
                     skipping_line = true;
-                    continue;
-                }
-                if (state == 1 && c == '+') {  // FASTQ separator line
+                } else if (state == 1 && c == '+') {  // FASTQ separator line
                     state = 2;
                     skipping_line = true;
-                    continue;
                 }
             }
-            if (skipping_line) continue;
-            if (state == 1) {
-                out.push_back((uint8_t)c);
-                ++seq_len;
-            } else if (state == 2) {
-                ++qual_len;
+            const char *nl = (const char *)std::memchr(buf.data() + i, '\n', N - i);
+            const size_t e = nl ? (size_t)(nl - buf.data()) : N;
+            take(buf.data() + i, e - i);
+            if (nl) {
+                at_line_start = true;
+                skipping_line = false;
+                if (state == 2 && qual_len >= seq_len) state = 0;
+                i = e + 1;
+            } else {
+                i = e;
             }
         }
     }

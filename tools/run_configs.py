@@ -89,6 +89,38 @@ def c4(n=100_000, p=10):
     ctx.close()
 
 
+def c2lite(n=200, L=5_000_000, k=31, p=10):
+    """configs[1]-shaped, scaled to 200 genomes: 5 Mbp FASTA files -> `dashing-amd dist` (parse + sketch + dist)."""
+    import torch
+
+    d = tempfile.mkdtemp(prefix="c2_")
+    paths = []
+    t0 = time.perf_counter()
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rng = np.random.default_rng(1)
+    base = lut[rng.integers(0, 4, L)]
+    for i in range(n):
+        g = base.copy()
+        pos = rng.integers(0, L, L // 100)       # 1 % substitutions per genome
+        g[pos] = lut[rng.integers(0, 4, pos.size)]
+        pth = os.path.join(d, "g%04d.fna" % i)
+        open(pth, "wb").write(synth.to_fasta(g, "g%d" % i))
+        paths.append(pth)
+    t_gen = time.perf_counter() - t0
+    lst = os.path.join(d, "paths.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+    res = {}
+    for thr in (1, 16):
+        out = os.path.join(d, "dist%d.bin" % thr)
+        t0 = time.perf_counter()
+        subprocess.check_call([cli, "dist", "-k", str(k), "-S", str(p), "-p", str(thr), "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst])
+        res["cli_seconds_p%d" % thr] = time.perf_counter() - t0
+    res["bases"] = n * L
+    res["bases_per_s_end_to_end_p16"] = n * L / res["cli_seconds_p16"]
+    print(json.dumps({"config": "C2-shaped: %d x %d bp FASTA (81-byte lines), k=%d, p=%d, dashing-amd dist -b end to end" % (n, L, k, p), **res, "gen_seconds": t_gen}))
+
+
 def c3_host(n=10_000, p=14):
     """C3 through the HOST-buffer boundary (what a patched dashing would call): dsh_upload_sketches
     + dsh_dist_rows into pageable host memory, i.e. PCIe both ways included."""
@@ -146,6 +178,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c4"]
     if "c3cli" in which:
         c3_cli_text()
+    if "c2lite" in which:
+        c2lite()
     if "c3host" in which:
         c3_host()
     if "c1" in which:
