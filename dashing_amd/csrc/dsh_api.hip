@@ -172,13 +172,19 @@ int prepare(dsh_ctx *c, int estim, int want_sorted)
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
         c->Npad = (uint32_t)((n + kTile - 1) / kTile * kTile);
-        // column order: identity, or a counting sort by key (threshold major, min value minor)
+        // column order: identity, or a counting sort by (threshold, min value, max value): the first
+        // two make the 128-column blocks need few planes, the third keeps the 64 pairs of a finalize
+        // wave alike in their largest register, i.e. in the trip count of the estimator's loops
         c->hperm.resize(n);
         if (want_sorted) {
-            std::vector<uint32_t> cnt(65537, 0);
-            for (uint64_t i = 0; i < n; ++i) cnt[c->hkeys[i] + 1u]++;
+            auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each
+                const uint32_t key = k32[i];
+                return (((key >> 8) & 63u) << 12) | ((key & 63u) << 6) | ((key >> 16) & 63u);
+            };
+            std::vector<uint32_t> cnt((1u << 18) + 1, 0);
+            for (uint64_t i = 0; i < n; ++i) cnt[skey(i) + 1u]++;
             for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-            for (uint64_t i = 0; i < n; ++i) c->hperm[cnt[c->hkeys[i]]++] = (uint32_t)i;
+            for (uint64_t i = 0; i < n; ++i) c->hperm[cnt[skey(i)]++] = (uint32_t)i;
             HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
             if (n) HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->hperm.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         } else {
