@@ -1,0 +1,80 @@
+"""GPU: seeded random sweep over (n, p, estimator, measure, register law) against the oracle --
+triangle, a random row range, a random rectangle and a random shard plan per case."""
+import numpy as np
+import pytest
+
+import dashing_amd
+from dashing_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _regs(rng, n, p, kind):
+    m = 1 << p
+    q = 64 - p
+    if kind == "law":
+        cards = np.exp(rng.uniform(np.log(50 * m / 1024 + 10), np.log(4e8), n))
+        return np.stack([synth.hll_registers(int(rng.integers(1 << 30)), int(c), p) for c in cards])
+    if kind == "related":
+        return synth.synthetic_sketches(n, p, seed=int(rng.integers(1 << 30)))
+    if kind == "uniform":
+        return rng.integers(0, q + 2, size=(n, m)).astype(np.uint8)
+    if kind == "narrow":
+        return rng.integers(5, 8, size=(n, m)).astype(np.uint8)
+    raise AssertionError(kind)
+
+
+def _close(got, want):
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all()
+    err = np.abs(got[fin].astype(np.float64) - want[fin])
+    assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9)).all(), err.max()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_case(ctx, oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    p = int(rng.choice([4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
+    n = int(rng.integers(2, 420 if p <= 12 else 180))
+    kind = str(rng.choice(["law", "related", "uniform", "narrow"]))
+    estim = int(rng.integers(0, 3))
+    rt = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8]))
+    k = int(rng.choice([15, 21, 31, 32]))
+    regs = _regs(rng, n, p, kind)
+    if n > 4 and rng.random() < 0.5:
+        regs[int(rng.integers(n))] = 0
+        a, b = rng.choice(n, 2, replace=False)
+        regs[a] = regs[b]
+    ctx.set_sketches(regs)
+    want = oracle.dist_tri(regs, estim, rt, k)
+    _close(ctx.dist_rows(estim=estim, result_type=rt, k=k), want)
+    # a row range (identity columns)
+    rb = int(rng.integers(0, n))
+    re = int(rng.integers(rb, n + 1))
+    lo = dashing_amd.tri_span(n, 0, rb)
+    part = ctx.dist_rows(rb, re, estim=estim, result_type=rt, k=k)
+    _close(part, want[lo : lo + part.size])
+    # a rectangle
+    q0 = int(rng.integers(0, n)); q1 = int(rng.integers(q0, n + 1))
+    r0 = int(rng.integers(0, n)); r1 = int(rng.integers(r0, n + 1))
+    rect = ctx.dist_rect(q0, q1, r0, r1, estim=estim, result_type=rt, k=k)
+    if rect.size:
+        _close(rect, oracle.dist_rect(regs[q0:q1], regs[r0:r1], estim, rt, k))
+    # shards of the sorted order, assembled
+    import torch
+
+    G = int(rng.integers(1, 6))
+    off = ctx.shard_plan(G, estim)
+    total = n * (n - 1) // 2
+    assert off[0] == 0 and off[-1] == total
+    sf = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda")
+    for r in range(G):
+        span = torch.zeros(max(off[r + 1] - off[r], 1), dtype=torch.float32, device="cuda")
+        ctx.dist_shard_device(span.data_ptr(), r, G, estim, rt, k)
+        ctx.synchronize()
+        sf[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
+    torch.cuda.synchronize()
+    fin = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda")
+    ctx.unpermute_device(sf.data_ptr(), fin.data_ptr())
+    ctx.synchronize()
+    _close(fin.cpu().numpy()[:total], want)
