@@ -49,7 +49,7 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
-    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm;
+    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm, tailhist;
     int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
     std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
@@ -61,7 +61,7 @@ struct dsh_ctx {
     std::vector<uint4> htiles;
     // options
     int kc = 16;  // 16 rows per LDS stage (32 KiB double-buffered): ~1 % faster than 32 in three sweeps (profiles/)
-    int emax_opt = -1;  // -1: min(32, 2^p / 512) -- sweep in profiles/r1e: 32 beats 16 and 64 at p=14
+    int emax_opt = -1;  // -1: min(64, 2^p / 256) -- sweeps in profiles/: 64..96 is the optimum at p=14 with the tail-histogram finalize
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
@@ -137,8 +137,8 @@ int prepare(dsh_ctx *c, int estim, int want_sorted)
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
     const uint64_t n = c->n;
-    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap)
-                                          : (int)std::min<uint64_t>(32, (1ull << c->p) >> 9);
+    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
+                                          : (int)std::min<uint64_t>(64, (1ull << c->p) >> 8);
     if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
     c->emax = emax_new;
     if (!c->planes_valid || c->card_estim != estim) {
@@ -146,9 +146,11 @@ int prepare(dsh_ctx *c, int estim, int want_sorted)
         HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
         HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->tailhist.ensure(std::max<uint64_t>(n, 1) * 64));
         HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
                                        (double *)c->card.ptr, (uint32_t *)c->exc.ptr,
-                                       (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr));
+                                       (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
+                                       (uint8_t *)c->tailhist.ptr));
         c->card_estim = estim;
     }
     if (!c->planes_valid || c->planes_sorted != want_sorted) {
@@ -379,6 +381,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.vhi = c->vhi;
         f.exc = (const uint32_t *)c->exc.ptr;
         f.exc_n = (const uint32_t *)c->exc_n.ptr;
+        f.tailhist = (const uint8_t *)c->tailhist.ptr;
         f.nslots = nslots;
         f.tiles = dt;
         f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
@@ -479,6 +482,7 @@ void dsh_destroy(dsh_ctx *c)
     c->exc.release();
     c->exc_n.release();
     c->keys.release();
+    c->tailhist.release();
     c->perm.release();
     c->items.release();
     c->cum.release();
@@ -1028,7 +1032,7 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         return DSH_OK;
     }
     if (!std::strcmp(name, "emax")) {
-        if (v < -1 || v > (int64_t)kExcCap) return fail(c, DSH_EINVAL, "emax must be in [-1,%u]", kExcCap);
+        if (v < -1 || v >= (int64_t)kExcCap) return fail(c, DSH_EINVAL, "emax must be in [-1,%u]", kExcCap - 1);
         c->emax_opt = (int)v;
         return DSH_OK;
     }

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                                                         double *__restrict__ card,
                                                         uint32_t *__restrict__ exc,
                                                         uint32_t *__restrict__ exc_n,
-                                                        uint32_t *__restrict__ keys)
+                                                        uint32_t *__restrict__ keys,
+                                                        uint8_t *__restrict__ tailhist)
 {
     __shared__ uint32_t hist[4][64];
     __shared__ uint32_t sub[4][8][64];  // 8 privatised copies per wave: the register values pile up
@@ -110,7 +111,11 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         keys[s] = ((uint32_t)hi << 16) | ((uint32_t)T << 8) | (uint32_t)lo;
     }
     __syncthreads();
-    if (s >= n || emax == 0) return;
+    if (s >= n) return;
+    // histogram of the listed registers (values above T_i), one byte per value: k_finalize starts a
+    // pair's tail bins from the two sketches' tail histograms and only corrects shared positions
+    tailhist[s * 64 + lane] = lane > thr[wave] ? (uint8_t)hist[wave][lane] : (uint8_t)0;
+    if (emax == 0) return;
     // second pass: registers above T_i, in position order (iteration-major, lane, byte)
     const uint32_t T = (uint32_t)thr[wave];
     uint32_t *dst = exc + s * kExcCap;
@@ -354,6 +359,7 @@ struct FinalizeArgs {
     const double *card;
     const uint32_t *exc;
     const uint32_t *exc_n;
+    const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value
     uint64_t n;
     // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
@@ -368,13 +374,13 @@ struct FinalizeArgs {
 };
 
 // Exception handling without a sequential merge: the block's 128 lanes share sketch i (one
-// tile row), so i's tail entries (value > T) go into a 128-slot open-addressing LDS hash keyed
-// by position, and their value histogram histA is the starting point of every lane's tail
-// bins.  A lane then walks only its own sketch j's list (independent iterations, 16-B loads):
-// for an entry (pos,vb) it looks up va = A's value at pos (0 if absent); if va > T that
-// position was counted in histA under va and is re-filed under max(va,vb); otherwise it is a
-// new union position iff vb > T.  Exact, order-independent.
-constexpr uint32_t kHashSlots = 128;  // 2 x kExcCap
+// tile row), so i's tail entries (value > T) go into an open-addressing LDS hash keyed by
+// position, and their value histogram histA plus sketch j's precomputed tail histogram
+// (tailhist, one byte per value) are the starting point of a lane's tail bins -- that counts a
+// position listed by BOTH sketches twice.  A lane therefore only walks its own sketch j's list
+// looking for shared positions (independent iterations, 16-B loads, one LDS probe each; hits are
+// rare: |list|^2 / 2^p per pair) and removes the smaller of the two values.  Exact, order-independent.
+constexpr uint32_t kHashSlots = 512;  // 2 x kExcCap
 
 template <typename CT>
 __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
@@ -397,12 +403,12 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     const int vlo_t = vlo + (int)tile.z, T = vlo + (int)tile.w;
     // block-level skip (uniform) when the row sketch cannot be wanted
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
-    hashA[tid] = 0xFFFFFFFFu;
+    for (uint32_t t = tid; t < kHashSlots; t += 128) hashA[t] = 0xFFFFFFFFu;
     if (tid < 64) histA[tid] = 0;
     __syncthreads();
     const uint32_t na = a.exc_n[i];
-    if ((uint32_t)tid < na) {
-        const uint32_t e = a.exc[i * kExcCap + tid];
+    for (uint32_t t = tid; t < na; t += 128) {
+        const uint32_t e = a.exc[i * kExcCap + t];
         if ((int)(e & 0xFFu) > T) {
             atomicAdd(&histA[e & 63u], 1u);
             uint32_t h = (e >> 8) & (kHashSlots - 1);
@@ -440,51 +446,87 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         col[pl * 128] = (CT)(cv - prev);
         prev = cv;
     }
-    // tail bins start from A's own tail histogram
+    // tail bins: histogram of i's listed values + histogram of j's listed values (both > T) ...
     uint32_t ucnt = 0;
     int maxv = T;
-    for (int x = T + 1; x <= vhi; ++x) {
-        const uint32_t h = histA[x];
-        col[(x - vlo) * 128] = (CT)h;
-        ucnt += h;
-        if (h) maxv = x;
-    }
-    const uint32_t nb = a.exc_n[j];
-    const uint4 *eb = reinterpret_cast<const uint4 *>(a.exc + j * kExcCap);
-    for (uint32_t q = 0; q * 4 < nb; ++q) {
-        const uint4 e4 = eb[q];
-        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+    {
+        const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
+        for (int w = (T + 1) >> 4; w <= (vhi >> 4); ++w) {
+            const uint4 q4 = tb[w];
+            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (q * 4 + t >= nb) break;
-            const uint32_t e = ev[t];
-            const int vb = (int)(e & 0xFFu);
-            if (vb <= T) continue;  // cannot change anything: either already filed under va > T, or no tail
-            const uint32_t pos = e >> 8;
-            int va = 0;
-            uint32_t h = pos & (kHashSlots - 1);
-            for (;;) {
-                const uint32_t s = hashA[h];
-                if (s == 0xFFFFFFFFu) break;
-                if ((s >> 8) == pos) {
-                    va = (int)(s & 0xFFu);
-                    break;
-                }
-                h = (h + 1) & (kHashSlots - 1);
-            }
-            if (va > T) {  // already counted under va: re-file under the max
-                if (vb > va) {
-                    col[(va - vlo) * 128] -= 1;
-                    col[(vb - vlo) * 128] += 1;
-                    if (vb > maxv) maxv = vb;
-                }
-            } else {
-                col[(vb - vlo) * 128] += 1;
-                ++ucnt;
-                if (vb > maxv) maxv = vb;
+            for (int b = 0; b < 16; ++b) {
+                const int x = w * 16 + b;
+                if (x <= T || x > vhi) continue;
+                const uint32_t h = histA[x] + ((qw[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+                col[(x - vlo) * 128] = (CT)h;
+                ucnt += h;
+                if (h) maxv = x;
             }
         }
     }
+    // ... minus the smaller value at every position both sketches list (counted twice above)
+    const uint32_t nb = a.exc_n[j];
+    const uint4 *eb = reinterpret_cast<const uint4 *>(a.exc + j * kExcCap);
+    // Branch-light probing: two slots are read unconditionally (the table is <= 50 % full, linear
+    // probing, no deletions: an empty first slot means "absent"); only a hit, or the rare case of
+    // two occupied non-matching slots, takes a branch.
+    constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    auto probe4 = [&](const uint4 e4, uint32_t first) {
+        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+        uint32_t s0[4], s1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t h = (ev[t] >> 8) & (kHashSlots - 1);
+            s0[t] = hashA[h];
+            s1[t] = hashA[(h + 1) & (kHashSlots - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t e = ev[t], pos = e >> 8;
+            const int vb = (int)(e & 0xFFu);
+            const bool live = first + t < nb && vb > T;  // inside the list and counted in the tail bins
+            const bool hit0 = (s0[t] >> 8) == pos;       // kEmpty never matches a real position
+            const bool hit1 = s0[t] != kEmpty && (s1[t] >> 8) == pos;
+            const bool more = s0[t] != kEmpty && s1[t] != kEmpty && !hit0 && !hit1;
+            if (live && (hit0 | hit1 | more)) {
+                uint32_t sv = hit0 ? s0[t] : s1[t];
+                bool hit = hit0 | hit1;
+                if (more) {  // keep walking the probe sequence
+                    uint32_t h = (pos + 2) & (kHashSlots - 1);
+                    for (;;) {
+                        sv = hashA[h];
+                        if (sv == kEmpty) break;
+                        if ((sv >> 8) == pos) {
+                            hit = true;
+                            break;
+                        }
+                        h = (h + 1) & (kHashSlots - 1);
+                    }
+                }
+                if (hit) {  // shared position: keep only the larger value
+                    const int va = (int)(sv & 0xFFu);
+                    col[((va < vb ? va : vb) - vlo) * 128] -= 1;
+                    --ucnt;
+                }
+            }
+        }
+    };
+    // 16 entries (4 x 16 B) per step, the next step's loads issued before this step's probes so
+    // the L2 round trip of the list is not on the critical path
+    const uint32_t nq = (nb + 3) / 4;  // 16-byte pieces
+    uint4 cur[4], nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cur[u] = (uint32_t)u < nq ? eb[u] : make_uint4(0, 0, 0, 0);
+    for (uint32_t q = 0; q < nq; q += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = q + 4 + u < nq ? eb[q + 4 + u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) probe4(cur[u], (q + u) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    }
+    // (a bin emptied by a correction can only lower the true maximum; maxv is just a scan bound)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
@@ -602,12 +644,12 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, double *card, uint32_t *exc, uint32_t *exc_n,
-                                uint32_t *keys)
+                                uint32_t *keys, uint8_t *tailhist)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
     hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                       card, exc, exc_n, keys);
+                       card, exc, exc_n, keys, tailhist);
     return hipGetLastError();
 }
 
@@ -677,7 +719,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out;
+    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);

@@ -119,7 +119,7 @@ def test_options_do_not_change_results(ctx):
         for kc in (16, 64, 32):
             ctx.set_option("kc", kc)
             assert ctx.dist_rows().tobytes() == base.tobytes()
-        for emax in (0, 1, 8, 64, -1):   # dense-only .. full exception lists: same exact histogram
+        for emax in (0, 1, 8, 64, 200, 255, -1):   # dense-only .. full exception lists: same exact histogram
             ctx.set_option("emax", emax)
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("xcd_swizzle", 0)
