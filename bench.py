@@ -51,7 +51,13 @@ def main():
     # DSH_BENCH_BACKEND=gloo is a dry-run of the N>1 code path on a box with ONE GPU: all ranks share
     # cuda:0 and the gather is staged through host memory.  Never used for reported numbers.
     backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # DSH_BENCH_FORCE_DIST=1 runs the sharded code path (process group, gather, un-permute) even with
+    # one rank -- a functional check of the RCCL plumbing on a 1-GPU box, not a reported configuration.
+    multi = world > 1 or bool(os.environ.get("DSH_BENCH_FORCE_DIST"))
+    if multi:
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "gloo":
@@ -78,12 +84,12 @@ def main():
     # N>1: every rank holds all sketches and computes one cost-balanced shard (a contiguous span
     # of the sorted-order triangle); the only exchange is the RCCL gather of the spans to rank 0,
     # which un-permutes them once into dashing's packed order.
-    span_off = ctx.shard_plan(world) if world > 1 else [0, total_pairs]
+    span_off = ctx.shard_plan(world) if multi else [0, total_pairs]
     span = span_off[rank + 1] - span_off[rank]
     mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
     out_d = torch.empty(mx, dtype=torch.float32, device=dev)
     stage = sorted_full = final = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         stage = torch.empty(world * mx, dtype=torch.float32, device=dev)
         sorted_full = torch.empty(total_pairs, dtype=torch.float32, device=dev)
         final = torch.empty(total_pairs, dtype=torch.float32, device=dev)
@@ -91,7 +97,7 @@ def main():
     def step():
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        if world == 1:
+        if not multi:
             ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             ctx.synchronize()
             return out_d[:span]
@@ -110,7 +116,7 @@ def main():
         return None
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +128,7 @@ def main():
         full = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -135,7 +141,7 @@ def main():
     reps = 3
     for _ in range(reps):
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        if world == 1:
+        if not multi:
             ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         else:
             ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
@@ -179,14 +185,14 @@ def main():
                             "note": "the binding resource of k_pair_counts (DESIGN.md 3.2); PMC SQ_INSTS_VALU in profiles/r1g agrees"}
     cpu = None
     parity = None
-    if rank == 0 and world > 1:
+    if rank == 0 and multi:
         # assembled multi-rank matrix vs one single-GPU call on rank 0 (outside the timed region)
         ref = torch.empty(total_pairs, dtype=torch.float32, device=dev)
         ctx.attach_device(regs_d.data_ptr(), n, p)
         ctx.dist_rows_device(ref.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
         parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full)), "pairs_checked": total_pairs}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
 
     if rank == 0:
@@ -198,14 +204,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
                        "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                       "sharding": "cost-balanced row shards of the sorted-order triangle, RCCL gather to rank 0 + un-permute" if world > 1 else "single GPU"},
+                       "sharding": "cost-balanced row shards of the sorted-order triangle, RCCL gather to rank 0 + un-permute" if multi else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
         }
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -66,6 +66,7 @@ struct dsh_ctx {
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
     int assembler_permille = 24;  // un-permute + span copies on rank 0 ~ 0.53 ms of a 22 ms pass (profiles/r1h)
+    uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
@@ -124,12 +125,12 @@ void invalidate(dsh_ctx *c)
 // cardinalities + thresholds/exception lists + planes for the current sketch matrix.
 // want_sorted: lay the plane-matrix columns out in (threshold, min value) order so that the
 // 128-column blocks are homogeneous and every tile can use its own narrow plane range.
-int prepare(dsh_ctx *c, int estim, int want_sorted)
+int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
 {
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
     if (want_sorted < 0) want_sorted = c->planes_sorted;  // "whatever is cached"
-    if (c->planes_valid && c->card_estim == estim && c->planes_sorted == want_sorted) return DSH_OK;
+    if (c->card_estim == estim && (card_only || (c->planes_valid && c->planes_sorted == want_sorted))) return DSH_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
@@ -153,7 +154,19 @@ int prepare(dsh_ctx *c, int estim, int want_sorted)
                                        (uint8_t *)c->tailhist.ptr));
         c->card_estim = estim;
     }
+    if (card_only) {  // a cardinality query never builds planes (and leaves stale ones marked so)
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, c->stream);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            c->prep_ms += ms;
+        }
+        return DSH_OK;
+    }
     if (!c->planes_valid || c->planes_sorted != want_sorted) {
+        if (c->p > kMaxPLds)
+            return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPLds, c->p);
         int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
         std::vector<uint32_t> k32(n);
         c->hkeys.resize(n);
@@ -252,6 +265,7 @@ struct PairJob {
     int estim, result_type, k;
     int rect;
     int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
+    int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *d_out;
@@ -394,6 +408,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.n = c->n;
         f.rect = job.rect;
         f.sorted_out = job.sorted_rows;
+        f.square = job.square;
         f.row_begin = job.row_begin;
         f.row_end = job.row_end;
         f.col_begin = job.col_begin;
@@ -509,7 +524,7 @@ void *dsh_stream(dsh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int dsh_sketches_alloc(dsh_ctx *c, uint64_t n, int p)
 {
     if (!c) return DSH_EINVAL;
-    if (p < 4 || p > 17) return fail(c, DSH_EINVAL, "p=%d outside [4,17]", p);
+    if (p < 4 || p > kMaxP) return fail(c, DSH_EINVAL, "p=%d outside [4,%d]", p, kMaxP);
     int rc = bind(c);
     if (rc) return rc;
     const size_t bytes = std::max<size_t>((size_t)n << p, 256);
@@ -526,7 +541,7 @@ int dsh_sketches_alloc(dsh_ctx *c, uint64_t n, int p)
 int dsh_attach_device_sketches(dsh_ctx *c, const void *d_regs, uint64_t n, int p)
 {
     if (!c || (!d_regs && n)) return DSH_EINVAL;
-    if (p < 4 || p > 17) return fail(c, DSH_EINVAL, "p=%d outside [4,17]", p);
+    if (p < 4 || p > kMaxP) return fail(c, DSH_EINVAL, "p=%d outside [4,%d]", p, kMaxP);
     if (((uintptr_t)d_regs & 15) != 0) return fail(c, DSH_EINVAL, "device sketches must be 16-byte aligned");
     c->regs = (const uint8_t *)d_regs;
     c->n = n;
@@ -674,10 +689,7 @@ int dsh_cardinalities(dsh_ctx *c, int estim, double *out)
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
     if (c->card_estim != estim) {
         // same per-sketch pass as prepare() (thresholds/exception lists come out identical)
-        const bool pv = c->planes_valid;
-        c->planes_valid = true;  // do not rebuild planes for a cardinality query
-        rc = prepare(c, estim, -1);
-        c->planes_valid = pv && c->planes_valid;
+        rc = prepare(c, estim, -1, /*card_only=*/true);
         if (rc) return rc;
     }
     if (c->n) {
@@ -814,6 +826,48 @@ int dsh_knn(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t
                              result_type == DSH_SYMMETRIC_CONTAINMENT_DIST);
     const uint64_t nq = qe - qb, nr = re > rb ? re - rb : 0;
     const bool overlap = qb < re && rb < qe;
+    if (qb == 0 && rb == 0 && qe == c->n && re == c->n && c->n > 1 &&
+        c->n * c->n * sizeof(float) <= c->knn_square_budget) {
+        // all-vs-all: every pair is computed ONCE (triangle tiles, sorted columns) and written at
+        // both (i,j) and (j,i) of an n x n matrix in HBM; then one selection pass per row
+        const uint64_t n = c->n;
+        DevBuf sq, didx, dval;
+        rc = DSH_OK;
+        do {
+            if (sq.ensure(n * n * sizeof(float)) != hipSuccess || didx.ensure(n * nn * sizeof(uint32_t)) != hipSuccess ||
+                dval.ensure(n * nn * sizeof(float)) != hipSuccess) {
+                rc = fail(c, DSH_ENOMEM, "device allocation failed");
+                break;
+            }
+            PairJob j;
+            j.estim = estim;
+            j.result_type = result_type;
+            j.k = k;
+            j.rect = 0;
+            j.square = 1;
+            j.row_begin = 0;
+            j.row_end = n;
+            j.col_begin = 0;
+            j.col_end = n;
+            j.base_index = 0;
+            j.d_out = (float *)sq.ptr;
+            if ((rc = run_pairs(c, j))) break;
+            hipError_t e = launch_topk(c->stream, (const float *)sq.ptr, n, n, 0, 0, descending, nn, 1,
+                                       (uint32_t *)didx.ptr, (float *)dval.ptr);
+            if (e != hipSuccess) {
+                rc = fail(c, DSH_EIO, "k_topk: %s", hipGetErrorString(e));
+                break;
+            }
+            if (hipMemcpyAsync(idx_out, didx.ptr, n * nn * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(val_out, dval.ptr, n * nn * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess)
+                rc = fail(c, DSH_EIO, "copy of neighbours failed");
+        } while (0);
+        sq.release();
+        didx.release();
+        dval.release();
+        return rc;
+    }
     DevBuf &rect = c->outbuf;
     const uint64_t qblock = std::max<uint64_t>(1, std::min<uint64_t>(nq, ((uint64_t)256 << 20) / std::max<uint64_t>(nr, 1)));
     HIPCHK(c, rect.ensure(std::max<uint64_t>(qblock * nr, 1) * sizeof(float)));
@@ -1009,6 +1063,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "knn_square_budget_bytes")) {
+        if (v < 0) return fail(c, DSH_EINVAL, "knn_square_budget_bytes must be >= 0");
+        c->knn_square_budget = (uint64_t)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "assembler_permille")) {

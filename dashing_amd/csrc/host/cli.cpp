@@ -60,7 +60,8 @@ static void usage(const char *sub)
         "  --device INT             GPU ordinal [0]\n"
         "  --ngpus INT | --devices a,b,..  (dist, -b only) share the rows of the matrix between several GPUs\n", kVersion, sub);
     if (!std::strcmp(sub, "sketch")) {
-        std::fprintf(stderr, "  -c, --skip-cached        skip genomes whose .hll already exists\n");
+        std::fprintf(stderr, "  -c, --skip-cached        skip genomes whose .hll already exists\n"
+                             "  -o FILE                  write all sketches into one file (+ FILE.labels.gz) instead of one .hll per genome\n");
     } else {
         std::fprintf(stderr,
             "  -o, --out-sizes FILE     cardinalities [stdout]\n"
@@ -190,7 +191,7 @@ static Opts parse(int argc, char **argv, bool is_dist)
 
 // Hot loop 1 for genomes [g0,g1): cache hit -> read .hll; else parse FASTA on host threads and
 // sketch on the GPU in batches of <= batch_bytes of sequence.
-static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool skip_cached)
+static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool skip_cached, bool load_cached = false)
 {
     const size_t n = o.inpaths.size();
     const size_t m = (size_t)1 << o.S;
@@ -227,7 +228,7 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
         uint64_t tot = 0;
         for (size_t i = 0; i < nb; ++i) {
             if (cached[i]) {
-                if (skip_cached) continue;  // `sketch -c`: nothing to do for this genome
+                if (skip_cached && !load_cached) continue;  // `sketch -c`: nothing to do for this genome
                 int p = 0;
                 std::vector<uint8_t> r;
                 if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
@@ -281,7 +282,182 @@ static int sketch_main(int argc, char **argv)
     dsh_ctx *ctx = nullptr;
     if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
     DSH(ctx, dsh_sketches_alloc(ctx, o.inpaths.size(), o.S));
-    fill_sketches(ctx, o, /*write_files=*/true, /*skip_cached=*/o.skip_cached != 0);
+    const std::string &output_file = o.out_sizes;  // `sketch -o FILE` (src/dashing.cpp:307-337)
+    if (output_file.empty()) {
+        fill_sketches(ctx, o, /*write_files=*/true, /*skip_cached=*/o.skip_cached != 0);
+    } else {
+        // all sketches into ONE gz stream + "<FILE>.labels.gz" (src/sketch_and_cmp.h:466-475,529-536);
+        // with -c an existing per-genome .hll is read instead of re-sketched (:504-507)
+        if (write_labels_gz(output_file + ".labels.gz", o.inpaths)) die("Failed to write sequence labels to file");
+        fill_sketches(ctx, o, /*write_files=*/false, /*skip_cached=*/o.skip_cached != 0, /*load_cached=*/true);
+        const size_t n = o.inpaths.size(), m = (size_t)1 << o.S;
+        std::vector<uint8_t> all(n * m);
+        DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
+        if (write_hll_multi(output_file, all.data(), n, o.S, o.estim)) die("Failed to write sketches to file");
+    }
+    dsh_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+// ---- utilities on .hll files ----------------------------------------------
+// `union` (src/union.cpp:60-107): register-wise maximum of HLL sketch files -> one .hll.
+static int union_main(int argc, char **argv)
+{
+    int level = 6, nthreads = 1;
+    std::string opath = "/dev/stdout";
+    std::vector<std::string> paths;
+    optind = 1;
+    for (int c; (c = getopt(argc, argv, "p:o:F:zZ:rHbh?")) >= 0;) {
+        switch (c) {
+        case 'Z': level = std::atoi(optarg); break;  // (the reference falls through into -o here: a bug we do not keep)
+        case 'z': break;                             // output is a gz stream unless -Z 0
+        case 'o': opath = optarg; break;
+        case 'F': paths = read_paths_file(optarg); break;
+        case 'p': nthreads = std::max(1, std::atoi(optarg)); break;
+        case 'r': case 'H': case 'b': die("union: only HLL sketches are in scope");
+        default:
+            std::fprintf(stderr, "Usage: dashing-amd union [-o out.hll] [-F paths.txt] [-p threads] [-Z level] a.hll b.hll ...\n");
+            return EXIT_FAILURE;
+        }
+    }
+    for (int i = optind; i < argc; ++i) paths.emplace_back(argv[i]);
+    if (paths.empty()) die("require >= 1 paths. See usage.");
+    std::vector<std::vector<uint8_t>> acc((size_t)nthreads);
+    std::vector<int> ps((size_t)nthreads, -1);
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (long i = 0; i < (long)paths.size(); ++i) {
+        const int t = omp_get_thread_num();
+        int p = 0;
+        std::vector<uint8_t> r;
+        if (read_hll(paths[i], r, p)) die("Could not read sketch %s", paths[i].c_str());
+        if (ps[t] < 0) {
+            ps[t] = p;
+            acc[t].swap(r);
+        } else {
+            if (p != ps[t]) die("For operator +=: np_ (%d) != other.get_np() (%d)", ps[t], p);
+            union_registers(acc[t].data(), r.data(), r.size());
+        }
+    }
+    int p = -1;
+    std::vector<uint8_t> *tot = nullptr;
+    for (int t = 0; t < nthreads; ++t) {
+        if (ps[t] < 0) continue;
+        if (!tot) {
+            tot = &acc[t];
+            p = ps[t];
+        } else {
+            if (ps[t] != p) die("For operator +=: np_ (%d) != other.get_np() (%d)", p, ps[t]);
+            union_registers(tot->data(), acc[t].data(), tot->size());
+        }
+    }
+    if (write_hll(opath, tot->data(), p, ERTL_MLE, ERTL_MLE, false, 0.0, level)) die("Could not open file at %s", opath.c_str());
+    return EXIT_SUCCESS;
+}
+
+// `view` (src/dashing.cpp:553-557)
+static int view_main(int argc, char **argv)
+{
+    if (argc < 2) die("Usage: dashing-amd view f1.hll [f2.hll ...]. Only HLLs currently supported.");
+    for (int i = 1; i < argc; ++i) {
+        int p = 0;
+        std::vector<uint8_t> r;
+        if (read_hll(argv[i], r, p)) die("Could not read sketch %s", argv[i]);
+        print_hll(stdout, argv[i], r.data(), p);
+    }
+    return EXIT_SUCCESS;
+}
+
+// `fold` (src/dashing.cpp:558-590): compress a sketch to a smaller precision
+static int fold_main(int argc, char **argv)
+{
+    std::string out = "/dev/stdout", in = "/dev/stdin";
+    int destp = -1;
+    optind = 1;
+    for (int c; (c = getopt(argc, argv, "p:o:h?")) >= 0;) {
+        switch (c) {
+        case 'o': out = optarg; break;
+        case 'p': destp = std::atoi(optarg); break;
+        default:
+            std::fprintf(stderr, "Usage: dashing-amd fold <flags> [in1.hll]\n-o: Write to <path> instead of stdout\n"
+                                 "-p: set destination p [must be smaller than the input sketch\n");
+            return EXIT_FAILURE;
+        }
+    }
+    if (argc - optind == 1) in = argv[optind];
+    else if (argc - optind > 1) die("Usage: dashing-amd fold <flags> [in1.hll]");
+    if (out == "-") out = "/dev/stdout";
+    if (in == "-") in = "/dev/stdin";
+    int p = 0;
+    std::vector<uint8_t> r, f;
+    if (read_hll(in, r, p)) die("Could not read sketch %s", in.c_str());
+    if (destp <= 0) destp = p - 1;
+    if (destp >= p || destp < 4) die("fold: destination p (%d) must be in [4, %d)", destp, p);
+    fold_registers(r.data(), p, destp, f);
+    if (write_hll(out, f.data(), destp, ERTL_MLE, ERTL_MLE, false, 0.0)) die("Could not write %s", out.c_str());
+    return EXIT_SUCCESS;
+}
+
+// `hll` (src/hllmain.cpp:4-45): cardinality of the union of the k-mers of all input files --
+// every file is sketched into ONE HLL (default p = 24: registers live in HBM, not LDS).
+static int hll_main(int argc, char **argv)
+{
+    int k = 31, S = 24, nthreads = 1, canon = 1, device = 0;
+    std::string paths_file;
+    if (argc < 2) {
+    usage:
+        std::fprintf(stderr, "Usage: dashing-amd hll <opts> <paths>\nFlags:\n-k:\tkmer length (Default: 31. Max: 32)\n"
+                             "-S:\tsketch size (default: 24). (2^S one-byte registers)\n-p:\tnumber of host threads.\n"
+                             "-F:\tPath to file which contains one path per line\n-C:\tdo not canonicalise\n-d:\tGPU ordinal\n");
+        return EXIT_FAILURE;
+    }
+    optind = 1;
+    for (int c; (c = getopt(argc, argv, "Cw:s:S:p:k:F:d:tfh?")) >= 0;) {
+        switch (c) {
+        case 'C': canon = 0; break;
+        case 'k': k = std::atoi(optarg); break;
+        case 'p': nthreads = std::max(1, std::atoi(optarg)); break;
+        case 's': if (optarg && *optarg) die("spaced seeds are out of scope (HLL hot path only)"); break;
+        case 'w': if (std::atoi(optarg) > k) die("minimizer windows are out of scope (HLL hot path only)"); break;
+        case 'S': S = std::atoi(optarg); break;
+        case 'F': paths_file = optarg; break;
+        case 'd': device = std::atoi(optarg); break;
+        case 't': case 'f': break;
+        default: goto usage;
+        }
+    }
+    if (k < 1 || k > 32) die("k must be in [1,32]");
+    if (S < 4 || S > 24) die("-S must be in [4,24]");
+    std::vector<std::string> inpaths = paths_file.empty() ? std::vector<std::string>(argv + optind, argv + argc) : read_paths_file(paths_file);
+    if (inpaths.empty()) goto usage;
+    dsh_ctx *ctx = nullptr;
+    if (int rc = dsh_create(device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
+    DSH(ctx, dsh_sketches_alloc(ctx, 1, S));
+    std::fprintf(stderr, "Processing %zu paths with %i threads\n", inpaths.size(), nthreads);
+    // batches of files, parsed on the host threads, all max-merged into slot 0
+    const size_t batch_bytes = (size_t)512 << 20;
+    for (size_t g = 0; g < inpaths.size();) {
+        size_t e = g, bytes = 0;
+        while (e < inpaths.size() && (e == g || bytes + genome_file_size(inpaths[e]) <= batch_bytes)) bytes += genome_file_size(inpaths[e++]);
+        std::vector<std::vector<uint8_t>> seqs(e - g);
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+        for (long i = 0; i < (long)(e - g); ++i)
+            for (const auto &f : split_genome_paths(inpaths[g + i])) {
+                if (!seqs[i].empty()) seqs[i].push_back('N');
+                if (append_fastx(f, seqs[i]) < 0) die("Could not open %s", f.c_str());
+            }
+        std::vector<uint8_t> all;
+        for (auto &sv : seqs) {
+            all.insert(all.end(), sv.begin(), sv.end());
+            all.push_back('N');
+            std::vector<uint8_t>().swap(sv);
+        }
+        const uint64_t off[2] = {0, all.size()};
+        DSH(ctx, dsh_sketch_batch(ctx, all.data(), off, 1, 0, k, canon, nullptr));
+        g = e;
+    }
+    double est = 0;
+    DSH(ctx, dsh_cardinalities(ctx, ERTL_MLE, &est));
+    std::fprintf(stdout, "Estimated number of unique exact matches: %lf\n", est);
     dsh_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -495,12 +671,16 @@ static int dist_main(int argc, char **argv)
 int main(int argc, char **argv)
 {
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
-        std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n", kVersion);
+        std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;
     }
     const std::string sub(argv[1]);
     if (sub == "sketch") return sketch_main(argc - 1, argv + 1);
     if (sub == "dist" || sub == "cmp" || sub == "setdist") return dist_main(argc - 1, argv + 1);
+    if (sub == "union") return union_main(argc - 1, argv + 1);
+    if (sub == "view") return view_main(argc - 1, argv + 1);
+    if (sub == "fold") return fold_main(argc - 1, argv + 1);
+    if (sub == "hll") return hll_main(argc - 1, argv + 1);
     if (sub == "version" || sub == "--version") {
         std::printf("%s\nbackend: %s\n", kVersion, dsh_backend_name());
         return EXIT_SUCCESS;

@@ -162,20 +162,19 @@ std::string make_fname(const std::string &path, unsigned sketch_p, int k, const 
     return ret;
 }
 
+static int gz_put_sketch(gzFile fp, const uint8_t *regs, int p, int estim, int jestim, bool is_calculated, double value);
+
 int write_hll(const std::string &path, const uint8_t *regs, int p, int estim, int jestim,
-              bool is_calculated, double value)
+              bool is_calculated, double value, int level)
 {
-    gzFile fp = gzopen(path.c_str(), "wb");
+    char mode[8] = "wb";
+    if (level == 0) std::snprintf(mode, sizeof mode, "wT");
+    else if (level > 0) std::snprintf(mode, sizeof mode, "wb%d", level % 10);
+    gzFile fp = gzopen(path.c_str(), mode);
     if (!fp) return -EIO;
-    const uint32_t bf[4] = {(uint32_t)is_calculated, (uint32_t)estim, (uint32_t)jestim, 1u};
-    const uint32_t np = (uint32_t)p;
-    int ok = gzwrite(fp, bf, sizeof bf) == (int)sizeof bf;
-    ok = ok && gzwrite(fp, &np, sizeof np) == (int)sizeof np;
-    ok = ok && gzwrite(fp, &value, sizeof value) == (int)sizeof value;
-    const size_t m = (size_t)1 << p;
-    ok = ok && gzwrite(fp, regs, (unsigned)m) == (int)m;
-    gzclose(fp);
-    return ok ? 0 : -EIO;
+    int rc = gz_put_sketch(fp, regs, p, estim, jestim, is_calculated, value);
+    if (gzclose(fp) != Z_OK && !rc) rc = -EIO;
+    return rc;
 }
 
 int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
@@ -201,6 +200,126 @@ int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
     if (try_layout(28, 16)) return 0;  // uint32[4] flags, uint32 p, double value
     if (try_layout(16, 4)) return 0;   // uint8[4] flags, uint32 p, double value
     return -EINVAL;
+}
+
+static int gz_put_sketch(gzFile fp, const uint8_t *regs, int p, int estim, int jestim, bool is_calculated, double value)
+{
+    const uint32_t bf[4] = {(uint32_t)is_calculated, (uint32_t)estim, (uint32_t)jestim, 1u};
+    const uint32_t np = (uint32_t)p;
+    int ok = gzwrite(fp, bf, sizeof bf) == (int)sizeof bf;
+    ok = ok && gzwrite(fp, &np, sizeof np) == (int)sizeof np;
+    ok = ok && gzwrite(fp, &value, sizeof value) == (int)sizeof value;
+    const size_t m = (size_t)1 << p;
+    for (size_t off = 0; ok && off < m; off += (size_t)1 << 30) {  // gzwrite takes an unsigned length
+        const unsigned len = (unsigned)std::min<size_t>(m - off, (size_t)1 << 30);
+        ok = gzwrite(fp, regs + off, len) == (int)len;
+    }
+    return ok ? 0 : -EIO;
+}
+
+int write_hll_multi(const std::string &path, const uint8_t *regs, size_t n, int p, int estim)
+{
+    gzFile fp = gzopen(path.c_str(), "wb");
+    if (!fp) return -EIO;
+    int rc = 0;
+    for (size_t i = 0; i < n && !rc; ++i) rc = gz_put_sketch(fp, regs + (i << p), p, estim, estim, false, 0.0);
+    if (gzclose(fp) != Z_OK && !rc) rc = -EIO;
+    return rc;
+}
+
+int read_hll_multi(const std::string &path, std::vector<uint8_t> &regs, int &p, size_t &n)
+{
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return -ENOENT;
+    regs.clear();
+    n = 0;
+    p = -1;
+    for (;;) {
+        uint8_t hdr[28];
+        const int got = gzread(fp, hdr, sizeof hdr);
+        if (got == 0) break;
+        uint32_t np;
+        std::memcpy(&np, hdr + 16, 4);
+        if (got != (int)sizeof hdr || np < 4 || np > 30 || (p >= 0 && (int)np != p)) {
+            gzclose(fp);
+            return -EINVAL;
+        }
+        p = (int)np;
+        const size_t m = (size_t)1 << p, at = regs.size();
+        regs.resize(at + m);
+        for (size_t off = 0; off < m;) {
+            const int r = gzread(fp, regs.data() + at + off, (unsigned)std::min<size_t>(m - off, (size_t)1 << 30));
+            if (r <= 0) {
+                gzclose(fp);
+                return -EINVAL;
+            }
+            off += (size_t)r;
+        }
+        ++n;
+    }
+    gzclose(fp);
+    return n ? 0 : -EINVAL;
+}
+
+int write_labels_gz(const std::string &path, const std::vector<std::string> &paths)
+{
+    gzFile fp = gzopen(path.c_str(), "w");
+    if (!fp) return -EIO;
+    for (const auto &s : paths) {
+        gzwrite(fp, s.data(), (unsigned)s.size());
+        gzputc(fp, '\n');
+    }
+    return gzclose(fp) == Z_OK ? 0 : -EIO;
+}
+
+void union_registers(uint8_t *acc, const uint8_t *other, size_t m)
+{
+    for (size_t i = 0; i < m; ++i) acc[i] = std::max(acc[i], other[i]);
+}
+
+void fold_registers(const uint8_t *in, int p, int new_p, std::vector<uint8_t> &out)
+{
+    const int d = p - new_p;
+    const size_t m = (size_t)1 << p;
+    out.assign((size_t)1 << new_p, 0);
+    for (size_t idx = 0; idx < m; ++idx) {
+        const unsigned v = in[idx];
+        if (!v) continue;  // nothing ever hashed here
+        const size_t low = idx & (((size_t)1 << d) - 1);
+        unsigned nv;
+        if (low) {
+            int lead = 0;  // leading zeros of `low` within its d-bit field
+            while (!((low >> (d - 1 - lead)) & 1)) ++lead;
+            nv = (unsigned)lead + 1;
+        } else {
+            nv = (unsigned)d + v;
+        }
+        uint8_t &dst = out[idx >> d];
+        if (nv > dst) dst = (uint8_t)nv;
+    }
+}
+
+void print_hll(std::FILE *fp, const std::string &name, const uint8_t *regs, int p)
+{
+    const size_t m = (size_t)1 << p;
+    size_t zeros = 0;
+    unsigned mx = 0;
+    for (size_t i = 0; i < m; ++i) {
+        zeros += regs[i] == 0;
+        mx = std::max<unsigned>(mx, regs[i]);
+    }
+    std::fprintf(fp, "#%s\tp=%d\tregisters=%zu\tempty=%zu\tmax=%u\n", name.c_str(), p, m, zeros, mx);
+    std::string s;
+    char num[8];
+    for (size_t i = 0; i < m; ++i) {
+        s.append(num, (size_t)std::snprintf(num, sizeof num, i ? ",%u" : "%u", (unsigned)regs[i]));
+        if (s.size() > (1u << 16)) {
+            std::fwrite(s.data(), 1, s.size(), fp);
+            s.clear();
+        }
+    }
+    s += '\n';
+    std::fwrite(s.data(), 1, s.size(), fp);
 }
 
 void emit_sizes(std::FILE *fp, const std::vector<std::string> &paths, const double *card)

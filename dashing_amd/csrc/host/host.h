@@ -38,10 +38,31 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out);
 std::string make_fname(const std::string &path, unsigned sketch_p, int k, const std::string &spacing,
                        const std::string &suffix, const std::string &prefix);
 // gz stream: uint32[4]{is_calculated, estim, jestim, 1}, uint32 p, double value, 2^p register bytes.
+// level: gz compression level 1..9, 0 = uncompressed ("wT", as union_main does), -1 = zlib default.
 int write_hll(const std::string &path, const uint8_t *regs, int p, int estim, int jestim,
-              bool is_calculated, double value);
+              bool is_calculated, double value, int level = -1);
 // Accepts the layout above and the older uint8[4] flag block; fills p. Returns 0 or -errno-style.
 int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p);
+
+// Several sketches back to back in ONE gz stream (`sketch -o FILE`, src/sketch_and_cmp.h:466-475,
+// 529-536: every sketch is written with the same write(gzFile) as a single-sketch file).
+int write_hll_multi(const std::string &path, const uint8_t *regs /*[n][2^p]*/, size_t n, int p, int estim);
+// Reads such a stream (n >= 1 sketches of equal p); regs gets n * 2^p bytes.
+int read_hll_multi(const std::string &path, std::vector<uint8_t> &regs, int &p, size_t &n);
+// "<FILE>.labels.gz": one input path per line, gz (src/sketch_and_cmp.h:466-472)
+int write_labels_gz(const std::string &path, const std::vector<std::string> &paths);
+
+// ---- utilities on sketches (`union`, `fold`, `view`; src/union.cpp:33-58, src/dashing.cpp:559-590) ----
+// hll_t::operator+= : element-wise register maximum (the sketch of the union of the two sets).
+void union_registers(uint8_t *acc, const uint8_t *other, size_t m);
+// hll_t::compress(new_p): the sketch the same k-mer stream would have produced at precision
+// new_p < p.  Derived from the register rule (src/readfilt.cpp:86-88): an item in register idx with
+// value v has hash bits [idx (p bits)][v-1 zeros][1]..., so at new_p its index is idx >> d
+// (d = p - new_p) and its value is clz_d(idx & (2^d - 1)) + 1 if those d bits are non-zero, else d + v.
+void fold_registers(const uint8_t *in, int p, int new_p, std::vector<uint8_t> &out);
+// `view`: human-readable dump (the reference's hll_t::printf lives in the absent sketch submodule;
+// the layout here is ours): one header line, then the register values comma-separated.
+void print_hll(std::FILE *fp, const std::string &name, const uint8_t *regs, int p);
 
 // ---- emitters -------------------------------------------------------------------------------
 // sizes file (src/sketch_and_cmp.h:372-385)

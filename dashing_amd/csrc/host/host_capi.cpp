@@ -109,6 +109,37 @@ int dshh_emit_matrix(const char *outpath, int fmt, const char *joined_paths, con
     return 0;
 }
 
+int dshh_fold(const uint8_t *in, int p, int new_p, uint8_t *out)
+{
+    if (new_p < 1 || new_p >= p) return -1;
+    std::vector<uint8_t> v;
+    fold_registers(in, p, new_p, v);
+    std::memcpy(out, v.data(), v.size());
+    return 0;
+}
+
+void dshh_union(uint8_t *acc, const uint8_t *other, size_t m) { union_registers(acc, other, m); }
+
+int dshh_write_hll_multi(const char *path, const uint8_t *regs, size_t n, int p, int estim)
+{
+    return write_hll_multi(path, regs, n, p, estim);
+}
+
+int dshh_read_hll_multi(const char *path, uint8_t *regs_out, size_t cap, int *p, size_t *n)
+{
+    std::vector<uint8_t> r;
+    int rc = read_hll_multi(path, r, *p, *n);
+    if (rc) return rc;
+    if (r.size() > cap) return -1;
+    std::memcpy(regs_out, r.data(), r.size());
+    return 0;
+}
+
+int dshh_write_labels_gz(const char *path, const char *joined_paths)
+{
+    return write_labels_gz(path, unpack(joined_paths));
+}
+
 int dshh_emit_sizes(const char *outpath, const char *joined_paths, const double *card)
 {
     std::FILE *fp = std::fopen(outpath, "wb");

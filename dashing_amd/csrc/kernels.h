@@ -31,7 +31,7 @@ struct FinalizeLaunch {
     const uint32_t *exc, *exc_n;
     const uint8_t *tailhist;
     uint64_t n;
-    int rect, sorted_out;
+    int rect, sorted_out, square;
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
 };
@@ -51,6 +51,8 @@ struct SketchWork {
     uint32_t nsub;   // number of 8192-base sub-chunks this workgroup walks
     uint32_t slot;   // row of the resident sketch matrix
 };
+constexpr int kMaxPLds = 17;   // largest p whose registers fit a workgroup's LDS (k_sketch) and the compare path takes
+constexpr int kMaxP = 24;      // largest p for sketching / cardinalities / up- and download (positions are 24-bit)
 constexpr uint32_t kSketchSub = 8192;  // bases per sub-chunk (256 threads x 32 start positions)
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs);

@@ -368,6 +368,9 @@ struct FinalizeArgs {
     // (sorted) order instead of original sketch order -- used for multi-GPU shards, whose spans
     // are gathered first and un-permuted once (k_unpermute)
     int sorted_out;
+    // square != 0 (triangle tiles, all rows): every pair is written at BOTH out[i*n+j] and
+    // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
+    int square;
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
@@ -422,6 +425,8 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     bool active;
     if (a.rect) {
         active = j >= a.col_begin && j < a.col_end;
+    } else if (a.square) {
+        active = si < sj;
     } else if (a.sorted_out) {
         oi = si;
         oj = sj;
@@ -534,6 +539,12 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
     const double us = estimate(c, raw, a.p, a.estim, vlo_t, maxv);
     const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
+    if (a.square) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
+        a.out[i * a.n + j] = res;
+        const bool asym = a.result_type == 4 || a.result_type == 5 || a.result_type == 6;
+        a.out[j * a.n + i] = asym ? result_cmp_from(a.card[i], a.card[j], us, a.result_type, a.ksinv) : res;
+        return;
+    }
     uint64_t oidx;
     if (a.rect) oidx = (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin);
     else oidx = oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
@@ -719,7 +730,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out;
+    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);

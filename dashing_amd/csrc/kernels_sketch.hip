@@ -15,6 +15,10 @@
 // cannot raise a register, the rest do a CAS on the containing word.  At the end each
 // workgroup max-merges its LDS array into the resident matrix with 32-bit CAS (byte-wise
 // SWAR max).  max is commutative/associative/idempotent => bit-exact, order-independent.
+// Sketches too large for LDS (p > 17; the `hll` subcommand's default is p = 24,
+// src/hllmain.cpp:5) take the GLOBAL variant: same k-mer pipeline, but the filter read and
+// the CAS go straight to the register array in HBM/L2 (a stale cached read can only be too
+// small, i.e. cause a CAS that then sees the true value -- never a lost update).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -95,6 +99,7 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
     return acc;
 }
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, int canon, uint8_t *__restrict__ regs)
@@ -103,12 +108,12 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     // [0, 2^p/4): registers as packed bytes; then the packed words of the current sub-chunk, one
     // slot per lane plus one for the 32 bases that follow it (each lane needs its right neighbour)
     const int tid = threadIdx.x;
-    const uint32_t mwords = (1u << p) >> 2;
-    uint32_t *lregs = lds;
+    const uint32_t mwords = GLOBAL ? 0u : (1u << p) >> 2;
+    const SketchWork wk = work[blockIdx.x];
+    uint32_t *lregs = GLOBAL ? reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p)) : lds;
     uint64_t *xF = reinterpret_cast<uint64_t *>(lds + ((mwords + 3) & ~3u));
     uint64_t *xR = xF + 260;
     uint32_t *xV = reinterpret_cast<uint32_t *>(xR + 260);
-    const SketchWork wk = work[blockIdx.x];
     for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = 0;
 
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             }
         }
     }
+    if (GLOBAL) return;
     __syncthreads();
     uint32_t *g = reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p));
     for (uint32_t w = tid; w < mwords; w += 256) {
@@ -189,14 +195,19 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs)
 {
     if (nwork == 0) return hipSuccess;
-    // registers (2^p bytes, 16-byte aligned) + 260 x (F, R) + 260 x V exchange slots
-    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + 260 * 16 + 260 * 4 + 16;
+    const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
+    if (p > kMaxPLds) {
+        hipLaunchKernelGGL(k_sketch<true>, dim3(nwork), dim3(256), xch, st, seq, work, k, p, canon, regs);
+        return hipGetLastError();
+    }
+    // registers (2^p bytes, 16-byte aligned) + the exchange slots
+    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
     if (lds > (48u << 10)) {  // per launch: the attribute is per device
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_sketch, dim3(nwork), dim3(256), lds, st, seq, work, k, p, canon, regs);
+    hipLaunchKernelGGL(k_sketch<false>, dim3(nwork), dim3(256), lds, st, seq, work, k, p, canon, regs);
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=Non
     sizes = [span_off[r + 1] - span_off[r] for r in range(world)]
     mx = max(max(sizes), 1)
     assert local.numel() >= mx
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local[: sizes[0]]
     send = local[:mx]
     if rank != dst:

@@ -243,5 +243,37 @@ def test_cli_rejects_out_of_scope(genomes):
     d, paths, seqs = genomes
     r = subprocess.run([CLI, "dist", "--use-bb-minhash", *paths], capture_output=True)
     assert r.returncode != 0
-    r = subprocess.run([CLI, "union", *paths], capture_output=True)
+    r = subprocess.run([CLI, "panel", *paths], capture_output=True)
     assert r.returncode != 0
+    r = subprocess.run([CLI, "union", *paths], capture_output=True)  # FASTA files are not sketches
+    assert r.returncode != 0
+
+
+def test_sketch_single_output_file(genomes, oracle, tmp_path):
+    """`sketch -o FILE`: all sketches in one gz stream + FILE.labels.gz (src/sketch_and_cmp.h:466-475,529-536)."""
+    d, paths, seqs = genomes
+    out = str(tmp_path / "all.hll")
+    run("sketch", "-k", 31, "-S", 12, "-p", 4, "--avoid-sorting", "-o", out, *paths)
+    want = oracle_regs(oracle, seqs, 31, 12)
+    raw = gzip.open(out).read()
+    rec = 28 + (1 << 12)
+    assert len(raw) == len(paths) * rec
+    for i in range(len(paths)):
+        assert raw[i * rec + 28 : (i + 1) * rec] == want[i].tobytes(), i
+    assert gzip.open(out + ".labels.gz").read().decode().split("\n")[:-1] == paths
+    assert not any(f.endswith(".hll") for f in os.listdir(d))  # no per-genome files in this mode
+
+
+@pytest.mark.parametrize("S", [12, 18, 24])
+def test_hll_subcommand(genomes, oracle, tmp_path, S):
+    """`hll` (src/hllmain.cpp): every input sketched into ONE HLL; p > 17 takes the HBM-register kernel."""
+    d, paths, seqs = genomes
+    r = run("hll", "-k", 31, "-S", S, "-p", 4, *paths)
+    line = r.stdout.decode().strip()
+    assert line.startswith("Estimated number of unique exact matches: ")
+    got = float(line.split(": ")[1])
+    sep = np.frombuffer(b"N", np.uint8)  # k-mers never span files or records
+    joined = np.concatenate([x for s_ in seqs for x in (s_, sep)])
+    one = oracle.sketch_batch(joined, np.array([0, joined.size], np.uint64), 31, S)
+    want = oracle.cardinalities(one)[0]
+    assert abs(got - want) <= 1e-6 * want + 1e-6   # printed with %lf: 6 decimals

@@ -290,6 +290,24 @@ def test_knn_vs_oracle(ctx, oracle, rt):
     assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("rt", [dashing_amd.JI, dashing_amd.CONTAINMENT_INDEX, dashing_amd.FULL_CONTAINMENT_DIST])
+def test_knn_all_vs_all_paths_agree(ctx, oracle, rt):
+    """All-vs-all kNN computes each pair once into an n x n matrix (both orientations -- the containment
+    measures are asymmetric); the block-of-queries fallback must select exactly the same neighbours."""
+    n, p = 700, 12
+    regs = synth.related_sketches(n, p, seed=91)[0]
+    ctx.set_sketches(regs)
+    gi, gv = ctx.knn(7, result_type=rt, k=31)
+    ctx.set_option("knn_square_budget_bytes", 0)
+    try:
+        fi, fv = ctx.knn(7, result_type=rt, k=31)
+    finally:
+        ctx.set_option("knn_square_budget_bytes", 96 << 30)
+    assert (gi == fi).all() and (gv.view(np.uint32) == fv.view(np.uint32)).all()
+    wi, wv = oracle.knn(regs, 7, result_type=rt, k=31)
+    assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)

@@ -44,6 +44,19 @@ def test_precisions(ctx, oracle, p):
     run(ctx, oracle, gs, 31, p)
 
 
+@pytest.mark.parametrize("p", [18, 20, 24])
+def test_large_precisions_hbm_registers(ctx, oracle, p):
+    """p > 17 does not fit LDS: the GLOBAL variant of k_sketch updates the registers in HBM directly.
+    Same bit-exact contract; cardinalities too (the compare path stops at p = 17 and says so)."""
+    gs = synth.synthetic_genomes(2, 150013, seed=p, decorate=True)
+    regs = run(ctx, oracle, gs, 31, p)
+    got = ctx.cardinalities()
+    want = oracle.cardinalities(regs)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    with pytest.raises(Exception, match="compare path"):
+        ctx.dist_rows(0, len(gs))
+
+
 def test_ragged_and_edge_genomes(ctx, oracle):
     """empty genome, shorter than k, exactly k, all-N, N every 31 bases, separators between records,
     lengths that straddle the 32/8192/131072-base chunk boundaries, unaligned offsets."""

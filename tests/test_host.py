@@ -25,6 +25,12 @@ def host():
     lib.dshh_split_genome_paths.argtypes = [cp, cp, sz]
     lib.dshh_emit_matrix.argtypes = [cp, C.c_int, cp, vp]
     lib.dshh_emit_sizes.argtypes = [cp, cp, vp]
+    lib.dshh_fold.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.dshh_union.argtypes = [vp, vp, sz]
+    lib.dshh_union.restype = None
+    lib.dshh_write_hll_multi.argtypes = [cp, vp, sz, C.c_int, C.c_int]
+    lib.dshh_read_hll_multi.argtypes = [cp, vp, sz, C.POINTER(C.c_int), C.POINTER(sz)]
+    lib.dshh_write_labels_gz.argtypes = [cp, cp]
     return lib
 
 
@@ -153,3 +159,116 @@ def test_sizes_file(host, tmp_path):
     card = np.array([1234.9, 5.0e6 + 0.2], np.float64)
     assert host.dshh_emit_sizes(out.encode(), b"a.fna\nb.fna", card.ctypes.data) == 0
     assert open(out).read() == "#Path\tSize (est.)\na.fna\t1234\nb.fna\t5000000\n"
+
+
+# ---- utilities on sketches: fold / union / multi-sketch files ----------------
+def test_fold_equals_sketching_at_lower_precision(host):
+    """hll_t::compress (src/dashing.cpp:588): folding the p-bit sketch of a k-mer stream must give
+    exactly the sketch the same stream produces at new_p (register rule, src/readfilt.cpp:86-88)."""
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    gs = synth.synthetic_genomes(3, 40000, seed=77, decorate=True)
+    seq, off = synth.concat_for_device(gs)
+    for p, newp in ((14, 13), (14, 10), (12, 4), (17, 9), (20, 12)):
+        hi = oracle_c.sketch_batch(seq, off, 31, p)
+        lo = oracle_c.sketch_batch(seq, off, 31, newp)
+        for g in range(len(gs)):
+            out = np.zeros(1 << newp, np.uint8)
+            assert host.dshh_fold(hi[g].ctypes.data, p, newp, out.ctypes.data) == 0
+            assert (out == lo[g]).all(), (p, newp, g)
+    # saturated and empty registers: value q+1 maps to q'+1, zero stays zero
+    p, newp = 10, 8
+    regs = np.zeros(1 << p, np.uint8)
+    regs[0] = 64 - p + 1
+    regs[5] = 3        # low bits 01 of index 5 -> value clz_2(01)+1 = 2 in register 1
+    out = np.zeros(1 << newp, np.uint8)
+    assert host.dshh_fold(regs.ctypes.data, p, newp, out.ctypes.data) == 0
+    assert out[0] == 64 - newp + 1 and out[1] == 2 and out[2:].sum() == 0
+    assert host.dshh_fold(regs.ctypes.data, p, p, out.ctypes.data) != 0
+
+
+def test_union_is_sketch_of_concatenation(host):
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    gs = synth.synthetic_genomes(2, 30000, seed=5)
+    seq, off = synth.concat_for_device(gs)
+    regs = oracle_c.sketch_batch(seq, off, 31, 12)
+    joined = np.concatenate([gs[0], np.frombuffer(b"N", np.uint8), gs[1]])  # k-mers must not span genomes
+    both = oracle_c.sketch_batch(joined, np.array([0, joined.size], np.uint64), 31, 12)[0]
+    acc = regs[0].copy()
+    host.dshh_union(acc.ctypes.data, regs[1].ctypes.data, acc.size)
+    assert (acc == np.maximum(regs[0], regs[1])).all()
+    assert (acc == both).all()
+
+
+def test_multi_sketch_file_and_labels(host, tmp_path):
+    rng = np.random.default_rng(3)
+    p, n = 9, 5
+    regs = rng.integers(0, 40, (n, 1 << p)).astype(np.uint8)
+    path = str(tmp_path / "all.hll")
+    assert host.dshh_write_hll_multi(path.encode(), regs.ctypes.data, n, p, 2) == 0
+    raw = gzip.open(path).read()
+    rec = 28 + (1 << p)
+    assert len(raw) == n * rec
+    for i in range(n):  # every record is a complete single-sketch image (src/sketch_and_cmp.h:529-536)
+        assert struct.unpack("<I", raw[i * rec + 16 : i * rec + 20]) == (p,)
+        assert raw[i * rec + 28 : (i + 1) * rec] == regs[i].tobytes()
+    out = np.zeros_like(regs)
+    pp, nn = C.c_int(), C.c_size_t()
+    assert host.dshh_read_hll_multi(path.encode(), out.ctypes.data, out.size, C.byref(pp), C.byref(nn)) == 0
+    assert pp.value == p and nn.value == n and (out == regs).all()
+    lab = str(tmp_path / "all.hll.labels.gz")
+    assert host.dshh_write_labels_gz(lab.encode(), b"a.fna\nb c.fna\n") == 0
+    assert gzip.open(lab).read() == b"a.fna\nb c.fna\n"
+
+
+def test_cli_union_fold_view_run_without_gpu(host, tmp_path):
+    """`union`, `fold`, `view` are host-only (no dsh_create): they must work on a CPU-only box."""
+    import subprocess
+
+    cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+    rng = np.random.default_rng(9)
+    p = 10
+    regs = rng.integers(0, 20, (3, 1 << p)).astype(np.uint8)
+    paths = []
+    for i in range(3):
+        f = str(tmp_path / ("s%d.hll" % i))
+        assert host.dshh_write_hll(f.encode(), regs[i].ctypes.data, p, 2) == 0
+        paths.append(f)
+    u = str(tmp_path / "u.hll")
+    r = subprocess.run([cli, "union", "-p", "2", "-o", u] + paths, capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    out = np.zeros(1 << p, np.uint8)
+    pp = C.c_int()
+    assert host.dshh_read_hll(u.encode(), out.ctypes.data, out.size, C.byref(pp)) == 0
+    assert pp.value == p and (out == regs.max(axis=0)).all()
+    # -F paths file and uncompressed output
+    lst = tmp_path / "l.txt"
+    lst.write_text("\n".join(paths[:2]) + "\n")
+    u2 = str(tmp_path / "u2.hll")
+    r = subprocess.run([cli, "union", "-Z", "0", "-F", str(lst), "-o", u2], capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    raw = open(u2, "rb").read()
+    assert len(raw) == 28 + (1 << p) and raw[28:] == np.maximum(regs[0], regs[1]).tobytes()
+    # mismatched precisions are an error
+    small = str(tmp_path / "small.hll")
+    assert host.dshh_write_hll(small.encode(), regs[0].ctypes.data, p - 1, 2) == 0
+    assert subprocess.run([cli, "union", "-o", u, paths[0], small], capture_output=True).returncode != 0
+    # fold: default destination is p-1 (src/dashing.cpp:587)
+    f1 = str(tmp_path / "f.hll")
+    r = subprocess.run([cli, "fold", "-o", f1, paths[0]], capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    want = np.zeros(1 << (p - 1), np.uint8)
+    assert host.dshh_fold(regs[0].ctypes.data, p, p - 1, want.ctypes.data) == 0
+    got = np.zeros(1 << (p - 1), np.uint8)
+    assert host.dshh_read_hll(f1.encode(), got.ctypes.data, got.size, C.byref(pp)) == 0
+    assert pp.value == p - 1 and (got == want).all()
+    assert subprocess.run([cli, "fold", "-p", str(p), "-o", f1, paths[0]], capture_output=True).returncode != 0
+    # view: header line + all register values
+    r = subprocess.run([cli, "view", paths[1]], capture_output=True, timeout=60)
+    assert r.returncode == 0
+    lines = r.stdout.decode().strip().split("\n")
+    assert lines[0].startswith("#" + paths[1]) and "p=%d" % p in lines[0]
+    assert [int(x) for x in lines[1].split(",")] == regs[1].tolist()
