@@ -20,7 +20,7 @@ _LIB = None
 # every symbol include/dashing_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "dsh_backend_name", "dsh_device_count", "dsh_create", "dsh_destroy", "dsh_last_error",
-    "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches",
+    "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches", "dsh_copy_sketches_device",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_alloc_host", "dsh_free_host",
@@ -61,6 +61,7 @@ def load_library():
     lib.dsh_sketches_alloc.argtypes = [vp, u64, i32]
     lib.dsh_upload_sketches.argtypes = [vp, vp, u64, u64]
     lib.dsh_download_sketches.argtypes = [vp, u64, u64, vp]
+    lib.dsh_copy_sketches_device.argtypes = [vp, u64, u64, vp]
     lib.dsh_attach_device_sketches.argtypes = [vp, vp, u64, i32]
     lib.dsh_sketch_batch.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32, vp]
     lib.dsh_sketch_batch_device.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
@@ -191,6 +192,10 @@ class Context:
         out = np.zeros((n, 1 << self.p), np.uint8)
         self._ck(self._lib.dsh_download_sketches(self._h, first_slot, n, out.ctypes.data))
         return out
+
+    def copy_sketches_device(self, out_ptr, first_slot=0, n=None):
+        n = self.n - first_slot if n is None else n
+        self._ck(self._lib.dsh_copy_sketches_device(self._h, first_slot, n, C.c_void_p(out_ptr)))
 
     def clear(self, first_slot=0, n=None):
         n = self.n - first_slot if n is None else n

@@ -583,6 +583,21 @@ int dsh_download_sketches(dsh_ctx *c, uint64_t first, uint64_t n, uint8_t *out)
     return DSH_OK;
 }
 
+int dsh_copy_sketches_device(dsh_ctx *c, uint64_t first, uint64_t n, void *d_out)
+{
+    if (!c || (!d_out && n)) return DSH_EINVAL;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches");
+    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    int rc = bind(c);
+    if (rc) return rc;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(d_out, c->regs + (first << c->p), (size_t)n << c->p,
+                                 hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return DSH_OK;
+}
+
 int dsh_clear_sketches(dsh_ctx *c, uint64_t first, uint64_t n)
 {
     if (!c) return DSH_EINVAL;

@@ -65,3 +65,30 @@ def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=Non
     for r in range(world):
         sorted_full[span_off[r] : span_off[r + 1]] = parts[r][: sizes[r]]
     return sorted_full
+
+
+# ---- sharded sketching: genomes dealt to ranks, register arrays all-gathered ----
+def deal_genomes(n_genomes, rank, world):
+    """Genome g (in the size-sorted input order of sort_paths_by_fsize, src/finalizers.cpp:6-21) goes to
+    rank g % world: round-robin over the descending sizes keeps the bases per rank balanced."""
+    return list(range(rank, n_genomes, world))
+
+
+def allgather_sketches(local, n_genomes, rank, world):
+    """local: uint8 tensor [ceil(n_genomes/world)][2^p] -- row t is this rank's t-th genome (genome
+    rank + t*world; rows past the rank's share are padding).  Returns the full matrix [n_genomes][2^p]
+    in input order on EVERY rank (one all_gather_into_tensor of equal-sized blocks: RCCL over xGMI on
+    the GPU box, gloo in the CPU tests), ready for Context.attach_device."""
+    per = (n_genomes + world - 1) // world
+    assert local.dim() == 2 and local.shape[0] == per and local.dtype == torch.uint8
+    if world == 1 and not dist.is_initialized():
+        return local[:n_genomes]
+    m = local.shape[1]
+    allr = torch.empty((world, per, m), dtype=torch.uint8, device=local.device)
+    if dist.get_backend() == "gloo":  # gloo has no all_gather_into_tensor for every build: use the list form
+        parts = [allr[r] for r in range(world)]
+        dist.all_gather(parts, local.contiguous())
+    else:
+        dist.all_gather_into_tensor(allr, local.contiguous())
+    # rank-major [r][t] -> genome order g = t*world + r
+    return allr.permute(1, 0, 2).reshape(per * world, m)[:n_genomes].contiguous()

@@ -69,6 +69,10 @@ int dsh_sketches_alloc(dsh_ctx *ctx, uint64_t n, int p);
 /* sketch.read(path) path (src/sketch_and_cmp.h:318-324, --presketched): host rows -> slots. */
 int dsh_upload_sketches(dsh_ctx *ctx, const uint8_t *regs, uint64_t first_slot, uint64_t n);
 int dsh_download_sketches(dsh_ctx *ctx, uint64_t first_slot, uint64_t n, uint8_t *regs_out);
+/* Same, into a caller-owned DEVICE buffer (device-to-device on the ctx stream; returns when done).
+ * Multi-GPU sketching: each rank sketches its share of the genomes, copies its rows
+ * out with this call and the ranks all-gather the register arrays over RCCL. */
+int dsh_copy_sketches_device(dsh_ctx *ctx, uint64_t first_slot, uint64_t n, void *d_regs_out);
 /* Use a caller-owned DEVICE buffer [n][2^p] as the sketch matrix (no copy; the caller keeps it
  * alive).  This is how bench.py hands over inputs already resident in HBM. */
 int dsh_attach_device_sketches(dsh_ctx *ctx, const void *d_regs, uint64_t n, int p);

@@ -1,0 +1,97 @@
+"""Worker for tests/test_gpu_multirank.py: the whole N-rank path on real GPU kernels --
+genomes dealt to ranks -> k_sketch -> all-gather of the register arrays -> cost-balanced shards of
+the all-pairs matrix -> gather to rank 0 -> un-permute -- checked against the CPU oracle on rank 0.
+
+Launched with torchrun (RANK/WORLD_SIZE/MASTER_* from the env).  E2E_BACKEND=nccl is the real thing
+(one GPU per rank; with WORLD_SIZE=1 it still initialises RCCL and runs every collective);
+E2E_BACKEND=gloo lets several ranks share cuda:0 on a 1-GPU box (collectives staged through the host)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    backend = os.environ.get("E2E_BACKEND", "nccl")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import dashing_amd
+    from dashing_amd import multigpu, synth
+
+    n, p, k = 301, 12, 31  # 3 tile rows of 128 sketches: every rank of a 2- or 3-rank run gets a shard
+    lens = [9000 + 477 * ((g * 7) % 11) for g in range(n)]
+    base = synth.synthetic_genomes(n, 14000, seed=0xE2E)
+    genomes = [g[:L] for g, L in zip(base, lens)]
+    m = 1 << p
+
+    ctx = dashing_amd.Context(local_rank)
+    # ---- sketch my share (genome g -> rank g % world), rows in local order
+    mine = multigpu.deal_genomes(n, rank, world)
+    per = (n + world - 1) // world
+    ctx.alloc(per, p)
+    if mine:
+        seq, off = synth.concat_for_device([genomes[g] for g in mine])
+        ctx.sketch_batch(seq, off, 0, k, True, want_regs=False)
+    local = torch.empty((per, m), dtype=torch.uint8, device=dev)
+    ctx.copy_sketches_device(local.data_ptr(), 0, per)
+    # ---- all-gather the register arrays: every rank gets all n sketches in input order
+    if backend == "gloo":
+        regs_d = multigpu.allgather_sketches(local.cpu(), n, rank, world).to(dev)
+    else:
+        regs_d = multigpu.allgather_sketches(local, n, rank, world)
+    torch.cuda.synchronize()
+    # ---- all-pairs: one cost-balanced shard per rank, gather on rank 0, un-permute
+    ctx.attach_device(regs_d.data_ptr(), n, p)
+    total = n * (n - 1) // 2
+    span_off = ctx.shard_plan(world)
+    mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
+    out_d = torch.zeros(mx, dtype=torch.float32, device=dev)
+    ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.MASH_DIST, k)
+    ctx.synchronize()
+    if backend == "gloo":
+        full = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
+        full = full.to(dev) if rank == 0 else None
+    else:
+        full = multigpu.gather_shard_spans(out_d, span_off, rank, world)
+    ok = True
+    if rank == 0:
+        torch.cuda.synchronize()
+        final = torch.empty(total, dtype=torch.float32, device=dev)
+        ctx.unpermute_device(full.data_ptr(), final.data_ptr())
+        ctx.synchronize()
+        from oracle import oracle_c  # the checker (tests only)
+
+        oracle_c.load(threads=4)
+        seq, off = synth.concat_for_device(genomes)
+        want_regs = oracle_c.sketch_batch(seq, off, k, p, True)
+        got_regs = regs_d.cpu().numpy()
+        assert (got_regs == want_regs).all(), "all-gathered registers differ from the oracle"
+        want = oracle_c.dist_tri(want_regs, result_type=dashing_amd.MASH_DIST, k=k)
+        got = final.cpu().numpy()
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-9)
+        assert rel.max() <= 1e-6, rel.max()
+        print("E2E_OK world=%d backend=%s pairs=%d max_rel=%.3g" % (world, backend, total, rel.max()), flush=True)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,33 @@
+"""GPU: the N-rank path end to end on real kernels (sketch shares -> all-gather of registers ->
+sharded all-pairs -> gather -> un-permute), see tests/e2e_multigpu_worker.py.  A 1-GPU box can run
+(a) RCCL with a single rank -- every collective is issued through the nccl backend -- and
+(b) two and three ranks sharing cuda:0 over gloo.  Real multi-GPU RCCL runs only in the driver's bench."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "e2e_multigpu_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2), ("gloo", 3)])
+def test_end_to_end_ranks(backend, world):
+    env = dict(os.environ, E2E_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=600, cwd=ROOT)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "E2E_OK world=%d backend=%s" % (world, backend) in out, out[-3000:]

@@ -98,3 +98,41 @@ def test_bounds_cover_and_align():
             assert b[0] == 0 and b[-1] == n
             assert sum(multigpu.span_sizes(n, b)) == n * (n - 1) // 2
             assert all(x % 128 == 0 or x == n for x in b)
+
+
+def _worker_sketch(rank, world, port, n, p, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dashing_amd import multigpu, synth
+    from oracle import oracle_c
+
+    oracle_c.load(threads=2)
+    gs = synth.synthetic_genomes(n, 6000, seed=31)
+    mine = multigpu.deal_genomes(n, rank, world)
+    per = (n + world - 1) // world
+    local = torch.zeros((per, 1 << p), dtype=torch.uint8)
+    if mine:  # the per-rank sketching is stood in by the oracle here (no GPU in this container)
+        seq, off = synth.concat_for_device([gs[g] for g in mine])
+        local[: len(mine)] = torch.from_numpy(oracle_c.sketch_batch(seq, off, 21, p))
+    full = multigpu.allgather_sketches(local, n, rank, world)
+    np.save(os.path.join(outdir, "regs_%d_%d.npy" % (world, rank)), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 7), (3, 7), (2, 1)])
+def test_sharded_sketching_allgather_gloo(tmp_path, world, n):
+    """Genomes dealt round-robin to the ranks, register arrays all-gathered: every rank ends up with
+    the matrix a single rank would have sketched, rows in input order (ragged shares are padded)."""
+    p = 8
+    mp.spawn(_worker_sketch, args=(world, _free_port(), n, p, str(tmp_path)), nprocs=world, join=True)
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    seq, off = synth.concat_for_device(synth.synthetic_genomes(n, 6000, seed=31))
+    want = oracle_c.sketch_batch(seq, off, 21, p)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "regs_%d_%d.npy" % (world, r)))
+        assert got.shape == want.shape and (got == want).all()
