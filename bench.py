@@ -174,6 +174,9 @@ def main():
         "sorted_columns": bool(ctx.info("sorted")),
         "finalize_ms_per_step": round(fin_ms / reps, 4), "prepare_ms_per_step": round(prep_ms / reps, 4),
         "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
+        # SURVEY.md 8d also asks for the physical HBM rate and the compulsory floor (inputs once + outputs once)
+        "physical_hbm_gbs": round(traffic / (pair_ms / max(launches, 1) * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
+        "compulsory_bytes_per_step": n * m + 4 * total_pairs,
     }
 
     # what actually bounds the kernel: integer VALU issue (v_and_b32 + v_bcnt_u32_b32 per 32 pair-bits,

@@ -65,7 +65,8 @@ struct dsh_ctx {
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
-    int assembler_permille = 24;  // un-permute + span copies on rank 0 ~ 0.53 ms of a 22 ms pass (profiles/r1h)
+    int assembler_permille = 24;  // span copies (0.12 ms) + un-permute (0.40 ms) on rank 0 of a 21 ms pass (profiles/r1j, r1k)
+    int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
@@ -200,8 +201,10 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
             for (uint64_t i = 0; i < n; ++i) cnt[skey(i) + 1u]++;
             for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
             for (uint64_t i = 0; i < n; ++i) c->hperm[cnt[skey(i)]++] = (uint32_t)i;
-            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
-            if (n) HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->hperm.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * 2 * sizeof(uint32_t)));  // perm, then its inverse
+            c->hperm.resize(2 * n);
+            for (uint64_t s = 0; s < n; ++s) c->hperm[n + c->hperm[s]] = (uint32_t)s;
+            if (n) HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->hperm.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         } else {
             for (uint64_t i = 0; i < n; ++i) c->hperm[i] = (uint32_t)i;
         }
@@ -1008,7 +1011,8 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     if (!c->planes_valid || !c->planes_sorted) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
     if (c->n < 2) return DSH_OK;
     if (!d_sorted_tri || !d_out_tri) return DSH_EINVAL;
-    HIPCHK(c, launch_unpermute(c->stream, (const float *)d_sorted_tri, (const uint32_t *)c->perm.ptr, c->n, (float *)d_out_tri));
+    HIPCHK(c, launch_unpermute(c->stream, (const float *)d_sorted_tri, (const uint32_t *)c->perm.ptr,
+                               c->unperm_gather ? (const uint32_t *)c->perm.ptr + c->n : nullptr, c->n, (float *)d_out_tri));
     return DSH_OK;
 }
 
@@ -1078,6 +1082,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "cum_budget_bytes")) {
         if (v < (1 << 20)) return fail(c, DSH_EINVAL, "cum_budget_bytes too small");
         c->cum_budget = (uint64_t)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "unpermute_gather")) {
+        c->unperm_gather = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "knn_square_budget_bytes")) {

@@ -36,8 +36,9 @@ struct FinalizeLaunch {
     float *out;
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
-hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, uint64_t n,
-                            float *out);
+// inv != nullptr: destination-driven variant (coalesced writes, gathered reads); else scatter via perm
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
+                            uint64_t n, float *out);
 
 hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
                        uint64_t row0, uint64_t col0, int descending, uint32_t nn,

@@ -566,11 +566,28 @@ __global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ in,
     }
 }
 
-hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, uint64_t n,
-                            float *out)
+// same mapping driven from the destination: one block per ORIGINAL row a, coalesced writes of
+// row a of the output, gathered reads (inv = inverse of perm)
+__global__ __launch_bounds__(256) void k_unpermute_gather(const float *__restrict__ in,
+                                                           const uint32_t *__restrict__ inv, uint64_t n,
+                                                           float *__restrict__ out)
+{
+    const uint64_t a = blockIdx.x;
+    const uint64_t sa = inv[a];
+    float *row = out + a * (2 * n - a - 1) / 2 - (a + 1);
+    for (uint64_t b = a + 1 + threadIdx.x; b < n; b += 256) {
+        const uint64_t sb = inv[b];
+        const uint64_t lo = sa < sb ? sa : sb, hi = sa < sb ? sb : sa;
+        row[b] = in[lo * (2 * n - lo - 1) / 2 + hi - (lo + 1)];
+    }
+}
+
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
+                            uint64_t n, float *out)
 {
     if (n < 2) return hipSuccess;
-    hipLaunchKernelGGL(k_unpermute, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, perm, n, out);
+    if (inv) hipLaunchKernelGGL(k_unpermute_gather, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, inv, n, out);
+    else hipLaunchKernelGGL(k_unpermute, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, perm, n, out);
     return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ def test_golden_pairs(ctx):
             assert ((got == 1.0) == (want == 1.0)).all()  # J==0 branch agrees exactly
 
 
-@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 127), (10, 128), (10, 129), (10, 300), (14, 130), (14, 260), (15, 40), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20)])
+@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 127), (10, 128), (10, 129), (10, 300), (14, 130), (14, 260), (15, 40), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20), (16, 140), (17, 6)])
 @pytest.mark.parametrize("estim", [0, 1, 2])
 def test_tri_vs_oracle(ctx, oracle, p, n, estim):
     regs = synth.synthetic_sketches(n, p, seed=0x1234 + p * 131 + n)
@@ -212,9 +212,13 @@ def test_virtual_shards_assemble(ctx, nshards):
         sorted_full[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
     torch.cuda.synchronize()
     final = torch.full((off[-1],), -3.0, dtype=torch.float32, device=dev)
-    ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
-    ctx.synchronize()
-    assert final.cpu().numpy().tobytes() == want.tobytes()
+    for mode in (1, 0):  # destination-driven (default) and source-driven un-permute
+        ctx.set_option("unpermute_gather", mode)
+        final.fill_(-3.0)
+        ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
+        ctx.synchronize()
+        assert final.cpu().numpy().tobytes() == want.tobytes()
+    ctx.set_option("unpermute_gather", 1)
 
 
 @pytest.mark.parametrize("rt", [2, 4, 5, 6, 7, 8])

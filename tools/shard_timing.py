@@ -40,9 +40,14 @@ full = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device="cuda")
 fin = torch.empty_like(full)
 ctx.attach_device(regs.data_ptr(), n, p)
 ctx.shard_plan(8)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10):
+res = {}
+for name, mode in (("gather", 1), ("scatter", 0)):
+    ctx.set_option("unpermute_gather", mode)
     ctx.unpermute_device(full.data_ptr(), fin.data_ptr())
-ctx.synchronize()
-print(json.dumps({"unpermute_ms": (time.perf_counter() - t0) * 100}))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.unpermute_device(full.data_ptr(), fin.data_ptr())
+    ctx.synchronize()
+    res["unpermute_%s_ms" % name] = (time.perf_counter() - t0) * 100
+print(json.dumps(res))
