@@ -67,7 +67,7 @@ long dshh_append_fastx(const char *path, uint8_t *out, size_t cap, size_t *len)
     long n = append_fastx(path, v);
     if (n < 0) return n;
     if (v.size() > cap) return -2;
-    std::memcpy(out, v.data(), v.size());
+    if (!v.empty()) std::memcpy(out, v.data(), v.size());
     *len = v.size();
     return n;
 }
