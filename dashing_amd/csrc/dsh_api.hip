@@ -140,7 +140,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
     }
     const uint64_t n = c->n;
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
-                                          : (int)std::min<uint64_t>(64, (1ull << c->p) >> 8);
+                                          : (int)std::min<uint64_t>(96, (1ull << c->p) >> 8);
     if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
     c->emax = emax_new;
     if (!c->planes_valid || c->card_estim != estim) {
@@ -404,6 +404,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
         f.vlo = c->vlo;
         f.p = c->p;
+        f.emax = c->emax;
         f.estim = job.estim;
         f.result_type = job.result_type;
         f.ksinv = (double)ksinv_f;

@@ -25,7 +25,7 @@ struct FinalizeLaunch {
     uint64_t nslots;
     const uint4 *tiles;
     const uint32_t *perm;
-    int vlo, vhi, p, estim, result_type;
+    int vlo, vhi, p, estim, result_type, emax;
     double ksinv;
     const double *card;
     const uint32_t *exc, *exc_n;

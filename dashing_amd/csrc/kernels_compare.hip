@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "estimators.h"
 #include "kernels.h"
 
@@ -159,6 +161,9 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         const uint64_t c = c0 + lane;
         emit16(c < nch ? src[c] : make_uint4(0, 0, 0, 0), c, c < nch);
     }
+    // pad to a whole 16-byte piece with value-0 entries (k_finalize reads the list 16 B at a time and
+    // tells live entries by value > T alone); base <= emax <= kExcCap - 1
+    if (lane < 4 && (base & 3u) && lane >= (int)(base & 3u)) dst[(base & ~3u) + lane] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -371,6 +376,7 @@ struct FinalizeArgs {
     // square != 0 (triangle tiles, all rows): every pair is written at BOTH out[i*n+j] and
     // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
     int square;
+    uint32_t hash_slots;  // power of two >= 2 * emax: LDS hash of the row sketch's tail entries
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
@@ -383,8 +389,6 @@ struct FinalizeArgs {
 // position listed by BOTH sketches twice.  A lane therefore only walks its own sketch j's list
 // looking for shared positions (independent iterations, 16-B loads, one LDS probe each; hits are
 // rare: |list|^2 / 2^p per pair) and removes the smaller of the two values.  Exact, order-independent.
-constexpr uint32_t kHashSlots = 512;  // 2 x kExcCap
-
 template <typename CT>
 __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
@@ -392,7 +396,12 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // doubles the resident waves of this latency-sensitive kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
     CT *hs = reinterpret_cast<CT *>(hs_raw);  // [(vhi-vlo+1)][128]
-    __shared__ uint32_t hashA[kHashSlots];
+    // then: bitA = one bit per register position, set where the row sketch lists a value > T (the
+    // prefilter every list entry of a column sketch is tested against), and the hash with the values
+    const uint32_t kHashSlots = a.hash_slots;
+    const uint32_t bit_words = (1u << a.p) >> 5 ? (1u << a.p) >> 5 : 1u;
+    uint32_t *bitA = reinterpret_cast<uint32_t *>(hs_raw + (((size_t)(a.vhi - a.vlo + 1) * 128 * sizeof(CT) + 15) & ~(size_t)15));
+    uint32_t *hashA = bitA + bit_words;
     __shared__ uint32_t histA[64];
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // block-level skip (uniform) when the row sketch cannot be wanted
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
     for (uint32_t t = tid; t < kHashSlots; t += 128) hashA[t] = 0xFFFFFFFFu;
+    for (uint32_t t = tid; t < bit_words; t += 128) bitA[t] = 0;
     if (tid < 64) histA[tid] = 0;
     __syncthreads();
     const uint32_t na = a.exc_n[i];
@@ -414,6 +424,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         const uint32_t e = a.exc[i * kExcCap + t];
         if ((int)(e & 0xFFu) > T) {
             atomicAdd(&histA[e & 63u], 1u);
+            atomicOr(&bitA[e >> 13], 1u << ((e >> 8) & 31u));
             uint32_t h = (e >> 8) & (kHashSlots - 1);
             while (atomicCAS(&hashA[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1) & (kHashSlots - 1);
         }
@@ -473,46 +484,39 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // ... minus the smaller value at every position both sketches list (counted twice above)
     const uint32_t nb = a.exc_n[j];
     const uint4 *eb = reinterpret_cast<const uint4 *>(a.exc + j * kExcCap);
-    // Branch-light probing: two slots are read unconditionally (the table is <= 50 % full, linear
-    // probing, no deletions: an empty first slot means "absent"); only a hit, or the rare case of
-    // two occupied non-matching slots, takes a branch.
+    // One bit test per entry: bitA says whether the row sketch lists this position above T (0.4 % of
+    // the probes at p=14 / 64 entries); only then the hash is consulted for the row sketch's value.
+    // Padding and masked-off pieces are value-0 entries, never "live".
     constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    auto probe4 = [&](const uint4 e4, uint32_t first) {
+    auto probe4 = [&](const uint4 e4) {
         const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
-        uint32_t s0[4], s1[4];
+        uint32_t w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = bitA[ev[t] >> 13];
+        uint32_t cand = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint32_t h = (ev[t] >> 8) & (kHashSlots - 1);
-            s0[t] = hashA[h];
-            s1[t] = hashA[(h + 1) & (kHashSlots - 1)];
+            const uint32_t bit = (w[t] >> ((ev[t] >> 8) & 31u)) & 1u;
+            cand |= ((int)(ev[t] & 0xFFu) > T ? bit : 0u) << t;
         }
+        if (cand) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t e = ev[t], pos = e >> 8;
-            const int vb = (int)(e & 0xFFu);
-            const bool live = first + t < nb && vb > T;  // inside the list and counted in the tail bins
-            const bool hit0 = (s0[t] >> 8) == pos;       // kEmpty never matches a real position
-            const bool hit1 = s0[t] != kEmpty && (s1[t] >> 8) == pos;
-            const bool more = s0[t] != kEmpty && s1[t] != kEmpty && !hit0 && !hit1;
-            if (live && (hit0 | hit1 | more)) {
-                uint32_t sv = hit0 ? s0[t] : s1[t];
-                bool hit = hit0 | hit1;
-                if (more) {  // keep walking the probe sequence
-                    uint32_t h = (pos + 2) & (kHashSlots - 1);
-                    for (;;) {
-                        sv = hashA[h];
-                        if (sv == kEmpty) break;
-                        if ((sv >> 8) == pos) {
-                            hit = true;
-                            break;
+            for (int t = 0; t < 4; ++t) {
+                if (!((cand >> t) & 1u)) continue;
+                const uint32_t e = ev[t], pos = e >> 8;
+                const int vb = (int)(e & 0xFFu);
+                uint32_t h = pos & (kHashSlots - 1);
+                for (;;) {  // the bit guarantees the position is in the table
+                    const uint32_t sv = hashA[h];
+                    if ((sv >> 8) == pos || sv == kEmpty) {
+                        if (sv != kEmpty) {  // shared position: keep only the larger value
+                            const int va = (int)(sv & 0xFFu);
+                            col[((va < vb ? va : vb) - vlo) * 128] -= 1;
+                            --ucnt;
                         }
-                        h = (h + 1) & (kHashSlots - 1);
+                        break;
                     }
-                }
-                if (hit) {  // shared position: keep only the larger value
-                    const int va = (int)(sv & 0xFFu);
-                    col[((va < vb ? va : vb) - vlo) * 128] -= 1;
-                    --ucnt;
+                    h = (h + 1) & (kHashSlots - 1);
                 }
             }
         }
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) nxt[u] = q + 4 + u < nq ? eb[q + 4 + u] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) probe4(cur[u], (q + u) * 4);
+        for (int u = 0; u < 4; ++u) probe4(cur[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
@@ -750,7 +754,18 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
-    const size_t lds = (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
+    uint32_t hs = 16;
+    while (hs < 2u * (uint32_t)f.emax) hs <<= 1;
+    a.hash_slots = hs;
+    const size_t bit_words = std::max<size_t>(((size_t)1 << f.p) >> 5, 1);
+    const size_t lds = (((size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4) + 15) & ~(size_t)15) +
+                       (bit_words + hs) * sizeof(uint32_t);
+    if (lds > (48u << 10)) {  // large p: the position bitmap alone is 2^p / 8 bytes
+        hipError_t e = f.cum_bytes == 2
+                           ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);
