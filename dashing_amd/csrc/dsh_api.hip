@@ -49,7 +49,7 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
-    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, exc_n, keys, perm, tailhist;
+    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
     int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
     std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
@@ -140,17 +140,18 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
     }
     const uint64_t n = c->n;
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
-                                          : (int)std::min<uint64_t>(96, (1ull << c->p) >> 8);
+                                          : (int)std::min<uint64_t>(c->p >= 16 ? 192 : 96, (1ull << c->p) >> 7);  // sweeps: profiles/r1k/README.md
     if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
     c->emax = emax_new;
     if (!c->planes_valid || c->card_estim != estim) {
         HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
-        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t)));
+        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t) + 256));  // + slack: k_finalize prefetches one step past a list
+        HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kExcCap));
         HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->tailhist.ensure(std::max<uint64_t>(n, 1) * 64));
         HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
-                                       (double *)c->card.ptr, (uint32_t *)c->exc.ptr,
+                                       (double *)c->card.ptr, (uint32_t *)c->exc.ptr, (uint8_t *)c->excv.ptr,
                                        (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
                                        (uint8_t *)c->tailhist.ptr));
         c->card_estim = estim;
@@ -398,6 +399,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.vhi = c->vhi;
         f.exc = (const uint32_t *)c->exc.ptr;
         f.exc_n = (const uint32_t *)c->exc_n.ptr;
+        f.excv = (const uint8_t *)c->excv.ptr;
         f.tailhist = (const uint8_t *)c->tailhist.ptr;
         f.nslots = nslots;
         f.tiles = dt;
@@ -500,6 +502,7 @@ void dsh_destroy(dsh_ctx *c)
     c->planes.release();
     c->exc.release();
     c->exc_n.release();
+    c->excv.release();
     c->keys.release();
     c->tailhist.release();
     c->perm.release();

@@ -9,7 +9,7 @@ constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
 constexpr uint32_t kExcCap = 256;  // capacity of a sketch's exception list (entries); emax <= 255
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, uint32_t *exc, uint32_t *exc_n,
+                                int emax, double *card, uint32_t *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
@@ -29,6 +29,7 @@ struct FinalizeLaunch {
     double ksinv;
     const double *card;
     const uint32_t *exc, *exc_n;
+    const uint8_t *excv;
     const uint8_t *tailhist;
     uint64_t n;
     int rect, sorted_out, square;

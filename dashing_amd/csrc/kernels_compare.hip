@@ -38,14 +38,18 @@ namespace dsh {
 
 // ------------------------------------------------------------------------------------------
 // per-sketch pass.  block = 256 threads = 4 waves, one sketch per wave.
+// PT = type of a listed position: uint16_t for p <= 15, uint32_t above.
+template <typename PT>
 __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs,
                                                         uint64_t n, int p, int estim, int emax,
                                                         double *__restrict__ card,
                                                         uint32_t *__restrict__ exc,
+                                                        uint8_t *__restrict__ excv,
                                                         uint32_t *__restrict__ exc_n,
                                                         uint32_t *__restrict__ keys,
                                                         uint8_t *__restrict__ tailhist)
 {
+    __shared__ uint32_t cursor[4][64];
     __shared__ uint32_t hist[4][64];
     __shared__ uint32_t sub[4][8][64];  // 8 privatised copies per wave: the register values pile up
                                         // in ~8 bins, so one copy would serialise its LDS atomics
@@ -118,52 +122,55 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     // pair's tail bins from the two sketches' tail histograms and only corrects shared positions
     tailhist[s * 64 + lane] = lane > thr[wave] ? (uint8_t)hist[wave][lane] : (uint8_t)0;
     if (emax == 0) return;
-    // second pass: registers above T_i, in position order (iteration-major, lane, byte)
+    // second pass: the registers above T_i as a list ordered by VALUE, largest first (any order within
+    // a value): for a tile threshold T >= T_i the entries that matter (value > T) are then a prefix
+    // whose length is the sum of the tail histogram above T.  Positions and values go to separate
+    // arrays (k_finalize streams positions only).  Slot = start of the value's run + a running counter.
     const uint32_t T = (uint32_t)thr[wave];
-    uint32_t *dst = exc + s * kExcCap;
-    uint32_t base = 0;
-    auto emit16 = [&](const uint4 x, uint64_t c, bool inrange) {
-        uint32_t w[4] = {x.x, x.y, x.z, x.w};
-        uint32_t mine = 0;
-        if (inrange) {
+    {
+        uint32_t start = 0;
+        for (int x = 63; x > lane; --x) start += hist[wave][x];  // entries with a larger value
+        cursor[wave][lane] = start;                              // only read for lane > T
+    }
+    // cursor[wave] is private to this wave (some waves of the block may already have returned)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PT *dstp = reinterpret_cast<PT *>(exc + s * kExcCap);
+    uint8_t *dstv = excv + s * kExcCap;
+    uint32_t *cur = cursor[wave];
+    auto emit16 = [&](const uint4 x, uint64_t c) {
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) mine += ((w[k] >> (8 * b)) & 0xFFu) > T;
-        }
-        // inclusive prefix sum over the wave
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        const uint32_t total = __shfl(incl, 63, 64);
-        if (mine) {
-            uint32_t off = base + incl - mine;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t v = (w[k] >> (8 * b)) & 0xFFu;
-                    if (v > T) dst[off++] = ((uint32_t)(c * 16 + k * 4 + b) << 8) | v;
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t v = (w[k] >> (8 * b)) & 0xFFu;
+                if (v > T) {
+                    const uint32_t slot = atomicAdd(&cur[v & 63u], 1u);
+                    dstp[slot] = (PT)(c * 16 + k * 4 + b);
+                    dstv[slot] = (uint8_t)v;
                 }
-        }
-        base += total;
+            }
     };
 #pragma unroll
     for (int k = 0; k < kRegCache; ++k) {
-        if ((uint64_t)k * 64 >= nch) break;  // uniform
         const uint64_t c = (uint64_t)k * 64 + lane;
-        emit16(cache[k], c, c < nch);
+        if (c < nch) emit16(cache[k], c);
     }
-    for (uint64_t c0 = (uint64_t)kRegCache * 64; c0 < nch; c0 += 64) {
-        const uint64_t c = c0 + lane;
-        emit16(c < nch ? src[c] : make_uint4(0, 0, 0, 0), c, c < nch);
+    for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) emit16(src[c], c);
+    // pad to a whole 16-byte piece of positions with the never-listed position 2^p (k_finalize reads
+    // the positions 16 B at a time and tests each against a bitmap that has no bit there)
+    {
+        uint32_t total = 0;
+        for (int x = 63; x > (int)T; --x) total += hist[wave][x];
+        constexpr uint32_t per = 16 / sizeof(PT);
+        const uint32_t end = (total + per - 1) / per * per;
+        if (total + lane < end) {
+            dstp[total + lane] = (PT)(1u << p);
+            dstv[total + lane] = 0;
+        }
     }
-    // pad to a whole 16-byte piece with value-0 entries (k_finalize reads the list 16 B at a time and
-    // tells live entries by value > T alone); base <= emax <= kExcCap - 1
-    if (lane < 4 && (base & 3u) && lane >= (int)(base & 3u)) dst[(base & ~3u) + lane] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,7 +369,8 @@ struct FinalizeArgs {
     int result_type;
     double ksinv;
     const double *card;
-    const uint32_t *exc;
+    const uint32_t *exc;      // [n][kExcCap] 4-byte slots: the listed POSITIONS as PT (uint16 for p <= 15), value-descending
+    const uint8_t *excv;      // [n][kExcCap]: the listed values, same order
     const uint32_t *exc_n;
     const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value
     uint64_t n;
@@ -394,15 +402,19 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
     // histogram columns hold counts <= 2^p: CT (uint16 when p <= 15) halves the LDS footprint and
     // doubles the resident waves of this latency-sensitive kernel
+    // dynamic LDS: bitA = one bit per register position, set where the row sketch lists a value > T (the
+    // prefilter every list entry of a column sketch is tested against; first, so its address is a
+    // constant), the hash with the row sketch's values, then the histogram columns [(vhi-vlo+1)][128]
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
-    CT *hs = reinterpret_cast<CT *>(hs_raw);  // [(vhi-vlo+1)][128]
-    // then: bitA = one bit per register position, set where the row sketch lists a value > T (the
-    // prefilter every list entry of a column sketch is tested against), and the hash with the values
     const uint32_t kHashSlots = a.hash_slots;
-    const uint32_t bit_words = (1u << a.p) >> 5 ? (1u << a.p) >> 5 : 1u;
-    uint32_t *bitA = reinterpret_cast<uint32_t *>(hs_raw + (((size_t)(a.vhi - a.vlo + 1) * 128 * sizeof(CT) + 15) & ~(size_t)15));
+    const uint32_t bit_words = ((1u << a.p) >> 5) + 1u;  // + one word that stays zero: position 2^p pads the lists
+    uint32_t *bitA = reinterpret_cast<uint32_t *>(hs_raw);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)hs_raw != 0u) __builtin_trap();  // see probe_piece
     uint32_t *hashA = bitA + bit_words;
-    __shared__ uint32_t histA[64];
+    uint32_t *histA = hashA + kHashSlots;  // [64] + the live length of the row sketch's list (no static LDS:
+    uint32_t &naLive = histA[64];          // the bitmap then sits at LDS address 0 and needs no base add)
+    CT *hs = reinterpret_cast<CT *>(hs_raw + ((((size_t)bit_words + kHashSlots + 65) * 4 + 15) & ~(size_t)15));
+    using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
     const uint4 tile = a.tiles[slot >> 14];
@@ -417,15 +429,24 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
     for (uint32_t t = tid; t < kHashSlots; t += 128) hashA[t] = 0xFFFFFFFFu;
     for (uint32_t t = tid; t < bit_words; t += 128) bitA[t] = 0;
-    if (tid < 64) histA[tid] = 0;
+    if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = live prefix length
+        const uint32_t h = tid > T ? a.tailhist[i * 64 + tid] : 0u;
+        histA[tid] = h;
+        uint32_t tot = h;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        if (tid == 0) naLive = tot;
+    }
     __syncthreads();
-    const uint32_t na = a.exc_n[i];
-    for (uint32_t t = tid; t < na; t += 128) {
-        const uint32_t e = a.exc[i * kExcCap + t];
-        if ((int)(e & 0xFFu) > T) {
-            atomicAdd(&histA[e & 63u], 1u);
-            atomicOr(&bitA[e >> 13], 1u << ((e >> 8) & 31u));
-            uint32_t h = (e >> 8) & (kHashSlots - 1);
+    {
+        const uint32_t na = naLive;
+        const PT *ap = reinterpret_cast<const PT *>(a.exc + i * kExcCap);
+        const uint8_t *av = a.excv + i * kExcCap;
+        for (uint32_t t = tid; t < na; t += 128) {
+            const uint32_t pos = ap[t];
+            const uint32_t e = (pos << 8) | av[t];
+            atomicOr(&bitA[pos >> 5], 1u << (pos & 31u));
+            uint32_t h = pos & (kHashSlots - 1);
             while (atomicCAS(&hashA[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1) & (kHashSlots - 1);
         }
     }
@@ -463,7 +484,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         prev = cv;
     }
     // tail bins: histogram of i's listed values + histogram of j's listed values (both > T) ...
-    uint32_t ucnt = 0;
+    uint32_t ucnt = 0, nb = 0;  // nb: sketch j's entries above T = the live prefix of its list
     int maxv = T;
     {
         const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
@@ -474,67 +495,103 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
             for (int b = 0; b < 16; ++b) {
                 const int x = w * 16 + b;
                 if (x <= T || x > vhi) continue;
-                const uint32_t h = histA[x] + ((qw[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+                const uint32_t qj = (qw[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                const uint32_t h = histA[x] + qj;
+                nb += qj;
                 col[(x - vlo) * 128] = (CT)h;
                 ucnt += h;
                 if (h) maxv = x;
             }
         }
     }
-    // ... minus the smaller value at every position both sketches list (counted twice above)
-    const uint32_t nb = a.exc_n[j];
-    const uint4 *eb = reinterpret_cast<const uint4 *>(a.exc + j * kExcCap);
-    // One bit test per entry: bitA says whether the row sketch lists this position above T (0.4 % of
-    // the probes at p=14 / 64 entries); only then the hash is consulted for the row sketch's value.
-    // Padding and masked-off pieces are value-0 entries, never "live".
+    // ... minus the smaller value at every position both sketches list (counted twice above).
+    // Sketch j's positions are streamed 16 B at a time (8 or 4 per load) and each is tested against the
+    // row sketch's position bitmap: one LDS read + one bit extract per entry, nothing else.  Entries past
+    // the live prefix inside the last piece (values <= T, or the 2^p padding) can at worst raise a false
+    // candidate; the rare candidate path checks the entry's value and fetches the row sketch's from the hash.
+    const uint4 *eb = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(a.exc + j * kExcCap, 16));
+    const uint8_t *bv = a.excv + j * kExcCap;
     constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    auto probe4 = [&](const uint4 e4) {
-        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
-        uint32_t w[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = bitA[ev[t] >> 13];
-        uint32_t cand = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t bit = (w[t] >> ((ev[t] >> 8) & 31u)) & 1u;
-            cand |= ((int)(ev[t] & 0xFFu) > T ? bit : 0u) << t;
+    constexpr uint32_t kPer = 16 / sizeof(PT);  // positions per 16-byte piece
+    auto candidate = [&](uint32_t pos, uint32_t idx) {
+        const int vb = (int)bv[idx];
+        if (vb <= T) return;  // not part of the tail bins (or padding)
+        uint32_t h = pos & (kHashSlots - 1);
+        for (;;) {
+            const uint32_t sv = hashA[h];
+            if (sv == kEmpty) return;
+            if ((sv >> 8) == pos) {  // shared position: keep only the larger value
+                const int va = (int)(sv & 0xFFu);
+                col[((va < vb ? va : vb) - vlo) * 128] -= 1;
+                --ucnt;
+                return;
+            }
+            h = (h + 1) & (kHashSlots - 1);
         }
-        if (cand) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (!((cand >> t) & 1u)) continue;
-                const uint32_t e = ev[t], pos = e >> 8;
-                const int vb = (int)(e & 0xFFu);
-                uint32_t h = pos & (kHashSlots - 1);
-                for (;;) {  // the bit guarantees the position is in the table
-                    const uint32_t sv = hashA[h];
-                    if ((sv >> 8) == pos || sv == kEmpty) {
-                        if (sv != kEmpty) {  // shared position: keep only the larger value
-                            const int va = (int)(sv & 0xFFu);
-                            col[((va < vb ? va : vb) - vlo) * 128] -= 1;
-                            --ucnt;
-                        }
-                        break;
-                    }
-                    h = (h + 1) & (kHashSlots - 1);
-                }
+    };
+    // pieces with a possible shared position, up to four numbers (+1) of 8 bits; looked at after the walk
+    uint32_t pending = 0;
+    auto flush = [&]() {
+        while (pending) {
+            const uint32_t pi = (pending & 0xFFu) - 1u;
+            pending >>= 8;
+            const uint4 e4 = eb[pi];
+            const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+            for (uint32_t t = 0; t < kPer; ++t) {
+                const uint32_t x = ev[sizeof(PT) == 2 ? (t >> 1) : t];
+                const uint32_t pos = sizeof(PT) == 2 ? ((x >> (16 * (t & 1))) & 0xFFFFu) : x;
+                if ((bitA[pos >> 5] >> (pos & 31u)) & 1u) candidate(pos, pi * kPer + t);
             }
         }
     };
-    // 16 entries (4 x 16 B) per step, the next step's loads issued before this step's probes so
-    // the L2 round trip of the list is not on the critical path
-    const uint32_t nq = (nb + 3) / 4;  // 16-byte pieces
+    // fast path: OR of the (shifted) bitmap words of a piece -- bit 0 set iff some entry may be shared.
+    // The bitmap starts at LDS address 0 (checked above), so a word's byte address is computed from the
+    // position alone and the read needs no base add.
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    auto bitword = [](uint32_t byte_addr) -> uint32_t { return *(lds_cu32 *)(uintptr_t)byte_addr; };
+    auto probe_piece = [&](const uint4 e4, uint32_t first) {
+        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+        uint32_t any = 0;
+        if (sizeof(PT) == 2) {
+            uint32_t w[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                w[2 * t] = bitword((ev[t] >> 3) & 0x1FFCu);   // ((pos & 0xFFFF) >> 5) * 4, pos < 2^16
+                w[2 * t + 1] = bitword((ev[t] >> 19) & 0x1FFCu);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) any |= (w[2 * t] >> (ev[t] & 31u)) | (w[2 * t + 1] >> ((ev[t] >> 16) & 31u));
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = bitword((ev[t] >> 3) & ~3u);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) any |= w[t] >> (ev[t] & 31u);
+        }
+        // A hit is rare per lane (|list_i| * |list_j| / 2^p per pair) but not per WAVE: some lane of the 64
+        // hits in almost every piece, so the expensive part must not sit here.  Only remember the piece.
+        if (any & 1u) {
+            if (pending >> 24) flush();  // four pieces already waiting (very rare)
+            pending = (pending << 8) | (first / kPer + 1u);
+        }
+    };
+    // 4 pieces per step, the next step's loads issued before this step's probes so the L2 round trip
+    // of the list is not on the critical path.  Loads are unconditional: a sketch's row of the list
+    // array is 1 KiB, so pieces past the live prefix are readable (and never probed).
+    const uint32_t nq = (nb + kPer - 1) / kPer;
     uint4 cur[4], nxt[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = (uint32_t)u < nq ? eb[u] : make_uint4(0, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) cur[u] = eb[u];
     for (uint32_t q = 0; q < nq; q += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = q + 4 + u < nq ? eb[q + 4 + u] : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) nxt[u] = eb[q + 4 + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) probe4(cur[u]);
+        for (int u = 0; u < 4; ++u)
+            if (q + u < nq) probe_piece(cur[u], (q + u) * kPer);
 #pragma unroll
         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
+    flush();
     // (a bin emptied by a correction can only lower the true maximum; maxv is just a scan bound)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
     auto c = [col, vlo, vhi](int v) -> uint32_t {
@@ -675,13 +732,17 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, uint32_t *exc, uint32_t *exc_n,
+                                int emax, double *card, uint32_t *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
-    hipLaunchKernelGGL(k_selfhist_card, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                       card, exc, exc_n, keys, tailhist);
+    if (p <= 15)
+        hipLaunchKernelGGL(k_selfhist_card<uint16_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
+                           card, exc, excv, exc_n, keys, tailhist);
+    else
+        hipLaunchKernelGGL(k_selfhist_card<uint32_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
+                           card, exc, excv, exc_n, keys, tailhist);
     return hipGetLastError();
 }
 
@@ -751,15 +812,15 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
+    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     uint32_t hs = 16;
     while (hs < 2u * (uint32_t)f.emax) hs <<= 1;
     a.hash_slots = hs;
-    const size_t bit_words = std::max<size_t>(((size_t)1 << f.p) >> 5, 1);
-    const size_t lds = (((size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4) + 15) & ~(size_t)15) +
-                       (bit_words + hs) * sizeof(uint32_t);
+    const size_t bit_words = (((size_t)1 << f.p) >> 5) + 1;
+    const size_t lds = (((bit_words + hs + 65) * sizeof(uint32_t) + 15) & ~(size_t)15) +
+                       (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
     if (lds > (48u << 10)) {  // large p: the position bitmap alone is 2^p / 8 bytes
         hipError_t e = f.cum_bytes == 2
                            ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)

@@ -60,6 +60,9 @@ def c4(n=100_000, p=10):
     total = n * (n - 1) // 2
     out = torch.empty(total, dtype=torch.float32, device=dev)
     ctx = dashing_amd.Context(0)
+    for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # tuning sweeps, e.g. "emax=4"
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     ctx.set_profiling(True)
     times = []
     for _ in range(2):
