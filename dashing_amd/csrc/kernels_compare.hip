@@ -390,13 +390,13 @@ struct FinalizeArgs {
     float *out;
 };
 
-// Exception handling without a sequential merge: the block's 128 lanes share sketch i (one
-// tile row), so i's tail entries (value > T) go into an open-addressing LDS hash keyed by
-// position, and their value histogram histA plus sketch j's precomputed tail histogram
-// (tailhist, one byte per value) are the starting point of a lane's tail bins -- that counts a
-// position listed by BOTH sketches twice.  A lane therefore only walks its own sketch j's list
-// looking for shared positions (independent iterations, 16-B loads, one LDS probe each; hits are
-// rare: |list|^2 / 2^p per pair) and removes the smaller of the two values.  Exact, order-independent.
+// Exception handling without a sequential merge: the block's 128 lanes share sketch i (one tile
+// row).  A lane's tail bins (values > T) start as i's tail histogram + sketch j's (tailhist, one
+// byte per value) -- that counts a position listed by BOTH sketches twice.  To find those, i's live
+// entries (value > T: a prefix of its value-ordered list) are put into a position bitmap and a
+// small open-addressing hash in LDS; each lane streams the positions of j's live prefix against the
+// bitmap (16-B loads, one LDS read + one shift per entry) and, for the few shared positions
+// (|list_i| * |list_j| / 2^p per pair), removes the smaller of the two values.  Exact, order-independent.
 template <typename CT>
 __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
