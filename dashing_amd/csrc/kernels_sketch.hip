@@ -99,10 +99,10 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
     return acc;
 }
 
-template <bool GLOBAL>
+template <bool GLOBAL, bool CANON>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
-                                                 int p, int canon, uint8_t *__restrict__ regs)
+                                                 int p, uint8_t *__restrict__ regs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // [0, 2^p/4): registers as packed bytes; then the packed words of the current sub-chunk, one
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
 
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int fshift = 64 - 2 * k;
+    const uint64_t guard = 1ull << (p - 1);  // ((h << 1) | 1) << (p - 1) == (h << p) | guard
 
     // pack the 32 bases at absolute offset B (bases outside [gbeg,gend) are invalid)
     auto pack_at = [&](uint64_t B, uint64_t &F, uint64_t &R, uint32_t &V) {
@@ -154,15 +155,29 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             if (!(ok & (1u << j))) continue;
-            const uint64_t fh = j ? ((F0 << (2 * j)) | (F1 >> (64 - 2 * j))) : F0;
-            const uint64_t rl = j ? ((R0 >> (2 * j)) | (R1 << (64 - 2 * j))) : R0;
+            // 64-bit windows of (F0:F1) << 2j and (R1:R0) >> 2j, one v_alignbit_b32 per 32-bit half
+            // (j is a constant after unrolling, so the word selection folds away)
+            const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
+            const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
+            const int q = (2 * j) >> 5, r = (2 * j) & 31;
+            const uint32_t fhi = r ? __builtin_amdgcn_alignbit(fwv[q], fwv[q + 1], 32 - r) : fwv[q];
+            const uint32_t flo = r ? __builtin_amdgcn_alignbit(fwv[q + 1], fwv[q + 2], 32 - r) : fwv[q + 1];
+            const uint32_t rlo = __builtin_amdgcn_alignbit(rwv[q + 1], rwv[q], r);
+            const uint32_t rhi = __builtin_amdgcn_alignbit(rwv[q + 2], rwv[q + 1], r);
+            const uint64_t fh = ((uint64_t)fhi << 32) | flo;
+            const uint64_t rl = ((uint64_t)rhi << 32) | rlo;
             const uint64_t fw = fh >> fshift;
             const uint64_t rc = rl & kmask;
-            const uint64_t km = (canon && rc < fw) ? rc : fw;
+            const uint64_t km = (CANON && rc < fw) ? rc : fw;
             const uint64_t h = wang64(km);
             const uint32_t idx = (uint32_t)(h >> (64 - p));
-            const uint64_t t = ((h << 1) | 1ull) << (p - 1);
-            const uint32_t val = (uint32_t)__builtin_clzll(t) + 1u;
+            // value = clz of the 64-p bits after the index, guard bit below them, + 1
+            const uint64_t t = (h << p) | guard;
+            uint32_t lz = (uint32_t)__builtin_clzll(t);
+            asm("" : "+v"(lz));  // keep the comparison below in 32 bits (hipcc otherwise widens it to u64)
+            const uint32_t val = lz + 1u;
+            // filter with a plain byte read: almost no k-mer can raise its register
+            if (reinterpret_cast<const uint8_t *>(lregs)[idx] > lz) continue;
             uint32_t *wp = &lregs[idx >> 2];
             const uint32_t sh = (idx & 3u) * 8u;
             uint32_t old = *wp;
@@ -197,17 +212,20 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
     if (nwork == 0) return hipSuccess;
     const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
     if (p > kMaxPLds) {
-        hipLaunchKernelGGL(k_sketch<true>, dim3(nwork), dim3(256), xch, st, seq, work, k, p, canon, regs);
+        if (canon) hipLaunchKernelGGL((k_sketch<true, true>), dim3(nwork), dim3(256), xch, st, seq, work, k, p, regs);
+        else hipLaunchKernelGGL((k_sketch<true, false>), dim3(nwork), dim3(256), xch, st, seq, work, k, p, regs);
         return hipGetLastError();
     }
     // registers (2^p bytes, 16-byte aligned) + the exchange slots
     const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
     if (lds > (48u << 10)) {  // per launch: the attribute is per device
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sketch<false>),
+        hipError_t e = hipFuncSetAttribute(canon ? reinterpret_cast<const void *>(k_sketch<false, true>)
+                                                 : reinterpret_cast<const void *>(k_sketch<false, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_sketch<false>, dim3(nwork), dim3(256), lds, st, seq, work, k, p, canon, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<false, true>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<false, false>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
 }
 

@@ -88,7 +88,7 @@ def main():
         "value": bases / dt, "unit": "bases/s", "ms_per_step": dt * 1e3,
         "roofline": {"bound": "hbm", "achieved": bases / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": bases / dt / 8e12, "bytes_per_base": 1,
-                     "note": "VALU-bound in practice (~110 integer ops per k-mer)"},
+                     "note": "VALU-bound in practice: ~47 VALU instructions per k-mer (25 of them the Wang hash), ~4.3 cycles each per wave64"},
         "cpu_baseline": {"value": nc * gstride / tc, "unit": "bases/s", "cores": cores, "kind": "port",
                          "sample": "%d genomes, oracle/dsh_oracle.c dsho_sketch_batch (one genome per thread, like src/sketch_and_cmp.h:314-360)" % nc},
         "registers_bit_exact": exact}))
