@@ -397,6 +397,49 @@ static int fold_main(int argc, char **argv)
     return EXIT_SUCCESS;
 }
 
+// `printmat` (src/dashing.cpp:425-452): a BINARY distance matrix ('\0', u64 n, packed upper triangle)
+// as the full n x n table of DistanceMatrix::printf (distmat/distmat.h:358-381): "%lf" values, tabs
+// between, the diagonal is the default value 0.
+static int printmat_main(int argc, char **argv)
+{
+    bool use_scientific = false;
+    std::string outpath = "/dev/stdout";
+    optind = 1;
+    for (int c; (c = getopt(argc, argv, ":o:sh?")) >= 0;) {
+        switch (c) {
+        case 'o': outpath = optarg; break;
+        case 's': use_scientific = true; break;
+        default:
+            std::fprintf(stderr, "dashing-amd printmat <path to binary file>\n-o\tSpecify output file (default: stdout)\n-s\tEmit in scientific notation\n");
+            return EXIT_FAILURE;
+        }
+    }
+    if (optind >= argc) die("dashing-amd printmat <path to binary file>");
+    std::FILE *in = std::fopen(std::strcmp(argv[optind], "-") ? argv[optind] : "/dev/stdin", "rb");
+    if (!in) die("[print_binary_main] Could not open file at %s", argv[optind]);
+    uint64_t n = 0;
+    const int magic = std::fgetc(in);
+    if (magic != 0 || std::fread(&n, sizeof n, 1, in) != 1) die("%s is not a float distance matrix", argv[optind]);
+    const uint64_t total = n ? n * (n - 1) / 2 : 0;
+    std::vector<float> tri(std::max<uint64_t>(total, 1));
+    if (total && std::fread(tri.data(), sizeof(float), total, in) != total) die("size %llu is not the file size", (unsigned long long)(total * 4 + 9));
+    std::fclose(in);
+    std::FILE *fp = std::fopen(outpath.c_str(), "wb");
+    if (!fp) die("[print_binary_main] Could not open file at %s", outpath.c_str());
+    const char *mid = use_scientific ? "%le\t" : "%lf\t", *last = use_scientific ? "%le\n" : "%lf\n";
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t j = 0; j < n; ++j) {
+            double v = 0.;
+            if (i != j) {
+                const uint64_t a = std::min(i, j), b = std::max(i, j);
+                v = (double)tri[dsh_tri_index(n, a, b)];
+            }
+            std::fprintf(fp, j + 1 == n ? last : mid, v);
+        }
+    std::fclose(fp);
+    return EXIT_SUCCESS;
+}
+
 // `hll` (src/hllmain.cpp:4-45): cardinality of the union of the k-mers of all input files --
 // every file is sketched into ONE HLL (default p = 24: registers live in HBM, not LDS).
 static int hll_main(int argc, char **argv)
@@ -671,7 +714,7 @@ static int dist_main(int argc, char **argv)
 int main(int argc, char **argv)
 {
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
-        std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
+        std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  printmat              (binary distance matrix -> text)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;
     }
     const std::string sub(argv[1]);
@@ -681,6 +724,7 @@ int main(int argc, char **argv)
     if (sub == "view") return view_main(argc - 1, argv + 1);
     if (sub == "fold") return fold_main(argc - 1, argv + 1);
     if (sub == "hll") return hll_main(argc - 1, argv + 1);
+    if (sub == "printmat") return printmat_main(argc - 1, argv + 1);
     if (sub == "version" || sub == "--version") {
         std::printf("%s\nbackend: %s\n", kVersion, dsh_backend_name());
         return EXIT_SUCCESS;

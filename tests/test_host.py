@@ -272,3 +272,30 @@ def test_cli_union_fold_view_run_without_gpu(host, tmp_path):
     lines = r.stdout.decode().strip().split("\n")
     assert lines[0].startswith("#" + paths[1]) and "p=%d" % p in lines[0]
     assert [int(x) for x in lines[1].split(",")] == regs[1].tolist()
+
+
+def test_cli_printmat(host, tmp_path):
+    """`printmat` (src/dashing.cpp:425-452): binary matrix -> full table, "%lf", diagonal 0."""
+    import subprocess
+
+    cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+    n = 4
+    tri = np.array([0.5, 0.25, 1.0, 0.125, 0.75, 3e-7], np.float32)
+    f = tmp_path / "m.bin"
+    f.write_bytes(b"\0" + struct.pack("<Q", n) + tri.tobytes())
+    r = subprocess.run([cli, "printmat", str(f)], capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    rows = [l.split("\t") for l in r.stdout.decode().strip().split("\n")]
+    full = np.zeros((n, n))
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            full[i, j] = full[j, i] = float(tri[k])
+            k += 1
+    assert [[float(x) for x in row] for row in rows] == [[float("%f" % v) for v in row] for row in full]
+    assert rows[0][0] == "0.000000" and rows[0][1] == "0.500000"
+    r = subprocess.run([cli, "printmat", "-s", str(f)], capture_output=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.decode().split("\t")[1] == "5.000000e-01"
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\1" + struct.pack("<Q", n))
+    assert subprocess.run([cli, "printmat", str(bad)], capture_output=True).returncode != 0
