@@ -106,12 +106,17 @@ def main():
         if backend == "gloo":  # dry-run only: stage through the host
             h = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
             full = sorted_full.copy_(h) if rank == 0 else None
-        else:
-            full = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, sorted_full, 0)
+            if rank == 0:
+                torch.cuda.current_stream().synchronize()
+                ctx.unpermute_device(full.data_ptr(), final.data_ptr())
+                ctx.synchronize()
+                return final
+            return None
+        # the gathered (padded) blocks are un-permuted where they arrived: no back-to-back copy
+        st = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, None, 0, staged=True)
         if rank == 0:
             torch.cuda.current_stream().synchronize()
-            ctx.unpermute_device(full.data_ptr(), final.data_ptr())
-            ctx.synchronize()
+            ctx.unpermute_staged_device(st.data_ptr(), mx, world, final.data_ptr())
             return final
         return None
 

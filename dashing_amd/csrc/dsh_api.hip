@@ -1020,6 +1020,32 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     return DSH_OK;
 }
 
+int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride, uint32_t nshards, void *d_out_tri)
+{
+    if (!c || nshards == 0) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->planes_valid || !c->planes_sorted) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
+    if (c->n < 2) return DSH_OK;
+    if (!d_stage || !d_out_tri) return DSH_EINVAL;
+    std::vector<uint32_t> tb;
+    shard_bounds(c, nshards, tb);
+    const uint32_t NT = c->Npad / kTile;
+    std::vector<int64_t> delta(NT, 0);
+    for (uint32_t r = 0; r < nshards; ++r) {
+        const uint64_t off = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r] * kTile));
+        const uint64_t end = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r + 1] * kTile));
+        if (end - off > stride) return fail(c, DSH_EINVAL, "stride %llu smaller than the span of shard %u", (unsigned long long)stride, r);
+        for (uint32_t t = tb[r]; t < tb[r + 1]; ++t) delta[t] = (int64_t)((uint64_t)r * stride) - (int64_t)off;
+    }
+    HIPCHK(c, c->workbuf.ensure(NT * sizeof(int64_t)));
+    HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, delta.data(), NT * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_unpermute_staged(c->stream, (const float *)d_stage, (const uint32_t *)c->perm.ptr + c->n,
+                                      (const int64_t *)c->workbuf.ptr, c->n, (float *)d_out_tri));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `delta` (pageable source) must outlive the copy
+    return DSH_OK;
+}
+
 void *dsh_alloc_host(size_t bytes)
 {
     void *p = nullptr;

@@ -37,6 +37,8 @@ struct FinalizeLaunch {
     float *out;
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
+hipError_t launch_unpermute_staged(hipStream_t st, const float *in, const uint32_t *inv,
+                                   const int64_t *rowdelta, uint64_t n, float *out);
 // inv != nullptr: destination-driven variant (coalesced writes, gathered reads); else scatter via perm
 hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
                             uint64_t n, float *out);

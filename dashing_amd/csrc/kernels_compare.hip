@@ -643,6 +643,31 @@ __global__ __launch_bounds__(256) void k_unpermute_gather(const float *__restric
     }
 }
 
+// as k_unpermute_gather, but the spans of the shards sit at a fixed stride in `in` (the padded blocks an
+// RCCL gather delivers): rowdelta[sorted row / 128] = shard * stride - span_off[shard]
+__global__ __launch_bounds__(256) void k_unpermute_staged(const float *__restrict__ in,
+                                                           const uint32_t *__restrict__ inv,
+                                                           const int64_t *__restrict__ rowdelta,
+                                                           uint64_t n, float *__restrict__ out)
+{
+    const uint64_t a = blockIdx.x;
+    const uint64_t sa = inv[a];
+    float *row = out + a * (2 * n - a - 1) / 2 - (a + 1);
+    for (uint64_t b = a + 1 + threadIdx.x; b < n; b += 256) {
+        const uint64_t sb = inv[b];
+        const uint64_t lo = sa < sb ? sa : sb, hi = sa < sb ? sb : sa;
+        row[b] = in[(int64_t)(lo * (2 * n - lo - 1) / 2 + hi - (lo + 1)) + rowdelta[lo / kTile]];
+    }
+}
+
+hipError_t launch_unpermute_staged(hipStream_t st, const float *in, const uint32_t *inv,
+                                   const int64_t *rowdelta, uint64_t n, float *out)
+{
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_unpermute_staged, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, inv, rowdelta, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
                             uint64_t n, float *out)
 {

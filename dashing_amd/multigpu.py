@@ -44,14 +44,16 @@ def max_span(n, bounds):
 
 
 # ---- shards of the sorted-order triangle (faster: narrow per-tile plane ranges, cost-balanced) ----
-def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=None, dst=0):
+def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=None, dst=0, staged=False):
     """local: this rank's span padded to max span.  On `dst` returns the spans laid back to back
-    (the packed triangle in sorted order) ready for Context.unpermute_device; None elsewhere."""
+    (the packed triangle in sorted order) ready for Context.unpermute_device; None elsewhere.
+    staged=True skips the back-to-back copy: `dst` gets the gathered blocks as they arrived, shard r
+    at stage[r*mx : r*mx+span_r] with mx = the largest span, for Context.unpermute_staged_device."""
     sizes = [span_off[r + 1] - span_off[r] for r in range(world)]
     mx = max(max(sizes), 1)
     assert local.numel() >= mx
     if world == 1 and not dist.is_initialized():
-        return local[: sizes[0]]
+        return local[:mx] if staged else local[: sizes[0]]
     send = local[:mx]
     if rank != dst:
         dist.gather(send, gather_list=None, dst=dst)
@@ -60,6 +62,8 @@ def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=Non
         stage = torch.empty(world * mx, dtype=local.dtype, device=local.device)
     parts = [stage[r * mx : (r + 1) * mx] for r in range(world)]
     dist.gather(send, gather_list=parts, dst=dst)
+    if staged:
+        return stage
     if sorted_full is None:
         sorted_full = torch.empty(max(span_off[-1], 1), dtype=local.dtype, device=local.device)
     for r in range(world):

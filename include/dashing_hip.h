@@ -148,6 +148,11 @@ int dsh_shard_plan(dsh_ctx *ctx, int estim, uint32_t nshards, uint64_t *span_off
 int dsh_dist_shard_device(dsh_ctx *ctx, int estim, int result_type, int k, uint32_t shard,
                           uint32_t nshards, void *d_span);
 int dsh_unpermute_device(dsh_ctx *ctx, const void *d_sorted_tri, void *d_out_tri);
+/* Same, reading the spans where a gather of equal-sized (padded) blocks left them: shard r's span
+ * starts at d_stage + r * stride (floats), stride >= the largest span.  Saves the copy that would lay
+ * the spans back to back first.  Returns after completion. */
+int dsh_unpermute_staged_device(dsh_ctx *ctx, const void *d_stage, uint64_t stride, uint32_t nshards,
+                                void *d_out_tri);
 
 /* ---- helpers shared by every host (C++ CLI, Python, a patched dashing) -------------------- */
 /* number of packed elements of rows [row_begin,row_end) of an n x n upper triangle */

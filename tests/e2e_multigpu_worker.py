@@ -67,13 +67,16 @@ def main():
     if backend == "gloo":
         full = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
         full = full.to(dev) if rank == 0 else None
-    else:
-        full = multigpu.gather_shard_spans(out_d, span_off, rank, world)
+    else:  # as bench.py: un-permute straight from the gathered (padded) blocks
+        full = multigpu.gather_shard_spans(out_d, span_off, rank, world, staged=True)
     ok = True
     if rank == 0:
         torch.cuda.synchronize()
         final = torch.empty(total, dtype=torch.float32, device=dev)
-        ctx.unpermute_device(full.data_ptr(), final.data_ptr())
+        if backend == "gloo":
+            ctx.unpermute_device(full.data_ptr(), final.data_ptr())
+        else:
+            ctx.unpermute_staged_device(full.data_ptr(), mx, world, final.data_ptr())
         ctx.synchronize()
         from oracle import oracle_c  # the checker (tests only)
 

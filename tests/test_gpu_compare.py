@@ -219,6 +219,15 @@ def test_virtual_shards_assemble(ctx, nshards):
         ctx.synchronize()
         assert final.cpu().numpy().tobytes() == want.tobytes()
     ctx.set_option("unpermute_gather", 1)
+    # the same from the padded blocks a gather delivers (shard r at r * stride)
+    stride = max(max(off[r + 1] - off[r] for r in range(nshards)), 1) + 5
+    stage = torch.full((nshards * stride,), -4.0, dtype=torch.float32, device=dev)
+    for r in range(nshards):
+        stage[r * stride : r * stride + off[r + 1] - off[r]] = sorted_full[off[r] : off[r + 1]]
+    final.fill_(-3.0)
+    torch.cuda.synchronize()
+    ctx.unpermute_staged_device(stage.data_ptr(), stride, nshards, final.data_ptr())
+    assert final.cpu().numpy().tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize("rt", [2, 4, 5, 6, 7, 8])
