@@ -61,11 +61,11 @@ struct dsh_ctx {
     std::vector<uint4> htiles;
     // options
     int kc = 16;  // 16 rows per LDS stage (32 KiB double-buffered): ~1 % faster than 32 in three sweeps (profiles/)
-    int emax_opt = -1;  // -1: min(64, 2^p / 256) -- sweeps in profiles/: 64..96 is the optimum at p=14 with the tail-histogram finalize
+    int emax_opt = -1;  // -1: min(96 | 192 for p >= 16, 2^p / 128) -- sweeps per precision in profiles/r1k/README.md
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
-    int assembler_permille = 24;  // span copies (0.12 ms) + un-permute (0.40 ms) on rank 0 of a 21 ms pass (profiles/r1j, r1k)
+    int assembler_permille = 21;  // the un-permute (0.42 ms) on rank 0 of a 19.9 ms pass (profiles/r1k)
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
