@@ -53,6 +53,8 @@ struct dsh_ctx {
     int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
     std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
+    uint32_t *pin_perm = nullptr;       // page-locked copy of hperm: its upload is then truly asynchronous
+    size_t pin_perm_cap = 0;
     std::vector<uint8_t> blk_T, blk_lo; // per 128-column block: max threshold, min register value
     std::vector<uint4> hitems;
     uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
@@ -198,14 +200,36 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
                 const uint32_t key = k32[i];
                 return (((key >> 8) & 63u) << 12) | ((key & 63u) << 6) | ((key >> 16) & 63u);
             };
-            std::vector<uint32_t> cnt((1u << 18) + 1, 0);
-            for (uint64_t i = 0; i < n; ++i) cnt[skey(i) + 1u]++;
-            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-            for (uint64_t i = 0; i < n; ++i) c->hperm[cnt[skey(i)]++] = (uint32_t)i;
+            // stable LSD radix sort, three 6-bit digits (a single 2^18-bucket counting sort spends
+            // ~0.1 ms clearing and scanning its counters -- a quarter of prepare())
+            std::vector<uint32_t> a(n), b(n), keys(n);
+            for (uint64_t i = 0; i < n; ++i) {
+                a[i] = (uint32_t)i;
+                keys[i] = skey(i);
+            }
+            for (int shift = 0; shift < 18; shift += 6) {
+                uint32_t cnt[65] = {0};
+                for (uint64_t i = 0; i < n; ++i) cnt[((keys[a[i]] >> shift) & 63u) + 1u]++;
+                for (int k = 1; k < 65; ++k) cnt[k] += cnt[k - 1];
+                for (uint64_t i = 0; i < n; ++i) b[cnt[(keys[a[i]] >> shift) & 63u]++] = a[i];
+                a.swap(b);
+            }
+            std::copy(a.begin(), a.end(), c->hperm.begin());
             HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * 2 * sizeof(uint32_t)));  // perm, then its inverse
             c->hperm.resize(2 * n);
             for (uint64_t s = 0; s < n; ++s) c->hperm[n + c->hperm[s]] = (uint32_t)s;
-            if (n) HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->hperm.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            if (n) {
+                if (2 * n > c->pin_perm_cap) {
+                    if (c->pin_perm) (void)hipHostFree(c->pin_perm);
+                    c->pin_perm = nullptr;
+                    c->pin_perm_cap = 0;
+                    HIPCHK(c, hipHostMalloc((void **)&c->pin_perm, 2 * n * sizeof(uint32_t), hipHostMallocDefault));
+                    c->pin_perm_cap = 2 * n;
+                }
+                // (the previous upload from this buffer finished before the key download above was synchronised)
+                std::memcpy(c->pin_perm, c->hperm.data(), 2 * n * sizeof(uint32_t));
+                HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->pin_perm, 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            }
         } else {
             for (uint64_t i = 0; i < n; ++i) c->hperm[i] = (uint32_t)i;
         }
@@ -230,7 +254,6 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
             HIPCHK(c, launch_transform(c->stream, c->regs, n, c->p, c->vlo, c->P, c->W, c->Npad,
                                        (uint32_t *)c->planes.ptr,
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
-            if (want_sorted) HIPCHK(c, hipStreamSynchronize(c->stream));  // hperm (pageable) upload done
         }
         c->planes_sorted = want_sorted;
         c->planes_valid = true;
@@ -503,6 +526,7 @@ void dsh_destroy(dsh_ctx *c)
     c->exc.release();
     c->exc_n.release();
     c->excv.release();
+    if (c->pin_perm) (void)hipHostFree(c->pin_perm);
     c->keys.release();
     c->tailhist.release();
     c->perm.release();
