@@ -423,6 +423,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.exc = (const uint32_t *)c->exc.ptr;
         f.exc_n = (const uint32_t *)c->exc_n.ptr;
         f.excv = (const uint8_t *)c->excv.ptr;
+        f.keys = (const uint32_t *)c->keys.ptr;
         f.tailhist = (const uint8_t *)c->tailhist.ptr;
         f.nslots = nslots;
         f.tiles = dt;

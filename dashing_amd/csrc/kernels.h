@@ -28,7 +28,7 @@ struct FinalizeLaunch {
     int vlo, vhi, p, estim, result_type, emax;
     double ksinv;
     const double *card;
-    const uint32_t *exc, *exc_n;
+    const uint32_t *exc, *exc_n, *keys;
     const uint8_t *excv;
     const uint8_t *tailhist;
     uint64_t n;

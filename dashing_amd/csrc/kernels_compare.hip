@@ -373,6 +373,7 @@ struct FinalizeArgs {
     const uint8_t *excv;      // [n][kExcCap]: the listed values, same order
     const uint32_t *exc_n;
     const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value
+    const uint32_t *keys;     // [n]: (max value << 16) | (T_i << 8) | min value
     uint64_t n;
     // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
@@ -474,36 +475,66 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     if (!active) return;
     const uint32_t m = 1u << a.p;
     CT *col = hs + tid;
+    // All global loads of this lane's inputs are issued together, before anything waits on them: the
+    // C(v) of up to 16 planes, 48 bins of sketch j's tail histogram, the two keys (one round trip
+    // instead of one per plane / per bin -- with dependent loads this part was half of the kernel).
+    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
+    constexpr int kBatch = 12;
+    uint32_t cvv[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+        const uint32_t pl = tile.z + (uint32_t)t;
+        cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
+    }
+    const int w0 = (T + 1) >> 4;  // first 16-byte word of the tail histogram that holds a bin > T (uniform)
+    const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
+    uint4 tq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
+    const uint32_t keyj = a.keys[j], keyi = a.keys[i];
     // bins below the tile's range are empty; dense part: c[x] = C(x+1) - C(x), x in [vlo_t, T)
     for (int x = vlo; x < vlo_t; ++x) col[(x - vlo) * 128] = 0;
-    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
     uint32_t prev = 0;
-    for (uint32_t pl = tile.z; pl < tile.w; ++pl) {
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+        const uint32_t pl = tile.z + (uint32_t)t;
+        if (pl < tile.w) {  // uniform
+            col[pl * 128] = (CT)(cvv[t] - prev);
+            prev = cvv[t];
+        }
+    }
+    for (uint32_t pl = tile.z + kBatch; pl < tile.w; ++pl) {  // wide plane ranges (heterogeneous tiles)
         const uint32_t cv = cum[(uint64_t)pl * a.nslots];
         col[pl * 128] = (CT)(cv - prev);
         prev = cv;
     }
     // tail bins: histogram of i's listed values + histogram of j's listed values (both > T) ...
-    uint32_t ucnt = 0, nb = 0;  // nb: sketch j's entries above T = the live prefix of its list
-    int maxv = T;
+    uint32_t nb = 0;  // sketch j's entries above T = the live prefix of its list
     {
-        const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
-        for (int w = (T + 1) >> 4; w <= (vhi >> 4); ++w) {
-            const uint4 q4 = tb[w];
-            const uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+        const uint32_t qw[12] = {tq[0].x, tq[0].y, tq[0].z, tq[0].w, tq[1].x, tq[1].y, tq[1].z, tq[1].w,
+                                 tq[2].x, tq[2].y, tq[2].z, tq[2].w};
+        const int x0 = w0 * 16;
+        CT *dst = col + (x0 - vlo) * 128;         // bin x0 + s lives at dst + s * 128 (x0 may be below vlo: never touched there)
+        const uint32_t *hA = histA + x0;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int x = w * 16 + b;
-                if (x <= T || x > vhi) continue;
-                const uint32_t qj = (qw[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                const uint32_t h = histA[x] + qj;
-                nb += qj;
-                col[(x - vlo) * 128] = (CT)h;
-                ucnt += h;
-                if (h) maxv = x;
-            }
+        for (int s_ = 0; s_ < 48; ++s_) {
+            const int x = x0 + s_;
+            if (x <= T || x > vhi) continue;  // uniform
+            const uint32_t qj = (qw[s_ >> 2] >> (8 * (s_ & 3))) & 0xFFu;
+            nb += qj;
+            dst[s_ * 128] = (CT)(hA[s_] + qj);
+        }
+        for (int x = x0 + 48; x <= vhi; ++x) {  // more than 48 bins above T: only with a very small emax
+            const uint32_t qj = a.tailhist[j * 64 + x];
+            nb += qj;
+            col[(x - vlo) * 128] = (CT)(histA[x] + qj);
         }
     }
+    uint32_t ucnt = naLive + nb;  // |list_i above T| + |list_j above T|, shared positions still counted twice
+    // largest bin that can be non-empty (a scan bound for the estimator): the larger of the two maxima
+    const int maxj = (int)(keyj >> 16), maxi = (int)(keyi >> 16);
+    int maxv = maxi > maxj ? maxi : maxj;
+    if (maxv < T) maxv = T;
     // ... minus the smaller value at every position both sketches list (counted twice above).
     // Sketch j's positions are streamed 16 B at a time (8 or 4 per load) and each is tested against the
     // row sketch's position bitmap: one LDS read + one bit extract per entry, nothing else.  Entries past
@@ -837,7 +868,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
+    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     uint32_t hs = 16;
