@@ -418,9 +418,11 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
-    const uint4 tile = a.tiles[slot >> 14];
-    const uint64_t si = (uint64_t)tile.x * kTile + ((slot >> 7) & 127);  // block-uniform
-    const uint64_t sj = (uint64_t)tile.y * kTile + (slot & 127);
+    // one block = one row of a 128 x 128 tile: everything derived from the tile is block-uniform and is
+    // written so that the compiler sees it (scalar loads, SGPR compares, scalar branches)
+    const uint4 tile = a.tiles[blockIdx.x >> 7];
+    const uint64_t si = (uint64_t)tile.x * kTile + (blockIdx.x & 127u);
+    const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
     if (si >= a.n) return;  // padding row (uniform)
     const uint64_t i = a.perm ? a.perm[si] : si;
     // this tile's own plane range: C(v) = 0 for v <= vlo_t, exceptions above T
