@@ -481,7 +481,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // C(v) of up to 16 planes, 48 bins of sketch j's tail histogram, the two keys (one round trip
     // instead of one per plane / per bin -- with dependent loads this part was half of the kernel).
     const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
-    constexpr int kBatch = 12;
+    constexpr int kBatch = 16;
     uint32_t cvv[kBatch];
 #pragma unroll
     for (int t = 0; t < kBatch; ++t) {
