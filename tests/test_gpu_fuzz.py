@@ -1,5 +1,7 @@
 """GPU: seeded random sweep over (n, p, estimator, measure, register law) against the oracle --
 triangle, a random row range, a random rectangle and a random shard plan per case."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,14 +26,29 @@ def _regs(rng, n, p, kind):
     raise AssertionError(kind)
 
 
-def _close(got, want):
+# distance measure -> the index it is a function of (result_cmp, src/dashing.h:568-592).  The distance
+# formulas jump at index == 0 (`ret != 0 ? -log(ret)/k : 1`), so where the index is 0 up to rounding an
+# ulp of the device log() in a cardinality (ORIGINAL/IMPROVED small-range terms) may pick the other side.
+INDEX_OF = {0: 1, 3: 1, 6: 5, 4: 5, 8: 7}
+
+
+def _close(got, want, index_got=None, index_want=None):
+    """index_*: the same pairs under the underlying index measure; a mismatch is tolerated only where
+    both implementations put that index within 1e-9 of zero (the discontinuity of the distance formulas)."""
+    if index_got is not None:
+        at_jump = (np.abs(index_got) < 1e-9) & (np.abs(index_want) < 1e-9)
+        got, want = got[~at_jump], want[~at_jump]
     fin = np.isfinite(want)
     assert (np.isfinite(got) == fin).all()
     err = np.abs(got[fin].astype(np.float64) - want[fin])
-    assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9)).all(), err.max()
+    # 1e-6 relative; plus an absolute floor of 1e-12 of the matrix scale: SIZES / containment values are
+    # differences of cardinalities, so one ulp of log() (device libm vs glibc, ORIGINAL/IMPROVED estimators)
+    # in a cardinality of ~1e2..1e8 can leave ~1e-14 where the CPU gets an exact 0
+    scale = float(np.abs(want[fin]).max()) if fin.any() else 1.0
+    assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9) + 1e-12 * max(scale, 1.0)).all(), err.max()
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES", "24"))))  # e.g. DSH_FUZZ_CASES=400 for a long soak
 def test_random_case(ctx, oracle, case):
     rng = np.random.default_rng(1000 + case)
     p = int(rng.choice([4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
@@ -46,20 +63,32 @@ def test_random_case(ctx, oracle, case):
         a, b = rng.choice(n, 2, replace=False)
         regs[a] = regs[b]
     ctx.set_sketches(regs)
+    emax = int(rng.choice([-1, -1, 0, 3, 17, 255]))  # exception-list length: a speed knob, never a result knob
+    ctx.set_option("emax", emax)
     want = oracle.dist_tri(regs, estim, rt, k)
-    _close(ctx.dist_rows(estim=estim, result_type=rt, k=k), want)
+    ig = iw = None
+    if rt in INDEX_OF:
+        ig = ctx.dist_rows(estim=estim, result_type=INDEX_OF[rt], k=k)
+        iw = oracle.dist_tri(regs, estim, INDEX_OF[rt], k)
+        _close(ig, iw)
+    _close(ctx.dist_rows(estim=estim, result_type=rt, k=k), want, ig, iw)
     # a row range (identity columns)
     rb = int(rng.integers(0, n))
     re = int(rng.integers(rb, n + 1))
     lo = dashing_amd.tri_span(n, 0, rb)
     part = ctx.dist_rows(rb, re, estim=estim, result_type=rt, k=k)
-    _close(part, want[lo : lo + part.size])
+    sl = slice(lo, lo + part.size)
+    _close(part, want[sl], None if ig is None else ig[sl], None if iw is None else iw[sl])
     # a rectangle
     q0 = int(rng.integers(0, n)); q1 = int(rng.integers(q0, n + 1))
     r0 = int(rng.integers(0, n)); r1 = int(rng.integers(r0, n + 1))
     rect = ctx.dist_rect(q0, q1, r0, r1, estim=estim, result_type=rt, k=k)
     if rect.size:
-        _close(rect, oracle.dist_rect(regs[q0:q1], regs[r0:r1], estim, rt, k))
+        rg = rw = None
+        if rt in INDEX_OF:
+            rg = ctx.dist_rect(q0, q1, r0, r1, estim=estim, result_type=INDEX_OF[rt], k=k)
+            rw = oracle.dist_rect(regs[q0:q1], regs[r0:r1], estim, INDEX_OF[rt], k)
+        _close(rect, oracle.dist_rect(regs[q0:q1], regs[r0:r1], estim, rt, k), rg, rw)
     # shards of the sorted order, assembled
     import torch
 
@@ -77,4 +106,5 @@ def test_random_case(ctx, oracle, case):
     fin = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda")
     ctx.unpermute_device(sf.data_ptr(), fin.data_ptr())
     ctx.synchronize()
-    _close(fin.cpu().numpy()[:total], want)
+    _close(fin.cpu().numpy()[:total], want, ig, iw)
+    ctx.set_option("emax", -1)
