@@ -108,3 +108,23 @@ def test_sketch_then_dist_c1_like(ctx, oracle):
     want = oracle.dist_tri(want_regs)
     assert np.allclose(got, want, rtol=1e-6, atol=1e-15)
     assert got.max() > 0.5 and got.min() < 0.05  # related and unrelated pairs both present
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES_SKETCH", "12"))))
+def test_random_sketch_case(ctx, oracle, case):
+    """Seeded random sweep: k, p (LDS and HBM-register variants), canonical or not, ragged genome
+    lengths (0 .. 70 000), random bytes from a dirty alphabet (N, lowercase, IUPAC, newline, NUL)."""
+    rng = np.random.default_rng(7000 + case)
+    k = int(rng.choice([1, 2, 7, 15, 16, 17, 21, 31, 32]))
+    p = int(rng.choice([4, 5, 9, 10, 12, 14, 16, 17, 18, 21]))
+    canon = bool(rng.integers(2))
+    ng = int(rng.integers(1, 9))
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnRYKM\n\x00-", np.uint8)
+    weights = np.ones(alphabet.size)
+    weights[:16] = rng.choice([1.0, 30.0, 300.0])  # from "mostly dirty" to "almost clean"
+    weights /= weights.sum()
+    genomes = []
+    for _ in range(ng):
+        L = int(rng.choice([0, 1, k - 1, k, k + 1, 31, 32, 33, 63, 64, 65, 8191, 8192, 8193, int(rng.integers(0, 70000))]))
+        genomes.append(alphabet[rng.choice(alphabet.size, size=max(L, 0), p=weights)].astype(np.uint8))
+    run(ctx, oracle, genomes, k, p, canon)
