@@ -184,7 +184,11 @@ int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
  * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "tiles",
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
-/* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work. */
+/* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.
+ * Every *_device entry point runs on THIS stream and returns after its work has completed, so results
+ * are ready for any other stream on return.  The other direction is the caller's job: whatever it
+ * enqueued on its own streams that touches a buffer passed in (filling d_out, producing d_regs or
+ * d_seq) must have completed -- or be synchronised with this stream -- before the call. */
 void *dsh_stream(dsh_ctx *ctx);
 
 #ifdef __cplusplus

@@ -62,6 +62,7 @@ def main():
     span_off = ctx.shard_plan(world)
     mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
     out_d = torch.zeros(mx, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
     ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.MASH_DIST, k)
     ctx.synchronize()
     if backend == "gloo":

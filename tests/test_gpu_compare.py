@@ -207,6 +207,7 @@ def test_virtual_shards_assemble(ctx, nshards):
     sorted_full = torch.full((off[-1],), -1.0, dtype=torch.float32, device=dev)
     for r in range(nshards):
         span = torch.full((max(off[r + 1] - off[r], 1),), -2.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # torch fills run on torch's stream, the library on its own: order them
         ctx.dist_shard_device(span.data_ptr(), r, nshards, result_type=dashing_amd.MASH_DIST, k=21)
         ctx.synchronize()
         sorted_full[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
@@ -215,6 +216,7 @@ def test_virtual_shards_assemble(ctx, nshards):
     for mode in (1, 0):  # destination-driven (default) and source-driven un-permute
         ctx.set_option("unpermute_gather", mode)
         final.fill_(-3.0)
+        torch.cuda.synchronize()
         ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
         ctx.synchronize()
         assert final.cpu().numpy().tobytes() == want.tobytes()

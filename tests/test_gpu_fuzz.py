@@ -99,11 +99,13 @@ def test_random_case(ctx, oracle, case):
     sf = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda")
     for r in range(G):
         span = torch.zeros(max(off[r + 1] - off[r], 1), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the zero fill (torch's stream) must land before the library's stream writes
         ctx.dist_shard_device(span.data_ptr(), r, G, estim, rt, k)
         ctx.synchronize()
         sf[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
     torch.cuda.synchronize()
     fin = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     ctx.unpermute_device(sf.data_ptr(), fin.data_ptr())
     ctx.synchronize()
     _close(fin.cpu().numpy()[:total], want, ig, iw)
