@@ -203,6 +203,7 @@ def main():
     if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
 
+    line = None
     if rank == 0:
         line = {
             "metric": "genome-pairs/sec, all-pairs HLL Jaccard (Ertl-MLE), N=%d p=%d" % (n, p),
@@ -217,11 +218,26 @@ def main():
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
         }
-        print(json.dumps(line), flush=True)
     ctx.close()
+    # The JSON line must be the LAST thing on stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes)
+    # prints its banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise
+    # come out at process exit, after the line.  Flush C stdio on every rank, tear the group down, then print.
+    import ctypes
+
+    def flush_c_stdio():
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+
     if multi:
+        flush_c_stdio()
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def cpu_baseline(regs_h, gpu_full, n, p, seconds):
