@@ -973,22 +973,29 @@ static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb
         }
         total += rowcost[ti];
     }
-    // boundary r = the tile row whose cumulative cost is nearest to r/nshards of the total
-    std::vector<double> cum(NT + 1, 0.);
-    for (uint32_t ti = 0; ti < NT; ++ti) cum[ti + 1] = cum[ti] + rowcost[ti];
-    tb.assign(nshards + 1, NT);
-    tb[0] = 0;
-    uint32_t ti = 0;
-    for (uint32_t r = 1; r < nshards; ++r) {
-        // shard 0 belongs to the rank that also assembles the result (copies + un-permute, about
-        // assembler_permille/1000 of a single-GPU pass): give it that much less work
-        const double f0 = std::max(0.0, 1.0 / nshards - c->assembler_permille / 1000.0 * (nshards - 1) / nshards);
-        const double target = total * (f0 + (1.0 - f0) * (r - 1) / (nshards - 1));
-        while (ti < NT && cum[ti + 1] <= target) ++ti;
-        uint32_t b = ti;  // cum[b] <= target < cum[b+1]
-        if (b < NT && target - cum[b] > cum[b + 1] - target) ++b;
-        tb[r] = std::max(b, tb[r - 1]);
+    // Contiguous tile-row ranges that minimise the largest shard (linear partition by bisection on the
+    // limit + greedy fill).  Shard 0 belongs to the rank that also assembles the result (the un-permute,
+    // about assembler_permille/1000 of a single-GPU pass): it carries that as extra cost.
+    const double extra0 = nshards > 1 ? total * c->assembler_permille / 1000.0 : 0.0;
+    auto fill = [&](double limit, std::vector<uint32_t> *out) -> bool {
+        uint32_t ti = 0;
+        for (uint32_t r = 0; r < nshards; ++r) {
+            double acc = r == 0 ? extra0 : 0.0;
+            if (out) (*out)[r] = ti;
+            while (ti < NT && acc + rowcost[ti] <= limit) acc += rowcost[ti++];
+        }
+        if (out) (*out)[nshards] = NT;
+        return ti == NT;
+    };
+    double lo = 0, hi = total + extra0;
+    for (uint32_t ti = 0; ti < NT; ++ti) lo = std::max(lo, rowcost[ti]);  // a shard holds whole tile rows
+    for (int it = 0; it < 60 && hi - lo > 1e-9 * (hi + 1); ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, nullptr)) hi = mid;
+        else lo = mid;
     }
+    tb.assign(nshards + 1, NT);
+    fill(hi, &tb);  // (the greedy fill front-loads: later shards may be lighter, the maximum is what counts)
 }
 
 int dsh_shard_plan(dsh_ctx *c, int estim, uint32_t nshards, uint64_t *span_off)
