@@ -217,6 +217,49 @@ __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ r
     }
 }
 
+// Same transform for 2^p >= 256 with coalesced reads: a workgroup takes 64 sketches x 256 register bytes,
+// reads them as 256-byte runs of one sketch each (the thread-per-(sketch, word) mapping above touches 64
+// different sketches per wave, 32 B each), stages them in LDS (row stride 17 x 16 B: conflict-free for the
+// 16-byte reads of the second phase) and writes 64 consecutive columns per plane row.
+__global__ __launch_bounds__(256) void k_transform_t(const uint8_t *__restrict__ regs, uint64_t n,
+                                                      int p, int vlo, uint32_t P, uint32_t W,
+                                                      uint32_t Npad, uint32_t *__restrict__ planes,
+                                                      const uint32_t *__restrict__ perm)
+{
+    constexpr uint32_t kRow = 272;  // bytes per staged sketch row (256 + 16)
+    __shared__ __attribute__((aligned(16))) uint8_t stage[64 * kRow];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i0 = blockIdx.x * 64;
+    const uint64_t b0 = (uint64_t)blockIdx.y * 256;
+    const uint64_t m = 1ull << p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t q = tid + 256u * r;
+        const uint32_t sl = q >> 4, c = q & 15u;
+        const uint32_t i = i0 + sl;
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // padding sketches: no bit ever set
+        if (i < n) v = *reinterpret_cast<const uint4 *>(regs + (uint64_t)(perm ? perm[i] : i) * m + b0 + c * 16u);
+        *reinterpret_cast<uint4 *>(stage + sl * kRow + c * 16u) = v;
+    }
+    __syncthreads();
+    const uint32_t il = tid & 63u, g = tid >> 6;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t wl = g * 2 + h;  // word (32 registers) within the 256-byte run
+        const uint4 a = *reinterpret_cast<const uint4 *>(stage + il * kRow + wl * 32u);
+        const uint4 b = *reinterpret_cast<const uint4 *>(stage + il * kRow + wl * 32u + 16u);
+        const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const uint64_t w = (uint64_t)blockIdx.y * 8 + wl;
+        for (uint32_t pl = 0; pl < P; ++pl) {
+            const uint32_t vrep = (uint32_t)(vlo + 1 + (int)pl) * 0x01010101u;
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) word |= (lt_nibble(x[k], vrep) & 0xFu) << (4 * k);
+            planes[((uint64_t)pl * W + w) * Npad + i0 + il] = word;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // all-pairs AND+popcount.  One 256-thread workgroup per 128x128 tile of sketches.
 //   waves 2x2, each covers 64x64 pairs; lane (ly,lx) of the 8x8 lane grid owns an 8x8 block.
@@ -809,6 +852,11 @@ hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int
                             const uint32_t *perm)
 {
     if (P == 0) return hipSuccess;
+    if (p >= 8 && ((uint64_t)1 << p) / 256 <= 65535) {  // Npad is a multiple of 128
+        hipLaunchKernelGGL(k_transform_t, dim3(Npad / 64, (uint32_t)(((uint64_t)1 << p) / 256)), dim3(256), 0, st, regs,
+                           n, p, vlo, P, W, Npad, planes, perm);
+        return hipGetLastError();
+    }
     const uint64_t threads = (uint64_t)Npad * W;
     const uint32_t blocks = (uint32_t)((threads + 255) / 256);
     hipLaunchKernelGGL(k_transform, dim3(blocks), dim3(256), 0, st, regs, n, p, vlo, P, W, Npad,
