@@ -81,18 +81,38 @@ def main():
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
     ctx.attach_device(regs_d.data_ptr(), n, p)
-    # N>1: every rank holds all sketches and computes one cost-balanced shard (a contiguous span
-    # of the sorted-order triangle); the only exchange is the RCCL gather of the spans to rank 0,
-    # which un-permutes them once into dashing's packed order.
-    span_off = ctx.shard_plan(world) if multi else [0, total_pairs]
-    span = span_off[rank + 1] - span_off[rank]
-    mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
-    out_d = torch.empty(mx, dtype=torch.float32, device=dev)
-    stage = sorted_full = final = None
-    if multi and rank == 0:
-        stage = torch.empty(world * mx, dtype=torch.float32, device=dev)
-        sorted_full = torch.empty(total_pairs, dtype=torch.float32, device=dev)
-        final = torch.empty(total_pairs, dtype=torch.float32, device=dev)
+    # N>1: every rank holds all sketches and computes its cost-balanced share of the sorted-order triangle
+    # (contiguous spans); the only exchange is the RCCL gather of the spans to rank 0, which un-permutes
+    # them once into dashing's packed order.  DSH_BENCH_PIECES=K cuts a rank's share into K shards and
+    # gathers piece h asynchronously while piece h+1 is computed (multigpu.PipelinedShards).  On one GPU
+    # every extra piece costs ~0.25 ms (smaller launches); the estimated gain is ~0.5 ms at 2 ranks (one xGMI
+    # link carries 100 MB), ~0.15 ms at 4 and nothing at 8 -- too little to make it the default before it
+    # has run on real links, so the default is one piece and a plain gather.
+    pieces = 1
+    if multi:
+        pieces = max(1, int(os.environ.get("DSH_BENCH_PIECES", "1")))
+    nshards = world * pieces
+    span_off = ctx.shard_plan(nshards) if multi else [0, total_pairs]
+    span = span_off[(rank + 1) * pieces] - span_off[rank * pieces] if multi else total_pairs
+    final = torch.empty(total_pairs, dtype=torch.float32, device=dev) if multi and rank == 0 else None
+    out_d = stage = pipe = None
+    if not multi:
+        out_d = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev)
+    elif pieces == 1 and backend == "nccl":
+        mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
+        out_d = torch.empty(mx, dtype=torch.float32, device=dev)
+        stage = torch.empty(world * mx, dtype=torch.float32, device=dev) if rank == 0 else None
+    else:
+        # gloo dry-run: the pieces travel through host memory (ranks share one GPU)
+        pipe = multigpu.PipelinedShards(span_off, rank, world, pieces, dev if backend == "nccl" else torch.device("cpu"))
+        gpu_out = [torch.empty(pipe.mx[h], dtype=torch.float32, device=dev) for h in range(pieces)] if backend != "nccl" else None
+
+    def compute_piece(h):
+        buf = pipe.out(h) if backend == "nccl" else gpu_out[h]
+        ctx.dist_shard_device(buf.data_ptr(), pipe.shard(h), nshards, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        if backend != "nccl":
+            pipe.out(h).copy_(buf)
 
     def step():
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
@@ -101,22 +121,29 @@ def main():
             ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             ctx.synchronize()
             return out_d[:span]
-        ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        ctx.synchronize()
-        if backend == "gloo":  # dry-run only: stage through the host
-            h = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
-            full = sorted_full.copy_(h) if rank == 0 else None
+        if pipe is None:
+            ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            # the gathered (padded) blocks are un-permuted where they arrived: no back-to-back copy
+            st = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, None, 0, staged=True)
+            # NCCL collectives only enqueue: wait on the host until this rank's part is done (rank 0 must
+            # see the data, the others must not overwrite out_d in the next step while it is being sent)
+            torch.cuda.current_stream().synchronize()
             if rank == 0:
-                torch.cuda.current_stream().synchronize()
-                ctx.unpermute_device(full.data_ptr(), final.data_ptr())
-                ctx.synchronize()
+                ctx.unpermute_staged_device(st.data_ptr(), mx, world, final.data_ptr())
                 return final
             return None
-        # the gathered (padded) blocks are un-permuted where they arrived: no back-to-back copy
-        st = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, None, 0, staged=True)
+        for h in range(pieces):
+            compute_piece(h)
+            pipe.submit(h)  # async gather of piece h; the next piece is computed meanwhile
+        got = pipe.wait()
+        torch.cuda.current_stream().synchronize()  # as above: the gathers have completed on this rank
         if rank == 0:
-            torch.cuda.current_stream().synchronize()
-            ctx.unpermute_staged_device(st.data_ptr(), mx, world, final.data_ptr())
+            st, block_off = got
+            if backend != "nccl":
+                st = st.to(dev)
+                torch.cuda.current_stream().synchronize()
+            ctx.unpermute_blocks_device(st.data_ptr(), block_off, final.data_ptr())
             return final
         return None
 
@@ -146,16 +173,19 @@ def main():
     reps = 3
     for _ in range(reps):
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        if not multi:
-            ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        else:
-            ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        ctx.synchronize()
-        k = ctx.last_kernel_ms()
-        pair_ms += k["pair_ms"]
-        fin_ms += k["finalize_ms"]
-        prep_ms += k["prepare_ms"]
-        launches += k["pair_launches"]
+        calls = [None] if not multi else ([(out_d, rank, world)] if pipe is None else
+                                         [((pipe.out(h) if backend == "nccl" else gpu_out[h]), pipe.shard(h), nshards) for h in range(pieces)])
+        for call in calls:
+            if call is None:
+                ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            else:
+                ctx.dist_shard_device(call[0].data_ptr(), call[1], call[2], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            k = ctx.last_kernel_ms()
+            pair_ms += k["pair_ms"]
+            fin_ms += k["finalize_ms"]
+            prep_ms += k["prepare_ms"]
+            launches += k["pair_launches"]
     ctx.set_profiling(False)
     traffic = None  # HBM bytes per launch from the committed PMC passes of the same workload
     try:
@@ -213,7 +243,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
                        "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                       "sharding": "cost-balanced row shards of the sorted-order triangle, RCCL gather to rank 0 + un-permute" if multi else "single GPU"},
+                       "sharding": ("cost-balanced row shards of the sorted-order triangle (%d per rank, gathered piece by piece while the next is computed), RCCL gather to rank 0 + un-permute" % pieces) if multi else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,

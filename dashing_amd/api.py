@@ -23,7 +23,7 @@ SYMBOLS = [
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches", "dsh_copy_sketches_device",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
-    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_alloc_host", "dsh_free_host",
+    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -75,6 +75,7 @@ def load_library():
     lib.dsh_dist_shard_device.argtypes = [vp, i32, i32, i32, C.c_uint32, C.c_uint32, vp]
     lib.dsh_unpermute_device.argtypes = [vp, vp, vp]
     lib.dsh_unpermute_staged_device.argtypes = [vp, vp, u64, C.c_uint32, vp]
+    lib.dsh_unpermute_blocks_device.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.dsh_tri_span.argtypes = [u64, u64, u64]
     lib.dsh_tri_span.restype = u64
     lib.dsh_tri_index.argtypes = [u64, u64, u64]
@@ -267,6 +268,10 @@ class Context:
 
     def unpermute_staged_device(self, stage_ptr, stride, nshards, out_ptr):
         self._ck(self._lib.dsh_unpermute_staged_device(self._h, C.c_void_p(stage_ptr), stride, nshards, C.c_void_p(out_ptr)))
+
+    def unpermute_blocks_device(self, stage_ptr, block_off, out_ptr):
+        off = np.ascontiguousarray(block_off, np.uint64)
+        self._ck(self._lib.dsh_unpermute_blocks_device(self._h, C.c_void_p(stage_ptr), off.ctypes.data, off.size, C.c_void_p(out_ptr)))
 
     # ---- misc
     def synchronize(self):

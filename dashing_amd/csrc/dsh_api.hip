@@ -1052,9 +1052,9 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     return DSH_OK;
 }
 
-int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride, uint32_t nshards, void *d_out_tri)
+int dsh_unpermute_blocks_device(dsh_ctx *c, const void *d_stage, const uint64_t *block_off, uint32_t nshards, void *d_out_tri)
 {
-    if (!c || nshards == 0) return DSH_EINVAL;
+    if (!c || nshards == 0 || !block_off) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
     if (!c->planes_valid || !c->planes_sorted) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
@@ -1066,9 +1066,7 @@ int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride
     std::vector<int64_t> delta(NT, 0);
     for (uint32_t r = 0; r < nshards; ++r) {
         const uint64_t off = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r] * kTile));
-        const uint64_t end = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r + 1] * kTile));
-        if (end - off > stride) return fail(c, DSH_EINVAL, "stride %llu smaller than the span of shard %u", (unsigned long long)stride, r);
-        for (uint32_t t = tb[r]; t < tb[r + 1]; ++t) delta[t] = (int64_t)((uint64_t)r * stride) - (int64_t)off;
+        for (uint32_t t = tb[r]; t < tb[r + 1]; ++t) delta[t] = (int64_t)block_off[r] - (int64_t)off;
     }
     HIPCHK(c, c->workbuf.ensure(NT * sizeof(int64_t)));
     HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, delta.data(), NT * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -1076,6 +1074,23 @@ int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride
                                       (const int64_t *)c->workbuf.ptr, c->n, (float *)d_out_tri));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // `delta` (pageable source) must outlive the copy
     return DSH_OK;
+}
+
+int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride, uint32_t nshards, void *d_out_tri)
+{
+    if (!c || nshards == 0) return DSH_EINVAL;
+    if (c->planes_valid && c->planes_sorted && c->n >= 2) {  // the spans must fit their blocks
+        std::vector<uint32_t> tb;
+        shard_bounds(c, nshards, tb);
+        for (uint32_t r = 0; r < nshards; ++r) {
+            const uint64_t off = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r] * kTile));
+            const uint64_t end = dsh_tri_span(c->n, 0, std::min<uint64_t>(c->n, (uint64_t)tb[r + 1] * kTile));
+            if (end - off > stride) return fail(c, DSH_EINVAL, "stride %llu smaller than the span of shard %u", (unsigned long long)stride, r);
+        }
+    }
+    std::vector<uint64_t> off(nshards);
+    for (uint32_t r = 0; r < nshards; ++r) off[r] = (uint64_t)r * stride;
+    return dsh_unpermute_blocks_device(c, d_stage, off.data(), nshards, d_out_tri);
 }
 
 void *dsh_alloc_host(size_t bytes)

@@ -96,3 +96,50 @@ def allgather_sketches(local, n_genomes, rank, world):
         dist.all_gather_into_tensor(allr, local.contiguous())
     # rank-major [r][t] -> genome order g = t*world + r
     return allr.permute(1, 0, 2).reshape(per * world, m)[:n_genomes].contiguous()
+
+
+# ---- pipelined gather: K pieces per rank, piece h travels while piece h+1 is computed -------------
+class PipelinedShards:
+    """Rank r owns the K consecutive shards r*K .. r*K+K-1 of a (world*K)-shard plan.  After computing
+    piece h (Context.dist_shard_device(out(h), shard(h), nshards)) the rank calls submit(h): the piece
+    is gathered to `dst` asynchronously (its own block of the staging buffer, all ranks' pieces h padded
+    to the largest), so the transfer over xGMI overlaps the computation of piece h+1.  wait() returns
+    (stage, block_off) on `dst` for Context.unpermute_blocks_device, None elsewhere.  The collectives are
+    issued in the same order on every rank (one gather per piece)."""
+
+    def __init__(self, span_off, rank, world, pieces, device, dst=0, dtype=torch.float32):
+        assert len(span_off) == world * pieces + 1
+        self.rank, self.world, self.K, self.dst = rank, world, pieces, dst
+        self.nshards = world * pieces
+        size = lambda s: span_off[s + 1] - span_off[s]
+        self.mx = [max(max(size(r * pieces + h) for r in range(world)), 1) for h in range(pieces)]
+        self.base = [0]
+        for h in range(pieces):
+            self.base.append(self.base[-1] + world * self.mx[h])
+        # shard s = r*K + h lives at base[h] + r*mx[h] of the staging buffer
+        self.block_off = [self.base[s % pieces] + (s // pieces) * self.mx[s % pieces] for s in range(self.nshards)]
+        self.outs = [torch.empty(self.mx[h], dtype=dtype, device=device) for h in range(pieces)]
+        self.stage = torch.empty(self.base[-1], dtype=dtype, device=device) if rank == dst else None
+        self.works = []
+
+    def shard(self, h):
+        return self.rank * self.K + h
+
+    def out(self, h):
+        return self.outs[h]
+
+    def submit(self, h):
+        send = self.outs[h]
+        if self.world == 1 and not dist.is_initialized():
+            self.stage[self.base[h] : self.base[h] + self.mx[h]].copy_(send)
+            return
+        parts = None
+        if self.rank == self.dst:
+            parts = [self.stage[self.base[h] + r * self.mx[h] : self.base[h] + (r + 1) * self.mx[h]] for r in range(self.world)]
+        self.works.append(dist.gather(send, gather_list=parts, dst=self.dst, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return (self.stage, self.block_off) if self.rank == self.dst else None

@@ -155,6 +155,11 @@ int dsh_unpermute_device(dsh_ctx *ctx, const void *d_sorted_tri, void *d_out_tri
  * the spans back to back first.  Returns after completion. */
 int dsh_unpermute_staged_device(dsh_ctx *ctx, const void *d_stage, uint64_t stride, uint32_t nshards,
                                 void *d_out_tri);
+/* General form: shard r's span starts at d_stage + block_off[r] (floats) -- any arrangement of the
+ * gathered blocks, e.g. the per-piece blocks of a pipelined gather (several shards per rank, each
+ * piece gathered while the next is computed). */
+int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_t *block_off,
+                                uint32_t nshards, void *d_out_tri);
 
 /* ---- helpers shared by every host (C++ CLI, Python, a patched dashing) -------------------- */
 /* number of packed elements of rows [row_begin,row_end) of an n x n upper triangle */

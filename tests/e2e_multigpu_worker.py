@@ -56,25 +56,48 @@ def main():
     else:
         regs_d = multigpu.allgather_sketches(local, n, rank, world)
     torch.cuda.synchronize()
-    # ---- all-pairs: one cost-balanced shard per rank, gather on rank 0, un-permute
+    # ---- all-pairs: cost-balanced shards (E2E_PIECES per rank), gather on rank 0, un-permute
     ctx.attach_device(regs_d.data_ptr(), n, p)
     total = n * (n - 1) // 2
-    span_off = ctx.shard_plan(world)
-    mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
-    out_d = torch.zeros(mx, dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
-    ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.MASH_DIST, k)
-    ctx.synchronize()
-    if backend == "gloo":
-        full = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
-        full = full.to(dev) if rank == 0 else None
-    else:  # as bench.py: un-permute straight from the gathered (padded) blocks
-        full = multigpu.gather_shard_spans(out_d, span_off, rank, world, staged=True)
+    pieces = int(os.environ.get("E2E_PIECES", "1"))
+    rt = dashing_amd.MASH_DIST
+    pipe = None
+    if pieces == 1:
+        span_off = ctx.shard_plan(world)
+        mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
+        out_d = torch.zeros(mx, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
+        ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, rt, k)
+        ctx.synchronize()
+        if backend == "gloo":
+            full = multigpu.gather_shard_spans(out_d.cpu(), span_off, rank, world)
+            full = full.to(dev) if rank == 0 else None
+        else:  # as bench.py: un-permute straight from the gathered (padded) blocks
+            full = multigpu.gather_shard_spans(out_d, span_off, rank, world, staged=True)
+    else:  # pipelined: piece h is gathered while piece h+1 is computed (multigpu.PipelinedShards)
+        span_off = ctx.shard_plan(world * pieces)
+        pipe = multigpu.PipelinedShards(span_off, rank, world, pieces, dev if backend == "nccl" else torch.device("cpu"))
+        for h in range(pieces):
+            buf = pipe.out(h) if backend == "nccl" else torch.empty(pipe.mx[h], dtype=torch.float32, device=dev)
+            ctx.dist_shard_device(buf.data_ptr(), pipe.shard(h), world * pieces, dashing_amd.ESTIM_ERTL_MLE, rt, k)
+            ctx.synchronize()
+            if backend != "nccl":
+                pipe.out(h).copy_(buf)
+            pipe.submit(h)
+        got = pipe.wait()
+        torch.cuda.current_stream().synchronize()
+        full = None
+        if rank == 0:
+            full, block_off = got
+            full = full.to(dev) if backend != "nccl" else full
     ok = True
     if rank == 0:
         torch.cuda.synchronize()
         final = torch.empty(total, dtype=torch.float32, device=dev)
-        if backend == "gloo":
+        torch.cuda.synchronize()
+        if pipe is not None:
+            ctx.unpermute_blocks_device(full.data_ptr(), block_off, final.data_ptr())
+        elif backend == "gloo":
             ctx.unpermute_device(full.data_ptr(), final.data_ptr())
         else:
             ctx.unpermute_staged_device(full.data_ptr(), mx, world, final.data_ptr())
@@ -86,11 +109,11 @@ def main():
         want_regs = oracle_c.sketch_batch(seq, off, k, p, True)
         got_regs = regs_d.cpu().numpy()
         assert (got_regs == want_regs).all(), "all-gathered registers differ from the oracle"
-        want = oracle_c.dist_tri(want_regs, result_type=dashing_amd.MASH_DIST, k=k)
+        want = oracle_c.dist_tri(want_regs, result_type=rt, k=k)
         got = final.cpu().numpy()
         rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-9)
         assert rel.max() <= 1e-6, rel.max()
-        print("E2E_OK world=%d backend=%s pairs=%d max_rel=%.3g" % (world, backend, total, rel.max()), flush=True)
+        print("E2E_OK world=%d backend=%s pieces=%d pairs=%d max_rel=%.3g" % (world, backend, pieces, total, rel.max()), flush=True)
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()

@@ -22,12 +22,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2), ("gloo", 3)])
-def test_end_to_end_ranks(backend, world):
-    env = dict(os.environ, E2E_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("backend,world,pieces", [("nccl", 1, 1), ("gloo", 2, 1), ("gloo", 3, 1), ("nccl", 1, 2), ("gloo", 2, 3)])
+def test_end_to_end_ranks(backend, world, pieces):
+    """pieces > 1: every rank's share is cut into that many shards, each gathered asynchronously while the
+    next is computed (multigpu.PipelinedShards, dsh_unpermute_blocks_device)."""
+    env = dict(os.environ, E2E_BACKEND=backend, E2E_PIECES=str(pieces), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER]
     r = subprocess.run(cmd, env=env, capture_output=True, timeout=600, cwd=ROOT)
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0, out[-3000:]
-    assert "E2E_OK world=%d backend=%s" % (world, backend) in out, out[-3000:]
+    assert "E2E_OK world=%d backend=%s pieces=%d" % (world, backend, pieces) in out, out[-3000:]
