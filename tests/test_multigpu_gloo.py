@@ -136,3 +136,42 @@ def test_sharded_sketching_allgather_gloo(tmp_path, world, n):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "regs_%d_%d.npy" % (world, r)))
         assert got.shape == want.shape and (got == want).all()
+
+
+def _worker_pipe(rank, world, port, pieces, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dashing_amd import multigpu
+
+    S = world * pieces
+    sizes = [37 + 11 * ((s * 5) % 7) for s in range(S)]
+    sizes[1] = 0  # an empty shard is legal (more shards than tile rows)
+    span_off = [0]
+    for z in sizes:
+        span_off.append(span_off[-1] + z)
+    pipe = multigpu.PipelinedShards(span_off, rank, world, pieces, torch.device("cpu"))
+    for h in range(pieces):
+        s_ = pipe.shard(h)
+        buf = pipe.out(h)
+        buf.fill_(-1.0)
+        buf[: sizes[s_]] = torch.arange(span_off[s_], span_off[s_ + 1], dtype=torch.float32)
+        pipe.submit(h)
+    got = pipe.wait()
+    if rank == 0:
+        stage, block_off = got
+        full = torch.cat([stage[block_off[s] : block_off[s] + sizes[s]] for s in range(S)])
+        np.save(os.path.join(outdir, "pipe_%d_%d.npy" % (world, pieces)), full.numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 3), (3, 2), (2, 1)])
+def test_pipelined_shards_gloo(tmp_path, world, pieces):
+    """Piece-by-piece asynchronous gather: every shard lands in its own block of the staging buffer."""
+    mp.spawn(_worker_pipe, args=(world, _free_port(), pieces, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "pipe_%d_%d.npy" % (world, pieces)))
+    assert (got == np.arange(got.size, dtype=np.float32)).all() and got.size >= 37
