@@ -1,5 +1,13 @@
-import sys, json, torch
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""k_finalize time per estimator and measure on the C3 matrix (10 000 x p=14): separates the estimator's
+share of the kernel from the histogram assembly and the list walk."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dashing_amd
 from dashing_amd import synth
 n, p = 10000, 14
