@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary p=10 workload line")
     args = ap.parse_args()
 
     import torch
