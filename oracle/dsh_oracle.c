@@ -29,6 +29,7 @@
  * -ffp-contract=off matters: the device estimator is compiled the same way so that
  * + - * / ldexp frexp are IEEE-identical on both sides ("MLE early stop").
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -178,6 +179,125 @@ void dsho_hist_union(const uint8_t *a, const uint8_t *b, uint64_t m, uint32_t *h
     }
     for (int v = 0; v < 64; ++v) hist[v] = h[0][v] + h[1][v] + h[2][v] + h[3][v];
 }
+
+/* ---- A.4 with SIMD: the form the reference's CPU builds take ----------------------------
+ * dashing ships SSE2 / AVX2 / AVX-512BW builds (Makefile:159-190, README.md:9) whose union_size does a
+ * vector byte-max and then counts (the code is in the absent sketch submodule; SURVEY.md A.4 [M]: "any
+ * method yields the same integers").  This is that form, written for the timed CPU baseline of bench.py:
+ * max_epu8 over 64 (32) registers at a time, one 8-bit counter vector per register value of the band
+ * [vlo, vhi] the pair can contain (cmpeq mask -> masked add; flushed with sad_epu8 before it can
+ * overflow), at most NVMAX values per sweep over the data.  Selected at run time (cpuid), so the
+ * portable liboracle.so carries it; tests/test_oracle.py asserts it equals dsho_hist_union bit for bit. */
+#define NV512 24
+__attribute__((target("avx512f,avx512bw"))) static void hist_union_avx512(const uint8_t *a, const uint8_t *b,
+                                                                            uint64_t m, int vlo, int vhi,
+                                                                            uint32_t *hist)
+{
+    const __m512i one = _mm512_set1_epi8(1), zero = _mm512_setzero_si512();
+    for (int v0 = vlo; v0 <= vhi; v0 += NV512) {
+        __m512i cnt[NV512];
+        uint64_t tot[NV512];
+        for (int g = 0; g < NV512; ++g) {
+            cnt[g] = zero;
+            tot[g] = 0;
+        }
+        const __m512i base = _mm512_set1_epi8((char)v0);
+        uint64_t t = 0;
+        while (t + 64 <= m) {
+            uint64_t stop = t + 64 * 255;  /* 8-bit counters: flush every 255 vectors */
+            if (stop > m) stop = m & ~UINT64_C(63);
+            for (; t < stop; t += 64) {
+                const __m512i mx = _mm512_max_epu8(_mm512_loadu_si512((const void *)(a + t)),
+                                                   _mm512_loadu_si512((const void *)(b + t)));
+                __m512i val = base;
+#pragma GCC unroll 24
+                for (int g = 0; g < NV512; ++g) {
+                    cnt[g] = _mm512_mask_add_epi8(cnt[g], _mm512_cmpeq_epi8_mask(mx, val), cnt[g], one);
+                    val = _mm512_add_epi8(val, one);
+                }
+            }
+#pragma GCC unroll 24
+            for (int g = 0; g < NV512; ++g) {
+                tot[g] += (uint64_t)_mm512_reduce_add_epi64(_mm512_sad_epu8(cnt[g], zero));
+                cnt[g] = zero;
+            }
+        }
+        for (int g = 0; g < NV512 && v0 + g <= vhi; ++g) hist[(v0 + g) & 63] += (uint32_t)tot[g];
+        if (v0 == vlo)
+            for (; t < m; ++t) ++hist[(a[t] > b[t] ? a[t] : b[t]) & 63];  /* tail shorter than one vector */
+    }
+}
+
+#define NV256 12
+__attribute__((target("avx2"))) static void hist_union_avx2(const uint8_t *a, const uint8_t *b, uint64_t m,
+                                                            int vlo, int vhi, uint32_t *hist)
+{
+    const __m256i one = _mm256_set1_epi8(1), zero = _mm256_setzero_si256();
+    for (int v0 = vlo; v0 <= vhi; v0 += NV256) {
+        __m256i cnt[NV256];
+        uint64_t tot[NV256];
+        for (int g = 0; g < NV256; ++g) {
+            cnt[g] = zero;
+            tot[g] = 0;
+        }
+        const __m256i base = _mm256_set1_epi8((char)v0);
+        uint64_t t = 0;
+        while (t + 32 <= m) {
+            uint64_t stop = t + 32 * 255;
+            if (stop > m) stop = m & ~UINT64_C(31);
+            for (; t < stop; t += 32) {
+                const __m256i mx = _mm256_max_epu8(_mm256_loadu_si256((const __m256i *)(a + t)),
+                                                   _mm256_loadu_si256((const __m256i *)(b + t)));
+                __m256i val = base;
+#pragma GCC unroll 12
+                for (int g = 0; g < NV256; ++g) {
+                    cnt[g] = _mm256_sub_epi8(cnt[g], _mm256_cmpeq_epi8(mx, val));  /* -(-1) per equal byte */
+                    val = _mm256_add_epi8(val, one);
+                }
+            }
+#pragma GCC unroll 12
+            for (int g = 0; g < NV256; ++g) {
+                const __m256i s = _mm256_sad_epu8(cnt[g], zero);
+                tot[g] += (uint64_t)_mm256_extract_epi64(s, 0) + (uint64_t)_mm256_extract_epi64(s, 1) +
+                          (uint64_t)_mm256_extract_epi64(s, 2) + (uint64_t)_mm256_extract_epi64(s, 3);
+                cnt[g] = zero;
+            }
+        }
+        for (int g = 0; g < NV256 && v0 + g <= vhi; ++g) hist[(v0 + g) & 63] += (uint32_t)tot[g];
+        if (v0 == vlo)
+            for (; t < m; ++t) ++hist[(a[t] > b[t] ? a[t] : b[t]) & 63];
+    }
+}
+
+/* 0 scalar, 1 AVX2, 2 AVX-512BW: what this host can run */
+int dsho_simd_level(void)
+{
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f")) return 2;
+    if (__builtin_cpu_supports("avx2")) return 1;
+    return 0;
+}
+
+/* histogram of max(a,b) when every max lies in [vlo, vhi] (vlo = the larger of the two sketches' smallest
+ * registers, vhi = the larger of their largest); level as dsho_simd_level(), capped by the host's. */
+void dsho_hist_union_simd(const uint8_t *a, const uint8_t *b, uint64_t m, int vlo, int vhi, int level,
+                          uint32_t *hist)
+{
+    const int have = dsho_simd_level();
+    if (level > have) level = have;
+    if (level <= 0 || vhi < vlo || vlo < 0 || vhi > 63) {
+        dsho_hist_union(a, b, m, hist);
+        return;
+    }
+    memset(hist, 0, 64 * sizeof(uint32_t));
+    if (level == 2) hist_union_avx512(a, b, m, vlo, vhi, hist);
+    else hist_union_avx2(a, b, m, vlo, vhi, hist);
+}
+
+/* 0 (default): the scalar histogram everywhere.  >0: dist_tri/dist_rows/dist_rect use the SIMD histogram of
+ * that level (bench.py's cpu_baseline); results are identical (same integers into the same estimator). */
+static int g_simd = 0;
+void dsho_set_simd(int level) { g_simd = level > 0 ? level : 0; }
 
 /* ---- A.5  estimators ------------------------------------------------------------------ */
 static double alpha_m(uint64_t m)
@@ -388,6 +508,35 @@ float dsho_pair(const uint8_t *a, const uint8_t *b, double ca, double cb, int p,
     return dsho_result_triple(ca, cb, us, result_type, k);
 }
 
+/* same pair through the SIMD histogram (g_simd > 0): lo/hi = smallest / largest register of each sketch */
+static float pair_banded(const uint8_t *a, const uint8_t *b, double ca, double cb, int p, int estim,
+                         int result_type, int k, int lo_a, int hi_a, int lo_b, int hi_b)
+{
+    uint32_t h[64];
+    dsho_hist_union_simd(a, b, UINT64_C(1) << p, lo_a > lo_b ? lo_a : lo_b, hi_a > hi_b ? hi_a : hi_b, g_simd, h);
+    const double us = dsho_estimate(h, p, estim);
+    if (result_type == DSHO_MASH_DIST || result_type == DSHO_JI || result_type == DSHO_FULL_MASH_DIST)
+        return dsho_result(dsho_jaccard_from(ca, cb, us), result_type, k);
+    return dsho_result_triple(ca, cb, us, result_type, k);
+}
+
+static uint8_t *ranges_(const uint8_t *regs, uint64_t n, uint64_t m)
+{
+    uint8_t *r = (uint8_t *)malloc(2 * (n ? n : 1));
+#pragma omp parallel for schedule(static) num_threads(nthreads_())
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint8_t lo = 255, hi = 0;
+        const uint8_t *x = regs + (uint64_t)i * m;
+        for (uint64_t t = 0; t < m; ++t) {
+            lo = x[t] < lo ? x[t] : lo;
+            hi = x[t] > hi ? x[t] : hi;
+        }
+        r[2 * i] = lo;
+        r[2 * i + 1] = hi;
+    }
+    return r;
+}
+
 /* ---- a7-a9: all-pairs, reference schedule (row i serial, dynamic over j > i) ---------- */
 static inline uint64_t tri_index(uint64_t n, uint64_t i, uint64_t j)
 {
@@ -420,15 +569,19 @@ uint64_t dsho_dist_rows(const uint8_t *regs, uint64_t n, int p, int estim, int r
     double *card = (double *)malloc(sizeof(double) * (n ? n : 1));
     dsho_cardinalities(regs, n, p, estim, card);
     uint64_t done = 0;
+    uint8_t *rg = g_simd ? ranges_(regs, n, m) : NULL;
     for (uint64_t i = row_begin; i < row_end && i + 1 < n; ++i) {
         const uint8_t *hi = regs + i * m;
         float *row = out + done;
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
         for (int64_t j = (int64_t)i + 1; j < (int64_t)n; ++j)
             row[j - (int64_t)i - 1] =
-                dsho_pair(regs + (uint64_t)j * m, hi, card[j], card[i], p, estim, result_type, k);
+                rg ? pair_banded(regs + (uint64_t)j * m, hi, card[j], card[i], p, estim, result_type, k,
+                                 rg[2 * j], rg[2 * j + 1], rg[2 * i], rg[2 * i + 1])
+                   : dsho_pair(regs + (uint64_t)j * m, hi, card[j], card[i], p, estim, result_type, k);
         done += n - i - 1;
     }
+    free(rg);
     free(card);
     return done;
 }

@@ -54,6 +54,11 @@ def _bind(lib):
     lib.dsho_set_threads.restype = None
     lib.dsho_set_threads.argtypes = [C.c_int]
     lib.dsho_wang.restype = C.c_uint64
+    lib.dsho_simd_level.restype = C.c_int
+    lib.dsho_set_simd.restype = None
+    lib.dsho_set_simd.argtypes = [C.c_int]
+    lib.dsho_hist_union_simd.restype = None
+    lib.dsho_hist_union_simd.argtypes = [_u8p, _u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, _u32p]
     lib.dsho_wang.argtypes = [C.c_uint64]
     lib.dsho_reg_rule.restype = None
     lib.dsho_reg_rule.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
@@ -219,6 +224,26 @@ def knn(regs, nn, qb=0, qe=None, rb=0, re=None, estim=ERTL_MLE, result_type=JI, 
     if idx.size:
         load().dsho_knn(regs, n, int(m).bit_length() - 1, estim, result_type, k, qb, qe, rb, re, nn, idx, val)
     return idx, val
+
+
+def simd_level(lib=None):
+    """0 scalar, 1 AVX2, 2 AVX-512BW: the widest histogram-of-max variant this host can run"""
+    return int((lib or load()).dsho_simd_level())
+
+
+def set_simd(level, lib=None):
+    """0: scalar histogram (default, what the tests check the GPU against); >0: dist_rows uses the SIMD histogram"""
+    (lib or load()).dsho_set_simd(int(level))
+
+
+def hist_union_simd(a, b, level, vlo=None, vhi=None, lib=None):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    vlo = int(max(a.min(), b.min())) if vlo is None else vlo
+    vhi = int(max(a.max(), b.max())) if vhi is None else vhi
+    h = np.zeros(64, np.uint32)
+    (lib or load()).dsho_hist_union_simd(a, b, a.size, vlo, vhi, level, h)
+    return h
 
 
 def num_threads():

@@ -39,7 +39,7 @@ def main():
     seqs = [
         "ACGT", "ACGTACGTAC", "ACGTNACGTTTGACCAGTacgtagctagGGATCGATCGATTTAGC",
         "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", "GATTACA", "acgtnnacgtRYacgtacgtacgtacgtacgtacgtacgtacgtac",
-        "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTACGT",
+        "T" * 31 + "ACGT",  # the longest poly-T run that is not affected by the upstream quirk noted below
     ]
     enc = []
     for s in seqs:
@@ -49,6 +49,13 @@ def main():
                 assert a == oc.kmers(s, k, canon), (s, k, canon)
                 enc.append({"seq": s, "k": k, "canon": canon, "kmers": [hex(x) for x in a]})
     kat["encoder"] = enc
+    # NOT a golden vector: SURVEY.md A.1 recalls that upstream bonsai detects ambiguity as "accumulator == all-ones",
+    # so a run of >= 32 consecutive T at k = 31/32 may spuriously reset the window there.  Our restatement (and the
+    # product) emit those k-mers.  Unverifiable without the bonsai submodule, so the case is recorded, not asserted.
+    kat["unpinned_notes"] = [{"case": "poly-T run of >= 32 bases (k >= 31)",
+                              "ours": "every window of k valid bases emits its k-mer",
+                              "upstream_recollection": "may reset the window (all-ones accumulator read as ambiguous)",
+                              "status": "unpinned; no test asserts either behaviour"}]
     # A.8-3 a ~1000-k-mer genome -> full register dump (p=10), with an N run and lowercase
     g = synth.synthetic_genomes(1, 1030, seed=0xBEEF, decorate=False)[0]
     g[500:503] = ord("N")
