@@ -48,7 +48,7 @@ def _close(got, want, index_got=None, index_want=None):
     assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9) + 1e-12 * max(scale, 1.0)).all(), err.max()
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES", "24"))))  # e.g. DSH_FUZZ_CASES=400 for a long soak
+@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES", "100"))))  # e.g. DSH_FUZZ_CASES=400 for a long soak
 def test_random_case(ctx, oracle, case):
     rng = np.random.default_rng(1000 + case)
     p = int(rng.choice([4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16]))

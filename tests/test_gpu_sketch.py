@@ -110,7 +110,7 @@ def test_sketch_then_dist_c1_like(ctx, oracle):
     assert got.max() > 0.5 and got.min() < 0.05  # related and unrelated pairs both present
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES_SKETCH", "12"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES_SKETCH", "50"))))
 def test_random_sketch_case(ctx, oracle, case):
     """Seeded random sweep: k, p (LDS and HBM-register variants), canonical or not, ragged genome
     lengths (0 .. 70 000), random bytes from a dirty alphabet (N, lowercase, IUPAC, newline, NUL)."""
