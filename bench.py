@@ -4,16 +4,23 @@
 Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted
 on: 10 000 synthetic sketches, p=14 (16 KiB register arrays), all-pairs Jaccard with dashing's
 default estimator (Ertl MLE), packed float32 upper triangle.  One "step" = one full pass of the
-hot path over register arrays already resident in HBM: cardinalities + bit-plane transform +
-all-pairs AND/popcount + per-pair estimator -> distances in HBM (+ for N>1 the RCCL gather of
-the per-rank row spans to rank 0).  Strong scaling: the matrix is fixed, rows are sharded.
+hot path over register arrays already resident in HBM: per-sketch pass (cardinalities, exception
+lists) + bit-plane transform + all-pairs AND/popcount + per-pair estimator -> distances in HBM.
+N>1 (strong scaling, the matrix is fixed): rank r computes the rows [b_r, b_{r+1}) of the triangle
+(tile-aligned bounds balanced by tile count, dsh_balance_rows; the plane matrix is laid out for that range, so the rank's result is ONE
+contiguous span of the final packed matrix) and the only exchange is point-to-point: every rank
+sends its span straight into its place on rank 0 (RCCL over xGMI) -- no collective inside the
+compare, no un-permute.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_pair_counts), timed
-with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement
-of the reference algorithm and row schedule -- the reference itself is not buildable: its
-bonsai/sketch submodules are absent) timed on this host on a bounded sample of the same rows.
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_pair_counts), timed
+with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement of the
+reference algorithm and row schedule with an AVX-512BW / AVX2 histogram-of-max -- the reference
+itself is not buildable: its bonsai/sketch submodules are absent) timed on this host on a bounded
+sample of the same rows; `secondary` is the same pass on a configs[3]-shaped matrix (100 000 x p=10),
+where the per-pair estimator, not the popcounts, is the hot kernel.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +35,52 @@ N_SKETCH = int(os.environ.get("DSH_BENCH_N", "10000"))
 P = int(os.environ.get("DSH_BENCH_P", "14"))
 K = 31
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+CLOCK_HZ = 2.4e9       # max shader clock (same guide); cycle figures below are "wall time x 2.4 GHz"
+N_SIMD = 256 * 4
+
+
+def source_hash():
+    """sha256 over the device sources (same function as tools/pmc_collect.py): PMC files measured on other
+    sources are refused."""
+    h = hashlib.sha256()
+    for rel in ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
+                "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/dsh_api.hip"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def measure_kernels(ctx, regs_d, n, p, calls, reps=3):
+    """HIP-event times of the three phases on the library's own stream, summed over `reps` full passes"""
+    import dashing_amd
+
+    ctx.set_profiling(True)
+    acc = {"pair_ms": 0.0, "finalize_ms": 0.0, "prepare_ms": 0.0, "pair_launches": 0}
+    for _ in range(reps):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        for (ptr, rb, re) in calls:
+            ctx.dist_rows_device(ptr, rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            k = ctx.last_kernel_ms()
+            for key in acc:
+                acc[key] += k[key]
+    ctx.set_profiling(False)
+    return acc
+
+
+def pair_slots(ctx):
+    """wave-level (AND, BCNT) slots of the last pair-kernel schedule: per tile, planes x words x 128x128 pairs / 64 lanes"""
+    return ctx.info("avg_tile_planes_x100") / 100.0 * ctx.info("words_per_plane") * ctx.info("tiles") * 128 * 128 / 64.0
 
 
 def main():
@@ -50,10 +103,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DSH_BENCH_BACKEND=gloo is a dry-run of the N>1 code path on a box with ONE GPU: all ranks share
-    # cuda:0 and the gather is staged through host memory.  Never used for reported numbers.
+    # cuda:0 and the spans travel through host memory.  Never used for reported numbers.
     backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
-    # DSH_BENCH_FORCE_DIST=1 runs the sharded code path (process group, gather, un-permute) even with
-    # one rank -- a functional check of the RCCL plumbing on a 1-GPU box, not a reported configuration.
+    # DSH_BENCH_FORCE_DIST=1 runs the distributed code path (process group, exchange) even with one rank --
+    # a functional check of the RCCL plumbing on a 1-GPU box, not a reported configuration.
     multi = world > 1 or bool(os.environ.get("DSH_BENCH_FORCE_DIST"))
     if multi:
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -82,71 +135,45 @@ def main():
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
     ctx.attach_device(regs_d.data_ptr(), n, p)
-    # N>1: every rank holds all sketches and computes its cost-balanced share of the sorted-order triangle
-    # (contiguous spans); the only exchange is the RCCL gather of the spans to rank 0, which un-permutes
-    # them once into dashing's packed order.  DSH_BENCH_PIECES=K cuts a rank's share into K shards and
-    # gathers piece h asynchronously while piece h+1 is computed (multigpu.PipelinedShards).  On one GPU
-    # every extra piece costs ~0.25 ms (smaller launches); the estimated gain is ~0.5 ms at 2 ranks (one xGMI
-    # link carries 100 MB), ~0.15 ms at 4 and nothing at 8 -- too little to make it the default before it
-    # has run on real links, so the default is one piece and a plain gather.
-    pieces = 1
-    if multi:
-        pieces = max(1, int(os.environ.get("DSH_BENCH_PIECES", "1")))
-    nshards = world * pieces
-    span_off = ctx.shard_plan(nshards) if multi else [0, total_pairs]
-    span = span_off[(rank + 1) * pieces] - span_off[rank * pieces] if multi else total_pairs
-    final = torch.empty(total_pairs, dtype=torch.float32, device=dev) if multi and rank == 0 else None
-    out_d = stage = pipe = None
-    if not multi:
-        out_d = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev)
-    elif pieces == 1 and backend == "nccl":
-        mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
-        out_d = torch.empty(mx, dtype=torch.float32, device=dev)
-        stage = torch.empty(world * mx, dtype=torch.float32, device=dev) if rank == 0 else None
-    else:
-        # gloo dry-run: the pieces travel through host memory (ranks share one GPU)
-        pipe = multigpu.PipelinedShards(span_off, rank, world, pieces, dev if backend == "nccl" else torch.device("cpu"))
-        gpu_out = [torch.empty(pipe.mx[h], dtype=torch.float32, device=dev) for h in range(pieces)] if backend != "nccl" else None
 
-    def compute_piece(h):
-        buf = pipe.out(h) if backend == "nccl" else gpu_out[h]
-        ctx.dist_shard_device(buf.data_ptr(), pipe.shard(h), nshards, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        ctx.synchronize()
-        if backend != "nccl":
-            pipe.out(h).copy_(buf)
+    bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
+    sizes = multigpu.span_sizes(n, bounds)
+    offs = [0]
+    for s_ in sizes:
+        offs.append(offs[-1] + s_)
+    my_pairs = sizes[rank] if multi else total_pairs
+    host_stage = backend == "gloo" and multi
+    final = None
+    if rank == 0:
+        final = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev)
+    # rank 0 computes in place (its rows are the head of the matrix); the others into a span-sized buffer
+    local = final if rank == 0 else torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
+    final_h = torch.empty(max(total_pairs, 1), dtype=torch.float32) if host_stage and rank == 0 else None
+    phase = {"compute": 0.0, "exchange": 0.0}
 
-    def step():
+    def step(timed=False):
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
+        t0 = time.perf_counter()
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        if not multi:
-            ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-            ctx.synchronize()
-            return out_d[:span]
-        if pipe is None:
-            ctx.dist_shard_device(out_d.data_ptr(), rank, world, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-            ctx.synchronize()
-            # the gathered (padded) blocks are un-permuted where they arrived: no back-to-back copy
-            st = multigpu.gather_shard_spans(out_d, span_off, rank, world, stage, None, 0, staged=True)
-            # NCCL collectives only enqueue: wait on the host until this rank's part is done (rank 0 must
-            # see the data, the others must not overwrite out_d in the next step while it is being sent)
-            torch.cuda.current_stream().synchronize()
-            if rank == 0:
-                ctx.unpermute_staged_device(st.data_ptr(), mx, world, final.data_ptr())
-                return final
-            return None
-        for h in range(pieces):
-            compute_piece(h)
-            pipe.submit(h)  # async gather of piece h; the next piece is computed meanwhile
-        got = pipe.wait()
-        torch.cuda.current_stream().synchronize()  # as above: the gathers have completed on this rank
-        if rank == 0:
-            st, block_off = got
-            if backend != "nccl":
-                st = st.to(dev)
-                torch.cuda.current_stream().synchronize()
-            ctx.unpermute_blocks_device(st.data_ptr(), block_off, final.data_ptr())
-            return final
-        return None
+        ctx.dist_rows_device(local.data_ptr(), bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        if multi:
+            if host_stage:
+                lh = local[: max(my_pairs, 1)].cpu()
+                if rank == 0:
+                    final_h[: sizes[0]] = lh[: sizes[0]]
+                multigpu.collect_row_spans(lh, final_h, n, bounds, rank, world, 0)
+                if rank == 0:
+                    final.copy_(final_h)
+                    torch.cuda.synchronize()
+            else:
+                multigpu.collect_row_spans(local, final, n, bounds, rank, world, 0)  # host-synchronised inside
+        t2 = time.perf_counter()
+        if timed:
+            phase["compute"] += t1 - t0
+            phase["exchange"] += t2 - t1
+        return final
 
     def fence():
         if multi:
@@ -158,70 +185,82 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        full = step()
+        full = step(True)
     fence()
     dt = time.perf_counter() - t0
+    phases = [phase["compute"] / max(args.steps, 1) * 1e3, phase["exchange"] / max(args.steps, 1) * 1e3]
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([dt] + phases, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        phases = [float(t[1].item()), float(t[2].item())]
     ms_per_step = dt / args.steps * 1e3
     value = total_pairs * args.steps / dt
 
-    # ---- roofline of the dominant kernel: HIP events on the library stream, outside the timed region
-    ctx.set_profiling(True)
-    pair_ms, launches, fin_ms, prep_ms = 0.0, 0, 0.0, 0.0
+    # ---- kernel phases: HIP events on the library stream, outside the timed region
     reps = 3
-    for _ in range(reps):
-        ctx.attach_device(regs_d.data_ptr(), n, p)
-        calls = [None] if not multi else ([(out_d, rank, world)] if pipe is None else
-                                         [((pipe.out(h) if backend == "nccl" else gpu_out[h]), pipe.shard(h), nshards) for h in range(pieces)])
-        for call in calls:
-            if call is None:
-                ctx.dist_rows_device(out_d.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-            else:
-                ctx.dist_shard_device(call[0].data_ptr(), call[1], call[2], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-            ctx.synchronize()
-            k = ctx.last_kernel_ms()
-            pair_ms += k["pair_ms"]
-            fin_ms += k["finalize_ms"]
-            prep_ms += k["prepare_ms"]
-            launches += k["pair_launches"]
-    ctx.set_profiling(False)
-    traffic = None  # HBM bytes per launch from the committed PMC passes of the same workload
+    km = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), bounds[rank], bounds[rank + 1])], reps)
+    pair_ms, fin_ms, prep_ms, launches = km["pair_ms"], km["finalize_ms"], km["prepare_ms"], km["pair_launches"]
+    kphase = [pair_ms / reps, fin_ms / reps, prep_ms / reps]
+    if multi:
+        t = torch.tensor(kphase, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kphase = [float(x) for x in t.tolist()]
+
+    src = source_hash()
+    traffic, traffic_note = None, "no PMC file for this workload (tools/pmc_collect.py writes profiles/pmc_pair_kernel.json)"
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pair_kernel.json")))
-        if pm["workload"]["n_sketches"] == n and pm["workload"]["p"] == p and world == 1:
+        if pm.get("source_sha256") != src:
+            traffic_note = "profiles/pmc_pair_kernel.json was measured on other kernel sources (sha256 differs): refused as stale"
+        elif pm["workload"]["n_sketches"] == n and pm["workload"]["p"] == p and world == 1:
             traffic = pm["hbm_bytes_per_launch"]
+            traffic_note = "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) collected by tools/pmc_collect.py in separate --pmc passes on these kernel sources (sha256 checked); not measured in this run"
     except (OSError, KeyError, ValueError):
         pass
     b_pair = 2 * m + 4                                   # algorithmic bytes per pair
-    my_pairs = span
     achieved = my_pairs * reps * b_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    avg_launch_ms = pair_ms / max(launches, 1)
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "traffic_note": "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/pmc_pair_kernel.json; collected in separate --pmc passes, not in this run",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
         "kernel": "k_pair_counts", "launches_per_step": launches // reps,
-        "avg_launch_ms": round(pair_ms / max(launches, 1), 4),
+        "avg_launch_ms": round(avg_launch_ms, 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
         "dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
         "exception_list_cap": ctx.info("emax"), "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
-        "sorted_columns": bool(ctx.info("sorted")),
-        "finalize_ms_per_step": round(fin_ms / reps, 4), "prepare_ms_per_step": round(prep_ms / reps, 4),
-        "note": "streaming-model bytes (2*2^p+4 per pair); >1.0 is possible because LDS tiles reuse each staged sketch",
-        # SURVEY.md 8d also asks for the physical HBM rate and the compulsory floor (inputs once + outputs once)
-        "physical_hbm_gbs": round(traffic / (pair_ms / max(launches, 1) * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
+        "key_ordered_columns": bool(ctx.info("sorted")),
+        "note": "SURVEY 8d streaming-model bytes (2*2^p+4 per pair, the reference's own traffic): frac > 1 only says the LDS-tiled kernel is not HBM-bound (each staged sketch is reused 128x); the binding resource is integer VALU issue, see valu_int; physical HBM is physical_hbm_gbs",
+        "physical_hbm_gbs": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
+        "physical_hbm_frac_of_peak": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pair_ms > 0 else None,
         "compulsory_bytes_per_step": n * m + 4 * total_pairs,
     }
+    # What actually bounds k_pair_counts: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
+    # Cycles are wall time x 2.4 GHz on 1024 SIMDs, the same convention as profiles/ubench/pair_sched.txt:
+    #   nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                     = 6.0
+    #   each op on its own   2.18 + 4.59  (and_only / bcnt_only rows of pair_sched.txt) = 6.77
+    #   the mix, registers only (no LDS, no DMA), best order (64 ANDs then 64 BCNTs)   = 8.18
+    slots = pair_slots(ctx)
+    cyc = pair_ms / reps * 1e-3 * CLOCK_HZ * N_SIMD / slots if pair_ms > 0 and slots > 0 else 0.0
+    roofline["valu_int"] = {
+        "cycles_per_and_bcnt_pair": round(cyc, 3),
+        "frac_of_measured_mix_ceiling": round(8.18 / cyc, 4) if cyc else 0.0,
+        "frac_of_isolated_rates": round(6.77 / cyc, 4) if cyc else 0.0,
+        "frac_of_nominal_issue_model": round(6.0 / cyc, 4) if cyc else 0.0,
+        "ceilings_cycles": {"measured_mix": 8.18, "isolated_sum": 6.77, "nominal_2_plus_4": 6.0},
+        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. The mix ceiling is an issue rule of the SIMD (profiles/ubench/pair_sched.txt: no order or VGPR-bank placement beats 7.93 shader cycles = 8.18 at wall x 2.4 GHz)",
+    }
+    roofline["finalize"] = {
+        "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",
+        "pairs_per_s": round(my_pairs / (kphase[1] * 1e-3), 1) if kphase[1] > 0 else 0.0,
+        "cycles_per_wave64_of_pairs": round(kphase[1] * 1e-3 * CLOCK_HZ * N_SIMD / (my_pairs / 64.0), 1) if kphase[1] > 0 and my_pairs else 0.0,
+        "note": "Ertl-MLE per pair: ~51 secant steps x 16 dependent fp64 ops (4 cycles each per wave64) ~ 3 300 cycles per 64 pairs is the floor of the estimator it must reproduce bit for bit (DESIGN.md 3.2)",
+    }
+    roofline["step"] = {
+        "ms": {"prepare": round(kphase[2], 4), "pair_counts": round(kphase[0], 4), "finalize": round(kphase[1], 4)},
+        "algorithmic_gbs_whole_step": round(total_pairs * b_pair / (ms_per_step * 1e-3) / 1e9, 1),
+    }
 
-    # what actually bounds the kernel: integer VALU issue (v_and_b32 + v_bcnt_u32_b32 per 32 pair-bits,
-    # 4 cycles per wave64 instruction => 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 3.93e13 lane-ops/s)
-    lane_ops = 2.0 * ctx.info("avg_tile_planes_x100") / 100.0 * ctx.info("words_per_plane") * ctx.info("tiles") * 128 * 128
-    roofline["valu_int"] = {"achieved_lane_ops_per_s": lane_ops * reps / (pair_ms * 1e-3) if pair_ms > 0 else 0.0,
-                            "peak_lane_ops_per_s": 3.93e13,
-                            "frac": round(lane_ops * reps / (pair_ms * 1e-3) / 3.93e13, 4) if pair_ms > 0 else 0.0,
-                            "note": "the binding resource of k_pair_counts (DESIGN.md 3.2); PMC SQ_INSTS_VALU in profiles/r1g agrees"}
     cpu = None
     parity = None
     if rank == 0 and multi:
@@ -230,9 +269,14 @@ def main():
         ctx.attach_device(regs_d.data_ptr(), n, p)
         ctx.dist_rows_device(ref.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
-        parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full)), "pairs_checked": total_pairs}
+        parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full[:total_pairs])), "pairs_checked": total_pairs}
+        del ref
     if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
+
+    secondary = None
+    if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
+        secondary = secondary_p10(ctx, torch, dev, synth, dashing_amd)
 
     line = None
     if rank == 0:
@@ -244,11 +288,22 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
                        "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                       "sharding": ("cost-balanced row shards of the sorted-order triangle (%d per rank, gathered piece by piece while the next is computed), RCCL gather to rank 0 + un-permute" % pieces) if multi else "single GPU"},
+                       "sharding": "tile-count-balanced row ranges of the final triangle, one per rank (plane matrix laid out per range); point-to-point send of each span into place on rank 0, no un-permute" if multi else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
+            "kernel_source_sha256": src,
         }
+        if multi:
+            line["multi_gpu"] = {
+                "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
+                "row_bounds": bounds, "pairs_per_rank": sizes,
+                "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange": round(phases[1], 4),
+                                            "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},
+                "exchange_bytes_into_rank0": 4 * (total_pairs - sizes[0]),
+            }
+        if secondary:
+            line["secondary"] = secondary
     ctx.close()
     # The JSON line must be the LAST thing on stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes)
     # prints its banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise
@@ -271,6 +326,34 @@ def main():
         print(json.dumps(line), flush=True)
 
 
+def secondary_p10(ctx, torch, dev, synth, dashing_amd, n=100_000, p=10):
+    """configs[3]-shaped matrix on ONE GPU (the 8-GPU run is the driver's): at 1 KiB per sketch the popcounts are
+    cheap and the per-pair estimator (k_finalize) is the hot kernel, which the p=14 headline hides."""
+    regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
+    regs_d = torch.from_numpy(regs).to(dev)
+    total = n * (n - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        t0 = time.perf_counter()
+        ctx.dist_rows_device(out.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        times.append(time.perf_counter() - t0)
+    km = measure_kernels(ctx, regs_d, n, p, [(out.data_ptr(), 0, n)], 1)
+    t = min(times[1:])
+    res = {"workload": "BASELINE configs[3] shape on one GPU: %d synthetic sketches, p=%d, full triangle (%.1f GB of float32 left in HBM)" % (n, p, total * 4 / 1e9),
+           "value": total / t, "unit": "pairs/s", "ms_per_step": t * 1e3, "steps": 2,
+           "kernel_ms": {"k_pair_counts": round(km["pair_ms"], 3), "k_finalize": round(km["finalize_ms"], 3), "prepare": round(km["prepare_ms"], 3),
+                         "pair_launches": km["pair_launches"]},
+           "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
+           "finalize_cycles_per_wave64_of_pairs": round(km["finalize_ms"] * 1e-3 * CLOCK_HZ * N_SIMD / (total / 64.0), 1)}
+    del out, regs_d
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(regs_h, gpu_full, n, p, seconds):
     """Time the CPU oracle (reference algorithm + row schedule) on a bounded sample of rows.
     The oracle is only the checker/baseline here -- never the thing measured as `value`."""
@@ -285,24 +368,35 @@ def cpu_baseline(regs_h, gpu_full, n, p, seconds):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "OUT=" + native],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         kind_lib = oracle_c.load(native, threads=cores)
-        isa = "-march=native"
+        build = "-march=native"
     except Exception:
         kind_lib = oracle_c.load(threads=cores)
-        isa = "-march=x86-64-v3 (prebuilt)"
+        build = "-march=x86-64-v3 (prebuilt)"
+    level = oracle_c.simd_level(kind_lib)  # the histogram-of-max variant is chosen by cpuid, not by the build flags
+    isa = {0: "scalar", 1: "avx2", 2: "avx512bw"}[level]
+
+    def timed_rows(rows, simd):
+        oracle_c.set_simd(simd, kind_lib)
+        t0 = time.perf_counter()
+        r = oracle_c.dist_rows(regs_h, 0, rows, lib=kind_lib)
+        return r, time.perf_counter() - t0
+
     # calibrate on a few rows, then size the sample for ~`seconds`
-    t0 = time.perf_counter()
-    r0 = oracle_c.dist_rows(regs_h, 0, 8, lib=kind_lib)
-    t_cal = time.perf_counter() - t0
+    r0, t_cal = timed_rows(8, level)
     rate = r0.size / max(t_cal, 1e-6)
     rows = int(min(n - 1, max(16, seconds * rate / n)))
-    t0 = time.perf_counter()
-    ref = oracle_c.dist_rows(regs_h, 0, rows, lib=kind_lib)
-    t = time.perf_counter() - t0
+    ref, t = timed_rows(rows, level)
+    # the scalar histogram on a quarter of the sample, for the record (and as a cross-check of the SIMD one)
+    rows_s = max(8, rows // 4)
+    ref_s, t_s = timed_rows(rows_s, 0)
+    oracle_c.set_simd(0, kind_lib)
+    assert (ref[: ref_s.size] == ref_s).all(), "SIMD and scalar CPU histograms disagree"
     got = gpu_full[: ref.size].cpu().numpy()
     rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
-    cpu = {"value": ref.size / t, "unit": "pairs/s", "cores": cores, "kind": "port",
-           "sample": "rows [0,%d) of the same %d-sketch p=%d matrix = %d pairs in %.1f s; oracle/dsh_oracle.c (%s, OpenMP dynamic over j per row as src/sketch_and_cmp.h:699-710)" % (rows, n, p, ref.size, t, isa),
-           "note": "CPU restatement; reference not buildable (bonsai/sketch submodules absent)"}
+    cpu = {"value": ref.size / t, "unit": "pairs/s", "cores": cores, "kind": "port", "isa": isa, "cpu_model": cpu_model(),
+           "sample": "rows [0,%d) of the same %d-sketch p=%d matrix = %d pairs in %.1f s; oracle/dsh_oracle.c (%s; %s histogram-of-max: 64-byte max_epu8 + per-value compare-and-count; OpenMP dynamic over j per row as src/sketch_and_cmp.h:699-710)" % (rows, n, p, ref.size, t, build, isa),
+           "scalar_histogram_value": ref_s.size / t_s,
+           "note": "CPU restatement of the reference's algorithm and schedule in its SIMD form (Makefile:159-190); the reference itself is not buildable (bonsai/sketch submodules absent)"}
     parity = {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6,
               "exact_float32_matches": int((got == ref).sum())}
     try:

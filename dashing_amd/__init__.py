@@ -22,6 +22,7 @@ from .api import (  # noqa: F401
     lib_path,
     load_library,
     partition_rows,
+    balance_rows,
     tri_index,
     tri_span,
 )

@@ -23,7 +23,8 @@ SYMBOLS = [
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches", "dsh_copy_sketches_device",
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
-    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_alloc_host", "dsh_free_host",
+    "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
+    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -69,6 +70,10 @@ def load_library():
     lib.dsh_cardinalities.argtypes = [vp, i32, vp]
     lib.dsh_dist_rows.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_dist_rows_device.argtypes = [vp, i32, i32, i32, u64, u64, vp]
+    lib.dsh_dist_rows_async.argtypes = [vp, i32, i32, i32, u64, u64, vp]
+    lib.dsh_dist_rows_device_async.argtypes = [vp, i32, i32, i32, u64, u64, vp]
+    lib.dsh_wait.argtypes = [vp]
+    lib.dsh_wait_event.argtypes = [vp, vp]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
     lib.dsh_knn.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, C.c_uint32, vp, vp]
     lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
@@ -81,6 +86,7 @@ def load_library():
     lib.dsh_tri_index.argtypes = [u64, u64, u64]
     lib.dsh_tri_index.restype = u64
     lib.dsh_partition_rows.argtypes = [u64, C.c_uint32, C.c_uint32, vp]
+    lib.dsh_balance_rows.argtypes = [u64, C.c_uint32, vp]
     lib.dsh_alloc_host.argtypes = [C.c_size_t]
     lib.dsh_alloc_host.restype = vp
     lib.dsh_free_host.argtypes = [vp]
@@ -117,6 +123,15 @@ def partition_rows(n, nparts, align=128):
     rc = load_library().dsh_partition_rows(n, nparts, align, b.ctypes.data)
     if rc:
         raise DshError(rc, "dsh_partition_rows")
+    return [int(x) for x in b]
+
+
+def balance_rows(n, nparts):
+    """Tile-aligned row ranges, one per rank, minimising the largest tile count (dsh_balance_rows)."""
+    b = np.zeros(nparts + 1, np.uint64)
+    rc = load_library().dsh_balance_rows(n, nparts, b.ctypes.data)
+    if rc:
+        raise DshError(rc, "dsh_balance_rows")
     return [int(x) for x in b]
 
 
@@ -236,6 +251,23 @@ class Context:
     def dist_rows_device(self, out_ptr, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
         row_end = self.n if row_end is None else row_end
         self._ck(self._lib.dsh_dist_rows_device(self._h, estim, result_type, k, row_begin, row_end, C.c_void_p(out_ptr)))
+
+    def dist_rows_async(self, out_pinned, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        """enqueue rows -> `out_pinned` (numpy view of PinnedArray memory); valid after wait()"""
+        row_end = self.n if row_end is None else row_end
+        assert out_pinned.size >= tri_span(self.n, row_begin, row_end)
+        self._ck(self._lib.dsh_dist_rows_async(self._h, estim, result_type, k, row_begin, row_end, out_pinned.ctypes.data))
+
+    def dist_rows_device_async(self, out_ptr, row_begin=0, row_end=None, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        row_end = self.n if row_end is None else row_end
+        self._ck(self._lib.dsh_dist_rows_device_async(self._h, estim, result_type, k, row_begin, row_end, C.c_void_p(out_ptr)))
+
+    def wait(self):
+        self._ck(self._lib.dsh_wait(self._h))
+
+    def wait_event(self, hip_event):
+        """order the ctx stream after a caller event (e.g. torch.cuda.Event().cuda_event, recorded on torch's stream)"""
+        self._ck(self._lib.dsh_wait_event(self._h, C.c_void_p(hip_event)))
 
     def dist_rect(self, q_begin, q_end, r_begin, r_end, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
         out = np.zeros((max(q_end - q_begin, 0), max(r_end - r_begin, 0)), np.float32)

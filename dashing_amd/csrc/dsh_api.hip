@@ -36,6 +36,30 @@ struct DevBuf {
     }
 };
 
+// page-locked host staging: a hipMemcpyAsync from it is a true asynchronous DMA, so the call that filled it
+// may return before the copy has run (the event says when it may be rewritten)
+struct PinBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2;
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
 struct dsh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -50,13 +74,25 @@ struct dsh_ctx {
     bool planes_valid = false;
     int card_estim = -1;
     DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
-    int planes_sorted = 0;              // column order of the cached plane matrix: 0 identity, 1 sorted
+    // column layout of the cached plane matrix.  0: identity over all n sketches.  1: the sub-collection
+    // {lay_rb .. n-1} -- the rows [lay_rb, lay_re) first, then the rows [lay_re, n), each part in key order
+    // (lay_rb = 0, lay_re = n: the whole collection sorted, what full-triangle calls and the shard path use)
+    int planes_sorted = 0;
+    uint64_t lay_rb = 0, lay_re = 0;
+    uint64_t ncols = 0;                 // real columns (sketches) of the plane matrix; Npad = ncols padded to 128
+    std::vector<uint32_t> hk32;         // host copy of the per-sketch keys (valid while the per-sketch pass is)
+    bool hk32_valid = false;
+    hipEvent_t ev_perm = nullptr;       // upload of pin_perm done (it is rewritten by the next layout)
+    bool perm_in_flight = false;
     std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
     uint32_t *pin_perm = nullptr;       // page-locked copy of hperm: its upload is then truly asynchronous
     size_t pin_perm_cap = 0;
     std::vector<uint8_t> blk_T, blk_lo; // per 128-column block: max threshold, min register value
     std::vector<uint4> hitems;
+    PinBuf pin_lists;                   // tiles then items of the call in flight
+    hipEvent_t ev_lists = nullptr;      // recorded after their upload; waited on before they are rewritten
+    bool lists_in_flight = false;
     uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
     int vlo = 0, vhi = 0;
     int emax = 0, cum_bytes = 4;
@@ -66,7 +102,8 @@ struct dsh_ctx {
     int emax_opt = -1;  // -1: min(96 | 192 for p >= 16, 2^p / 128) -- sweeps per precision in profiles/r1k/README.md
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
-    int sort_mode = -1;  // -1 auto (sorted columns for full-triangle calls), 0 never, 1 always when legal
+    int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
+    int range_sort_min_rows = 1024;  // smaller row ranges keep the cached identity layout (a rebuild costs more than it saves)
     int assembler_permille = 21;  // the un-permute (0.42 ms) on rank 0 of a 19.9 ms pass (profiles/r1k)
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
@@ -119,33 +156,53 @@ hipEvent_t next_event(dsh_ctx *c)
     return c->ev_pool[c->ev_used++];
 }
 
+bool whole_sorted(const dsh_ctx *c)
+{
+    return c->planes_valid && c->planes_sorted && c->lay_rb == 0 && c->lay_re == c->n;
+}
+
 void invalidate(dsh_ctx *c)
 {
     c->planes_valid = false;
     c->card_estim = -1;
+    c->hk32_valid = false;
 }
 
 // cardinalities + thresholds/exception lists + planes for the current sketch matrix.
 // want_sorted: lay the plane-matrix columns out in (threshold, min value) order so that the
 // 128-column blocks are homogeneous and every tile can use its own narrow plane range.
-int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
+int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint64_t want_rb = 0,
+            uint64_t want_re = ~0ull)
 {
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
-    if (want_sorted < 0) want_sorted = c->planes_sorted;  // "whatever is cached"
-    if (c->card_estim == estim && (card_only || (c->planes_valid && c->planes_sorted == want_sorted))) return DSH_OK;
+    if (want_sorted < 0) {  // "whatever is cached"
+        want_sorted = c->planes_sorted;
+        want_rb = c->lay_rb;
+        want_re = c->lay_re;
+    }
+    if (want_re > c->n) want_re = c->n;
+    if (!want_sorted) want_rb = 0, want_re = c->n;
+    if (want_rb > want_re) want_rb = want_re;
+    const uint64_t n = c->n;
+    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
+                                          : (int)std::min<uint64_t>(c->p >= 16 ? 192 : 96, (1ull << c->p) >> 7);  // sweeps: profiles/r1k/README.md
+    if (emax_new != c->emax) {  // thresholds and lists (hence planes) depend on it
+        c->planes_valid = false;
+        c->card_estim = -1;
+    }
+    c->emax = emax_new;
+    const bool same_layout = c->planes_valid && c->planes_sorted == want_sorted &&
+                             (!want_sorted || (c->lay_rb == want_rb && c->lay_re == want_re));
+    if (c->card_estim == estim && (card_only || same_layout)) return DSH_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
         e1 = next_event(c);
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
-    const uint64_t n = c->n;
-    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
-                                          : (int)std::min<uint64_t>(c->p >= 16 ? 192 : 96, (1ull << c->p) >> 7);  // sweeps: profiles/r1k/README.md
-    if (emax_new != c->emax) c->planes_valid = false;  // thresholds (hence planes) depend on it
-    c->emax = emax_new;
-    if (!c->planes_valid || c->card_estim != estim) {
+    // the per-sketch pass depends on (registers, estimator, emax) only: a new column layout reuses it
+    if (c->card_estim != estim) {
         HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
         HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t) + 256));  // + slack: k_finalize prefetches one step past a list
         HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kExcCap));
@@ -157,6 +214,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
                                        (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
                                        (uint8_t *)c->tailhist.ptr));
         c->card_estim = estim;
+        c->hk32_valid = false;
     }
     if (card_only) {  // a cardinality query never builds planes (and leaves stale ones marked so)
         if (e0 && e1) {
@@ -168,33 +226,48 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
         }
         return DSH_OK;
     }
-    if (!c->planes_valid || c->planes_sorted != want_sorted) {
+    if (!same_layout) {
         if (c->p > kMaxPLds)
             return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPLds, c->p);
         int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
-        std::vector<uint32_t> k32(n);
+        // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no
+        // device round trip and so does not wait for the work still queued on the stream
+        if (!c->hk32_valid) {
+            c->hk32.resize(n);
+            if (n) HIPCHK(c, hipMemcpyAsync(c->hk32.data(), c->keys.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->hk32_valid = true;
+        }
+        const std::vector<uint32_t> &k32 = c->hk32;
         c->hkeys.resize(n);
-        if (n) HIPCHK(c, hipMemcpyAsync(k32.data(), c->keys.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // the plane matrix holds the sketches col0 .. n-1 (a row range [rb,re) of the triangle never looks at
+        // sketches before rb); value range and thresholds are taken over those only
+        const uint64_t col0 = want_sorted ? want_rb : 0;
+        const uint64_t ncols = n - col0;
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t key = k32[i];
-            vr[0] = std::min<int>(vr[0], (int)(key & 0xFF));
-            vr[1] = std::max<int>(vr[1], (int)(key >> 16));
-            vr[2] = std::max<int>(vr[2], (int)((key >> 8) & 0xFF));
+            if (i >= col0) {
+                vr[0] = std::min<int>(vr[0], (int)(key & 0xFF));
+                vr[1] = std::max<int>(vr[1], (int)(key >> 16));
+                vr[2] = std::max<int>(vr[2], (int)((key >> 8) & 0xFF));
+            }
             c->hkeys[i] = (uint16_t)(key & 0xFFFF);
         }
-        if (n == 0) vr[0] = vr[1] = vr[2] = 0;
+        if (ncols == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
         c->vhi = vr[1];
         c->P = (uint32_t)(vr[2] - vr[0]);  // dense planes cover v in (lo, Tmax]
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
-        c->Npad = (uint32_t)((n + kTile - 1) / kTile * kTile);
+        c->ncols = ncols;
+        c->Npad = (uint32_t)((ncols + kTile - 1) / kTile * kTile);
         // column order: identity, or a counting sort by (threshold, min value, max value): the first
         // two make the 128-column blocks need few planes, the third keeps the 64 pairs of a finalize
-        // wave alike in their largest register, i.e. in the trip count of the estimator's loops
-        c->hperm.resize(n);
+        // wave alike in their largest register, i.e. in the trip count of the estimator's loops.
+        // With a row range the wanted rows [rb,re) come first (their tile rows are the only ones computed),
+        // then the later rows; each part is key-ordered on its own.
+        c->hperm.resize(ncols);
         if (want_sorted) {
             auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each
                 const uint32_t key = k32[i];
@@ -202,33 +275,49 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
             };
             // stable LSD radix sort, three 6-bit digits (a single 2^18-bucket counting sort spends
             // ~0.1 ms clearing and scanning its counters -- a quarter of prepare())
-            std::vector<uint32_t> a(n), b(n), keys(n);
-            for (uint64_t i = 0; i < n; ++i) {
-                a[i] = (uint32_t)i;
-                keys[i] = skey(i);
+            std::vector<uint32_t> a, b, keys(n);
+            for (uint64_t i = col0; i < n; ++i) keys[i] = skey(i);
+            auto sort_part = [&](uint64_t lo, uint64_t hi, uint32_t *dst) {
+                const uint64_t cnt_ = hi - lo;
+                a.resize(cnt_);
+                b.resize(cnt_);
+                for (uint64_t i = 0; i < cnt_; ++i) a[i] = (uint32_t)(lo + i);
+                for (int shift = 0; shift < 18; shift += 6) {
+                    uint32_t cnt[65] = {0};
+                    for (uint64_t i = 0; i < cnt_; ++i) cnt[((keys[a[i]] >> shift) & 63u) + 1u]++;
+                    for (int k = 1; k < 65; ++k) cnt[k] += cnt[k - 1];
+                    for (uint64_t i = 0; i < cnt_; ++i) b[cnt[(keys[a[i]] >> shift) & 63u]++] = a[i];
+                    a.swap(b);
+                }
+                std::copy(a.begin(), a.end(), dst);
+            };
+            sort_part(want_rb, want_re, c->hperm.data());
+            sort_part(want_re, n, c->hperm.data() + (want_re - want_rb));
+            // perm, then (whole collection only) its inverse for the un-permute of the shard path
+            const bool whole = want_rb == 0 && want_re == n;
+            const uint64_t nperm = whole ? 2 * n : ncols;
+            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(nperm, 1) * sizeof(uint32_t)));
+            if (whole) {
+                c->hperm.resize(2 * n);
+                for (uint64_t s = 0; s < n; ++s) c->hperm[n + c->hperm[s]] = (uint32_t)s;
             }
-            for (int shift = 0; shift < 18; shift += 6) {
-                uint32_t cnt[65] = {0};
-                for (uint64_t i = 0; i < n; ++i) cnt[((keys[a[i]] >> shift) & 63u) + 1u]++;
-                for (int k = 1; k < 65; ++k) cnt[k] += cnt[k - 1];
-                for (uint64_t i = 0; i < n; ++i) b[cnt[(keys[a[i]] >> shift) & 63u]++] = a[i];
-                a.swap(b);
-            }
-            std::copy(a.begin(), a.end(), c->hperm.begin());
-            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(n, 1) * 2 * sizeof(uint32_t)));  // perm, then its inverse
-            c->hperm.resize(2 * n);
-            for (uint64_t s = 0; s < n; ++s) c->hperm[n + c->hperm[s]] = (uint32_t)s;
-            if (n) {
-                if (2 * n > c->pin_perm_cap) {
+            if (nperm) {
+                if (c->perm_in_flight) {  // the previous layout's upload from pin_perm
+                    HIPCHK(c, hipEventSynchronize(c->ev_perm));
+                    c->perm_in_flight = false;
+                }
+                if (nperm > c->pin_perm_cap) {
                     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
                     c->pin_perm = nullptr;
                     c->pin_perm_cap = 0;
-                    HIPCHK(c, hipHostMalloc((void **)&c->pin_perm, 2 * n * sizeof(uint32_t), hipHostMallocDefault));
-                    c->pin_perm_cap = 2 * n;
+                    HIPCHK(c, hipHostMalloc((void **)&c->pin_perm, nperm * sizeof(uint32_t), hipHostMallocDefault));
+                    c->pin_perm_cap = nperm;
                 }
-                // (the previous upload from this buffer finished before the key download above was synchronised)
-                std::memcpy(c->pin_perm, c->hperm.data(), 2 * n * sizeof(uint32_t));
-                HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->pin_perm, 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                std::memcpy(c->pin_perm, c->hperm.data(), nperm * sizeof(uint32_t));
+                HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->pin_perm, nperm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                if (!c->ev_perm) HIPCHK(c, hipEventCreateWithFlags(&c->ev_perm, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->ev_perm, c->stream));
+                c->perm_in_flight = true;
             }
         } else {
             for (uint64_t i = 0; i < n; ++i) c->hperm[i] = (uint32_t)i;
@@ -236,7 +325,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
         const uint32_t NT = c->Npad / kTile;
         c->blk_T.assign(NT, 0);
         c->blk_lo.assign(NT, 255);
-        for (uint64_t s = 0; s < n; ++s) {
+        for (uint64_t s = 0; s < ncols; ++s) {
             const uint16_t key = c->hkeys[c->hperm[s]];
             const uint32_t b = (uint32_t)(s / kTile);
             c->blk_T[b] = std::max<uint8_t>(c->blk_T[b], (uint8_t)(key >> 8));
@@ -251,11 +340,13 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false)
                 HIPCHK(c, hipMemsetAsync((uint32_t *)c->planes.ptr + K * c->Npad, 0,
                                          (size_t)(c->Kpad - K) * c->Npad * sizeof(uint32_t),
                                          c->stream));
-            HIPCHK(c, launch_transform(c->stream, c->regs, n, c->p, c->vlo, c->P, c->W, c->Npad,
+            HIPCHK(c, launch_transform(c->stream, c->regs, ncols, c->p, c->vlo, c->P, c->W, c->Npad,
                                        (uint32_t *)c->planes.ptr,
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
         }
         c->planes_sorted = want_sorted;
+        c->lay_rb = want_rb;
+        c->lay_re = want_re;
         c->planes_valid = true;
     }
     if (e0 && e1) {
@@ -300,10 +391,22 @@ struct PairJob {
 
 int run_pairs(dsh_ctx *c, const PairJob &job)
 {
-    // sorted columns pay off only when (nearly) all tiles are wanted: full-triangle calls
-    const bool full_tri = !job.rect && job.row_begin == 0 && job.row_end >= c->n;
-    const int want_sorted = job.sorted_rows ? 1 : (c->sort_mode == 0 ? 0 : (full_tri ? 1 : 0));
-    int rc = prepare(c, job.estim, want_sorted);
+    // Triangle rows [rb,re): the plane matrix is laid out for exactly that range (wanted rows first, both
+    // parts key-ordered), so every tile is homogeneous and the result lands at its final packed position --
+    // whatever the range (a full triangle, one rank's rows, a row block of the CLI).  Tiny ranges and
+    // rectangles keep the identity layout, which stays cached across calls.
+    const uint64_t jre = std::min<uint64_t>(job.row_end, c->n);
+    const bool full_tri = !job.rect && job.row_begin == 0 && jre >= c->n;
+    int want_sorted = 0;
+    uint64_t lrb = 0, lre = c->n;
+    if (job.sorted_rows) want_sorted = 1;
+    else if (!job.rect && c->sort_mode != 0 && jre > job.row_begin &&
+             (full_tri || jre - job.row_begin >= (uint64_t)c->range_sort_min_rows)) {
+        want_sorted = 1;
+        lrb = job.row_begin;
+        lre = jre;
+    }
+    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre);
     if (rc) return rc;
     if (job.result_type < 0 || job.result_type > 8)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
@@ -333,6 +436,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         if (!c->planes_sorted || job.sorted_rows) {  // rows index plane columns: only their tile rows
             r0 = (uint32_t)(job.row_begin / kTile);
             r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
+        } else {  // the wanted rows are the first lay_re - lay_rb columns
+            r1 = std::min<uint32_t>(NT, (uint32_t)((c->lay_re - c->lay_rb + kTile - 1) / kTile));
         }
         for (uint32_t ti = r0; ti < r1; ++ti)
             for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(tile_of(ti, tj));
@@ -388,11 +493,23 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             }
         band_items.emplace_back(i0, I.size());
     }
+    // tile and item lists travel through page-locked staging, so nothing below needs the host to wait
+    if (c->lists_in_flight) {  // the previous call's upload (long done unless calls are issued back to back)
+        HIPCHK(c, hipEventSynchronize(c->ev_lists));
+        c->lists_in_flight = false;
+    }
+    HIPCHK(c, c->pin_lists.ensure((T.size() + std::max<size_t>(I.size(), 1)) * sizeof(uint4)));
+    uint4 *pinT = (uint4 *)c->pin_lists.ptr, *pinI = pinT + T.size();
+    std::memcpy(pinT, T.data(), T.size() * sizeof(uint4));
+    if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
     HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
-    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, T.data(), T.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, pinT, T.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
     if (!I.empty())
-        HIPCHK(c, hipMemcpyAsync(c->items.ptr, I.data(), I.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->items.ptr, pinI, I.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    if (!c->ev_lists) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));
+    c->lists_in_flight = true;
     size_t max_band = 0;
     for (auto &bd : bands) max_band = std::max(max_band, bd.second - bd.first);
     HIPCHK(c, c->cum.ensure(std::max<uint64_t>(per_tile * max_band, 256)));
@@ -436,6 +553,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.ksinv = (double)ksinv_f;
         f.card = (const double *)c->card.ptr;
         f.n = c->n;
+        f.ncols = c->ncols;
         f.rect = job.rect;
         f.sorted_out = job.sorted_rows;
         f.square = job.square;
@@ -452,9 +570,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             evf.emplace_back(b, d);
         }
     }
-    // T and I are pageable sources of async copies: make sure they were consumed before reuse
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // everything is enqueued; the blocking entry points synchronise, the *_async ones return here
     if (c->profiling) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         for (auto &e : evp) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e.first, e.second);
@@ -528,6 +646,9 @@ void dsh_destroy(dsh_ctx *c)
     c->exc_n.release();
     c->excv.release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
+    c->pin_lists.release();
+    if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
+    if (c->ev_perm) (void)hipEventDestroy(c->ev_perm);
     c->keys.release();
     c->tailhist.release();
     c->perm.release();
@@ -785,7 +906,37 @@ int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bo
     return DSH_OK;
 }
 
-int dsh_dist_rows_device(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, void *d_out)
+int dsh_balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds)
+{
+    if (!bounds || nparts == 0) return DSH_EINVAL;
+    // Contiguous row ranges on 128-row (tile) boundaries that minimise the largest number of 128 x 128 tiles
+    // any part computes: a part with the tile rows [a,b) of NT computes sum_{t=a}^{b-1} (NT - t) tiles (its
+    // triangle + the rectangle to its right).  Unaligned bounds would leave part of a tile row empty on
+    // every rank (at n = 10 000 / 8 ranks the first rank has ~5 tile rows: up to 16 % waste).
+    const uint64_t NT = (n + kTile - 1) / kTile;
+    auto cost = [NT](uint64_t t) { return (double)(NT - t); };
+    auto fill = [&](double limit, uint64_t *out) -> bool {
+        uint64_t t = 0;
+        for (uint32_t r = 0; r < nparts; ++r) {
+            double acc = 0;
+            if (out) out[r] = std::min<uint64_t>(n, t * kTile);
+            while (t < NT && acc + cost(t) <= limit) acc += cost(t++);
+        }
+        if (out) out[nparts] = n;
+        return t == NT;
+    };
+    double lo = (double)NT, hi = (double)NT * (double)(NT + 1) / 2.0 + 1.0;  // a part holds whole tile rows
+    if (NT == 0) lo = hi = 0;
+    for (int it = 0; it < 80 && hi - lo > 0.25; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, nullptr)) hi = mid;
+        else lo = mid;
+    }
+    fill(hi, bounds);
+    return DSH_OK;
+}
+
+int dsh_dist_rows_device_async(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, void *d_out)
 {
     if (!c) return DSH_EINVAL;
     int rc = bind(c);
@@ -808,7 +959,15 @@ int dsh_dist_rows_device(dsh_ctx *c, int estim, int result_type, int k, uint64_t
     return run_pairs(c, j);
 }
 
-int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, float *out)
+int dsh_dist_rows_device(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, void *d_out)
+{
+    int rc = dsh_dist_rows_device_async(c, estim, result_type, k, rb, re, d_out);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_dist_rows_async(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, float *out)
 {
     if (!c) return DSH_EINVAL;
     int rc = bind(c);
@@ -818,11 +977,31 @@ int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, ui
     const uint64_t span = dsh_tri_span(c->n, rb, re);
     if (span == 0) return DSH_OK;
     if (!out) return DSH_EINVAL;
+    // (the stream orders a later call's kernels after this call's copy out of outbuf; growing outbuf frees the
+    // old buffer, which the runtime does only after the work using it has drained)
     HIPCHK(c, c->outbuf.ensure(span * sizeof(float)));
-    rc = dsh_dist_rows_device(c, estim, result_type, k, rb, re, c->outbuf.ptr);
+    rc = dsh_dist_rows_device_async(c, estim, result_type, k, rb, re, c->outbuf.ptr);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->outbuf.ptr, span * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return DSH_OK;
+}
+
+int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, float *out)
+{
+    int rc = dsh_dist_rows_async(c, estim, result_type, k, rb, re, out);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_wait(dsh_ctx *c) { return dsh_synchronize(c); }
+
+int dsh_wait_event(dsh_ctx *c, void *hip_event)
+{
+    if (!c || !hip_event) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
     return DSH_OK;
 }
 
@@ -1036,7 +1215,9 @@ int dsh_dist_shard_device(dsh_ctx *c, int estim, int result_type, int k, uint32_
     j.d_out = (float *)d_span;
     if (j.row_begin >= j.row_end) return DSH_OK;
     if (!d_span) return DSH_EINVAL;
-    return run_pairs(c, j);
+    if ((rc = run_pairs(c, j))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
 }
 
 int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
@@ -1044,7 +1225,7 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     if (!c) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    if (!c->planes_valid || !c->planes_sorted) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
+    if (!whole_sorted(c)) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
     if (c->n < 2) return DSH_OK;
     if (!d_sorted_tri || !d_out_tri) return DSH_EINVAL;
     HIPCHK(c, launch_unpermute(c->stream, (const float *)d_sorted_tri, (const uint32_t *)c->perm.ptr,
@@ -1057,7 +1238,7 @@ int dsh_unpermute_blocks_device(dsh_ctx *c, const void *d_stage, const uint64_t 
     if (!c || nshards == 0 || !block_off) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    if (!c->planes_valid || !c->planes_sorted) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
+    if (!whole_sorted(c)) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
     if (c->n < 2) return DSH_OK;
     if (!d_stage || !d_out_tri) return DSH_EINVAL;
     std::vector<uint32_t> tb;
@@ -1079,7 +1260,7 @@ int dsh_unpermute_blocks_device(dsh_ctx *c, const void *d_stage, const uint64_t 
 int dsh_unpermute_staged_device(dsh_ctx *c, const void *d_stage, uint64_t stride, uint32_t nshards, void *d_out_tri)
 {
     if (!c || nshards == 0) return DSH_EINVAL;
-    if (c->planes_valid && c->planes_sorted && c->n >= 2) {  // the spans must fit their blocks
+    if (whole_sorted(c) && c->n >= 2) {  // the spans must fit their blocks
         std::vector<uint32_t> tb;
         shard_bounds(c, nshards, tb);
         for (uint32_t r = 0; r < nshards; ++r) {
@@ -1136,6 +1317,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "kpad")) *out = c->Kpad;
     else if (!std::strcmp(name, "cum_bytes")) *out = c->cum_bytes;
     else if (!std::strcmp(name, "sorted")) *out = c->planes_sorted;
+    else if (!std::strcmp(name, "ncols")) *out = (int64_t)c->ncols;
     else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->htiles.size();
     else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
@@ -1183,6 +1365,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "sort")) {
         if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "sort must be -1, 0 or 1");
         c->sort_mode = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "range_sort_min_rows")) {
+        if (v < 1) return fail(c, DSH_EINVAL, "range_sort_min_rows must be >= 1");
+        c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
         return DSH_OK;
     }
     if (!std::strcmp(name, "nsplit")) {

@@ -607,7 +607,7 @@ static int dist_main(int argc, char **argv)
         }
     } else if (o.fmt == BINARY && o.devices.size() > 1 && !o.out_dists.empty()) {
         // Several GPUs of one node: every device holds all sketches, device d computes the row range
-        // dsh_partition_rows gives it (near-equal pair counts, 128-row boundaries) and writes its
+        // dsh_balance_rows gives it (tile-aligned, equal tile counts) and writes its
         // contiguous span of the packed matrix straight into the output file.
         if (write_binary_header(pairofp, n)) die("Failure");
         std::fflush(pairofp);
@@ -617,7 +617,7 @@ static int dist_main(int argc, char **argv)
         std::vector<uint8_t> all(n * m);
         DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
         std::vector<uint64_t> bounds(G + 1);
-        if (dsh_partition_rows(n, (uint32_t)G, 128, bounds.data())) die("dsh_partition_rows failed");
+        if (dsh_balance_rows(n, (uint32_t)G, bounds.data())) die("dsh_balance_rows failed");
         std::vector<std::thread> workers;
         for (size_t d = 0; d < G; ++d)
             workers.emplace_back([&, d]() {
@@ -627,24 +627,36 @@ static int dist_main(int argc, char **argv)
                     DSH(c, dsh_sketches_alloc(c, n, o.S));
                     DSH(c, dsh_upload_sketches(c, all.data(), 0, n));
                 }
-                const uint64_t block_vals = (uint64_t)64 << 20;
-                float *buf = (float *)dsh_alloc_host((block_vals + n) * sizeof(float));
-                if (!buf) die("could not allocate pinned host memory");
-                for (uint64_t rb = bounds[d]; rb < bounds[d + 1];) {
+                // as below: large row blocks (each one a range the library lays its planes out for), two
+                // page-locked buffers, block b+1 enqueued before block b is written at its file offset
+                const uint64_t block_vals = (uint64_t)512 << 20;
+                std::vector<uint64_t> cuts{bounds[d]};
+                while (cuts.back() < bounds[d + 1]) {
+                    const uint64_t rb = cuts.back();
                     uint64_t re = rb + 1;
                     while (re < bounds[d + 1] && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
-                    const uint64_t span = dsh_tri_span(n, rb, re);
-                    DSH(c, dsh_dist_rows(c, o.estim, o.result_type, o.k, rb, re, buf));
-                    const off_t pos = (off_t)(9 + dsh_tri_span(n, 0, rb) * sizeof(float));
+                    cuts.push_back(re);
+                }
+                uint64_t cap = 1;
+                for (size_t b = 0; b + 1 < cuts.size(); ++b) cap = std::max<uint64_t>(cap, dsh_tri_span(n, cuts[b], cuts[b + 1]));
+                float *bufs[2] = {nullptr, nullptr};
+                for (int w = 0; w < (cuts.size() > 2 ? 2 : 1); ++w)
+                    if (!(bufs[w] = (float *)dsh_alloc_host(cap * sizeof(float)))) die("could not allocate pinned host memory");
+                const size_t nblocks = cuts.size() - 1;
+                if (nblocks) DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[0], cuts[1], bufs[0]));
+                for (size_t b = 0; b < nblocks; ++b) {
+                    DSH(c, dsh_wait(c));
+                    if (b + 1 < nblocks) DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[b + 1], cuts[b + 2], bufs[(b + 1) & 1]));
+                    const uint64_t span = dsh_tri_span(n, cuts[b], cuts[b + 1]);
+                    const off_t pos = (off_t)(9 + dsh_tri_span(n, 0, cuts[b]) * sizeof(float));
                     size_t done = 0;
                     while (done < span * sizeof(float)) {
-                        const ssize_t w = ::pwrite(fd, (const char *)buf + done, span * sizeof(float) - done, pos + (off_t)done);
+                        const ssize_t w = ::pwrite(fd, (const char *)bufs[b & 1] + done, span * sizeof(float) - done, pos + (off_t)done);
                         if (w <= 0) die("Failed to write rows to disk");
                         done += (size_t)w;
                     }
-                    rb = re;
                 }
-                dsh_free_host(buf);
+                for (auto &bf : bufs) dsh_free_host(bf);
                 if (d > 0) dsh_destroy(c);
             });
         for (auto &w : workers) w.join();
@@ -659,46 +671,51 @@ static int dist_main(int argc, char **argv)
         } else {
             emit_header(pairofp, o.fmt, o.inpaths);
         }
-        // row blocks of <= 64 Mi values, two ping-pong buffers: the GPU computes block b+1 while a
-        // writer thread emits block b (as dist_loop does with dps[i & 1], src/sketch_and_cmp.h:804-816)
-        const uint64_t block_vals = (uint64_t)64 << 20;
-        // page-locked ping-pong buffers: the D2H copy of a block is then a direct DMA
-        float *bufs[2] = {nullptr, nullptr};
-        const uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(block_vals + n, std::max<uint64_t>(total, 1)), 1);
-        for (auto &b : bufs)
-            if (!(b = (float *)dsh_alloc_host(cap * sizeof(float)))) die("could not allocate %llu bytes of pinned host memory", (unsigned long long)(cap * sizeof(float)));
-        std::thread writer;
-        int which = 0;
-        uint64_t rb = 0;
-        while (rb < n) {
+        // Row blocks, two page-locked ping-pong buffers, asynchronous C-ABI calls: block b+1 is enqueued
+        // (compute + copy into its buffer) before block b is emitted, so the GPU works while this thread
+        // formats / writes -- dist_loop's dps[i & 1] scheme (src/sketch_and_cmp.h:804-816) without the
+        // writer thread.  Blocks are large (<= 512 Mi values) so that each one is a row range the library
+        // lays its plane matrix out for (few planes per tile, values at their final positions).
+        const uint64_t block_vals = (uint64_t)512 << 20;
+        std::vector<uint64_t> cuts{0};
+        while (cuts.back() < n) {
+            const uint64_t rb = cuts.back();
             uint64_t re = rb + 1;
             while (re < n && dsh_tri_span(n, rb, re + 1) <= block_vals) ++re;
-            const uint64_t span = dsh_tri_span(n, rb, re);
-            float *buf = bufs[which];
-            DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, rb, re, buf));
-            if (writer.joinable()) writer.join();
-            writer = std::thread([&o, buf, pairofp, rb, re, n, span]() {
-                if (o.fmt == BINARY) {
-                    if (span && std::fwrite(buf, sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
-                    return;
-                }
-                // format rows on all host threads (snprintf dominates text output), write in order
-                std::vector<uint64_t> off(re - rb + 1, 0);
-                for (uint64_t i = rb; i < re; ++i) off[i - rb + 1] = off[i - rb] + (n - i - 1);
-                const uint64_t group = 64;
-                for (uint64_t g0 = rb; g0 < re; g0 += group * (uint64_t)o.nthreads) {
-                    const uint64_t g1 = std::min<uint64_t>(re, g0 + group * (uint64_t)o.nthreads);
-                    std::vector<std::string> rows(g1 - g0);
-#pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads)
-                    for (int64_t i = (int64_t)g0; i < (int64_t)g1; ++i)
-                        format_ut_row(rows[i - g0], o.fmt, o.inpaths, (size_t)i, buf + off[i - rb]);
-                    for (auto &r : rows) std::fwrite(r.data(), 1, r.size(), pairofp);
-                }
-            });
-            which ^= 1;
-            rb = re;
+            cuts.push_back(re);
         }
-        if (writer.joinable()) writer.join();
+        uint64_t cap = 1;
+        for (size_t b = 0; b + 1 < cuts.size(); ++b) cap = std::max<uint64_t>(cap, dsh_tri_span(n, cuts[b], cuts[b + 1]));
+        float *bufs[2] = {nullptr, nullptr};
+        for (int w = 0; w < (cuts.size() > 2 ? 2 : 1); ++w)
+            if (!(bufs[w] = (float *)dsh_alloc_host(cap * sizeof(float)))) die("could not allocate %llu bytes of pinned host memory", (unsigned long long)(cap * sizeof(float)));
+        auto enqueue = [&](size_t b) {
+            DSH(ctx, dsh_dist_rows_async(ctx, o.estim, o.result_type, o.k, cuts[b], cuts[b + 1], bufs[b & 1]));
+        };
+        const size_t nblocks = cuts.size() - 1;
+        if (nblocks) enqueue(0);
+        for (size_t b = 0; b < nblocks; ++b) {
+            DSH(ctx, dsh_wait(ctx));                 // block b has arrived in bufs[b & 1]
+            if (b + 1 < nblocks) enqueue(b + 1);     // the other buffer was emitted in the previous iteration
+            const uint64_t rb = cuts[b], re = cuts[b + 1], span = dsh_tri_span(n, rb, re);
+            const float *buf = bufs[b & 1];
+            if (o.fmt == BINARY) {
+                if (span && std::fwrite(buf, sizeof(float), span, pairofp) != span) die("Failed to write rows to disk");
+                continue;
+            }
+            // format rows on all host threads (snprintf dominates text output), write in order
+            std::vector<uint64_t> off(re - rb + 1, 0);
+            for (uint64_t i = rb; i < re; ++i) off[i - rb + 1] = off[i - rb] + (n - i - 1);
+            const uint64_t group = 64;
+            for (uint64_t g0 = rb; g0 < re; g0 += group * (uint64_t)o.nthreads) {
+                const uint64_t g1 = std::min<uint64_t>(re, g0 + group * (uint64_t)o.nthreads);
+                std::vector<std::string> rows(g1 - g0);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads)
+                for (int64_t i = (int64_t)g0; i < (int64_t)g1; ++i)
+                    format_ut_row(rows[i - g0], o.fmt, o.inpaths, (size_t)i, buf + off[i - rb]);
+                for (auto &r : rows) std::fwrite(r.data(), 1, r.size(), pairofp);
+            }
+        }
         for (auto &b : bufs) dsh_free_host(b);
     }
     std::fflush(pairofp);

@@ -31,7 +31,7 @@ struct FinalizeLaunch {
     const uint32_t *exc, *exc_n, *keys;
     const uint8_t *excv;
     const uint8_t *tailhist;
-    uint64_t n;
+    uint64_t n, ncols;  // collection size (output dimension); real columns of the plane matrix
     int rect, sorted_out, square;
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;

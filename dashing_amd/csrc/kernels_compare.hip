@@ -417,7 +417,8 @@ struct FinalizeArgs {
     const uint32_t *exc_n;
     const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value
     const uint32_t *keys;     // [n]: (max value << 16) | (T_i << 8) | min value
-    uint64_t n;
+    uint64_t n;      // sketches in the collection = dimension of the output matrix
+    uint64_t ncols;  // real columns of the plane matrix (a sub-collection when only a row range is wanted)
     // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
     // rect mode (rect != 0): i in [row_begin,row_end) x j in [col_begin,col_end), row-major
     int rect;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     const uint4 tile = a.tiles[blockIdx.x >> 7];
     const uint64_t si = (uint64_t)tile.x * kTile + (blockIdx.x & 127u);
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
-    if (si >= a.n) return;  // padding row (uniform)
+    if (si >= a.ncols) return;  // padding row (uniform)
     const uint64_t i = a.perm ? a.perm[si] : si;
     // this tile's own plane range: C(v) = 0 for v <= vlo_t, exceptions above T
     const int vlo = a.vlo, vhi = a.vhi;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         }
     }
     __syncthreads();
-    if (sj >= a.n) return;
+    if (sj >= a.ncols) return;
     const uint64_t j = a.perm ? a.perm[sj] : sj;
     uint64_t oi = i, oj = j;
     bool active;
@@ -918,7 +919,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist; a.n = f.n; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
+    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist; a.n = f.n; a.ncols = f.ncols; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     uint32_t hs = 16;

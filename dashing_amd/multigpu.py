@@ -12,6 +12,14 @@ import torch.distributed as dist
 from . import api
 
 
+def _host_sync(t):
+    """Collectives on CUDA tensors only ENQUEUE on torch's current stream; the library runs on its own
+    stream.  Block the host until the transfer has completed so that whatever the caller does next with the
+    buffers (another dsh_* call on the library stream, reuse of the send buffer) is ordered after it."""
+    if t is not None and t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def row_bounds(n, world):
     return api.partition_rows(n, world, 128)
 
@@ -34,13 +42,43 @@ def gather_spans(local, n, bounds, rank, world, dst=0, staging=None):
         if staging is None:
             staging = [torch.empty(mx, dtype=local.dtype, device=local.device) for _ in range(world)]
         dist.gather(send, gather_list=staging, dst=dst)
-        return torch.cat([staging[r][: sizes[r]] for r in range(world)])
+        out = torch.cat([staging[r][: sizes[r]] for r in range(world)])
+        _host_sync(out)
+        return out
     dist.gather(send, gather_list=None, dst=dst)
+    _host_sync(send)
     return None
 
 
 def max_span(n, bounds):
     return max(span_sizes(n, bounds))
+
+
+def collect_row_spans(local, final, n, bounds, rank, world, dst=0):
+    """The multi-GPU exchange of the distance matrix: rank r has computed the rows [bounds[r], bounds[r+1])
+    (Context.dist_rows_device), i.e. ONE contiguous span of the packed triangle already in its final
+    order, in `local` (>= its span long).  Every rank != dst sends its span, dst receives each span
+    straight into its place in `final` (n(n-1)/2 floats; dst's own span is expected to be there already
+    -- compute it in place) -- point-to-point, one message per peer, all 7 xGMI links of dst busy at once,
+    no staging copy and no un-permute.  Returns when the data has arrived (host-synchronised)."""
+    sizes = span_sizes(n, bounds)
+    offs = [0]
+    for s_ in sizes:
+        offs.append(offs[-1] + s_)
+    if world == 1:
+        return final
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            if r != dst and sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, final[offs[r] : offs[r + 1]], r))
+    elif sizes[rank]:
+        ops.append(dist.P2POp(dist.isend, local[: sizes[rank]], dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    _host_sync(final if rank == dst else local)
+    return final if rank == dst else None
 
 
 # ---- shards of the sorted-order triangle (faster: narrow per-tile plane ranges, cost-balanced) ----
@@ -57,17 +95,20 @@ def gather_shard_spans(local, span_off, rank, world, stage=None, sorted_full=Non
     send = local[:mx]
     if rank != dst:
         dist.gather(send, gather_list=None, dst=dst)
+        _host_sync(send)  # the send buffer may be overwritten by the next dsh_* call only after this
         return None
     if stage is None:
         stage = torch.empty(world * mx, dtype=local.dtype, device=local.device)
     parts = [stage[r * mx : (r + 1) * mx] for r in range(world)]
     dist.gather(send, gather_list=parts, dst=dst)
     if staged:
+        _host_sync(stage)  # the un-permute runs on the library's stream, not torch's
         return stage
     if sorted_full is None:
         sorted_full = torch.empty(max(span_off[-1], 1), dtype=local.dtype, device=local.device)
     for r in range(world):
         sorted_full[span_off[r] : span_off[r + 1]] = parts[r][: sizes[r]]
+    _host_sync(sorted_full)
     return sorted_full
 
 
@@ -139,7 +180,11 @@ class PipelinedShards:
         self.works.append(dist.gather(send, gather_list=parts, dst=self.dst, async_op=True))
 
     def wait(self):
+        """Returns after every submitted piece has ARRIVED (w.wait() only orders torch's stream; the host
+        is synchronised here so the caller may hand the stage to Context.unpermute_blocks_device, which runs
+        on the library's own stream, or overwrite the piece buffers)."""
         for w in self.works:
             w.wait()
         self.works = []
+        _host_sync(self.outs[0] if self.outs else None)
         return (self.stage, self.block_off) if self.rank == self.dst else None

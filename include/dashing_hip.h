@@ -116,6 +116,31 @@ int dsh_dist_rows(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_
  * (dsh_stream); the call returns after it has completed. */
 int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
                          uint64_t row_end, void *d_out);
+/* Asynchronous forms -- the reference overlaps the comparison of one batch of rows with the emission of
+ * the previous one through two ping-pong buffers (dist_loop's dps[i & 1] + std::async writer,
+ * src/sketch_and_cmp.h:804-816; parallel_fill's writer thread, distmat/distmat.h:475-479,504-508).  These
+ * calls ENQUEUE the whole computation (and, for the host form, the copy into `out`) on the ctx stream and
+ * return; dsh_wait(ctx) blocks until everything enqueued on the ctx has completed.  Calls may be issued
+ * back to back (they execute in order).  `out` must stay valid until dsh_wait and should come from
+ * dsh_alloc_host: the copy into pageable memory is staged by the runtime and is not asynchronous.
+ * Typical use: async(block b+1 -> buf[(b+1)&1]); emit block b from buf[b&1]; dsh_wait; ... (the CLI does this).
+ * The call itself may still block briefly at its start while a new column layout is built on the host
+ * (only the first call after the sketches changed touches the device for that). */
+int dsh_dist_rows_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
+                        uint64_t row_end, float *out_pinned);
+int dsh_dist_rows_device_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
+                               uint64_t row_end, void *d_out);
+int dsh_wait(dsh_ctx *ctx);
+/* Make all work enqueued on the ctx stream AFTER this call wait for `hip_event` (a hipEvent_t recorded by
+ * the caller on its own stream, e.g. torch.cuda.Event.cuda_event after producing d_regs / a gathered
+ * staging buffer) -- the device-side alternative to synchronising the host before a *_device call. */
+int dsh_wait_event(dsh_ctx *ctx, void *hip_event);
+/* Row ranges and layouts: for a range of at least "range_sort_min_rows" rows (option, default 1024; always
+ * for the full triangle) the plane matrix is rebuilt for exactly that range -- the wanted rows first, then the
+ * later rows, both in (threshold, min value) order, earlier rows left out -- so every tile is homogeneous
+ * (few planes) and every value is written at its final packed position: any split of the rows into
+ * ranges concatenates to the byte-identical matrix, at the speed of the full-triangle call.  Smaller
+ * ranges use the identity layout, which stays cached between calls. */
 /* Query x reference rectangle (partdist_loop, src/dashing.h:660-712): queries are slots
  * [q_begin,q_end), references slots [r_begin,r_end); out[(qi-q_begin)*(r_end-r_begin)+(rj-r_begin)]. */
 int dsh_dist_rect(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin,
@@ -171,6 +196,12 @@ uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j);
  * bounds_out[0..nparts] receives the boundaries (bounds_out[0]=0, bounds_out[nparts]=n). */
 int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds_out);
 
+/* Row ranges for the ranks of a multi-GPU run (or the devices of the CLI): bounds on 128-row boundaries that
+ * minimise the largest number of 128 x 128 tiles any part computes (triangle of its rows + the rectangle
+ * to their right).  Each range is then one dsh_dist_rows* call whose result is one contiguous span of the
+ * final packed triangle -- the ranks' spans concatenate, nothing is re-ordered. */
+int dsh_balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds_out);
+
 /* Page-locked host memory for the host-buffer entry points (dsh_dist_rows, dsh_upload_sketches,
  * dsh_sketch_batch): with such buffers the copies are direct DMA at PCIe rate instead of going
  * through the runtime's staging of pageable memory.  Optional -- any host pointer works. */
@@ -192,10 +223,11 @@ int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.
- * Every *_device entry point runs on THIS stream and returns after its work has completed, so results
- * are ready for any other stream on return.  The other direction is the caller's job: whatever it
- * enqueued on its own streams that touches a buffer passed in (filling d_out, producing d_regs or
- * d_seq) must have completed -- or be synchronised with this stream -- before the call. */
+ * Every *_device entry point runs on THIS stream and (except the *_async forms) returns after its work has
+ * completed, so results are ready for any other stream on return.  The other direction is the caller's
+ * job: whatever it enqueued on its own streams that touches a buffer passed in (filling d_out, producing
+ * d_regs or d_seq, an RCCL gather into a staging buffer) must have completed on the host -- or be ordered
+ * before this stream's work with dsh_wait_event -- before the call. */
 void *dsh_stream(dsh_ctx *ctx);
 
 #ifdef __cplusplus

@@ -1,6 +1,8 @@
 """Worker for tests/test_gpu_multirank.py: the whole N-rank path on real GPU kernels --
-genomes dealt to ranks -> k_sketch -> all-gather of the register arrays -> cost-balanced shards of
-the all-pairs matrix -> gather to rank 0 -> un-permute -- checked against the CPU oracle on rank 0.
+genomes dealt to ranks -> k_sketch -> all-gather of the register arrays -> all-pairs matrix split over
+the ranks -> assembled on rank 0 -- checked against the CPU oracle on rank 0.  E2E_PIECES=0: the scheme
+bench.py uses (tile-balanced row ranges of the final triangle, each rank's span sent point-to-point into
+place, nothing re-ordered); >= 1: cost-balanced shards of the key-ordered triangle, gather, un-permute.
 
 Launched with torchrun (RANK/WORLD_SIZE/MASTER_* from the env).  E2E_BACKEND=nccl is the real thing
 (one GPU per rank; with WORLD_SIZE=1 it still initialises RCCL and runs every collective);
@@ -62,7 +64,25 @@ def main():
     pieces = int(os.environ.get("E2E_PIECES", "1"))
     rt = dashing_amd.MASH_DIST
     pipe = None
-    if pieces == 1:
+    ranges = pieces == 0  # the scheme bench.py uses: tile-balanced row ranges of the FINAL triangle, point-to-point
+    if ranges:
+        # n = 301 has 3 tile rows; min rows for the key-ordered layout lowered so the small ranges take that path too
+        ctx.set_option("range_sort_min_rows", 1)
+        bounds = dashing_amd.balance_rows(n, world)
+        sizes = multigpu.span_sizes(n, bounds)
+        final_r = torch.zeros(total, dtype=torch.float32, device=dev) if rank == 0 else None
+        my = torch.zeros(max(sizes[rank], 1), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        dst_ptr = final_r.data_ptr() if rank == 0 else my.data_ptr()  # rank 0 computes in place
+        ctx.dist_rows_device(dst_ptr, bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, rt, k)
+        ctx.synchronize()
+        if backend == "gloo":
+            fh = final_r.cpu() if rank == 0 else None
+            multigpu.collect_row_spans(my.cpu(), fh, n, bounds, rank, world, 0)
+            full = fh.to(dev) if rank == 0 else None
+        else:
+            full = multigpu.collect_row_spans(my, final_r, n, bounds, rank, world, 0)
+    elif pieces == 1:
         span_off = ctx.shard_plan(world)
         mx = max(max(span_off[r + 1] - span_off[r] for r in range(world)), 1)
         out_d = torch.zeros(mx, dtype=torch.float32, device=dev)
@@ -95,7 +115,9 @@ def main():
         torch.cuda.synchronize()
         final = torch.empty(total, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        if pipe is not None:
+        if ranges:
+            final = full  # already in dashing's packed order: nothing to un-permute
+        elif pipe is not None:
             ctx.unpermute_blocks_device(full.data_ptr(), block_off, final.data_ptr())
         elif backend == "gloo":
             ctx.unpermute_device(full.data_ptr(), final.data_ptr())

@@ -73,3 +73,29 @@ def test_partition_rows(n, parts):
         spans = [dashing_amd.tri_span(n, b[i], b[i + 1]) for i in range(parts)]
         assert max(spans) / (sum(spans) / parts) < 1.05  # balanced within 5 %
         assert sum(spans) == n * (n - 1) // 2
+
+
+@pytest.mark.parametrize("n,parts", [(10000, 8), (10000, 2), (10000, 1), (1000, 4), (65, 8), (129, 2), (1, 2), (0, 3), (100000, 8), (300000, 8)])
+def test_balance_rows(n, parts):
+    """tile-aligned row ranges for the ranks of a multi-GPU run: cover [0,n), 128-row boundaries, and the
+    largest tile count is the smallest any contiguous aligned split can reach (checked by brute force when small)"""
+    b = dashing_amd.balance_rows(n, parts)
+    assert b[0] == 0 and b[-1] == n and len(b) == parts + 1
+    assert all(b[i] <= b[i + 1] for i in range(parts))
+    assert all(x % 128 == 0 for x in b[1:-1] if x != n)
+    nt = (n + 127) // 128
+
+    def tiles(lo, hi):  # tile rows [lo,hi): triangle of the part + rectangle to its right
+        return sum(nt - t for t in range(lo, hi))
+
+    cost = [tiles(b[i] // 128, (b[i + 1] + 127) // 128) if b[i + 1] > b[i] else 0 for i in range(parts)]
+    assert sum(cost) == nt * (nt + 1) // 2
+    if nt and parts > 1:
+        assert max(cost) <= (nt * (nt + 1) / 2) / parts + nt  # never more than one tile row above the mean
+    if 1 < parts <= 4 and nt <= 80:  # exact minimax by enumeration
+        import itertools
+
+        best = min(max(tiles(c[i], c[i + 1]) for i in range(parts))
+                   for mid in itertools.combinations_with_replacement(range(nt + 1), parts - 1)
+                   for c in [(0,) + mid + (nt,)])
+        assert max(cost) == best

@@ -96,6 +96,100 @@ def test_row_ranges_concatenate(ctx):
     assert odd.tobytes() == full.tobytes()
 
 
+@pytest.mark.parametrize("n,p", [(333, 10), (2500, 12), (1300, 14)])
+def test_row_ranges_key_ordered_layout(ctx, oracle, n, p):
+    """Row ranges computed with the plane matrix laid out for the range (wanted rows first, both parts
+    key-ordered; results land at their final packed positions): any split -- unaligned, tiny, a single
+    row, with or without the layout -- concatenates to the byte-identical full triangle."""
+    parts_h = []
+    for k, card in enumerate((40_000, 600_000, 9_000_000)):  # heterogeneous: the key order matters
+        parts_h += [synth.hll_registers(1000 * k + g, card * (1 + g % 3), p) for g in range(n // 3 + 1)]
+    regs = np.stack(parts_h)[:n]
+    regs = regs[np.random.default_rng(3).permutation(n)]
+    ctx.set_sketches(regs)
+    full = ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=21)
+    assert ctx.info("sorted") == 1 and ctx.info("ncols") == n
+    for r in (0, n // 2, n - 2):
+        want = oracle.dist_rows(regs, r, r + 1, 2, oracle.MASH_DIST, 21)
+        lo = dashing_amd.tri_index(n, r, r + 1)
+        close(full[lo : lo + want.size], want)
+    rng = np.random.default_rng(n)
+    try:
+        for min_rows in (1024, 1):
+            ctx.set_option("range_sort_min_rows", min_rows)
+            for parts in (2, 3, 8):
+                b = dashing_amd.partition_rows(n, parts, 1)
+                cat = np.concatenate([ctx.dist_rows(b[i], b[i + 1], result_type=dashing_amd.MASH_DIST, k=21) for i in range(parts)])
+                assert cat.tobytes() == full.tobytes()
+            cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, 5)] + [1, 127, 128, 129, n - 1]))
+            cat = np.concatenate([ctx.dist_rows(cuts[i], cuts[i + 1], result_type=dashing_amd.MASH_DIST, k=21) for i in range(len(cuts) - 1)])
+            assert cat.tobytes() == full.tobytes()
+            if min_rows == 1:
+                ctx.dist_rows(n // 3, n // 2)
+                assert ctx.info("sorted") == 1 and ctx.info("ncols") == n - n // 3  # sketches before the range are left out
+        ctx.set_option("sort", 0)
+        assert ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=21).tobytes() == full.tobytes()
+    finally:
+        ctx.set_option("sort", -1)
+        ctx.set_option("range_sort_min_rows", 1024)
+
+
+def test_async_rows_and_wait(ctx):
+    """dsh_dist_rows_async / dsh_wait (the reference's ping-pong buffers, src/sketch_and_cmp.h:804-816): calls
+    return before the work is done, may be issued back to back, and deliver the blocking call's bytes."""
+    n, p = 900, 12
+    regs = synth.synthetic_sketches(n, p, seed=4242)
+    ctx.set_sketches(regs)
+    full = ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=25)
+    cuts = [0, 300, 301, 650, n]
+    bufs = [dashing_amd.PinnedArray(dashing_amd.tri_span(n, cuts[i], cuts[i + 1]) + 4) for i in range(len(cuts) - 1)]
+    for b in bufs:
+        b.array[:] = -5.0
+    for i, b in enumerate(bufs):  # four calls in flight on the ctx stream
+        ctx.dist_rows_async(b.array, cuts[i], cuts[i + 1], result_type=dashing_amd.MASH_DIST, k=25)
+    ctx.wait()
+    got = np.concatenate([b.array[: dashing_amd.tri_span(n, cuts[i], cuts[i + 1])] for i, b in enumerate(bufs)])
+    assert got.tobytes() == full.tobytes()
+    assert all((b.array[-4:] == -5.0).all() for b in bufs)  # nothing written past a span
+    # the classic loop: block b+1 enqueued before block b is consumed
+    two = [dashing_amd.PinnedArray(max(dashing_amd.tri_span(n, cuts[i], cuts[i + 1]) for i in range(4))) for _ in range(2)]
+    out = []
+    ctx.dist_rows_async(two[0].array, cuts[0], cuts[1])
+    for i in range(4):
+        ctx.wait()
+        if i + 1 < 4:
+            ctx.dist_rows_async(two[(i + 1) & 1].array, cuts[i + 1], cuts[i + 2])
+        out.append(two[i & 1].array[: dashing_amd.tri_span(n, cuts[i], cuts[i + 1])].copy())
+    assert np.concatenate(out).tobytes() == ctx.dist_rows().tobytes()
+
+
+def test_device_async_and_wait_event(ctx):
+    """*_device_async leaves the result in a caller buffer without blocking; dsh_wait_event orders the ctx
+    stream after work the caller enqueued on ITS stream (here: torch producing the sketches)."""
+    import torch
+
+    n, p = 700, 10
+    dev = torch.device("cuda", 0)
+    regs = synth.synthetic_sketches(n, p, seed=99)
+    want = None
+    ctx.set_sketches(regs)
+    want = ctx.dist_rows()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        regs_d = torch.from_numpy(regs).to(dev, non_blocking=False)
+        for _ in range(20):  # keep torch's stream busy so that a missing dependency would show
+            regs_d = torch.maximum(regs_d, regs_d)
+        ev = torch.cuda.Event()
+        ev.record(s)
+    out = torch.full((n * (n - 1) // 2,), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.current_stream().synchronize()  # `out` is filled on torch's default stream
+    ctx.attach_device(regs_d.data_ptr(), n, p)
+    ctx.wait_event(ev.cuda_event)
+    ctx.dist_rows_device_async(out.data_ptr(), 0, n)
+    ctx.wait()
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+
+
 def test_rect_matches_tri(ctx, oracle):
     n, p = 150, 10
     regs = synth.synthetic_sketches(n, p, seed=43)

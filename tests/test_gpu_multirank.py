@@ -22,9 +22,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("backend,world,pieces", [("nccl", 1, 1), ("gloo", 2, 1), ("gloo", 3, 1), ("nccl", 1, 2), ("gloo", 2, 3)])
+@pytest.mark.parametrize("backend,world,pieces", [("nccl", 1, 0), ("gloo", 2, 0), ("gloo", 3, 0), ("nccl", 1, 1), ("gloo", 2, 1), ("gloo", 3, 1), ("nccl", 1, 2), ("gloo", 2, 3)])
 def test_end_to_end_ranks(backend, world, pieces):
-    """pieces > 1: every rank's share is cut into that many shards, each gathered asynchronously while the
+    """pieces == 0: row ranges of the final triangle, point-to-point into place (bench.py's N>1 path).
+    pieces > 1: every rank's share is cut into that many shards, each gathered asynchronously while the
     next is computed (multigpu.PipelinedShards, dsh_unpermute_blocks_device)."""
     env = dict(os.environ, E2E_BACKEND=backend, E2E_PIECES=str(pieces), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),

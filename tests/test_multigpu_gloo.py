@@ -89,6 +89,50 @@ def test_gather_shard_spans_gloo(tmp_path, world):
     assert (got == np.arange(end, dtype=np.float32)).all()
 
 
+def _worker_collect(rank, world, port, n, p, outdir, dst):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dashing_amd import api, multigpu, synth
+    from oracle import oracle_c
+
+    oracle_c.load(threads=2)
+    regs = synth.synthetic_sketches(n, p, seed=321)
+    bounds = api.partition_rows(n, world, 1)  # pair-balanced, unaligned: any row range is a contiguous final span
+    sizes = multigpu.span_sizes(n, bounds)
+    total = n * (n - 1) // 2
+    rows = torch.from_numpy(oracle_c.dist_rows(regs, bounds[rank], bounds[rank + 1]))
+    final = torch.full((total,), -7.0) if rank == dst else None
+    local = torch.full((max(sizes[rank], 1) + 3,), -1.0)
+    if rank == dst:  # the receiver computes its own rows in place
+        off = sum(sizes[:rank])
+        final[off : off + sizes[rank]] = rows
+    else:
+        local[: sizes[rank]] = rows
+    got = multigpu.collect_row_spans(local, final, n, bounds, rank, world, dst)
+    if rank == dst:
+        np.save(os.path.join(outdir, "collect_%d.npy" % world), got.numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, 0), (3, 2)])
+def test_collect_row_spans_gloo(tmp_path, world, dst):
+    """bench.py's N>1 exchange: every rank computes a row range (a contiguous span of the FINAL packed
+    triangle); point-to-point into place on the receiver -- no padding, no staging, no un-permute."""
+    n, p = 301, 8
+    mp.spawn(_worker_collect, args=(world, _free_port(), n, p, str(tmp_path), dst), nprocs=world, join=True)
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    want = oracle_c.dist_tri(synth.synthetic_sketches(n, p, seed=321))
+    got = np.load(os.path.join(str(tmp_path), "collect_%d.npy" % world))
+    assert got.tobytes() == want.tobytes()
+
+
 def test_bounds_cover_and_align():
     from dashing_amd import multigpu
 

@@ -119,6 +119,16 @@ def main():
     except (OSError, IndexError, ValueError):
         pass
     json.dump(summary, open(os.path.join(outdir, "pmc_summary.json"), "w"), indent=1)
+    # the file bench.py reads for roofline.traffic (copy it to profiles/pmc_pair_kernel.json): pair kernel only,
+    # stamped with the sources it was measured on
+    for k, kk in summary["kernels"].items():
+        if "k_pair_counts" in k and "hbm_bytes_per_launch" in kk:
+            json.dump({"source_sha256": summary["source_sha256"], "kernel": k,
+                       "workload": {"n_sketches": int(env.get("DSH_BENCH_N", "10000")), "p": int(env.get("DSH_BENCH_P", "14"))},
+                       "fetch_size_kib_raw": kk["FETCH_SIZE"], "write_size_kib": kk["WRITE_SIZE"],
+                       "hbm_bytes_per_launch": kk["hbm_bytes_per_launch"],
+                       "how": "tools/pmc_collect.py: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 counts wide coalesced reads at half their bytes, MI355X_MICROARCH.md)"},
+                      open(os.path.join(outdir, "pmc_pair_kernel.json"), "w"), indent=1)
     for d in glob.glob(os.path.join(outdir, "raw_*")):
         shutil.rmtree(d, ignore_errors=True)
     print(json.dumps({k: {c: v for c, v in kk.items()} for k, kk in summary["kernels"].items() if "k_" in k}, indent=1))

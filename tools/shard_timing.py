@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Times every shard of a G-way plan sequentially on ONE GPU (what each rank of a G-GPU run would
-spend in compute, incl. its own prepare): shows shard balance and the fixed per-rank overhead."""
+"""Times every rank's share of a G-way run sequentially on ONE GPU (what each rank of a G-GPU run would
+spend in compute, incl. its own prepare): shows the balance and the fixed per-rank overhead.
+  range_ms  the scheme bench.py uses: pair-balanced row ranges of the final triangle (plane matrix laid out per range)
+  shard_ms  the older scheme: cost-balanced shards of the sorted-order triangle (+ gather + un-permute on rank 0)"""
 import json
 import os
 import sys
@@ -18,6 +20,22 @@ regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
 ctx = dashing_amd.Context(0)
 if os.environ.get("C0"):
     ctx.set_option("shard_c0_x10", int(os.environ["C0"]))
+for G in (1, 2, 4, 8):
+    b = dashing_amd.balance_rows(n, G)
+    mx = max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(G))
+    out = torch.empty(mx, dtype=torch.float32, device="cuda")
+    rows = []
+    for r in range(G):
+        best = 1e9
+        for _ in range(3):
+            ctx.attach_device(regs.data_ptr(), n, p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.dist_rows_device(out.data_ptr(), b[r], b[r + 1])
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        rows.append(round(best * 1e3, 3))
+    print(json.dumps({"G": G, "range_ms": rows, "max_ms": max(rows), "row_bounds": b, "planes_per_tile_last_rank": ctx.info("avg_tile_planes_x100") / 100}))
 for G in (1, 2, 4, 8):
     ctx.attach_device(regs.data_ptr(), n, p)
     off = ctx.shard_plan(G)
