@@ -108,6 +108,7 @@ struct dsh_ctx {
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
+    int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
     bool profiling = false;
@@ -554,6 +555,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.card = (const double *)c->card.ptr;
         f.n = c->n;
         f.ncols = c->ncols;
+        f.stop = c->finalize_stop;
         f.rect = job.rect;
         f.sorted_out = job.sorted_rows;
         f.square = job.square;
@@ -1370,6 +1372,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "range_sort_min_rows")) {
         if (v < 1) return fail(c, DSH_EINVAL, "range_sort_min_rows must be >= 1");
         c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_stop")) {
+        c->finalize_stop = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "nsplit")) {

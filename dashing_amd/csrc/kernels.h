@@ -33,6 +33,7 @@ struct FinalizeLaunch {
     const uint8_t *tailhist;
     uint64_t n, ncols;  // collection size (output dimension); real columns of the plane matrix
     int rect, sorted_out, square;
+    int stop = 0;  // profiling: k_finalize leaves after phase `stop`
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
 };

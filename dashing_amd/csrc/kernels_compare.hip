@@ -430,6 +430,7 @@ struct FinalizeArgs {
     // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
     int square;
     uint32_t hash_slots;  // power of two >= 2 * emax: LDS hash of the row sketch's tail entries
+    int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
@@ -519,6 +520,10 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         active = si < sj && oi >= a.row_begin && oi < a.row_end;
     }
     if (!active) return;
+    if (a.stop == 1) {
+        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)naLive;
+        return;
+    }
     const uint32_t m = 1u << a.p;
     CT *col = hs + tid;
     // All global loads of this lane's inputs are issued together, before anything waits on them: the
@@ -577,6 +582,10 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         }
     }
     uint32_t ucnt = naLive + nb;  // |list_i above T| + |list_j above T|, shared positions still counted twice
+    if (a.stop == 2) {
+        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)(ucnt + prev + keyj);
+        return;
+    }
     // largest bin that can be non-empty (a scan bound for the estimator): the larger of the two maxima
     const int maxj = (int)(keyj >> 16), maxi = (int)(keyi >> 16);
     int maxv = maxi > maxj ? maxi : maxj;
@@ -671,11 +680,19 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     flush();
     // (a bin emptied by a correction can only lower the true maximum; maxv is just a scan bound)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
+    if (a.stop == 3) {
+        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)(ucnt + maxv);
+        return;
+    }
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
     const double us = estimate(c, raw, a.p, a.estim, vlo_t, maxv);
+    if (a.stop == 4) {
+        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)us;
+        return;
+    }
     const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
     if (a.square) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
         a.out[i * a.n + j] = res;
@@ -925,6 +942,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     uint32_t hs = 16;
     while (hs < 2u * (uint32_t)f.emax) hs <<= 1;
     a.hash_slots = hs;
+    a.stop = f.stop;
     const size_t bit_words = (((size_t)1 << f.p) >> 5) + 1;
     const size_t lds = (((bit_words + hs + 65) * sizeof(uint32_t) + 15) & ~(size_t)15) +
                        (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
