@@ -100,6 +100,13 @@ __device__ __forceinline__ double div_normal(double num, double den)
     return __builtin_fma(rem, r, q);
 }
 
+// x + x for a positive normal double far from overflow (the iteration's x' = x * 2^-s, doubled at most ~60
+// times): one integer add on the exponent field -- a 2-cycle op instead of a 4-cycle v_add_f64, same bits.
+__device__ __forceinline__ double twice(double x)
+{
+    return __longlong_as_double(__double_as_longlong(x) + (1ll << 52));
+}
+
 // lo_hint/hi_hint: a range known to contain every non-empty bin; `raw(v)` may be called only for
 // v in [lo_hint, hi_hint] and skips the bounds test that `c(v)` performs (the iteration's
 // count reads all fall in that range).  The next count is fetched one step ahead so the LDS
@@ -125,34 +132,38 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     const double a = z + (double)c0;
     const double mPrime = (double)(int)(m - c0);
     double gprev = z + ldexp((double)cq1, -q);
-    double x = gprev <= 1.5 * a ? mPrime / (0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
+    double x = gprev <= 1.5 * a ? div_normal(mPrime, 0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
     gprev = 0.;
     double deltaX = x;
-    const double relerr = 1e-2 / sqrt((double)m);
+    // sqrt(2^p) without the sqrt sequence: 2^(p/2), times the correctly rounded sqrt(2) for odd p (a power-of-two
+    // scaling keeps it the correctly rounded root, i.e. what sqrt() returns)
+    const double relerr = 1e-2 / ldexp((p & 1) ? 0x1.6a09e667f3bcdp+0 : 1.0, p >> 1);
     while (deltaX > x * relerr) {
         int kappaMinus1;
         (void)frexp(x, &kappaMinus1);
         const int sh = kMaxPrime + 1 > kappaMinus1 + 2 ? kMaxPrime + 1 : kappaMinus1 + 2;
         double xPrime = ldexp(x, -sh);
         const double xPrime2 = xPrime * xPrime;
-        double h = xPrime - xPrime2 / 3. + (xPrime2 * xPrime2) * (1. / 45. - xPrime2 / 472.5);
+        double h = xPrime - div_normal(xPrime2, 3.) + (xPrime2 * xPrime2) * (1. / 45. - div_normal(xPrime2, 472.5));
         for (int k = kappaMinus1; k >= kMaxPrime; --k) {
             const double hPrime = 1. - h;
             h = (xPrime + h * hPrime) / (xPrime + hPrime);
-            xPrime += xPrime;
+            xPrime = twice(xPrime);
         }
         double g = (double)cPrime * h;
+        // the count of the NEXT step is read one step ahead, unconditionally: below kMinPrime that is one bin
+        // under the range (never used; `raw` must tolerate the read -- an LDS column / array slot below its start)
         uint32_t cnext = kMaxPrime - 1 >= kMinPrime ? raw(kMaxPrime - 1) : 0u;
         for (int k = kMaxPrime - 1; k >= kMinPrime; --k) {
             const double ck = (double)cnext;
-            if (k > kMinPrime) cnext = raw(k - 1);
+            cnext = raw(k - 1);
             const double hPrime = 1. - h;
             h = div_normal(xPrime + h * hPrime, xPrime + hPrime);
-            xPrime += xPrime;
+            xPrime = twice(xPrime);
             g += ck * h;
         }
         g += x * a;
-        if (gprev < g && g <= mPrime) deltaX *= (g - mPrime) / (gprev - g);
+        if (gprev < g && g <= mPrime) deltaX *= div_normal(g - mPrime, gprev - g);
         else deltaX = 0.;
         x += deltaX;
         gprev = g;
