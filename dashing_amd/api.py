@@ -21,7 +21,7 @@ _LIB = None
 SYMBOLS = [
     "dsh_backend_name", "dsh_device_count", "dsh_create", "dsh_destroy", "dsh_last_error",
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches", "dsh_copy_sketches_device",
-    "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_device",
+    "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_async", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
@@ -65,6 +65,7 @@ def load_library():
     lib.dsh_copy_sketches_device.argtypes = [vp, u64, u64, vp]
     lib.dsh_attach_device_sketches.argtypes = [vp, vp, u64, i32]
     lib.dsh_sketch_batch.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32, vp]
+    lib.dsh_sketch_batch_async.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
     lib.dsh_sketch_batch_device.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
     lib.dsh_clear_sketches.argtypes = [vp, u64, u64]
     lib.dsh_cardinalities.argtypes = [vp, i32, vp]
@@ -228,6 +229,12 @@ class Context:
             self._h, seq.ctypes.data if seq.size else None, off.ctypes.data, ng, first_slot, k,
             int(bool(canon)), out.ctypes.data if want_regs else None))
         return out
+
+    def sketch_batch_async(self, seq_pinned, genome_off, first_slot=0, k=31, canon=True):
+        """seq_pinned: numpy view of PinnedArray memory; complete after wait()"""
+        off = np.ascontiguousarray(genome_off, np.uint64)
+        self._ck(self._lib.dsh_sketch_batch_async(
+            self._h, seq_pinned.ctypes.data, off.ctypes.data, off.size - 1, first_slot, k, int(bool(canon))))
 
     def sketch_batch_device(self, seq_ptr, genome_off, first_slot=0, k=31, canon=True):
         off = np.ascontiguousarray(genome_off, np.uint64)

@@ -90,6 +90,9 @@ struct dsh_ctx {
     size_t pin_perm_cap = 0;
     std::vector<uint8_t> blk_T, blk_lo; // per 128-column block: max threshold, min register value
     std::vector<uint4> hitems;
+    PinBuf pin_work;                    // sketch work list of the call in flight
+    hipEvent_t ev_work = nullptr;
+    bool work_in_flight = false;
     PinBuf pin_lists;                   // tiles then items of the call in flight
     hipEvent_t ev_lists = nullptr;      // recorded after their upload; waited on before they are rewritten
     bool lists_in_flight = false;
@@ -649,6 +652,8 @@ void dsh_destroy(dsh_ctx *c)
     c->excv.release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
     c->pin_lists.release();
+    c->pin_work.release();
+    if (c->ev_work) (void)hipEventDestroy(c->ev_work);
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
     if (c->ev_perm) (void)hipEventDestroy(c->ev_perm);
     c->keys.release();
@@ -789,12 +794,22 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
         }
     }
     if (work.empty()) return DSH_OK;
+    // the work list travels through page-locked staging (rewritten only after its previous upload has run),
+    // so nothing here waits: the blocking entry points synchronise, dsh_sketch_batch_async returns
+    if (c->work_in_flight) {
+        HIPCHK(c, hipEventSynchronize(c->ev_work));
+        c->work_in_flight = false;
+    }
+    HIPCHK(c, c->pin_work.ensure(work.size() * sizeof(SketchWork)));
+    std::memcpy(c->pin_work.ptr, work.data(), work.size() * sizeof(SketchWork));
     HIPCHK(c, c->workbuf.ensure(work.size() * sizeof(SketchWork)));
-    HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, work.data(), work.size() * sizeof(SketchWork),
+    HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, c->pin_work.ptr, work.size() * sizeof(SketchWork),
                              hipMemcpyHostToDevice, c->stream));
+    if (!c->ev_work) HIPCHK(c, hipEventCreateWithFlags(&c->ev_work, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_work, c->stream));
+    c->work_in_flight = true;
     HIPCHK(c, launch_sketch(c->stream, d_seq, (const SketchWork *)c->workbuf.ptr,
                             (uint32_t)work.size(), k, c->p, canon, (uint8_t *)c->regs_own.ptr));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // `work` (pageable source) must outlive the copy
     return DSH_OK;
 }
 
@@ -809,8 +824,8 @@ static int sketch_check(dsh_ctx *c, const uint64_t *genome_off, uint32_t n_genom
     return DSH_OK;
 }
 
-int dsh_sketch_batch(dsh_ctx *c, const uint8_t *seq, const uint64_t *genome_off, uint32_t n_genomes,
-                     uint64_t first_slot, int k, int canon, uint8_t *regs_out)
+int dsh_sketch_batch_async(dsh_ctx *c, const uint8_t *seq, const uint64_t *genome_off, uint32_t n_genomes,
+                           uint64_t first_slot, int k, int canon)
 {
     int rc = sketch_check(c, genome_off, n_genomes, first_slot, k);
     if (rc) return rc;
@@ -832,6 +847,15 @@ int dsh_sketch_batch(dsh_ctx *c, const uint8_t *seq, const uint64_t *genome_off,
     rc = sketch_common(c, (const uint8_t *)c->seqbuf.ptr, off.data(), n_genomes, first_slot, k, canon);
     if (rc) return rc;
     invalidate(c);
+    return DSH_OK;
+}
+
+int dsh_sketch_batch(dsh_ctx *c, const uint8_t *seq, const uint64_t *genome_off, uint32_t n_genomes,
+                     uint64_t first_slot, int k, int canon, uint8_t *regs_out)
+{
+    int rc = dsh_sketch_batch_async(c, seq, genome_off, n_genomes, first_slot, k, canon);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (a pageable `seq` was copied synchronously anyway)
     if (regs_out) return dsh_download_sketches(c, first_slot, n_genomes, regs_out);
     return DSH_OK;
 }
@@ -847,6 +871,7 @@ int dsh_sketch_batch_device(dsh_ctx *c, const void *d_seq, const uint64_t *genom
     rc = sketch_common(c, (const uint8_t *)d_seq, genome_off, n_genomes, first_slot, k, canon);
     if (rc) return rc;
     invalidate(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DSH_OK;
 }
 

@@ -11,6 +11,9 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
+#include <future>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -189,25 +192,110 @@ static Opts parse(int argc, char **argv, bool is_dist)
     return o;
 }
 
-// Hot loop 1 for genomes [g0,g1): cache hit -> read .hll; else parse FASTA on host threads and
-// sketch on the GPU in batches of <= batch_bytes of sequence.
-static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool skip_cached, bool load_cached = false)
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static const bool g_timing = std::getenv("DSH_TIMING") != nullptr;  // phase times on stderr
+
+static const size_t kSketchBatchBytes = (size_t)128 << 20;  // file bytes per sketching batch
+
+// The GPU context is created on its own thread while the host already parses the first batch: bringing the HIP
+// runtime up costs ~0.2 s, as much as reading a gigabase of FASTA on 16 threads.
+struct CtxFuture {
+    std::promise<dsh_ctx *> ready;
+    std::future<dsh_ctx *> fut;
+    std::future<void> done;  // the context thread itself (it goes on to allocate the staging buffers)
+    dsh_ctx *ctx = nullptr;
+    uint8_t *stage[2] = {nullptr, nullptr};  // page-locked staging for fill_sketches, allocated on the ctx thread too
+    size_t stage_cap = 0;
+    CtxFuture(int device, size_t n, int S, size_t staging_bytes = 0)
+    {
+        fut = ready.get_future();
+        done = std::async(std::launch::async, [this, device, n, S, staging_bytes]() {
+            const double t0 = now_s();
+            dsh_ctx *c = nullptr;
+            if (int rc = dsh_create(device, &c)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
+            DSH(c, dsh_sketches_alloc(c, n, S));
+            ready.set_value(c);  // the main thread may use the context from here on
+            const double t1 = now_s();
+            if (staging_bytes) {
+                for (auto &b : stage)
+                    if (!(b = (uint8_t *)dsh_alloc_host(staging_bytes))) die("could not allocate %zu bytes of pinned host memory", staging_bytes);
+                stage_cap = staging_bytes;
+            }
+            if (g_timing) std::fprintf(stderr, "[timing] on the context thread: dsh_create + alloc %.3f s, pinned staging %.3f s\n", t1 - t0, now_s() - t1);
+        });
+    }
+    dsh_ctx *get()
+    {
+        if (!ctx) ctx = fut.get();
+        return ctx;
+    }
+    void wait_staging()
+    {
+        if (done.valid()) done.get();
+    }
+    ~CtxFuture()
+    {
+        wait_staging();
+        for (auto &b : stage)
+            if (b) dsh_free_host(b);
+    }
+};
+
+// Hot loop 1 (src/sketch_and_cmp.h:314-360, 484-528) as a stream: genomes are taken in batches of <= ~128 MB of
+// file bytes; a batch is parsed on the host threads STRAIGHT INTO page-locked staging (every genome has its
+// region reserved from the file sizes; what the headers and newlines leave over is filled with 'N'), then
+// copied and sketched asynchronously (dsh_sketch_batch_async) while the next batch is parsed into the other
+// staging buffer.  Cache hits (-W / sketch -c) read the .hll instead; .hll files of a batch are written after its
+// kernel has run, again overlapped with the next batch.
+static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool skip_cached, bool load_cached = false)
 {
     const size_t n = o.inpaths.size();
     const size_t m = (size_t)1 << o.S;
-    const size_t batch_bytes = (size_t)512 << 20;
-    std::vector<uint8_t> row(m);
-    uint8_t *pin = nullptr;  // page-locked staging buffer for a batch of sequence, reused
-    size_t pin_cap = 0;
-    size_t g = 0;
+    const size_t batch_bytes = kSketchBatchBytes;
+    // staging: the FIRST batch is parsed into pageable memory (the HIP runtime is still coming up on the context
+    // thread, and page-locking memory needs it); later batches alternate between the two page-locked buffers
+    // that thread allocated meanwhile
+    uint8_t *pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    std::unique_ptr<uint8_t[]> first_stage;  // uninitialised: the parsing threads touch its pages first
+    struct Done {  // a batch whose kernel is in flight / finished: what is left to do on the host
+        std::vector<size_t> slots;
+        std::vector<std::string> fnames;
+    } pending;
+    auto finish = [&](dsh_ctx *ctx) {  // after dsh_wait: write the .hll files of the previous batch
+        if (!write_files || pending.slots.empty()) {
+            pending.slots.clear();
+            pending.fnames.clear();
+            return;
+        }
+        std::vector<uint8_t> rows(pending.slots.size() * m);
+        size_t r0 = 0;
+        while (r0 < pending.slots.size()) {  // consecutive slots in one download
+            size_t r1 = r0 + 1;
+            while (r1 < pending.slots.size() && pending.slots[r1] == pending.slots[r1 - 1] + 1) ++r1;
+            DSH(ctx, dsh_download_sketches(ctx, pending.slots[r0], r1 - r0, rows.data() + r0 * m));
+            r0 = r1;
+        }
+#pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
+        for (long t = 0; t < (long)pending.slots.size(); ++t)
+            if (write_hll(pending.fnames[t], rows.data() + (size_t)t * m, o.S, o.estim, o.estim, false, 0.0)) die("Could not write %s", pending.fnames[t].c_str());
+        pending.slots.clear();
+        pending.fnames.clear();
+    };
+    size_t g = 0, bi = 0;
     while (g < n) {
-        // decide the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
+        const double t_b0 = now_s();
+        // the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
         size_t e = g, bytes = 0;
         while (e < n && (e == g || bytes + genome_file_size(o.inpaths[e]) <= batch_bytes)) bytes += genome_file_size(o.inpaths[e++]);
         const size_t nb = e - g;
-        std::vector<std::vector<uint8_t>> seqs(nb);
-        std::vector<int> cached(nb, 0);
+        std::vector<int> cached(nb, 0), gz(nb, 0);
         std::vector<std::string> fnames(nb);
+        std::vector<std::vector<std::string>> files(nb);
+        std::vector<std::vector<uint8_t>> zseq(nb);  // gzip'ed genomes only: their size is not known from the file
 #pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
         for (long i = 0; i < (long)nb; ++i) {
             const std::string &entry = o.inpaths[g + i];
@@ -216,80 +304,118 @@ static void fill_sketches(dsh_ctx *ctx, const Opts &o, bool write_files, bool sk
                 cached[i] = 1;
                 continue;
             }
-            for (const auto &f : split_genome_paths(entry)) {
-                if (!seqs[i].empty()) seqs[i].push_back('N');
-                if (append_fastx(f, seqs[i]) < 0) die("Could not open %s", f.c_str());
-            }
+            files[i] = split_genome_paths(entry);
+            for (const auto &f : files[i]) gz[i] |= is_gzip_file(f) ? 1 : 0;
+            if (gz[i])
+                for (const auto &f : files[i]) {
+                    if (!zseq[i].empty()) zseq[i].push_back('N');
+                    if (append_fastx(f, zseq[i]) < 0) die("Could not open %s", f.c_str());
+                }
         }
-        // upload cached sketches; lay the parsed genomes out back to back ('N' after each) in one
-        // page-locked buffer (parallel copies) so the host->device transfer is a single direct DMA
+        // regions of the staging buffer: file bytes (an upper bound of the sequence bytes) + one separator per
+        // file, rounded up to 32
         std::vector<uint64_t> off;
         std::vector<size_t> slot_of, src_of;
         uint64_t tot = 0;
         for (size_t i = 0; i < nb; ++i) {
-            if (cached[i]) {
-                if (skip_cached && !load_cached) continue;  // `sketch -c`: nothing to do for this genome
-                int p = 0;
-                std::vector<uint8_t> r;
-                if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
-                DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
-            } else {
-                off.push_back(tot);
-                tot += seqs[i].size() + 1;
-                slot_of.push_back(g + i);
-                src_of.push_back(i);
-            }
+            if (cached[i]) continue;
+            const uint64_t need = gz[i] ? zseq[i].size() + 1 : genome_file_size(o.inpaths[g + i]) + files[i].size() + 1;
+            off.push_back(tot);
+            tot += (need + 31) & ~(uint64_t)31;
+            slot_of.push_back(g + i);
+            src_of.push_back(i);
         }
         off.push_back(tot);
-        if (!slot_of.empty()) {
-            if (tot > pin_cap) {
-                dsh_free_host(pin);
-                pin_cap = tot + (tot >> 3);
-                if (!(pin = (uint8_t *)dsh_alloc_host(pin_cap))) die("could not allocate %zu bytes of pinned host memory", pin_cap);
+        uint8_t *buf = nullptr;
+        if (bi == 0) {
+            first_stage.reset(new uint8_t[std::max<uint64_t>(tot, 1)]);
+            buf = first_stage.get();
+        } else {
+            if (bi <= 2 && !pin[bi & 1]) {  // adopt the buffers the context thread prepared
+                cf.wait_staging();
+                pin[bi & 1] = cf.stage[bi & 1];
+                cf.stage[bi & 1] = nullptr;
+                pin_cap[bi & 1] = pin[bi & 1] ? cf.stage_cap : 0;
             }
+            if (tot > pin_cap[bi & 1]) {  // (this buffer's previous batch completed at the dsh_wait of the last iteration)
+                if (pin[bi & 1]) dsh_free_host(pin[bi & 1]);
+                pin_cap[bi & 1] = tot + (tot >> 4);
+                if (!(pin[bi & 1] = (uint8_t *)dsh_alloc_host(pin_cap[bi & 1]))) die("could not allocate %zu bytes of pinned host memory", pin_cap[bi & 1]);
+            }
+            buf = pin[bi & 1];
+        }
+        const double t_alloc = now_s();
 #pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
-            for (long t = 0; t < (long)slot_of.size(); ++t) {
-                std::vector<uint8_t> &sv = seqs[src_of[t]];
-                if (!sv.empty()) std::memcpy(pin + off[t], sv.data(), sv.size());
-                pin[off[t] + sv.size()] = 'N';  // an invalid base closes every span: harmless
-                std::vector<uint8_t>().swap(sv);
-            }
-            // consecutive runs of slots go in one call each
-            size_t r0 = 0;
-            while (r0 < slot_of.size()) {
-                size_t r1 = r0 + 1;
-                while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
-                DSH(ctx, dsh_sketch_batch(ctx, pin, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon, nullptr));
-                r0 = r1;
-            }
-            if (write_files) {
-                for (size_t t = 0; t < slot_of.size(); ++t) {
-                    DSH(ctx, dsh_download_sketches(ctx, slot_of[t], 1, row.data()));
-                    const std::string &fn = fnames[slot_of[t] - g];
-                    if (write_hll(fn, row.data(), o.S, o.estim, o.estim, false, 0.0)) die("Could not write %s", fn.c_str());
+        for (long t = 0; t < (long)slot_of.size(); ++t) {
+            const size_t i = src_of[t];
+            uint8_t *dst = buf + off[t];
+            const size_t cap = (size_t)(off[t + 1] - off[t]);
+            size_t len = 0;
+            if (gz[i]) {
+                if (!zseq[i].empty()) std::memcpy(dst, zseq[i].data(), zseq[i].size());
+                len = zseq[i].size();
+                std::vector<uint8_t>().swap(zseq[i]);
+            } else {
+                for (const auto &f : files[i]) {
+                    if (len) dst[len++] = 'N';
+                    const long rc = append_fastx_into(f, dst, cap, len);
+                    if (rc == -1) die("Could not open %s", f.c_str());
+                    if (rc == -2) die("%s grew while it was being read", f.c_str());
                 }
             }
+            std::memset(dst + len, 'N', cap - len);  // invalid bases close every span: no k-mer, harmless
         }
+        const double t_parsed = now_s();
+        dsh_ctx *ctx = cf.get();
+        DSH(ctx, dsh_wait(ctx));  // the previous batch has been sketched: its staging buffer is free, its rows are final
+        finish(ctx);
+        for (size_t i = 0; i < nb; ++i) {
+            if (!cached[i] || (skip_cached && !load_cached)) continue;  // `sketch -c`: nothing to do for a cached genome
+            int p = 0;
+            std::vector<uint8_t> r;
+            if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
+            DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
+        }
+        size_t r0 = 0;
+        while (r0 < slot_of.size()) {  // consecutive runs of slots go in one call each
+            size_t r1 = r0 + 1;
+            while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
+            DSH(ctx, dsh_sketch_batch_async(ctx, buf, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon));
+            r0 = r1;
+        }
+        for (size_t t = 0; t < slot_of.size(); ++t) {
+            pending.slots.push_back(slot_of[t]);
+            pending.fnames.push_back(fnames[src_of[t]]);
+        }
+        if (g_timing)
+            std::fprintf(stderr, "[timing] batch %zu: %zu genomes, %.1f MB staged: pinned alloc %.3f s, parse into staging %.3f s, wait+enqueue %.3f s\n",
+                         bi, nb, tot / 1e6, t_alloc - t_b0, t_parsed - t_alloc, now_s() - t_parsed);
         g = e;
+        ++bi;
     }
-    dsh_free_host(pin);
+    dsh_ctx *ctx = cf.get();
+    DSH(ctx, dsh_wait(ctx));
+    finish(ctx);
+    for (auto &b : pin)
+        if (b) dsh_free_host(b);  // (buffers never adopted are freed by the CtxFuture)
 }
 
 static int sketch_main(int argc, char **argv)
 {
     Opts o = parse(argc, argv, false);
     if (!o.avoid_sorting) sort_paths_by_fsize(o.inpaths);  // src/dashing.cpp:356-357
-    dsh_ctx *ctx = nullptr;
-    if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
-    DSH(ctx, dsh_sketches_alloc(ctx, o.inpaths.size(), o.S));
+    CtxFuture cf(o.device, o.inpaths.size(), o.S, kSketchBatchBytes + (kSketchBatchBytes >> 3));
     const std::string &output_file = o.out_sizes;  // `sketch -o FILE` (src/dashing.cpp:307-337)
+    dsh_ctx *ctx = nullptr;
     if (output_file.empty()) {
-        fill_sketches(ctx, o, /*write_files=*/true, /*skip_cached=*/o.skip_cached != 0);
+        fill_sketches(cf, o, /*write_files=*/true, /*skip_cached=*/o.skip_cached != 0);
+        ctx = cf.get();
     } else {
         // all sketches into ONE gz stream + "<FILE>.labels.gz" (src/sketch_and_cmp.h:466-475,529-536);
         // with -c an existing per-genome .hll is read instead of re-sketched (:504-507)
         if (write_labels_gz(output_file + ".labels.gz", o.inpaths)) die("Failed to write sequence labels to file");
-        fill_sketches(ctx, o, /*write_files=*/false, /*skip_cached=*/o.skip_cached != 0, /*load_cached=*/true);
+        fill_sketches(cf, o, /*write_files=*/false, /*skip_cached=*/o.skip_cached != 0, /*load_cached=*/true);
+        ctx = cf.get();
         const size_t n = o.inpaths.size(), m = (size_t)1 << o.S;
         std::vector<uint8_t> all(n * m);
         DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
@@ -524,10 +650,12 @@ static int dist_main(int argc, char **argv)
     const size_t nq = o.querypaths.size();
     for (auto &q : o.querypaths) o.inpaths.push_back(q);  // queries follow the references (src/distmain.cpp:130-133)
     const size_t n = o.inpaths.size();
+    const double t_start = now_s();
+    CtxFuture cf(o.device, n, o.S, o.presketched ? 0 : kSketchBatchBytes + (kSketchBatchBytes >> 3));  // the HIP runtime comes up while the first batch is read
     dsh_ctx *ctx = nullptr;
-    if (int rc = dsh_create(o.device, &ctx)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
-    DSH(ctx, dsh_sketches_alloc(ctx, n, o.S));
+    const double t_fill0 = now_s();
     if (o.presketched) {  // sketch.read(path), src/sketch_and_cmp.h:318-324
+        ctx = cf.get();
         // read on all host threads into a staging matrix, upload in batches
         const size_t m = (size_t)1 << o.S, batch = std::max<size_t>(1, ((size_t)256 << 20) / m);
         std::vector<uint8_t> stage(std::min(n, batch) * m);
@@ -544,8 +672,10 @@ static int dist_main(int argc, char **argv)
             DSH(ctx, dsh_upload_sketches(ctx, stage.data(), b0, b1 - b0));
         }
     } else {
-        fill_sketches(ctx, o, /*write_files=*/o.cache != 0, false);
+        fill_sketches(cf, o, /*write_files=*/o.cache != 0, false);
+        ctx = cf.get();
     }
+    if (g_timing) std::fprintf(stderr, "[timing] all sketches resident after %.3f s\n", now_s() - t_fill0);
     // sizes (src/sketch_and_cmp.h:372-385)
     std::vector<double> card(std::max<size_t>(n, 1));
     DSH(ctx, dsh_cardinalities(ctx, o.estim, card.data()));
@@ -720,6 +850,7 @@ static int dist_main(int argc, char **argv)
     }
     std::fflush(pairofp);
     if (pairofp != stdout) std::fclose(pairofp);
+    if (g_timing) std::fprintf(stderr, "[timing] total since dsh_create %.3f s\n", now_s() - t_start);
     if (o.fmt == BINARY && !o.nneighbors) {  // src/distmain.cpp:191-200 (emit_fmt == BINARY exactly)
         const std::string labels = o.out_dists.empty() ? "unspecified" : o.out_dists + ".labels";
         if (write_labels(labels, o.inpaths)) die("Could not open file at '%s' for writing", labels.c_str());
@@ -730,6 +861,9 @@ static int dist_main(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
+    // idle OpenMP workers sleep instead of spinning: between the parallel regions the HIP runtime's own threads
+    // (start-up, copies) need the cores (must be set before the OpenMP runtime starts)
+    ::setenv("OMP_WAIT_POLICY", "passive", 0);
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
         std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  printmat              (binary distance matrix -> text)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;

@@ -2,6 +2,8 @@
 #include "host.h"
 
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -64,39 +66,69 @@ void sort_paths_by_fsize(std::vector<std::string> &paths)
     for (auto &p : ps) paths.emplace_back(std::move(p.second));
 }
 
-long append_fastx(const std::string &path, std::vector<uint8_t> &out)
-{
-    gzFile fp = gzopen(path.c_str(), "rb");
-    if (!fp) return -1;
-    gzbuffer(fp, 1 << 20);
-    std::vector<char> buf(1 << 20);
+namespace {
+
+struct VecSink {
+    std::vector<uint8_t> &out;
+    bool overflow = false;
+    void push(uint8_t b) { out.push_back(b); }
+    void append(const uint8_t *p, size_t len) { out.insert(out.end(), p, p + len); }
+};
+struct BufSink {  // caller-owned memory (page-locked staging): no growth, overflow is recorded
+    uint8_t *dst;
+    size_t cap, len = 0;
+    bool overflow = false;
+    void push(uint8_t b)
+    {
+        if (len < cap) dst[len++] = b;
+        else overflow = true;
+    }
+    void append(const uint8_t *p, size_t n)
+    {
+        if (len + n <= cap) {
+            std::memcpy(dst + len, p, n);
+            len += n;
+        } else {
+            overflow = true;
+        }
+    }
+};
+
+// FASTA/FASTQ state machine over a stream of text blocks: 0 = expect header, 1 = sequence lines, 2 = quality
+// lines; whole line pieces are handed to the sink at once (memchr for the newline), not byte by byte
+template <class Sink>
+struct FastxParser {
+    Sink &out;
     long nrec = 0;
-    // line-oriented state machine: 0 = expect header, 1 = sequence lines, 2 = quality lines;
-    // whole line pieces are appended at once (memchr for the newline), not byte by byte
     int state = 0;
     bool at_line_start = true, skipping_line = false;
     size_t seq_len = 0, qual_len = 0;
-    auto take = [&](const char *p, size_t len) {  // a piece of a line's content
+    explicit FastxParser(Sink &s) : out(s) {}
+    void take(const char *p, size_t len)  // a piece of a line's content
+    {
         if (skipping_line || len == 0) return;
         if (std::memchr(p, '\r', len)) {  // rare: strip carriage returns the slow way
             for (size_t t = 0; t < len; ++t) {
                 if (p[t] == '\r') continue;
-                if (state == 1) { out.push_back((uint8_t)p[t]); ++seq_len; }
-                else if (state == 2) ++qual_len;
+                if (state == 1) {
+                    out.push((uint8_t)p[t]);
+                    ++seq_len;
+                } else if (state == 2) {
+                    ++qual_len;
+                }
             }
             return;
         }
         if (state == 1) {
-            out.insert(out.end(), (const uint8_t *)p, (const uint8_t *)p + len);
+            out.append((const uint8_t *)p, len);
             seq_len += len;
         } else if (state == 2) {
             qual_len += len;
         }
-    };
-    int n;
-    while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+    }
+    void feed(const char *buf, size_t N)
+    {
         size_t i = 0;
-        const size_t N = (size_t)n;
         while (i < N) {
             if (at_line_start) {
                 const char c = buf[i];
@@ -107,7 +139,7 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out)
                 }
                 at_line_start = false;
                 if (state != 2 && (c == '>' || c == '@')) {  // new record header
-                    if (nrec) out.push_back('N');
+                    if (nrec) out.push('N');
                     ++nrec;
                     state = 1;
                     seq_len = qual_len = 0;
@@ -117,9 +149,9 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out)
                     skipping_line = true;
                 }
             }
-            const char *nl = (const char *)std::memchr(buf.data() + i, '\n', N - i);
-            const size_t e = nl ? (size_t)(nl - buf.data()) : N;
-            take(buf.data() + i, e - i);
+            const char *nl = (const char *)std::memchr(buf + i, '\n', N - i);
+            const size_t e = nl ? (size_t)(nl - buf) : N;
+            take(buf + i, e - i);
             if (nl) {
                 at_line_start = true;
                 skipping_line = false;
@@ -130,8 +162,62 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out)
             }
         }
     }
-    gzclose(fp);
+};
+
+template <class Sink>
+long parse_fastx(const std::string &path, Sink &sink)
+{
+    // plain text is read with read(2) (zlib's transparent mode copies every byte once more); gzip through zlib
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    FastxParser<Sink> ps(sink);
+    std::vector<char> buf(1 << 20);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        gzFile fp = gzdopen(fd, "rb");
+        if (!fp) {
+            ::close(fd);
+            return -1;
+        }
+        gzbuffer(fp, 1 << 20);
+        int n;
+        while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
+        gzclose(fp);
+        return ps.nrec;
+    }
+    ssize_t n;
+    while ((n = ::read(fd, buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
+    ::close(fd);
+    return ps.nrec;
+}
+
+}  // namespace
+
+long append_fastx(const std::string &path, std::vector<uint8_t> &out)
+{
+    VecSink s{out};
+    return parse_fastx(path, s);
+}
+
+long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len)
+{
+    BufSink s{dst + len, cap > len ? cap - len : 0};
+    const long nrec = parse_fastx(path, s);
+    if (nrec < 0) return nrec;
+    if (s.overflow) return -2;
+    len += s.len;
     return nrec;
+}
+
+bool is_gzip_file(const std::string &path)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    ::close(fd);
+    return got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
 }
 
 std::string make_fname(const std::string &path, unsigned sketch_p, int k, const std::string &spacing,

@@ -31,6 +31,10 @@ void sort_paths_by_fsize(std::vector<std::string> &paths);
 // separated by one 'N' (k-mers never span records, as with kseq records read one at a time by
 // Encoder::for_each, src/sketch_and_cmp.h:342).  Returns number of records, or -1 on open failure.
 long append_fastx(const std::string &path, std::vector<uint8_t> &out);
+// Same into caller-owned memory (e.g. page-locked staging): appends at dst[len...] and advances len; -2 if the
+// `cap` bytes would not hold it.  An uncompressed file never yields more sequence bytes than its size.
+long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len);
+bool is_gzip_file(const std::string &path);  // gzip magic 1f 8b
 
 // ---- .hll files (header layout is a best-effort restatement) --------
 // make_fname<hll_t> (src/dashing.h:497-526): "<prefix/><genome>.w.<k>.spacing<spacing>.[suf<x>.]<S>.hll"

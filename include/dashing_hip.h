@@ -92,6 +92,11 @@ int dsh_attach_device_sketches(dsh_ctx *ctx, const void *d_regs, uint64_t n, int
 int dsh_sketch_batch(dsh_ctx *ctx, const uint8_t *seq, const uint64_t *genome_off,
                      uint32_t n_genomes, uint64_t first_slot, int k, int canon,
                      uint8_t *regs_out);
+/* Asynchronous form: enqueues the host-to-device copy of `seq` (page-locked memory from dsh_alloc_host, else
+ * the copy is synchronous) and the kernel, and returns; dsh_wait(ctx) completes it.  `seq` must stay untouched
+ * until then.  A host that streams many genomes parses batch b+1 while batch b is copied and sketched. */
+int dsh_sketch_batch_async(dsh_ctx *ctx, const uint8_t *seq_pinned, const uint64_t *genome_off,
+                           uint32_t n_genomes, uint64_t first_slot, int k, int canon);
 /* Same with `seq` already on the device (d_seq device pointer; genome_off stays on the host). */
 int dsh_sketch_batch_device(dsh_ctx *ctx, const void *d_seq, const uint64_t *genome_off,
                             uint32_t n_genomes, uint64_t first_slot, int k, int canon);

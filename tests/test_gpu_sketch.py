@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import dashing_amd
 from dashing_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -128,3 +129,29 @@ def test_random_sketch_case(ctx, oracle, case):
         L = int(rng.choice([0, 1, k - 1, k, k + 1, 31, 32, 33, 63, 64, 65, 8191, 8192, 8193, int(rng.integers(0, 70000))]))
         genomes.append(alphabet[rng.choice(alphabet.size, size=max(L, 0), p=weights)].astype(np.uint8))
     run(ctx, oracle, genomes, k, p, canon)
+
+
+def test_async_batches_from_pinned_staging(ctx, oracle):
+    """dsh_sketch_batch_async: batches are enqueued back to back from page-locked staging (what the CLI's streaming
+    loader does while it parses the next batch) and complete at dsh_wait; a genome may be split across batches."""
+    k, p = 31, 12
+    gs = synth.synthetic_genomes(9, 40_000, seed=0xA5)
+    seq, off = synth.concat_for_device(gs)
+    want = oracle.sketch_batch(seq, off, k, p, True)
+    ctx.alloc(len(gs), p)
+    stage = [dashing_amd.PinnedArray(seq.size + 64, np.uint8) for _ in range(2)]
+    # batch A: genomes 0..4 ; batch B: genomes 5..8 -- each from its own staging buffer, offsets local to the buffer
+    cut = int(off[5])
+    stage[0].array[:cut] = seq[:cut]
+    stage[1].array[: seq.size - cut] = seq[cut:]
+    ctx.sketch_batch_async(stage[0].array, off[:6], 0, k, True)
+    ctx.sketch_batch_async(stage[1].array, off[5:] - np.uint64(cut), 5, k, True)
+    ctx.wait()
+    assert (ctx.download() == want).all()
+    # max-merge across asynchronous calls: the same genomes fed again in two halves change nothing
+    half = int(off[2]) + 20_000
+    oa = off[:4].copy()
+    oa[3] = half
+    ctx.sketch_batch_async(stage[0].array, oa, 0, k, True)
+    ctx.wait()
+    assert (ctx.download() == want).all()

@@ -207,6 +207,8 @@ if __name__ == "__main__":
         c3_cli_text()
     if "c2lite" in which:
         c2lite()
+    if "c2" in which:  # configs[1] at full size: 1 000 genomes of 5 Mbp
+        c2lite(n=1000)
     if "c3host" in which:
         c3_host()
     if "c1" in which:
