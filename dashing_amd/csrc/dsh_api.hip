@@ -243,6 +243,10 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
             c->hk32_valid = true;
         }
         const std::vector<uint32_t> &k32 = c->hk32;
+        for (uint64_t i = 0; i < n; ++i)
+            if (k32[i] & 0x80000000u)
+                return fail(c, DSH_EINVAL, "sketch %llu holds a register value above %d (= 64 - p + 1): not an HLL of precision %d (corrupt or foreign .hll?)",
+                            (unsigned long long)i, 64 - c->p + 1, c->p);
         c->hkeys.resize(n);
         // the plane matrix holds the sketches col0 .. n-1 (a row range [rb,re) of the triangle never looks at
         // sketches before rb); value range and thresholds are taken over those only
@@ -388,6 +392,7 @@ struct PairJob {
     int rect;
     int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
     int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
+    int ksinv_double = 0; // 1./k as a double (nndist_loop, src/sketch_and_cmp.h:729) instead of the float of dist_loop (:797)
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *d_out;
@@ -554,7 +559,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.emax = c->emax;
         f.estim = job.estim;
         f.result_type = job.result_type;
-        f.ksinv = (double)ksinv_f;
+        f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
         f.card = (const double *)c->card.ptr;
         f.n = c->n;
         f.ncols = c->ncols;
@@ -1098,6 +1103,7 @@ int dsh_knn(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t
             j.k = k;
             j.rect = 0;
             j.square = 1;
+            j.ksinv_double = 1;
             j.row_begin = 0;
             j.row_end = n;
             j.col_begin = 0;
@@ -1139,6 +1145,7 @@ int dsh_knn(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t
                 j.result_type = result_type;
                 j.k = k;
                 j.rect = 1;
+                j.ksinv_double = 1;
                 j.row_begin = q0;
                 j.row_end = q1;
                 j.col_begin = rb;

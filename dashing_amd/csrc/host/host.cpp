@@ -279,6 +279,11 @@ int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
         uint32_t np;
         std::memcpy(&np, all.data() + np_off, 4);
         if (np < 4 || np > 30 || ((size_t)1 << np) != m) return false;
+        // a register of a precision-np HLL is at most 64 - np + 1 (src/readfilt.cpp:86-88): anything larger is a
+        // corrupt file or the other header layout read at the wrong offset
+        const uint8_t lim = (uint8_t)(64 - (int)np + 1);
+        for (size_t t = hdr; t < all.size(); ++t)
+            if (all[t] > lim) return false;
         p = (int)np;
         regs.assign(all.begin() + hdr, all.end());
         return true;

@@ -71,12 +71,17 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         const uint64_t c = (uint64_t)k * 64 + lane;
         cache[k] = (s < n && c < nch) ? src[c] : make_uint4(0, 0, 0, 0);
     }
+    // registers above q+1 = 64-p+1 cannot come from the register rule (a corrupt or foreign .hll): they would alias
+    // into wrong histogram bins (& 63) and break the bit-planes (bytes >= 128); flagged in bit 31 of the key
+    uint32_t bad = 0;
+    const uint32_t limrep = (uint32_t)(64 - p + 2) * 0x01010101u;
     if (s < n) {
         uint32_t *mysub = sub[wave][lane & 7];
-        auto count16 = [mysub](const uint4 x) {
+        auto count16 = [mysub, limrep, &bad](const uint4 x) {
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                bad |= (w[k] | (((w[k] & 0x7F7F7F7Fu) | 0x80808080u) - limrep)) & 0x80808080u;  // byte >= 128, or >= q+2
                 atomicAdd(&mysub[w[k] & 63], 1u);
                 atomicAdd(&mysub[(w[k] >> 8) & 63], 1u);
                 atomicAdd(&mysub[(w[k] >> 16) & 63], 1u);
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         // same-address global atomics: 3 x N of them cost ~12 ns each) and sorts columns by the low 16 bits
         keys[s] = ((uint32_t)hi << 16) | ((uint32_t)T << 8) | (uint32_t)lo;
     }
+    if (s < n && __any(bad != 0) && lane == 0) atomicOr(&keys[s], 0x80000000u);  // (after lane 0's plain store above)
     __syncthreads();
     if (s >= n) return;
     // histogram of the listed registers (values above T_i), one byte per value: k_finalize starts a

@@ -461,12 +461,16 @@ double dsho_jaccard_from(double ca, double cb, double us)
     return (0. < ret) ? ret : 0.;
 }
 
+/* dist_loop and partdist_loop pass ksinv as a FLOAT (src/sketch_and_cmp.h:797, src/dashing.h:664); nndist_loop
+ * (--nearest-neighbors) keeps the DOUBLE 1./k (src/sketch_and_cmp.h:729).  dsho_knn raises this flag for its duration. */
+static int g_ksinv_double = 0;
+
 /* result_cmp for JI / MASH_DIST / FULL_MASH_DIST, src/dashing.h:568-592; ksinv is the
  * float 1./k promoted to double (src/sketch_and_cmp.h:797). */
 float dsho_result(double ji, int result_type, int k)
 {
     const float ksinv_f = (float)(1. / (double)k);
-    const double ksinv = (double)ksinv_f;
+    const double ksinv = g_ksinv_double ? 1. / (double)k : (double)ksinv_f;
     double ret = ji;
     if (result_type == DSHO_MASH_DIST) ret = ji ? -log(2. * ji / (1. + ji)) * ksinv : 1.;
     else if (result_type == DSHO_FULL_MASH_DIST) ret = 1. - pow(2. * ji / (1. + ji), ksinv);
@@ -482,7 +486,7 @@ static double max0(double x) { return x < 0. ? 0. : x; }
 float dsho_result_triple(double mys, double os, double us, int result_type, int k)
 {
     const float ksinv_f = (float)(1. / (double)k);
-    const double ksinv = (double)ksinv_f;
+    const double ksinv = g_ksinv_double ? 1. / (double)k : (double)ksinv_f;
     const double is = max0(mys + os - us);
     const double t0 = max0(mys - is), t1 = max0(os - is), t2 = is;
     double ret = t2;
@@ -618,6 +622,7 @@ void dsho_knn(const uint8_t *regs, uint64_t n, int p, int estim, int result_type
     const float worst = descending ? -INFINITY : INFINITY;
     double *card = (double *)malloc(sizeof(double) * (n ? n : 1));
     dsho_cardinalities(regs, n, p, estim, card);
+    g_ksinv_double = 1;  /* src/sketch_and_cmp.h:729 */
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads_())
     for (int64_t qi = (int64_t)qb; qi < (int64_t)qe; ++qi) {
         const uint64_t nr = re > rb ? re - rb : 0;
@@ -647,6 +652,7 @@ void dsho_knn(const uint8_t *regs, uint64_t n, int p, int estim, int result_type
         free(row);
         free(used);
     }
+    g_ksinv_double = 0;
     free(card);
 }
 

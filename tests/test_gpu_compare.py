@@ -417,6 +417,23 @@ def test_knn_all_vs_all_paths_agree(ctx, oracle, rt):
     assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
 
 
+def test_out_of_range_registers_are_refused(ctx):
+    """uploaded registers above 64 - p + 1 (corrupt / foreign sketches) make the compare entry points fail loudly
+    instead of aliasing into wrong histogram bins"""
+    p = 12
+    regs = synth.synthetic_sketches(40, p, seed=3)
+    for badval in (64 - p + 2, 100, 200, 255):
+        r = regs.copy()
+        r[17, 1234] = badval
+        ctx.set_sketches(r)
+        with pytest.raises(dashing_amd.DshError) as e:
+            ctx.dist_rows()
+        assert e.value.code == -22 and "sketch 17" in str(e.value)
+    regs[17, 1234] = 64 - p + 1  # the largest legal value is fine
+    ctx.set_sketches(regs)
+    assert np.isfinite(ctx.dist_rows()).all()
+
+
 def test_errors(ctx):
     with pytest.raises(dashing_amd.DshError):
         ctx.alloc(10, 3)

@@ -299,3 +299,19 @@ def test_cli_printmat(host, tmp_path):
     bad = tmp_path / "bad.bin"
     bad.write_bytes(b"\1" + struct.pack("<Q", n))
     assert subprocess.run([cli, "printmat", str(bad)], capture_output=True).returncode != 0
+
+
+def test_read_hll_rejects_out_of_range_registers(host, tmp_path):
+    """a register above 64 - p + 1 cannot come from the register rule (src/readfilt.cpp:86-88): refuse the file"""
+    p = 10
+    regs = np.zeros(1 << p, np.uint8)
+    regs[5] = 64 - p + 1  # the largest legal value
+    good = str(tmp_path / "good.hll")
+    assert host.dshh_write_hll(good.encode(), regs.ctypes.data, p, 2) == 0
+    out = np.zeros(1 << p, np.uint8)
+    pp = C.c_int()
+    assert host.dshh_read_hll(good.encode(), out.ctypes.data, out.size, C.byref(pp)) == 0 and pp.value == p
+    regs[7] = 64 - p + 2
+    bad = str(tmp_path / "bad.hll")
+    assert host.dshh_write_hll(bad.encode(), regs.ctypes.data, p, 2) == 0
+    assert host.dshh_read_hll(bad.encode(), out.ctypes.data, out.size, C.byref(pp)) != 0

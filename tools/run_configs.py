@@ -199,8 +199,54 @@ def c3_knn(n=10_000, p=14, nn=10):
     ctx.close()
 
 
+def unfriendly(n=10_000, p=14):
+    """C3-sized collections the headline workload is NOT: (a) cardinalities log-uniform over 1e4..1e8 (a RefSeq-like
+    spread: thresholds and minima differ a lot between sketches), (b) registers uniform over [0, q+1] (the adversary of
+    the thermometer planes: every value level is populated), (c) the bench workload for reference.  Records planes per
+    tile, pairs/s and the kernel split; a few rows are checked against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", 0)
+    cases = []
+    cards = np.exp(rng.uniform(np.log(1e4), np.log(1e8), n))
+    t0 = time.perf_counter()
+    cases.append(("log-uniform cardinalities 1e4..1e8", np.stack([synth.hll_registers(1000 + g, int(c), p) for g, c in enumerate(cards)])))
+    cases.append(("uniform registers 0..%d (adversary)" % (64 - p + 1), rng.integers(0, 64 - p + 2, size=(n, 1 << p)).astype(np.uint8)))
+    cases.append(("bench workload (cardinalities 2e6..8e6)", synth.survey_sketches(n, p, seed=0x5EED0000)[0]))
+    t_gen = time.perf_counter() - t0
+    oracle_c.load(threads=oracle_c.effective_cpus())
+    total = n * (n - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    ctx = dashing_amd.Context(0)
+    ctx.set_profiling(True)
+    for name, regs in cases:
+        regs_d = torch.from_numpy(regs).to(dev)
+        best = 1e9
+        for _ in range(3):
+            ctx.attach_device(regs_d.data_ptr(), n, p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.dist_rows_device(out.data_ptr(), 0, n)
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        k = ctx.last_kernel_ms()
+        worst = 0.0
+        for r in (0, n // 3, n - 2):
+            want = oracle_c.dist_rows(regs, r, r + 1)
+            lo = dashing_amd.tri_index(n, r, r + 1)
+            got = out[lo : lo + want.size].cpu().numpy()
+            worst = max(worst, float((np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-9)).max()))
+        print(json.dumps({"config": "%d sketches p=%d, %s" % (n, p, name), "seconds": best, "pairs_per_s": total / best,
+                          "kernel_ms": k, "dense_planes_global": ctx.info("planes"), "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100,
+                          "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")], "max_rel_diff_vs_oracle_3_rows": worst}))
+    ctx.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c4"]
+    if "unfriendly" in which:
+        unfriendly()
     if "c3knn" in which:
         c3_knn()
     if "c3cli" in which:
