@@ -2,6 +2,7 @@
 #include "host.h"
 
 #include <sys/stat.h>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -65,6 +66,153 @@ void sort_paths_by_fsize(std::vector<std::string> &paths)
     paths.clear();
     for (auto &p : ps) paths.emplace_back(std::move(p.second));
 }
+
+// ---- transparent input: plain, gzip (zlib) or zstd, by magic number -------------------------------------------
+// dashing reads every input through zlib's gz* API, which its build swaps for zstd's zlibWrapper (Makefile:58-62,
+// README.md:79): plain, gzip'ed and zstd-compressed files all work.  zstd ships here as a runtime library without
+// headers, so its streaming API (stable since 1.0) is declared by hand and bound with dlopen; a host without
+// libzstd.so.1 reports an error for .zst inputs only.
+namespace {
+
+struct ZstdIn {
+    const void *src;
+    size_t size, pos;
+};
+struct ZstdOut {
+    void *dst;
+    size_t size, pos;
+};
+struct ZstdApi {
+    void *(*createDStream)() = nullptr;
+    size_t (*freeDStream)(void *) = nullptr;
+    size_t (*initDStream)(void *) = nullptr;
+    size_t (*decompressStream)(void *, ZstdOut *, ZstdIn *) = nullptr;
+    unsigned (*isError)(size_t) = nullptr;
+    bool ok = false;
+    static const ZstdApi &get()
+    {
+        static const ZstdApi api = [] {
+            ZstdApi a;
+            void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return a;
+            a.createDStream = (void *(*)())dlsym(h, "ZSTD_createDStream");
+            a.freeDStream = (size_t(*)(void *))dlsym(h, "ZSTD_freeDStream");
+            a.initDStream = (size_t(*)(void *))dlsym(h, "ZSTD_initDStream");
+            a.decompressStream = (size_t(*)(void *, ZstdOut *, ZstdIn *))dlsym(h, "ZSTD_decompressStream");
+            a.isError = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+            a.ok = a.createDStream && a.freeDStream && a.initDStream && a.decompressStream && a.isError;
+            return a;
+        }();
+        return api;
+    }
+};
+
+class InStream {
+public:
+    enum Kind { CLOSED, PLAIN, GZIP, ZSTD };
+    // 0 on success, -ENOENT if the file cannot be opened, -ENOSYS for a zstd file on a host without libzstd
+    int open(const std::string &path)
+    {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) return -ENOENT;
+        unsigned char magic[4] = {0, 0, 0, 0};
+        const ssize_t got = ::pread(fd_, magic, 4, 0);
+        if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            gz_ = gzdopen(fd_, "rb");
+            if (!gz_) {
+                ::close(fd_);
+                fd_ = -1;
+                return -ENOENT;
+            }
+            gzbuffer(gz_, 1 << 20);
+            kind_ = GZIP;
+        } else if (got == 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD) {
+            const ZstdApi &z = ZstdApi::get();
+            if (!z.ok) {
+                ::close(fd_);
+                fd_ = -1;
+                return -ENOSYS;
+            }
+            zs_ = z.createDStream();
+            z.initDStream(zs_);
+            zin_.resize(1 << 17);
+            kind_ = ZSTD;
+        } else {
+            kind_ = PLAIN;
+        }
+        return 0;
+    }
+    Kind kind() const { return kind_; }
+    // up to n bytes; 0 at end of data, -1 on a read / decode error
+    ssize_t read(void *dst, size_t n)
+    {
+        if (kind_ == PLAIN) {
+            size_t done = 0;
+            while (done < n) {
+                const ssize_t r = ::read(fd_, (char *)dst + done, n - done);
+                if (r < 0) return -1;
+                if (r == 0) break;
+                done += (size_t)r;
+            }
+            return (ssize_t)done;
+        }
+        if (kind_ == GZIP) {
+            size_t done = 0;
+            while (done < n) {
+                const int r = gzread(gz_, (char *)dst + done, (unsigned)std::min<size_t>(n - done, 1u << 30));
+                if (r < 0) return -1;
+                if (r == 0) break;
+                done += (size_t)r;
+            }
+            return (ssize_t)done;
+        }
+        if (kind_ == ZSTD) {
+            const ZstdApi &z = ZstdApi::get();
+            ZstdOut out{dst, n, 0};
+            while (out.pos < out.size) {
+                if (zpos_ == zlen_ && !zeof_) {
+                    const ssize_t r = ::read(fd_, zin_.data(), zin_.size());
+                    if (r < 0) return -1;
+                    if (r == 0) zeof_ = true;
+                    zlen_ = (size_t)std::max<ssize_t>(r, 0);
+                    zpos_ = 0;
+                }
+                if (zpos_ == zlen_ && zeof_) break;
+                ZstdIn in{zin_.data(), zlen_, zpos_};
+                const size_t rc = z.decompressStream(zs_, &out, &in);
+                zpos_ = in.pos;
+                if (z.isError(rc)) return -1;
+            }
+            return (ssize_t)out.pos;
+        }
+        return -1;
+    }
+    void close()
+    {
+        if (kind_ == GZIP) gzclose(gz_);  // closes fd_ too
+        else if (fd_ >= 0) ::close(fd_);
+        if (zs_) ZstdApi::get().freeDStream(zs_);
+        zs_ = nullptr;
+        fd_ = -1;
+        kind_ = CLOSED;
+    }
+    ~InStream()
+    {
+        if (kind_ != CLOSED) close();
+    }
+
+private:
+    Kind kind_ = CLOSED;
+    int fd_ = -1;
+    gzFile gz_ = nullptr;
+    void *zs_ = nullptr;
+    std::vector<char> zin_;
+    size_t zpos_ = 0, zlen_ = 0;
+    bool zeof_ = false;
+};
+
+}  // namespace
 
 namespace {
 
@@ -167,29 +315,13 @@ struct FastxParser {
 template <class Sink>
 long parse_fastx(const std::string &path, Sink &sink)
 {
-    // plain text is read with read(2) (zlib's transparent mode copies every byte once more); gzip through zlib
-    const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return -1;
-    unsigned char magic[2] = {0, 0};
-    const ssize_t got = ::pread(fd, magic, 2, 0);
+    InStream in;  // plain text through read(2) (zlib's transparent mode copies every byte once more), gzip, zstd
+    if (in.open(path) != 0) return -1;
     FastxParser<Sink> ps(sink);
     std::vector<char> buf(1 << 20);
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-        gzFile fp = gzdopen(fd, "rb");
-        if (!fp) {
-            ::close(fd);
-            return -1;
-        }
-        gzbuffer(fp, 1 << 20);
-        int n;
-        while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
-        gzclose(fp);
-        return ps.nrec;
-    }
     ssize_t n;
-    while ((n = ::read(fd, buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
-    ::close(fd);
-    return ps.nrec;
+    while ((n = in.read(buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
+    return n < 0 ? -1 : ps.nrec;
 }
 
 }  // namespace
@@ -214,10 +346,11 @@ bool is_gzip_file(const std::string &path)
 {
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
-    unsigned char magic[2] = {0, 0};
-    const ssize_t got = ::pread(fd, magic, 2, 0);
+    unsigned char magic[4] = {0, 0, 0, 0};
+    const ssize_t got = ::pread(fd, magic, 4, 0);
     ::close(fd);
-    return got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    return (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) ||
+           (got == 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD);
 }
 
 std::string make_fname(const std::string &path, unsigned sketch_p, int k, const std::string &spacing,
@@ -265,13 +398,13 @@ int write_hll(const std::string &path, const uint8_t *regs, int p, int estim, in
 
 int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
 {
-    gzFile fp = gzopen(path.c_str(), "rb");
-    if (!fp) return -ENOENT;
+    InStream fp;
+    if (int rc = fp.open(path)) return rc;
     std::vector<uint8_t> all;
     uint8_t buf[1 << 16];
-    int n;
-    while ((n = gzread(fp, buf, sizeof buf)) > 0) all.insert(all.end(), buf, buf + n);
-    gzclose(fp);
+    ssize_t n;
+    while ((n = fp.read(buf, sizeof buf)) > 0) all.insert(all.end(), buf, buf + n);
+    fp.close();
     auto try_layout = [&](size_t hdr, size_t np_off) -> bool {
         if (all.size() <= hdr) return false;
         const size_t m = all.size() - hdr;
@@ -320,35 +453,24 @@ int write_hll_multi(const std::string &path, const uint8_t *regs, size_t n, int 
 
 int read_hll_multi(const std::string &path, std::vector<uint8_t> &regs, int &p, size_t &n)
 {
-    gzFile fp = gzopen(path.c_str(), "rb");
-    if (!fp) return -ENOENT;
+    InStream fp;
+    if (int rc = fp.open(path)) return rc;
     regs.clear();
     n = 0;
     p = -1;
     for (;;) {
         uint8_t hdr[28];
-        const int got = gzread(fp, hdr, sizeof hdr);
+        const ssize_t got = fp.read(hdr, sizeof hdr);
         if (got == 0) break;
         uint32_t np;
         std::memcpy(&np, hdr + 16, 4);
-        if (got != (int)sizeof hdr || np < 4 || np > 30 || (p >= 0 && (int)np != p)) {
-            gzclose(fp);
-            return -EINVAL;
-        }
+        if (got != (ssize_t)sizeof hdr || np < 4 || np > 30 || (p >= 0 && (int)np != p)) return -EINVAL;
         p = (int)np;
         const size_t m = (size_t)1 << p, at = regs.size();
         regs.resize(at + m);
-        for (size_t off = 0; off < m;) {
-            const int r = gzread(fp, regs.data() + at + off, (unsigned)std::min<size_t>(m - off, (size_t)1 << 30));
-            if (r <= 0) {
-                gzclose(fp);
-                return -EINVAL;
-            }
-            off += (size_t)r;
-        }
+        if (fp.read(regs.data() + at, m) != (ssize_t)m) return -EINVAL;
         ++n;
     }
-    gzclose(fp);
     return n ? 0 : -EINVAL;
 }
 

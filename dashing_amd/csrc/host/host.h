@@ -27,14 +27,15 @@ uint64_t genome_file_size(const std::string &entry);
 // a stable sort so equal sizes keep their input order.
 void sort_paths_by_fsize(std::vector<std::string> &paths);
 
-// Append the sequence of every record of a FASTA/FASTQ file (plain or gzip) to `out`, records
+// Append the sequence of every record of a FASTA/FASTQ file (plain, gzip or zstd -- by magic number, as dashing's
+// zlib/zstd wrapper does, README.md:79) to `out`, records
 // separated by one 'N' (k-mers never span records, as with kseq records read one at a time by
 // Encoder::for_each, src/sketch_and_cmp.h:342).  Returns number of records, or -1 on open failure.
 long append_fastx(const std::string &path, std::vector<uint8_t> &out);
 // Same into caller-owned memory (e.g. page-locked staging): appends at dst[len...] and advances len; -2 if the
 // `cap` bytes would not hold it.  An uncompressed file never yields more sequence bytes than its size.
 long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len);
-bool is_gzip_file(const std::string &path);  // gzip magic 1f 8b
+bool is_gzip_file(const std::string &path);  // compressed input: gzip (1f 8b) or zstd (28 b5 2f fd) magic
 
 // ---- .hll files (header layout is a best-effort restatement) --------
 // make_fname<hll_t> (src/dashing.h:497-526): "<prefix/><genome>.w.<k>.spacing<spacing>.[suf<x>.]<S>.hll"

@@ -15,6 +15,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "dashing_amd", "dashing-amd")
 
 
+def _zstd(data):
+    import ctypes as C
+
+    try:
+        z = C.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    cap = z.ZSTD_compressBound(len(data))
+    dst = C.create_string_buffer(cap)
+    return dst.raw[: z.ZSTD_compress(dst, cap, data, len(data), 3)]
+
+
 def run(*args, cwd=None):
     r = subprocess.run([CLI] + [str(a) for a in args], cwd=cwd, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
@@ -39,6 +55,9 @@ def genomes(tmp_path_factory):
             p = d / "g5.fna.gz"
             with gzip.open(p, "wb") as f:
                 f.write(fa)
+        elif i == 6 and _zstd(fa) is not None:  # zstd input, transparent like gzip (README.md:79 of the reference)
+            p = d / "g6.fna.zst"
+            p.write_bytes(_zstd(fa))
         else:
             p.write_bytes(fa)
         paths.append(str(p))

@@ -81,8 +81,8 @@ def test_hll_roundtrip_and_layouts(host, tmp_path):
     assert host.dshh_read_hll(b"/nonexistent.hll", out.ctypes.data, out.size, C.byref(pp)) != 0
 
 
-def parse(host, path):
-    buf = np.zeros(1 << 16, np.uint8)
+def parse(host, path, cap=1 << 16):
+    buf = np.zeros(cap, np.uint8)
     n = C.c_size_t()
     rc = host.dshh_append_fastx(path.encode(), buf.ctypes.data, buf.size, C.byref(n))
     return rc, buf[: n.value].tobytes()
@@ -315,3 +315,55 @@ def test_read_hll_rejects_out_of_range_registers(host, tmp_path):
     bad = str(tmp_path / "bad.hll")
     assert host.dshh_write_hll(bad.encode(), regs.ctypes.data, p, 2) == 0
     assert host.dshh_read_hll(bad.encode(), out.ctypes.data, out.size, C.byref(pp)) != 0
+
+
+def _zstd_compress(data, level=3):
+    """frame made with the host's libzstd (the same runtime library the product binds with dlopen); None if absent"""
+    try:
+        z = C.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    cap = z.ZSTD_compressBound(len(data))
+    dst = C.create_string_buffer(cap)
+    n = z.ZSTD_compress(dst, cap, data, len(data), level)
+    assert n <= cap
+    return dst.raw[:n]
+
+
+def test_zstd_inputs_are_transparent(host, tmp_path):
+    """dashing reads inputs through zstd's zlibWrapper (Makefile:58-62, README.md:79): .zst FASTA and .hll files work
+    like plain and gzip'ed ones (detected by magic number, not by extension)"""
+    text = b">r1 desc\nACGT\nacgtN\n\n>r2\nGGGG\r\nCC\n" + b">big\n" + b"ACGTTGCA" * 40000 + b"\n"
+    frame = _zstd_compress(text)
+    if frame is None:
+        pytest.skip("no libzstd.so.1 on this host")
+    plain = tmp_path / "a.fa"
+    plain.write_bytes(text)
+    zst = tmp_path / "a.fa.zst"
+    zst.write_bytes(frame)
+    assert parse(host, str(zst), 1 << 20) == parse(host, str(plain), 1 << 20)
+    assert parse(host, str(zst), 1 << 20)[0] == 3
+    # two frames back to back decode as their concatenation (as `cat a.zst b.zst` does)
+    two = tmp_path / "two.zst"
+    two.write_bytes(_zstd_compress(b">x\nAC\n") + _zstd_compress(b"GT\n>y\nTT\n"))
+    assert parse(host, str(two)) == (2, b"ACGTNTT")
+    # a zstd-compressed .hll (write plain with level 0, compress, read back)
+    p = 9
+    regs = np.arange(1 << p, dtype=np.uint64).astype(np.uint8) % 50
+    raw = str(tmp_path / "s.hll")
+    assert host.dshh_write_hll(raw.encode(), regs.ctypes.data, p, 2) == 0
+    payload = gzip.open(raw, "rb").read()
+    zh = tmp_path / "s.hll.zst"
+    zh.write_bytes(_zstd_compress(payload))
+    out = np.zeros(1 << p, np.uint8)
+    pp = C.c_int()
+    assert host.dshh_read_hll(str(zh).encode(), out.ctypes.data, out.size, C.byref(pp)) == 0
+    assert pp.value == p and (out == regs).all()
+    # garbage after the magic number: a decode error, not silently empty input
+    bad = tmp_path / "bad.fa.zst"
+    bad.write_bytes(frame[:4] + b"\xff" * 64)
+    assert parse(host, str(bad), 1 << 20)[0] == -1
