@@ -178,11 +178,20 @@ public:
                     zlen_ = (size_t)std::max<ssize_t>(r, 0);
                     zpos_ = 0;
                 }
-                if (zpos_ == zlen_ && zeof_) break;
+                // with the input exhausted the decoder may still hold decoded bytes: keep draining until it yields
+                // nothing; the stream ends cleanly only on a frame boundary (return value 0 of the last call)
+                const bool drained_input = zpos_ == zlen_ && zeof_;
+                if (drained_input && zframe_done_) break;
                 ZstdIn in{zin_.data(), zlen_, zpos_};
+                const size_t before = out.pos;
                 const size_t rc = z.decompressStream(zs_, &out, &in);
                 zpos_ = in.pos;
                 if (z.isError(rc)) return -1;
+                zframe_done_ = rc == 0;
+                if (drained_input && out.pos == before) {
+                    if (!zframe_done_) return -1;  // the last frame is incomplete: truncated file
+                    break;
+                }
             }
             return (ssize_t)out.pos;
         }
@@ -209,7 +218,7 @@ private:
     void *zs_ = nullptr;
     std::vector<char> zin_;
     size_t zpos_ = 0, zlen_ = 0;
-    bool zeof_ = false;
+    bool zeof_ = false, zframe_done_ = true;  // (an empty file is a clean end)
 };
 
 }  // namespace

@@ -84,18 +84,23 @@ def test_balance_rows(n, parts):
     assert all(b[i] <= b[i + 1] for i in range(parts))
     assert all(x % 128 == 0 for x in b[1:-1] if x != n)
     nt = (n + 127) // 128
+    kprep = 0.9  # prepare cost of a part in tile-equivalents per 128 of its columns (dsh_balance_rows)
 
     def tiles(lo, hi):  # tile rows [lo,hi): triangle of the part + rectangle to its right
         return sum(nt - t for t in range(lo, hi))
 
-    cost = [tiles(b[i] // 128, (b[i + 1] + 127) // 128) if b[i + 1] > b[i] else 0 for i in range(parts)]
-    assert sum(cost) == nt * (nt + 1) // 2
+    def cost(lo, hi):  # + the part's own plane matrix over the columns lo*128 .. n
+        return tiles(lo, hi) + kprep * (nt - lo) if hi > lo else 0.0
+
+    tr = [(b[i] // 128, (b[i + 1] + 127) // 128) if b[i + 1] > b[i] else (0, 0) for i in range(parts)]
+    assert sum(tiles(lo, hi) for lo, hi in tr if hi > lo) == nt * (nt + 1) // 2
+    worst = max(cost(lo, hi) for lo, hi in tr)
     if nt and parts > 1:
-        assert max(cost) <= (nt * (nt + 1) / 2) / parts + nt  # never more than one tile row above the mean
+        assert worst <= (nt * (nt + 1) / 2) / parts + (1 + kprep) * nt  # never more than one tile row (+ prepare) above the mean
     if 1 < parts <= 4 and nt <= 80:  # exact minimax by enumeration
         import itertools
 
-        best = min(max(tiles(c[i], c[i + 1]) for i in range(parts))
+        best = min(max(cost(c[i], c[i + 1]) for i in range(parts))
                    for mid in itertools.combinations_with_replacement(range(nt + 1), parts - 1)
                    for c in [(0,) + mid + (nt,)])
-        assert max(cost) == best
+        assert worst <= best + 1e-2

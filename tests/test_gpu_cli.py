@@ -28,7 +28,8 @@ def _zstd(data):
     z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
     cap = z.ZSTD_compressBound(len(data))
     dst = C.create_string_buffer(cap)
-    return dst.raw[: z.ZSTD_compress(dst, cap, data, len(data), 3)]
+    n = z.ZSTD_compress(dst, cap, data, len(data), 3)  # (before dst.raw is read)
+    return dst.raw[:n]
 
 
 def run(*args, cwd=None):

@@ -363,6 +363,15 @@ def test_zstd_inputs_are_transparent(host, tmp_path):
     pp = C.c_int()
     assert host.dshh_read_hll(str(zh).encode(), out.ctypes.data, out.size, C.byref(pp)) == 0
     assert pp.value == p and (out == regs).all()
+    # a small single-block frame (everything is decoded before the input runs out: the decoder must be drained)
+    small = b">s\n" + b"ACGTTGCAAC" * 4900 + b"\n"
+    sp = tmp_path / "small.fa.zst"
+    sp.write_bytes(_zstd_compress(small))
+    assert parse(host, str(sp), 1 << 20) == (1, b"ACGTTGCAAC" * 4900)
+    # a truncated frame is an error, not a short genome
+    tr = tmp_path / "trunc.fa.zst"
+    tr.write_bytes(frame[: len(frame) - 7])
+    assert parse(host, str(tr), 1 << 20)[0] == -1
     # garbage after the magic number: a decode error, not silently empty input
     bad = tmp_path / "bad.fa.zst"
     bad.write_bytes(frame[:4] + b"\xff" * 64)
