@@ -274,6 +274,26 @@ def main():
     if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
 
+    what_if = None
+    if rank == 0 and not multi and not args.no_secondary:
+        # WHAT-IF, never the product path (the north star excludes the matrix cores; `value` above is the integer-VALU
+        # kernel): the same tile kernel with the AND+popcount done as a 0/1 i8 MFMA (option pair_mfma), same inputs
+        ref = full[:total_pairs].clone()
+        ctx.set_option("pair_mfma", 1)
+        ts = []
+        for _ in range(3):
+            ctx.attach_device(regs_d.data_ptr(), n, p)
+            t0 = time.perf_counter()
+            ctx.dist_rows_device(local.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t0)
+        same = bool(torch.equal(ref, local[:total_pairs]))
+        kw = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), 0, n)], 1)
+        ctx.set_option("pair_mfma", 0)
+        what_if = {"label": "WHAT-IF ONLY, not the shipped path and not `value`: v_mfma_i32_32x32x32_i8 on 0/1 bytes expanded from the bit-planes in registers (option pair_mfma=1, default 0)",
+                   "ms_per_step": round(min(ts) * 1e3, 3), "pairs_per_s": total_pairs / min(ts),
+                   "k_pair_counts_mfma_ms": round(kw["pair_ms"], 3), "output_identical_to_valu_path": same}
+        del ref
     secondary = None
     if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
         secondary = secondary_p10(ctx, torch, dev, synth, dashing_amd)
@@ -304,6 +324,8 @@ def main():
             }
         if secondary:
             line["secondary"] = secondary
+        if what_if:
+            line["what_if_mfma"] = what_if
     ctx.close()
     # The JSON line must be the LAST thing on stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes)
     # prints its banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise

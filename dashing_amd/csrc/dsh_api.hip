@@ -111,6 +111,7 @@ struct dsh_ctx {
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
+    int pair_mfma = 0;  // WHAT-IF only: 1 = the AND+popcount tile kernel on the matrix cores (never the default)
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
@@ -539,8 +540,12 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             d = next_event(c);
             if (a) (void)hipEventRecord(a, c->stream);
         }
-        HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
-                                     c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
+        if (c->pair_mfma)
+            HIPCHK(c, launch_pair_counts_mfma(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                              c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
+        else
+            HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                         c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
         FinalizeLaunch f;
         f.cum = c->cum.ptr;
@@ -1413,6 +1418,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "range_sort_min_rows")) {
         if (v < 1) return fail(c, DSH_EINVAL, "range_sort_min_rows must be >= 1");
         c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "pair_mfma")) {
+        c->pair_mfma = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "finalize_stop")) {

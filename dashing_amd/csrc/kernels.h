@@ -19,6 +19,12 @@ hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint3
                               const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
                               uint64_t nslots);
 
+// what-if variant on the matrix cores (option "pair_mfma"; never the default: the north star excludes MFMA)
+hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
+                                   uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
+                                   const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
+                                   uint64_t nslots);
+
 struct FinalizeLaunch {
     const void *cum;
     int cum_bytes;  // 2 or 4

@@ -404,6 +404,155 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// WHAT-IF, NOT THE PRODUCT PATH (option "pair_mfma" = 1; default 0).  The north star of this
+// build excludes the matrix cores ("the path is integer max + fp reduction, not a dense contraction"), and the
+// shipped k_pair_counts above is integer VALU only.  With the bit-plane formulation, though, C(v)[i][j] =
+// popcount(A_v[i] & B_v[j]) IS a 0/1 GEMM, and the MFMA pipe is separate from the VALU pipe -- this variant measures
+// what that would buy, behind the same interface (same tiles, items, LDS staging, cum output: byte-identical
+// results, integer-exact i32 accumulation).  Per k-row (one 32-bit plane word per sketch = 32 register positions =
+// the K of one v_mfma_i32_32x32x32_i8) a wave covers 64 x 64 pairs with 2 x 2 MFMAs; lane (r = l & 31, h = l >> 5)
+// supplies row/column r of a 32-block and the 16 positions [16h, 16h+16) as 16 bytes of 0/1, expanded in registers
+// (nibble -> 4 bytes by one multiply + one mask).  A and B are expanded the same way, so byte e of an A lane and
+// byte e of the B lane with the same h stand for the same register position: whatever k-order the hardware assigns
+// to the 16 bytes of a lane, the dot product pairs equal positions.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v4i_t expand16(uint32_t w16)
+{
+    // nibble x = b3 b2 b1 b0 -> bytes (b0, b1, b2, b3): x * (1 + 2^7 + 2^14 + 2^21) puts b_j at bit 8j (the four
+    // shifted copies occupy disjoint bit ranges, no carries), the mask keeps exactly those
+    v4i_t v;
+    v.x = (int)((((w16)&0xFu) * 0x00204081u) & 0x01010101u);
+    v.y = (int)((((w16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+    v.z = (int)((((w16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+    v.w = (int)((((w16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+    return v;
+}
+
+template <int KC, typename CT>
+__global__ __launch_bounds__(256, 2) void k_pair_counts_mfma(const uint32_t *__restrict__ planes,
+                                                           uint32_t Npad, uint32_t Kpad, uint32_t W,
+                                                           uint32_t P, const uint4 *__restrict__ tiles,
+                                                           const uint4 *__restrict__ items,
+                                                           CT *__restrict__ cum, uint64_t nslots)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128], as k_pair_counts
+    constexpr int NPASS = KC / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ii0 = (wave >> 1) * 64, jj0 = (wave & 1) * 64;
+    const uint4 item = items[blockIdx.x];
+    const uint32_t tile_id = item.x;
+    const uint4 tile = tiles[tile_id];
+    const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
+    const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
+    const uint32_t *gB = planes + lrow * Npad + (uint64_t)tile.y * kTile + (lane & 31) * 4;
+    const uint64_t pass_stride = (uint64_t)8 * Npad;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem + wave * 1024;
+    auto stage = [&](uint32_t chunk, int buf) {
+        const uint32_t la = lds_base + buf * (2 * KC * 512);
+        const uint32_t lb = la + KC * 512;
+        const uint32_t *a = gA + (uint64_t)chunk * KC * Npad;
+        const uint32_t *b = gB + (uint64_t)chunk * KC * Npad;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            glds16(a + ps * pass_stride, la + ps * 4096);
+            glds16(b + ps * pass_stride, lb + ps * 4096);
+        }
+    };
+    v16i_t acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[x][y][e] = 0;
+    const uint32_t ch_begin = item.y, ch_end = item.z;
+    if (ch_begin >= ch_end) return;
+    CT *cum_tile = cum + (uint64_t)tile_id * (kTile * kTile);
+    stage(ch_begin, ch_begin & 1);
+    for (uint32_t ch = ch_begin; ch < ch_end; ++ch) {
+        dma_wait();
+        __syncthreads();
+        if (ch + 1 < ch_end) stage(ch + 1, (ch + 1) & 1);
+        const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + ii0 + r;
+        const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 128) + KC * 128 + jj0 + r;
+#pragma unroll 2
+        for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
+            const uint32_t sh = 16u * (uint32_t)h;
+            const v4i_t a0 = expand16(As[kk * 128] >> sh);
+            const v4i_t a1 = expand16(As[kk * 128 + 32] >> sh);
+            const v4i_t b0 = expand16(Bs[kk * 128] >> sh);
+            const v4i_t b1 = expand16(Bs[kk * 128 + 32] >> sh);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+            const uint32_t row_end = ch * KC + kk + 1;
+            if ((row_end & (W - 1)) == 0) {  // plane boundary (uniform)
+                const uint32_t pl = row_end / W - 1;
+                if (pl < P) {
+                    CT *dst = cum_tile + (uint64_t)pl * nslots;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {  // C/D map of the 32x32 shapes: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+                                const int row = ii0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * h;
+                                const int col = jj0 + 32 * y + r;
+                                dst[row * kTile + col] = (CT)(uint32_t)acc[x][y][e];
+                            }
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0;
+            }
+        }
+    }
+}
+
+template <int KC, typename CT>
+static hipError_t launch_pcm(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad, uint32_t W,
+                             uint32_t P, const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
+                             uint64_t nslots)
+{
+    const size_t lds = (size_t)KC * 2048;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts_mfma<KC, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_pair_counts_mfma<KC, CT>), dim3(nitems), dim3(256), lds, st, planes, Npad, Kpad, W, P, tiles,
+                       items, reinterpret_cast<CT *>(cum), nslots);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes, uint32_t Npad,
+                                   uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
+                                   uint32_t nitems, void *cum, uint64_t nslots)
+{
+    if (nitems == 0 || Kpad == 0) return hipSuccess;
+    if (cum_bytes == 2) {
+        switch (kc) {
+        case 16: return launch_pcm<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        case 32: return launch_pcm<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        case 64: return launch_pcm<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (kc) {
+    case 16: return launch_pcm<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    case 32: return launch_pcm<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    case 64: return launch_pcm<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // finalize: one lane per pair slot of a band of tiles.  128 threads per block = one tile row
 // (consecutive lanes = consecutive j: coalesced cum reads and output writes).
 struct FinalizeArgs {

@@ -227,7 +227,14 @@ def test_options_do_not_change_results(ctx):
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
+        ctx.set_option("cum_budget_bytes", 2 << 30)
+        # the what-if variant of the tile kernel on the matrix cores (never the default): same integers
+        ctx.set_option("pair_mfma", 1)
+        for kc in (16, 32):
+            ctx.set_option("kc", kc)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
     finally:
+        ctx.set_option("pair_mfma", 0)
         ctx.set_option("kc", 16)
         ctx.set_option("emax", -1)
         ctx.set_option("sort", -1)
