@@ -254,7 +254,7 @@ def main():
         "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",
         "pairs_per_s": round(my_pairs / (kphase[1] * 1e-3), 1) if kphase[1] > 0 else 0.0,
         "cycles_per_wave64_of_pairs": round(kphase[1] * 1e-3 * CLOCK_HZ * N_SIMD / (my_pairs / 64.0), 1) if kphase[1] > 0 and my_pairs else 0.0,
-        "note": "VALU-issue bound (VALU busy ~80 %); ~75 % of its VALU instructions are the Ertl-MLE estimator (2-3 secant iterations x ~8-10 bins x 19 instructions, 15 of them dependent fp64 operations, plus fp64 divisions per iteration) that must be reproduced bit for bit -- PMC per phase in profiles/r2g, DESIGN.md 3.2",
+        "note": "VALU-issue bound (VALU busy ~80 %); ~75 % of its VALU instructions are the Ertl-MLE estimator (~3 secant iterations x ~17 bins = ~51 steps x 19 instructions, 15 of them dependent fp64 operations, plus fp64 divisions per iteration) that must be reproduced bit for bit -- PMC per phase in profiles/r2g, DESIGN.md 3.2",
     }
     roofline["step"] = {
         "ms": {"prepare": round(kphase[2], 4), "pair_counts": round(kphase[0], 4), "finalize": round(kphase[1], 4)},
