@@ -72,13 +72,22 @@ def test_random_case(ctx, oracle, case):
         iw = oracle.dist_tri(regs, estim, INDEX_OF[rt], k)
         _close(ig, iw)
     _close(ctx.dist_rows(estim=estim, result_type=rt, k=k), want, ig, iw)
-    # a row range (identity columns)
+    # a row range: identity columns, and the layout built for the range (wanted rows first, key-ordered), which
+    # normally starts at 1024 rows -- the two must give the same bytes
     rb = int(rng.integers(0, n))
     re = int(rng.integers(rb, n + 1))
     lo = dashing_amd.tri_span(n, 0, rb)
     part = ctx.dist_rows(rb, re, estim=estim, result_type=rt, k=k)
     sl = slice(lo, lo + part.size)
     _close(part, want[sl], None if ig is None else ig[sl], None if iw is None else iw[sl])
+    ctx.set_option("range_sort_min_rows", 1)
+    try:
+        part2 = ctx.dist_rows(rb, re, estim=estim, result_type=rt, k=k)
+        if part.size:  # (a range without pairs returns before any layout is built)
+            assert ctx.info("sorted") == 1 and ctx.info("ncols") == n - rb
+    finally:
+        ctx.set_option("range_sort_min_rows", 1024)
+    assert part2.tobytes() == part.tobytes()
     # a rectangle
     q0 = int(rng.integers(0, n)); q1 = int(rng.integers(q0, n + 1))
     r0 = int(rng.integers(0, n)); r1 = int(rng.integers(r0, n + 1))
