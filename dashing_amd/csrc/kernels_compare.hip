@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 // popcount(A_v[i] & B_v[j]) IS a 0/1 GEMM, and the MFMA pipe is separate from the VALU pipe -- this variant measures
 // what that would buy, behind the same interface (same tiles, items, LDS staging, cum output: byte-identical
 // results, integer-exact i32 accumulation).  Per k-row (one 32-bit plane word per sketch = 32 register positions =
-// the K of one v_mfma_i32_32x32x32_i8) a wave covers 64 x 64 pairs with 2 x 2 MFMAs; lane (r = l & 31, h = l >> 5)
+// the K of one v_mfma_i32_32x32x32_i8) a wave covers 128 x 64 pairs with 4 x 2 MFMAs; lane (r = l & 31, h = l >> 5)
 // supplies row/column r of a 32-block and the 16 positions [16h, 16h+16) as 16 bytes of 0/1, expanded in registers
 // (nibble -> 4 bytes by one multiply + one mask).  A and B are expanded the same way, so byte e of an A lane and
 // byte e of the B lane with the same h stand for the same register position: whatever k-order the hardware assigns
@@ -431,25 +431,28 @@ __device__ __forceinline__ v4i_t expand16(uint32_t w16)
 }
 
 template <int KC, typename CT>
-__global__ __launch_bounds__(256, 2) void k_pair_counts_mfma(const uint32_t *__restrict__ planes,
+__global__ __launch_bounds__(128, 2) void k_pair_counts_mfma(const uint32_t *__restrict__ planes,
                                                            uint32_t Npad, uint32_t Kpad, uint32_t W,
                                                            uint32_t P, const uint4 *__restrict__ tiles,
                                                            const uint4 *__restrict__ items,
                                                            CT *__restrict__ cum, uint64_t nslots)
 {
+    // 128 threads = 2 waves per 128x128 tile; wave w covers all 128 rows x columns [64w, 64w+64): 4 A fragments and
+    // 2 B fragments feed 8 MFMAs per plane word (6 expansions per 8 MFMAs instead of 4 per 4 with 64x64 wave tiles:
+    // the first version was bound by the expansion's VALU instructions, 7.99 ms on C3)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128], as k_pair_counts
-    constexpr int NPASS = KC / 8;
+    constexpr int NPASS = KC / 4;  // a wave-instruction of the LDS-DMA covers 2 rows; 2 waves -> 4 rows per pass
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int ii0 = (wave >> 1) * 64, jj0 = (wave & 1) * 64;
+    const int jj0 = wave * 64;
     const uint4 item = items[blockIdx.x];
     const uint32_t tile_id = item.x;
     const uint4 tile = tiles[tile_id];
     const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
     const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
     const uint32_t *gB = planes + lrow * Npad + (uint64_t)tile.y * kTile + (lane & 31) * 4;
-    const uint64_t pass_stride = (uint64_t)8 * Npad;
+    const uint64_t pass_stride = (uint64_t)4 * Npad;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem + wave * 1024;
     auto stage = [&](uint32_t chunk, int buf) {
         const uint32_t la = lds_base + buf * (2 * KC * 512);
@@ -458,13 +461,13 @@ __global__ __launch_bounds__(256, 2) void k_pair_counts_mfma(const uint32_t *__r
         const uint32_t *b = gB + (uint64_t)chunk * KC * Npad;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            glds16(a + ps * pass_stride, la + ps * 4096);
-            glds16(b + ps * pass_stride, lb + ps * 4096);
+            glds16(a + ps * pass_stride, la + ps * 2048);
+            glds16(b + ps * pass_stride, lb + ps * 2048);
         }
     };
-    v16i_t acc[2][2];
+    v16i_t acc[4][2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
@@ -477,37 +480,40 @@ __global__ __launch_bounds__(256, 2) void k_pair_counts_mfma(const uint32_t *__r
         dma_wait();
         __syncthreads();
         if (ch + 1 < ch_end) stage(ch + 1, (ch + 1) & 1);
-        const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + ii0 + r;
+        const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + r;
         const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 128) + KC * 128 + jj0 + r;
-#pragma unroll 2
+#pragma unroll 1
         for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
             const uint32_t sh = 16u * (uint32_t)h;
-            const v4i_t a0 = expand16(As[kk * 128] >> sh);
-            const v4i_t a1 = expand16(As[kk * 128 + 32] >> sh);
             const v4i_t b0 = expand16(Bs[kk * 128] >> sh);
             const v4i_t b1 = expand16(Bs[kk * 128 + 32] >> sh);
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const v4i_t a = expand16(As[kk * 128 + 32 * x] >> sh);
+                acc[x][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[x][1], 0, 0, 0);
+            }
             const uint32_t row_end = ch * KC + kk + 1;
             if ((row_end & (W - 1)) == 0) {  // plane boundary (uniform)
                 const uint32_t pl = row_end / W - 1;
                 if (pl < P) {
-                    CT *dst = cum_tile + (uint64_t)pl * nslots;
+                    // per-lane base made opaque here so that the 128 store addresses are formed inside this rare block
+                    // (hoisted out of the k loop they cost >100 VGPRs and spill the accumulators)
+                    uint64_t base = (uint64_t)(uintptr_t)(cum_tile + (uint64_t)pl * nslots) + (uint64_t)((4 * h) * kTile + jj0 + r) * sizeof(CT);
+                    asm volatile("" : "+v"(base));
+                    CT *dst = reinterpret_cast<CT *>((uintptr_t)base);
 #pragma unroll
-                    for (int x = 0; x < 2; ++x)
+                    for (int x = 0; x < 4; ++x)
 #pragma unroll
                         for (int y = 0; y < 2; ++y)
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {  // C/D map of the 32x32 shapes: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-                                const int row = ii0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * h;
-                                const int col = jj0 + 32 * y + r;
-                                dst[row * kTile + col] = (CT)(uint32_t)acc[x][y][e];
+                                const int row = 32 * x + (e & 3) + 8 * (e >> 2);  // (+ 4h and the column are in `dst`)
+                                dst[row * kTile + 32 * y] = (CT)(uint32_t)acc[x][y][e];
                             }
                 }
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+                for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int y = 0; y < 2; ++y)
 #pragma unroll
@@ -526,7 +532,7 @@ static hipError_t launch_pcm(hipStream_t st, const uint32_t *planes, uint32_t Np
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts_mfma<KC, CT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pair_counts_mfma<KC, CT>), dim3(nitems), dim3(256), lds, st, planes, Npad, Kpad, W, P, tiles,
+    hipLaunchKernelGGL((k_pair_counts_mfma<KC, CT>), dim3(nitems), dim3(128), lds, st, planes, Npad, Kpad, W, P, tiles,
                        items, reinterpret_cast<CT *>(cum), nslots);
     return hipGetLastError();
 }
