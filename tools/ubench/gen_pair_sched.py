@@ -15,8 +15,9 @@ ACC0 = 64                # acc[r][c] = v(64 + 8r + c)
 TMP0 = 128               # 64 temporaries v128..v191
 
 
-def body(order, tmp_bank_shift=0, ops="and+bcnt"):
-    """one k-row: 64 (AND, BCNT) pairs; `order` = batch size of ANDs issued before their BCNTs"""
+def body(order, tmp_bank_shift=0, ops="and+bcnt", barrier=False):
+    """one k-row: 64 (AND, BCNT) pairs; `order` = batch size of ANDs issued before their BCNTs;
+    barrier: s_barrier after every AND batch and every BCNT batch (keeps the waves of a SIMD in the same phase)"""
     lines = []
     pairs = [(r, c) for r in range(8) for c in range(8)]
     for s in range(0, 64, order):
@@ -27,6 +28,8 @@ def body(order, tmp_bank_shift=0, ops="and+bcnt"):
                 lines.append("v_and_b32 v%d, v%d, v%d" % (t, A0 + r, B0 + c))
             elif ops == "and+add":
                 lines.append("v_and_b32 v%d, v%d, v%d" % (t, A0 + r, B0 + c))
+        if barrier:
+            lines.append("s_barrier")
         for i, (r, c) in enumerate(grp):
             t = TMP0 + ((s + i + tmp_bank_shift) % 64)
             acc = ACC0 + 8 * r + c
@@ -36,6 +39,8 @@ def body(order, tmp_bank_shift=0, ops="and+bcnt"):
                 lines.append("v_bcnt_u32_b32 v%d, v%d, v%d" % (acc, A0 + ((r + c) % 8), acc))
             elif ops == "and+add":
                 lines.append("v_add_u32 v%d, v%d, v%d" % (acc, t, acc))
+        if barrier:
+            lines.append("s_barrier")
     return lines
 
 
@@ -52,12 +57,16 @@ VARIANTS = [
     ("and_only", 8, 0, "and"),
     ("bcnt_only", 8, 0, "bcnt"),
     ("and_add", 8, 0, "and+add"),
+    # the two waves of a SIMD kept in the same phase by barriers (needs both in ONE workgroup: 512 threads)
+    ("batch64_wg512", 64, 0, "and+bcnt", 512, False),
+    ("batch64_wg512_bar", 64, 0, "and+bcnt", 512, True),
+    ("batch32_wg512_bar", 32, 0, "and+bcnt", 512, True),
 ]
 
 ROWS_PER_ITER = 4  # k-rows per loop iteration (the real kernel unrolls 8)
 
 
-def kernel(name, order, shift, ops):
+def kernel(name, order, shift, ops, wg=256, barrier=False):
     clob = ", ".join('"v%d"' % i for i in list(range(A0, B0 + 8)) + list(range(ACC0, ACC0 + 64)) + list(range(TMP0, TMP0 + 64)))
     L = []
     # operands from the lane id and a seed (seed 0 -> all-zero data: the low-power arm)
@@ -75,7 +84,7 @@ def kernel(name, order, shift, ops):
     L.append("s_waitcnt lgkmcnt(0)")
     L.append("1:")
     for _ in range(ROWS_PER_ITER):
-        L += body(order, shift, ops)
+        L += body(order, shift, ops, barrier)
     L.append("s_sub_u32 %[it], %[it], 1")
     L.append("s_cmp_lg_u32 %[it], 0")
     L.append("s_cbranch_scc1 1b")
@@ -86,21 +95,21 @@ def kernel(name, order, shift, ops):
         L.append("v_xor_b32 %%[res], %%[res], v%d" % (ACC0 + i))
     asm = "\\n\\t".join(L)
     return """
-__global__ __launch_bounds__(256) void k_%s(uint32_t *out, uint64_t *cyc, uint32_t seed, int iters)
+__global__ __launch_bounds__(%d) void k_%s(uint32_t *out, uint64_t *cyc, uint32_t seed, int iters)
 {
     extern __shared__ uint32_t pad[];  // sized by the host to pin workgroups per CU
     uint32_t res;
     uint64_t t0, t1;
     int it = iters;
-    const uint32_t tid = threadIdx.x + blockIdx.x * 256u;
+    const uint32_t tid = threadIdx.x + blockIdx.x * blockDim.x;
     asm volatile("%s"
                  : [res] "=&v"(res), [t0] "=&s"(t0), [t1] "=&s"(t1), [it] "+s"(it)
                  : [tid] "v"(tid), [seed] "v"(seed), [m0] "v"(2654435761u), [m1] "v"(40503u)
                  : %s, "scc", "memory");
-    out[blockIdx.x * 256 + threadIdx.x] = res + (pad == nullptr);
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = res + (pad == nullptr);
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = t1 - t0;
 }
-""" % (name, asm, clob)
+""" % (wg, name, asm, clob)
 
 
 def main():
@@ -111,26 +120,26 @@ def main():
         o.write(kernel(*v))
     o.write("""
 typedef void (*kern_t)(uint32_t *, uint64_t *, uint32_t, int);
-static void run(const char *name, kern_t k, int wg_per_cu, uint32_t seed, int pairs_per_row)
+static void run(const char *name, kern_t k, int wg_per_cu, uint32_t seed, int pairs_per_row, int wg_threads = 256)
 {
     const int blocks = 256 * wg_per_cu, iters = 40000;
     const size_t lds = wg_per_cu >= 4 ? 32 * 1024 : (wg_per_cu == 2 ? 64 * 1024 : 128 * 1024);
     uint32_t *out; uint64_t *cyc;
-    hipMalloc(&out, blocks * 256 * 4); hipMalloc(&cyc, blocks * 4 * 8);
+    hipMalloc(&out, blocks * wg_threads * 4); hipMalloc(&cyc, blocks * (wg_threads / 64) * 8);
     hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, 0, out, cyc, seed, 2000);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(wg_threads), lds, 0, out, cyc, seed, 2000);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, 0, out, cyc, seed, iters);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(wg_threads), lds, 0, out, cyc, seed, iters);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    std::vector<uint64_t> h(blocks * 4);
+    std::vector<uint64_t> h(blocks * (wg_threads / 64));
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double med = (double)h[h.size() / 2];
     const double rows = (double)iters * %d;
-    const int waves_per_simd = wg_per_cu;  // 4 waves per workgroup, 4 SIMDs per CU
+    const int waves_per_simd = wg_per_cu * wg_threads / 256;  // waves per workgroup / 4 SIMDs per CU
     // per (AND,BCNT) pair-slot and wave: shader cycles of one wave / waves sharing the SIMD
     printf("%%-18s seed=%%u wg/CU=%%d  wall %%7.2f ms  wave %%10.0f cyc  eff.clock %%.3f GHz  %%.2f SIMD-cycles per pair-slot (wall@2.4GHz: %%.2f)\\n",
            name, seed, wg_per_cu, ms, med, med / (ms * 1e-3) / 1e9, med / (rows * pairs_per_row * waves_per_simd),
