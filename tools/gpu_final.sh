@@ -10,5 +10,9 @@ cp gpurun_out/${TAG}_pmc/kernel_stats.csv gpurun_out/${TAG}_pmc/pmc_summary.json
 python tools/shard_timing.py > gpurun_out/$TAG/shard_timing.jsonl 2>/dev/null
 python tools/bench_sketch.py > gpurun_out/$TAG/bench_sketch.json 2>/dev/null
 DSH_BENCH_FORCE_DIST=1 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_forced_rccl1.json 2>/dev/null
-python tools/run_configs.py c4 c5 c3cli c3knn > gpurun_out/$TAG/configs.jsonl 2>/dev/null
+python tools/run_configs.py c3cli c3knn unfriendly > gpurun_out/$TAG/configs.jsonl 2>gpurun_out/$TAG/configs.err
+python tools/run_configs.py c4 >> gpurun_out/$TAG/configs.jsonl 2>>gpurun_out/$TAG/configs.err
+python tools/run_configs.py c5 >> gpurun_out/$TAG/configs.jsonl 2>>gpurun_out/$TAG/configs.err
+python tools/run_configs.py c2 >> gpurun_out/$TAG/configs.jsonl 2>>gpurun_out/$TAG/configs.err
+python tools/mfma_whatif.py > gpurun_out/$TAG/mfma_whatif.jsonl 2>/dev/null
 tail -c 400 gpurun_out/$TAG/bench.json

@@ -53,10 +53,26 @@ def c4(n=100_000, p=10):
     import torch
 
     t0 = time.perf_counter()
-    regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
-    t_gen = time.perf_counter() - t0
     dev = torch.device("cuda", 0)
-    regs_d = torch.from_numpy(regs).to(dev)
+    if n <= 100_000:
+        regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
+        regs_d = torch.from_numpy(regs).to(dev)
+    else:
+        # drawing 300 000 register arrays from the law takes minutes of numpy: draw 20 000 and build the rest on the
+        # device as unions of two of them (exactly the sketch of the union of the two sets), as tests/test_gpu_configs.py
+        nbase = 20_000
+        bd = torch.from_numpy(synth.survey_sketches(nbase, p, seed=0x5EED0000)[0]).to(dev)
+        regs_d = torch.empty((n, 1 << p), dtype=torch.uint8, device=dev)
+        regs_d[:nbase] = bd
+        g = torch.arange(nbase, n, device=dev, dtype=torch.int64)
+        a_, b_ = g % nbase, (g * 2654435761 + 12345) % nbase
+        for s_ in range(0, n - nbase, 1 << 14):
+            e_ = min(n - nbase, s_ + (1 << 14))
+            regs_d[nbase + s_ : nbase + e_] = torch.maximum(bd[a_[s_:e_]], bd[b_[s_:e_]])
+        del bd
+        torch.cuda.synchronize()
+        regs = None
+    t_gen = time.perf_counter() - t0
     total = n * (n - 1) // 2
     out = torch.empty(total, dtype=torch.float32, device=dev)
     ctx = dashing_amd.Context(0)
@@ -75,6 +91,8 @@ def c4(n=100_000, p=10):
     k = ctx.last_kernel_ms()
     oracle_c.load(threads=oracle_c.effective_cpus())
     worst, checked = 0.0, 0
+    if regs is None:
+        regs = regs_d.cpu().numpy()
     for r in (0, 1, 4999, n // 2, n - 1000, n - 2):
         want = oracle_c.dist_rows(regs, r, r + 1)
         lo = dashing_amd.tri_index(n, r, r + 1)
