@@ -232,8 +232,8 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         return DSH_OK;
     }
     if (!same_layout) {
-        if (c->p > kMaxPLds)
-            return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPLds, c->p);
+        if (c->p > kMaxPCompare)
+            return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPCompare, c->p);
         int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
         // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no
         // device round trip and so does not wait for the work still queued on the stream

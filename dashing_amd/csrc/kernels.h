@@ -62,7 +62,8 @@ struct SketchWork {
     uint32_t nsub;   // number of 8192-base sub-chunks this workgroup walks
     uint32_t slot;   // row of the resident sketch matrix
 };
-constexpr int kMaxPLds = 17;   // largest p whose registers fit a workgroup's LDS (k_sketch) and the compare path takes
+constexpr int kMaxPLds = 17;   // largest p whose registers fit a workgroup's LDS (k_sketch)
+constexpr int kMaxPCompare = 24;  // the compare path takes every p the sketches can have (k_finalize: position bitmap in LDS up to p = 19, hash-only probing above)
 constexpr int kMaxP = 24;      // largest p for sketching / cardinalities / up- and download (positions are 24-bit)
 constexpr uint32_t kSketchSub = 8192;  // bases per sub-chunk (256 threads x 32 start positions)
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,

@@ -591,6 +591,7 @@ struct FinalizeArgs {
     // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
     int square;
     uint32_t hash_slots;  // power of two >= 2 * emax: LDS hash of the row sketch's tail entries
+    int use_bitmap;       // p <= 19: position bitmap of the row sketch in LDS as a prefilter; above: every entry probes the hash
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
@@ -614,7 +615,9 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // constant), the hash with the row sketch's values, then the histogram columns [(vhi-vlo+1)][128]
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
     const uint32_t kHashSlots = a.hash_slots;
-    const uint32_t bit_words = ((1u << a.p) >> 5) + 1u;  // + one word that stays zero: position 2^p pads the lists
+    // + one word that stays zero: position 2^p pads the lists.  Without the bitmap (p > 19: 2^p bits do not fit LDS
+    // next to the columns) a single dummy word keeps the layout
+    const uint32_t bit_words = a.use_bitmap ? ((1u << a.p) >> 5) + 1u : 1u;
     uint32_t *bitA = reinterpret_cast<uint32_t *>(hs_raw);
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)hs_raw != 0u) __builtin_trap();  // see probe_piece
     uint32_t *hashA = bitA + bit_words;
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         for (uint32_t t = tid; t < na; t += 128) {
             const uint32_t pos = ap[t];
             const uint32_t e = (pos << 8) | av[t];
-            atomicOr(&bitA[pos >> 5], 1u << (pos & 31u));
+            if (a.use_bitmap) atomicOr(&bitA[pos >> 5], 1u << (pos & 31u));
             uint32_t h = pos & (kHashSlots - 1);
             while (atomicCAS(&hashA[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1) & (kHashSlots - 1);
         }
@@ -826,19 +829,24 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // of the list is not on the critical path.  Loads are unconditional: a sketch's row of the list
     // array is 1 KiB, so pieces past the live prefix are readable (and never probed).
     const uint32_t nq = (nb + kPer - 1) / kPer;
-    uint4 cur[4], nxt[4];
+    if (a.use_bitmap) {
+        uint4 cur[4], nxt[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = eb[u];
-    for (uint32_t q = 0; q < nq; q += 4) {
+        for (int u = 0; u < 4; ++u) cur[u] = eb[u];
+        for (uint32_t q = 0; q < nq; q += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = eb[q + 4 + u];
+            for (int u = 0; u < 4; ++u) nxt[u] = eb[q + 4 + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (q + u < nq) probe_piece(cur[u], (q + u) * kPer);
+            for (int u = 0; u < 4; ++u)
+                if (q + u < nq) probe_piece(cur[u], (q + u) * kPer);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+        flush();
+    } else {  // very large sketches (p 20..24): no prefilter, every live entry of the column sketch probes the hash
+        const PT *plist = reinterpret_cast<const PT *>(eb);
+        for (uint32_t t = 0; t < nb; ++t) candidate((uint32_t)plist[t], t);
     }
-    flush();
     // (a bin emptied by a correction can only lower the true maximum; maxv is just a scan bound)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
     if (a.stop == 3) {
@@ -1104,7 +1112,8 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     while (hs < 2u * (uint32_t)f.emax) hs <<= 1;
     a.hash_slots = hs;
     a.stop = f.stop;
-    const size_t bit_words = (((size_t)1 << f.p) >> 5) + 1;
+    a.use_bitmap = f.p <= 19;
+    const size_t bit_words = f.p <= 19 ? (((size_t)1 << f.p) >> 5) + 1 : 1;
     const size_t lds = (((bit_words + hs + 65) * sizeof(uint32_t) + 15) & ~(size_t)15) +
                        (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
     if (lds > (48u << 10)) {  // large p: the position bitmap alone is 2^p / 8 bytes

@@ -66,7 +66,7 @@ int dsh_synchronize(dsh_ctx *ctx);
  * Replaces `std::vector<hll_t> sketches` (src/sketch_and_cmp.h:282-288): n register arrays
  * of 2^p bytes, resident in HBM for the lifetime of the ctx (or until re-allocated).
  * p in [4,24] for sketching, cardinalities, up- and download (24 = the `hll` subcommand's default,
- * src/hllmain.cpp:5); the compare entry points take p <= 17 and fail with DSH_EINVAL above. */
+ * src/hllmain.cpp:5); the compare entry points take the same range (tuned for p <= 17; 20..24 work but are not a performance target). */
 int dsh_sketches_alloc(dsh_ctx *ctx, uint64_t n, int p);
 /* sketch.read(path) path (src/sketch_and_cmp.h:318-324, --presketched): host rows -> slots. */
 int dsh_upload_sketches(dsh_ctx *ctx, const uint8_t *regs, uint64_t first_slot, uint64_t n);

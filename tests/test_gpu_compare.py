@@ -49,7 +49,7 @@ def test_golden_pairs(ctx):
             assert ((got == 1.0) == (want == 1.0)).all()  # J==0 branch agrees exactly
 
 
-@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 127), (10, 128), (10, 129), (10, 300), (14, 130), (14, 260), (15, 40), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20), (16, 140), (17, 6)])
+@pytest.mark.parametrize("p,n", [(10, 1), (10, 2), (10, 127), (10, 128), (10, 129), (10, 300), (14, 130), (14, 260), (15, 40), (12, 97), (7, 70), (4, 33), (5, 40), (16, 20), (16, 140), (17, 6), (18, 5), (19, 4), (19, 131), (20, 5), (22, 3), (24, 3)])
 @pytest.mark.parametrize("estim", [0, 1, 2])
 def test_tri_vs_oracle(ctx, oracle, p, n, estim):
     regs = synth.synthetic_sketches(n, p, seed=0x1234 + p * 131 + n)
