@@ -440,8 +440,14 @@ __global__ __launch_bounds__(128, 2) void k_pair_counts_mfma(const uint32_t *__r
     // 128 threads = 2 waves per 128x128 tile; wave w covers all 128 rows x columns [64w, 64w+64): 4 A fragments and
     // 2 B fragments feed 8 MFMAs per plane word (6 expansions per 8 MFMAs instead of 4 per 4 with 64x64 wave tiles:
     // the first version was bound by the expansion's VALU instructions, 7.99 ms on C3)
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128], as k_pair_counts
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [2][A|B][KC][128], as k_pair_counts; then the LUT
     constexpr int NPASS = KC / 4;  // a wave-instruction of the LDS-DMA covers 2 rows; 2 waves -> 4 rows per pass
+    // byte -> 8 bytes of 0/1 (bit j -> byte j): with the expansion done in VALU (bfe + multiply + mask per nibble, 13
+    // instructions per fragment) the kernel issued 11 VALU instructions per MFMA and was bound by them (8.0 ms on C3,
+    // matrix pipe 45 % busy); a 2 KiB table in LDS costs 2 VALU + one ds_read_b64 per byte
+    uint2 *lut = reinterpret_cast<uint2 *>(smem + 4 * KC * 128);
+    for (uint32_t b = threadIdx.x; b < 256; b += 128)
+        lut[b] = make_uint2(((b & 0xFu) * 0x00204081u) & 0x01010101u, ((b >> 4) * 0x00204081u) & 0x01010101u);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -485,11 +491,21 @@ __global__ __launch_bounds__(128, 2) void k_pair_counts_mfma(const uint32_t *__r
 #pragma unroll 1
         for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
             const uint32_t sh = 16u * (uint32_t)h;
-            const v4i_t b0 = expand16(Bs[kk * 128] >> sh);
-            const v4i_t b1 = expand16(Bs[kk * 128 + 32] >> sh);
+            auto expand = [lut, sh](uint32_t w) -> v4i_t {
+                const uint32_t w16 = w >> sh;
+                const uint2 lo = lut[w16 & 0xFFu], hi = lut[(w16 >> 8) & 0xFFu];
+                v4i_t v;
+                v.x = (int)lo.x;
+                v.y = (int)lo.y;
+                v.z = (int)hi.x;
+                v.w = (int)hi.y;
+                return v;
+            };
+            const v4i_t b0 = expand(Bs[kk * 128]);
+            const v4i_t b1 = expand(Bs[kk * 128 + 32]);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const v4i_t a = expand16(As[kk * 128 + 32 * x] >> sh);
+                const v4i_t a = expand(As[kk * 128 + 32 * x]);
                 acc[x][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[x][0], 0, 0, 0);
                 acc[x][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[x][1], 0, 0, 0);
             }
@@ -528,7 +544,7 @@ static hipError_t launch_pcm(hipStream_t st, const uint32_t *planes, uint32_t Np
                              uint32_t P, const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
                              uint64_t nslots)
 {
-    const size_t lds = (size_t)KC * 2048;
+    const size_t lds = (size_t)KC * 2048 + 2048;  // staging + the byte -> 8 bytes table
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts_mfma<KC, CT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -36,6 +36,8 @@ PASSES = {
     "write": ["WRITE_SIZE"],
     "sq1": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
             "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
+    "mfma": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
+             "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
     "sq2": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD",
             "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "GRBM_GUI_ACTIVE"],
 }
