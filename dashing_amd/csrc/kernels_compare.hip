@@ -51,8 +51,10 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
 {
     __shared__ uint32_t cursor[4][64];
     __shared__ uint32_t hist[4][64];
-    __shared__ uint32_t sub[4][8][64];  // 8 privatised copies per wave: the register values pile up
-                                        // in ~8 bins, so one copy would serialise its LDS atomics
+    __shared__ uint32_t sub[4][8][65];  // 8 privatised copies per wave: the register values pile up in ~8 bins, so
+                                        // one copy would serialise its LDS atomics; rows padded to 65 words so that
+                                        // the same bin of different copies falls into different banks (with a stride
+                                        // of 64 every copy's bin b shared bank b and the copies bought nothing)
     __shared__ int thr[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
@@ -488,27 +490,46 @@ __global__ __launch_bounds__(128, 2) void k_pair_counts_mfma(const uint32_t *__r
         if (ch + 1 < ch_end) stage(ch + 1, (ch + 1) & 1);
         const uint32_t *As = smem + (ch & 1) * (2 * KC * 128) + r;
         const uint32_t *Bs = smem + (ch & 1) * (2 * KC * 128) + KC * 128 + jj0 + r;
+        // software pipeline inside a chunk: the 8 MFMAs of plane word kk are issued first, then -- while the matrix
+        // pipe works on them (8 x 32 cycles) -- this wave reads the words of kk+1 from LDS and expands them through the
+        // table, so neither LDS round trip sits between two groups of MFMAs (un-pipelined: matrix pipe 50 % busy)
+        const uint32_t sh = 16u * (uint32_t)h;
+        auto expand = [lut, sh](uint32_t w) -> v4i_t {
+            const uint32_t w16 = w >> sh;
+            const uint2 lo = lut[w16 & 0xFFu], hi = lut[(w16 >> 8) & 0xFFu];
+            v4i_t v;
+            v.x = (int)lo.x;
+            v.y = (int)lo.y;
+            v.z = (int)hi.x;
+            v.w = (int)hi.y;
+            return v;
+        };
+        v4i_t fa[4], fb[2];
+        fb[0] = expand(Bs[0]);
+        fb[1] = expand(Bs[32]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[x] = expand(As[32 * x]);
 #pragma unroll 1
         for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
-            const uint32_t sh = 16u * (uint32_t)h;
-            auto expand = [lut, sh](uint32_t w) -> v4i_t {
-                const uint32_t w16 = w >> sh;
-                const uint2 lo = lut[w16 & 0xFFu], hi = lut[(w16 >> 8) & 0xFFu];
-                v4i_t v;
-                v.x = (int)lo.x;
-                v.y = (int)lo.y;
-                v.z = (int)hi.x;
-                v.w = (int)hi.y;
-                return v;
-            };
-            const v4i_t b0 = expand(Bs[kk * 128]);
-            const v4i_t b1 = expand(Bs[kk * 128 + 32]);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const v4i_t a = expand(As[kk * 128 + 32 * x]);
-                acc[x][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc[x][0], 0, 0, 0);
-                acc[x][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc[x][1], 0, 0, 0);
+                acc[x][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[x], fb[0], acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[x], fb[1], acc[x][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < (uint32_t)KC) {  // (the first word of the next chunk is fetched after its barrier, un-overlapped)
+                const uint32_t kn = kk + 1;
+                v4i_t na[4], nb[2];
+                nb[0] = expand(Bs[kn * 128]);
+                nb[1] = expand(Bs[kn * 128 + 32]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) na[x] = expand(As[kn * 128 + 32 * x]);
+                fb[0] = nb[0];
+                fb[1] = nb[1];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fa[x] = na[x];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t row_end = ch * KC + kk + 1;
             if ((row_end & (W - 1)) == 0) {  // plane boundary (uniform)
                 const uint32_t pl = row_end / W - 1;
