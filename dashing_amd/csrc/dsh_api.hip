@@ -161,6 +161,9 @@ hipEvent_t next_event(dsh_ctx *c)
     return c->ev_pool[c->ev_used++];
 }
 
+// slots [first, first + cnt) inside [0, total) -- written so that first + cnt cannot wrap
+bool slots_ok(uint64_t first, uint64_t cnt, uint64_t total) { return first <= total && cnt <= total - first; }
+
 bool whole_sorted(const dsh_ctx *c)
 {
     return c->planes_valid && c->planes_sorted && c->lay_rb == 0 && c->lay_re == c->n;
@@ -726,7 +729,7 @@ int dsh_upload_sketches(dsh_ctx *c, const uint8_t *regs, uint64_t first, uint64_
     if (!c || (!regs && n)) return DSH_EINVAL;
     if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
         return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
-    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots [%llu,%llu) out of range", (unsigned long long)first, (unsigned long long)(first + n));
+    if (!slots_ok(first, n, c->n)) return fail(c, DSH_EINVAL, "slots [%llu,+%llu) out of range", (unsigned long long)first, (unsigned long long)n);
     int rc = bind(c);
     if (rc) return rc;
     if (n) {
@@ -742,7 +745,7 @@ int dsh_download_sketches(dsh_ctx *c, uint64_t first, uint64_t n, uint8_t *out)
 {
     if (!c || (!out && n)) return DSH_EINVAL;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches");
-    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    if (!slots_ok(first, n, c->n)) return fail(c, DSH_EINVAL, "slots out of range");
     int rc = bind(c);
     if (rc) return rc;
     if (n) {
@@ -757,7 +760,7 @@ int dsh_copy_sketches_device(dsh_ctx *c, uint64_t first, uint64_t n, void *d_out
 {
     if (!c || (!d_out && n)) return DSH_EINVAL;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches");
-    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    if (!slots_ok(first, n, c->n)) return fail(c, DSH_EINVAL, "slots out of range");
     int rc = bind(c);
     if (rc) return rc;
     if (n) {
@@ -773,7 +776,7 @@ int dsh_clear_sketches(dsh_ctx *c, uint64_t first, uint64_t n)
     if (!c) return DSH_EINVAL;
     if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
         return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
-    if (first + n > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    if (!slots_ok(first, n, c->n)) return fail(c, DSH_EINVAL, "slots out of range");
     int rc = bind(c);
     if (rc) return rc;
     if (n) HIPCHK(c, hipMemsetAsync((uint8_t *)c->regs_own.ptr + (first << c->p), 0, (size_t)n << c->p, c->stream));
@@ -830,7 +833,7 @@ static int sketch_check(dsh_ctx *c, const uint64_t *genome_off, uint32_t n_genom
     if (k < 1 || k > 32) return fail(c, DSH_EINVAL, "k=%d outside [1,32]", k);
     if (!c->have_sketches || c->regs != (const uint8_t *)c->regs_own.ptr)
         return fail(c, DSH_ESTATE, "dsh_sketches_alloc first");
-    if (first_slot + n_genomes > c->n) return fail(c, DSH_EINVAL, "slots out of range");
+    if (!slots_ok(first_slot, n_genomes, c->n)) return fail(c, DSH_EINVAL, "slots out of range");
     return DSH_OK;
 }
 

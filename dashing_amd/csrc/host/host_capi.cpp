@@ -72,6 +72,15 @@ long dshh_append_fastx(const char *path, uint8_t *out, size_t cap, size_t *len)
     return n;
 }
 
+// the CLI's streaming loader path: parse straight into caller-owned (page-locked) memory at dst[*len ..), no growth
+long dshh_append_fastx_into(const char *path, uint8_t *dst, size_t cap, size_t *len)
+{
+    size_t l = *len;
+    const long n = append_fastx_into(path, dst, cap, l);
+    if (n >= 0) *len = l;
+    return n;
+}
+
 int dshh_sort_paths(const char *joined, char *out, size_t cap)
 {
     auto v = unpack(joined);

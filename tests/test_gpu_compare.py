@@ -451,6 +451,14 @@ def test_errors(ctx):
         ctx.dist_rows(result_type=9)
     with pytest.raises(dashing_amd.DshError):
         ctx.set_option("nope", 1)
+    # slot ranges whose end wraps around 2^64 are out of range, not "slot 0"
+    with pytest.raises(dashing_amd.DshError):
+        ctx.clear((1 << 64) - 1, 2)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.upload(np.zeros((2, 1 << 10), np.uint8), first_slot=(1 << 64) - 1)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.clear(3, 2)
+    ctx.clear(3, 1)
     # empty / degenerate
     ctx.alloc(0, 10)
     assert ctx.dist_rows().size == 0
