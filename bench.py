@@ -12,7 +12,7 @@ contiguous span of the final packed matrix) and the only exchange is point-to-po
 sends its span straight into its place on rank 0 (RCCL over xGMI) -- no collective inside the
 compare, no un-permute.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_pair_counts), timed
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_pair_counts_ls / k_pair_counts), timed
 with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement of the
 reference algorithm and row schedule with an AVX-512BW / AVX2 histogram-of-max -- the reference
 itself is not buildable: its bonsai/sketch submodules are absent) timed on this host on a bounded
@@ -235,20 +235,26 @@ def main():
         "physical_hbm_frac_of_peak": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pair_ms > 0 else None,
         "compulsory_bytes_per_step": n * m + 4 * total_pairs,
     }
-    # What actually bounds k_pair_counts: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
+    # What actually bounds the tile kernel: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
     # Cycles are wall time x 2.4 GHz on 1024 SIMDs, the same convention as profiles/ubench/pair_sched.txt:
-    #   nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                     = 6.0
-    #   each op on its own   2.18 + 4.59  (and_only / bcnt_only rows of pair_sched.txt) = 6.77
-    #   the mix, registers only (no LDS, no DMA), best order (64 ANDs then 64 BCNTs)   = 8.18
+    #   nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                                  = 6.0
+    #   each op on its own   2.07 + 4.42  (and_only / bcnt_only rows of pair_sched.txt)             = 6.49
+    #   the mix with the waves of a SIMD phase-locked (all ANDs, barrier, all BCNTs, barrier),
+    #     registers only 6.4-6.8, with the LDS operand reads 6.9                                     = 6.9
+    #   the mix free-running (waves of a SIMD in different instruction classes), any order/banks    = 8.18
     slots = pair_slots(ctx)
     cyc = pair_ms / reps * 1e-3 * CLOCK_HZ * N_SIMD / slots if pair_ms > 0 and slots > 0 else 0.0
+    lockstep = bool(ctx.info("lockstep"))
+    roofline["kernel"] = "k_pair_counts_ls" if lockstep else "k_pair_counts"
     roofline["valu_int"] = {
         "cycles_per_and_bcnt_pair": round(cyc, 3),
-        "frac_of_measured_mix_ceiling": round(8.18 / cyc, 4) if cyc else 0.0,
-        "frac_of_isolated_rates": round(6.77 / cyc, 4) if cyc else 0.0,
+        "frac_of_free_running_mix_ceiling": round(8.18 / cyc, 4) if cyc else 0.0,
+        "frac_of_phase_locked_mix_ceiling": round(6.9 / cyc, 4) if cyc else 0.0,
+        "frac_of_isolated_rates": round(6.49 / cyc, 4) if cyc else 0.0,
         "frac_of_nominal_issue_model": round(6.0 / cyc, 4) if cyc else 0.0,
-        "ceilings_cycles": {"measured_mix": 8.18, "isolated_sum": 6.77, "nominal_2_plus_4": 6.0},
-        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. The mix ceiling is an issue rule of the SIMD (profiles/ubench/pair_sched.txt: no order or VGPR-bank placement beats 7.93 shader cycles = 8.18 at wall x 2.4 GHz)",
+        "ceilings_cycles": {"free_running_mix": 8.18, "phase_locked_mix_with_lds_reads": 6.9, "isolated_sum": 6.49, "nominal_2_plus_4": 6.0},
+        "phase_locked_kernel": lockstep,
+        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.07 cycles and BCNTs at one per 4.42, but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with two s_barrier per k-row. In-kernel s_memtime (profiles/r2k): 955 cycles per k-row of two waves = 850 for the phases and barriers + ~65 LDS operand reads + ~40 DMA arrival, + 40 per-chunk overhead",
     }
     roofline["finalize"] = {
         "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",

@@ -111,6 +111,11 @@ struct dsh_ctx {
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
+    int ls_item_chunks = 16;  // lockstep kernel: work items of about this many K-chunks (whole planes)
+    // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
+    // (planes of >= 8 chunks, i.e. p >= 12 at kc = 16: tools/lockstep_ab.py -- 4-6 % faster at p = 14/18, 2-3 % at 12,
+    // 5 % SLOWER at p = 10 where a plane is two chunks), 0 never (the free-running k_pair_counts), 1 wherever W >= kc
+    int pair_lockstep = -1;
     int pair_mfma = 0;  // WHAT-IF only: 1 = the AND+popcount tile kernel on the matrix cores (never the default)
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
@@ -163,6 +168,12 @@ hipEvent_t next_event(dsh_ctx *c)
 
 // slots [first, first + cnt) inside [0, total) -- written so that first + cnt cannot wrap
 bool slots_ok(uint64_t first, uint64_t cnt, uint64_t total) { return first <= total && cnt <= total - first; }
+
+bool use_lockstep(const dsh_ctx *c)
+{
+    if (c->pair_mfma || c->kc > 32 || c->W < (uint32_t)c->kc || c->pair_lockstep == 0) return false;
+    return c->pair_lockstep > 0 || c->W >= 8u * (uint32_t)c->kc;
+}
 
 bool whole_sorted(const dsh_ctx *c)
 {
@@ -374,20 +385,21 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
 // Order the tiles of a band so that workgroups that run on the same XCD (block b -> XCD b % 8,
 // observed dispatch behaviour; speed only, never correctness) walk one tile row together and
 // share its A panel in that XCD's L2.
-void xcd_order(std::vector<uint4> &t, size_t b, size_t e)
+void xcd_order(std::vector<uint4> &t, size_t b, size_t e, size_t group)
 {
     const size_t cnt = e - b;
     if (cnt < 16) return;
     std::vector<uint4> tmp(cnt);
     const size_t nx = 8, per = (cnt + nx - 1) / nx;
-    // position q in launch order runs on XCD q % 8; give XCD x the contiguous range
-    // [x*per, (x+1)*per) of the row-major list
+    // `group` consecutive positions of the launch order share a workgroup (2 with the lockstep kernel); workgroup w
+    // runs on XCD w % 8; give XCD x the contiguous range [x*per, (x+1)*per) of the row-major list
     size_t q = 0;
-    for (size_t r = 0; r < per; ++r)
-        for (size_t x = 0; x < nx; ++x) {
-            const size_t src = x * per + r;
-            if (src < cnt) tmp[q++] = t[b + src];
-        }
+    for (size_t r = 0; r < per; r += group)
+        for (size_t x = 0; x < nx; ++x)
+            for (size_t u = 0; u < group && r + u < per; ++u) {
+                const size_t src = x * per + r + u;
+                if (src < cnt) tmp[q++] = t[b + src];
+            }
     std::copy(tmp.begin(), tmp.begin() + q, t.begin() + b);
 }
 
@@ -466,7 +478,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         b = e;
     }
     if (c->xcd_swizzle)
-        for (auto &bd : bands) xcd_order(T, bd.first, bd.second);
+        for (auto &bd : bands) xcd_order(T, bd.first, bd.second, use_lockstep(c) ? 2 : 1);
     // work items per band: {tile index in band, chunk begin, chunk end}
     const uint32_t KC = (uint32_t)c->kc;
     auto chunk_range = [&](const uint4 &t, uint32_t &cb, uint32_t &ce) {
@@ -477,6 +489,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     I.clear();
     std::vector<std::pair<size_t, size_t>> band_items;
     const uint32_t cpp = c->W >= KC ? c->W / KC : 1;  // chunks per plane when a plane spans chunks
+    const bool lockstep = use_lockstep(c);
     for (auto &bd : bands) {
         const size_t nt = bd.second - bd.first;
         uint64_t tot = 0;
@@ -488,6 +501,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
         uint64_t piece = c->nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + c->nsplit - 1) / c->nsplit)
                                        : std::max<uint64_t>(1, tot / (16 * 512));
+        if (c->nsplit == 0 && lockstep)  // equal, short items: the two items of a workgroup run in lockstep
+            piece = std::min<uint64_t>(piece, std::max<uint64_t>(cpp, (uint64_t)c->ls_item_chunks));
         piece = (piece + cpp - 1) / cpp * cpp;
         const size_t i0 = I.size();
         uint32_t maxpieces = 0;
@@ -546,6 +561,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         if (c->pair_mfma)
             HIPCHK(c, launch_pair_counts_mfma(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                               c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
+        else if (use_lockstep(c))
+            HIPCHK(c, launch_pair_counts_lockstep(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                                  c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
         else
             HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                          c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
@@ -1369,6 +1387,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "cum_bytes")) *out = c->cum_bytes;
     else if (!std::strcmp(name, "sorted")) *out = c->planes_sorted;
     else if (!std::strcmp(name, "ncols")) *out = (int64_t)c->ncols;
+    else if (!std::strcmp(name, "lockstep")) *out = c->planes_valid && use_lockstep(c) ? 1 : 0;
     else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->htiles.size();
     else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
@@ -1421,6 +1440,16 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "range_sort_min_rows")) {
         if (v < 1) return fail(c, DSH_EINVAL, "range_sort_min_rows must be >= 1");
         c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "ls_item_chunks")) {
+        if (v < 1 || v > (1 << 20)) return fail(c, DSH_EINVAL, "ls_item_chunks out of range");
+        c->ls_item_chunks = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "pair_lockstep")) {
+        if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "pair_lockstep must be -1, 0 or 1");
+        c->pair_lockstep = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "pair_mfma")) {

@@ -406,6 +406,137 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pair_counts_ls ("lockstep"): the arithmetic, tiles, work items, LDS staging and cum output of k_pair_counts --
+// scheduled so that the waves sharing a SIMD are always in the SAME instruction class.
+// Why: on gfx950 a SIMD issues v_and_b32 from two waves alternately at one per ~2.07 cycles and v_bcnt_u32_b32 at one
+// per ~4.42, but an AND stream of one wave next to a BCNT stream of another costs 8.03 cycles per (AND,BCNT) pair
+// instead of 6.49, whatever the order, batch size or register banks inside a wave (profiles/ubench/pair_sched.txt:
+// batch64 8.0, batch64_wg512_bar 6.4-6.8, ..._bar_ldsspread 6.9).  Independent workgroups drift apart; here ONE
+// 512-thread workgroup per CU (8 waves = 2 per SIMD) takes TWO work items (waves 0-3 item 2b, waves 4-7 item 2b+1, each
+// with its own LDS staging) and every k-row is: 64 ANDs into temporaries | s_barrier | 64 BCNTs | s_barrier.  The
+// operands of the next k-row are read from LDS during the BCNT phase (the AND phase was their last use), one 16-byte
+// read per quarter of the phase (all 8 waves arrive together: 32 ds_read_b128 at once back up the LDS queue).
+// With a single workgroup per CU nothing hides a stall, so the plane-boundary flush (16 stores per lane) is deferred
+// to the start of the next chunk, after that chunk's DMA has been issued: the vmcnt(0) in front of the following
+// chunk then finds the stores long retired (un-deferred it costs ~100 cycles per k-row).  Requires W >= KC (p >= 9 at
+// KC = 16): plane boundaries are chunk boundaries and the k loop carries no flush test.
+// Measured per k-row (s_memtime, profiles/r2k): 955 cycles in the k loop + 40 per-chunk overhead, of which 850 are the
+// two phases and their barriers, ~65 the LDS operand reads, ~40 the arrival of the DMA data; folding the chunk
+// transition into the last row of a chunk (no extra barrier, no exposed LDS latency) was slower (14.7 vs 14.4 ms).
+// A half whose item is shorter (or missing) keeps executing the same instruction stream on stale LDS data -- the
+// barriers need every wave -- and simply stores nothing.
+template <int KC, typename CT>
+__global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restrict__ planes, uint32_t Npad,
+                                                         uint32_t Kpad, uint32_t W, uint32_t P,
+                                                         const uint4 *__restrict__ tiles,
+                                                         const uint4 *__restrict__ items, uint32_t nitems,
+                                                         CT *__restrict__ cum, uint64_t nslots)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // [half][2][A|B][KC][128]
+    constexpr int NPASS = KC / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave8 >> 2, wave = wave8 & 3;
+    const int ii = (wave >> 1) * 64 + (lane >> 3) * 8;
+    const int jj = (wave & 1) * 64 + (lane & 7) * 8;
+    const uint32_t mine = 2 * blockIdx.x + (uint32_t)half, other = 2 * blockIdx.x + (uint32_t)(1 - half);
+    uint4 item = make_uint4(0, 0, 0, 0);
+    if (mine < nitems) item = items[mine];
+    uint32_t other_len = 0;
+    if (other < nitems) {
+        const uint4 o = items[other];
+        other_len = o.z > o.y ? o.z - o.y : 0;
+    }
+    const uint32_t my_len = item.z > item.y ? item.z - item.y : 0;
+    const uint32_t trips = my_len > other_len ? my_len : other_len;
+    const uint32_t tile_id = item.x;
+    const uint4 tile = tiles[tile_id];
+    const uint64_t lrow = (uint64_t)(wave * 2 + (lane >> 5));
+    const uint32_t *gA = planes + lrow * Npad + (uint64_t)tile.x * kTile + (lane & 31) * 4;
+    const uint32_t *gB = planes + lrow * Npad + (uint64_t)tile.y * kTile + (lane & 31) * 4;
+    const uint64_t pass_stride = (uint64_t)8 * Npad;
+    uint32_t *hsm = smem + half * (4 * KC * 128);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)hsm + wave * 1024;  // bytes
+    auto stage = [&](uint32_t chunk, int buf) {
+        const uint32_t la = lds_base + buf * (2 * KC * 512);
+        const uint32_t lb = la + KC * 512;
+        const uint32_t *a = gA + (uint64_t)chunk * KC * Npad;
+        const uint32_t *b = gB + (uint64_t)chunk * KC * Npad;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            glds16(a + ps * pass_stride, la + ps * 4096);
+            glds16(b + ps * pass_stride, lb + ps * 4096);
+        }
+    };
+    uint32_t acc[8][8], tmp[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+    CT *cum_tile = cum + (uint64_t)tile_id * (kTile * kTile) + (uint64_t)ii * kTile + jj;
+    if (trips == 0) return;
+    const uint32_t cpp = W / (uint32_t)KC;  // chunks per plane (W >= KC, both powers of two)
+    bool flush_due = false;                // the chunk just finished ended a plane: store + clear the counters
+    uint32_t flush_pl = 0;
+    auto flush = [&]() {
+        if (flush_pl < P) {
+            CT *dst = cum_tile + (uint64_t)flush_pl * nslots;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) store8(dst + r * kTile, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+    };
+    if (my_len) stage(item.y, item.y & 1);
+    for (uint32_t it = 0; it < trips; ++it) {
+        const bool active = it < my_len;  // wave-uniform
+        const uint32_t ch = item.y + it;
+        if (active) dma_wait();
+        __syncthreads();
+        if (it + 1 < my_len) stage(ch + 1, (ch + 1) & 1);
+        if (flush_due) flush();  // (after the DMA issue: a whole chunk of arithmetic passes before the next vmcnt(0))
+        const uint32_t *As = hsm + (ch & 1) * (2 * KC * 128) + ii;
+        const uint32_t *Bs = hsm + (ch & 1) * (2 * KC * 128) + KC * 128 + jj;
+        uint4 a0 = *reinterpret_cast<const uint4 *>(As), a1 = *reinterpret_cast<const uint4 *>(As + 4);
+        uint4 b0 = *reinterpret_cast<const uint4 *>(Bs), b1 = *reinterpret_cast<const uint4 *>(Bs + 4);
+#pragma unroll 4
+        for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
+            {
+                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) tmp[r][c] = av[r] & bv[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t kn = kk + 1 < (uint32_t)KC ? kk + 1 : kk;  // (the last row is simply read again)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g == 0) a0 = *reinterpret_cast<const uint4 *>(As + kn * 128);
+                if (g == 1) a1 = *reinterpret_cast<const uint4 *>(As + kn * 128 + 4);
+                if (g == 2) b0 = *reinterpret_cast<const uint4 *>(Bs + kn * 128);
+                if (g == 3) b1 = *reinterpret_cast<const uint4 *>(Bs + kn * 128 + 4);
+#pragma unroll
+                for (int r = 2 * g; r < 2 * g + 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) popc_acc(acc[r][c], tmp[r][c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        flush_due = active && ((ch + 1) & (cpp - 1)) == 0;  // the same chunk in both halves (items are whole planes)
+        flush_pl = (ch + 1) / cpp - 1;
+    }
+    if (flush_due) flush();
+}
+
+// ------------------------------------------------------------------------------------------
 // WHAT-IF, NOT THE PRODUCT PATH (option "pair_mfma" = 1; default 0).  The north star of this
 // build excludes the matrix cores ("the path is integer max + fp reduction, not a dense contraction"), and the
 // shipped k_pair_counts above is integer VALU only.  With the bit-plane formulation, though, C(v)[i][j] =
@@ -1132,6 +1263,41 @@ hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint3
     case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int KC, typename CT>
+static hipError_t launch_pcl(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad, uint32_t W,
+                             uint32_t P, const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,
+                             uint64_t nslots)
+{
+    const size_t lds = (size_t)KC * 4096;  // two halves, each double-buffered A|B
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts_ls<KC, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_pair_counts_ls<KC, CT>), dim3((nitems + 1) / 2), dim3(512), lds, st, planes, Npad, Kpad, W,
+                       P, tiles, items, nitems, reinterpret_cast<CT *>(cum), nslots);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_counts_lockstep(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes, uint32_t Npad,
+                                       uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
+                                       uint32_t nitems, void *cum, uint64_t nslots)
+{
+    if (nitems == 0 || Kpad == 0) return hipSuccess;
+    if (W < (uint32_t)kc)  // plane boundaries inside a chunk (p < 9): the kernel with the in-loop flush
+        return launch_pair_counts(st, kc, cum_bytes, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    if (cum_bytes == 2) {
+        switch (kc) {
+        case 16: return launch_pcl<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        case 32: return launch_pcl<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (kc) {
+    case 16: return launch_pcl<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
+    case 32: return launch_pcl<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     default: return hipErrorInvalidValue;
     }
 }

@@ -228,6 +228,19 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 2 << 30)
+        # the r1 tile kernel (256-thread workgroups, no phase-locking) vs the default lockstep kernel: same integers
+        ctx.set_option("pair_lockstep", 0)
+        for kc, ns in ((16, 0), (32, 0), (16, 3), (16, 64)):
+            ctx.set_option("kc", kc)
+            ctx.set_option("nsplit", ns)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+        ctx.set_option("pair_lockstep", 1)
+        ctx.set_option("nsplit", 0)
+        for chunks in (1, 16, 64, 100000):  # item size of the lockstep kernel
+            ctx.set_option("ls_item_chunks", chunks)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+        ctx.set_option("ls_item_chunks", 16)
+        ctx.set_option("pair_lockstep", -1)
         # the what-if variant of the tile kernel on the matrix cores (never the default): same integers
         ctx.set_option("pair_mfma", 1)
         for kc in (16, 32):
@@ -235,12 +248,49 @@ def test_options_do_not_change_results(ctx):
             assert ctx.dist_rows().tobytes() == base.tobytes()
     finally:
         ctx.set_option("pair_mfma", 0)
+        ctx.set_option("pair_lockstep", -1)
+        ctx.set_option("ls_item_chunks", 16)
         ctx.set_option("kc", 16)
         ctx.set_option("emax", -1)
         ctx.set_option("sort", -1)
         ctx.set_option("nsplit", 0)
         ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("cum_budget_bytes", 2 << 30)
+
+
+@pytest.mark.parametrize("p,n", [(8, 300), (9, 300), (10, 700), (11, 300), (12, 260), (13, 300), (15, 200), (16, 150), (18, 40)])
+def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
+    """k_pair_counts_ls (two work items per 512-thread workgroup, AND/BCNT batches phase-locked, deferred plane flush,
+    a shorter or missing partner item idling at the barriers) vs k_pair_counts, forced on at every precision where a
+    plane spans whole chunks (p >= 9; below, the option falls back); odd item counts and unequal item lengths included."""
+    regs = synth.synthetic_sketches(n, p, seed=900 + p)
+    ctx.set_sketches(regs)
+    try:
+        ctx.set_option("pair_lockstep", 0)
+        free = ctx.dist_rows()
+        assert ctx.info("lockstep") == 0
+        ctx.set_option("pair_lockstep", 1)
+        for kc, ns, chunks in ((16, 0, 16), (32, 0, 16), (16, 3, 16), (16, 0, 1), (16, 0, 100000), (16, 5, 7)):
+            ctx.set_option("kc", kc)
+            ctx.set_option("nsplit", ns)
+            ctx.set_option("ls_item_chunks", chunks)
+            got = ctx.dist_rows()
+            assert ctx.info("lockstep") == (1 if (1 << p) // 32 >= kc else 0)
+            assert got.tobytes() == free.tobytes(), (kc, ns, chunks)
+        # a row range (odd tile counts) and a rectangle through the same kernel
+        ctx.set_option("kc", 16)
+        ctx.set_option("nsplit", 0)
+        ctx.set_option("ls_item_chunks", 16)
+        part = ctx.dist_rows(5, n - 3)
+        rect = ctx.dist_rect(0, n // 2, n // 3, n)
+        ctx.set_option("pair_lockstep", 0)
+        assert ctx.dist_rows(5, n - 3).tobytes() == part.tobytes()
+        assert ctx.dist_rect(0, n // 2, n // 3, n).tobytes() == rect.tobytes()
+    finally:
+        ctx.set_option("pair_lockstep", -1)
+        ctx.set_option("kc", 16)
+        ctx.set_option("nsplit", 0)
+        ctx.set_option("ls_item_chunks", 16)
 
 
 def test_properties_at_scale(ctx, oracle):

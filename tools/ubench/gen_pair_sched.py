@@ -13,13 +13,50 @@ import sys
 A0, B0 = 16, 24          # a[r] = v16..v23, b[c] = v24..v31
 ACC0 = 64                # acc[r][c] = v(64 + 8r + c)
 TMP0 = 128               # 64 temporaries v128..v191
+A1, B1 = 32, 40          # second k-row's operands (carry-save variant): v32..v39, v40..v47
+ONES0 = 192              # carry-save variant: 64 "ones" bit-vectors v192..v255
 
 
-def body(order, tmp_bank_shift=0, ops="and+bcnt", barrier=False):
+def body_csa(order):
+    """TWO k-rows: per pair x = a0&b0, y = a1&b1, (ones, carry) = CSA(ones, x, y) with u = ones^x,
+    carry = bfi(u, y, x) = majority, ones = u^y; acc += bcnt(carry) (weight 2, applied at the plane flush).
+    6 instructions per 2 pair-slots (5 bitwise + 1 BCNT) instead of 4 (2 AND + 2 BCNT)."""
+    lines = []
+    pairs = [(r, c) for r in range(8) for c in range(8)]
+    for s in range(0, 64, order):
+        grp = pairs[s:s + order]
+        tx = lambda i: TMP0 + (2 * i) % 64
+        ty = lambda i: TMP0 + (2 * i + 1) % 64
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_and_b32 v%d, v%d, v%d" % (tx(i), A0 + r, B0 + c))
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_and_b32 v%d, v%d, v%d" % (ty(i), A1 + r, B1 + c))
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_xor_b32 v%d, v%d, v%d" % (ONES0 + 8 * r + c, ONES0 + 8 * r + c, tx(i)))
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_bfi_b32 v%d, v%d, v%d, v%d" % (tx(i), ONES0 + 8 * r + c, ty(i), tx(i)))
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_xor_b32 v%d, v%d, v%d" % (ONES0 + 8 * r + c, ONES0 + 8 * r + c, ty(i)))
+        for i, (r, c) in enumerate(grp):
+            lines.append("v_bcnt_u32_b32 v%d, v%d, v%d" % (ACC0 + 8 * r + c, tx(i), ACC0 + 8 * r + c))
+    return lines
+
+
+def lds_reads(row):
+    """the real kernel's operand traffic: 4 ds_read_b128 per k-row (A: broadcast over the lane's column index, B: over its
+    row index), issued right after the AND batch (its last use of the operands)"""
+    o = row * 512
+    return ["ds_read_b128 v[%d:%d], v8 offset:%d" % (A0, A0 + 3, o), "ds_read_b128 v[%d:%d], v8 offset:%d" % (A0 + 4, A0 + 7, o + 16),
+            "ds_read_b128 v[%d:%d], v9 offset:%d" % (B0, B0 + 3, 8192 + o), "ds_read_b128 v[%d:%d], v9 offset:%d" % (B0 + 4, B0 + 7, 8192 + o + 16)]
+
+
+def body(order, tmp_bank_shift=0, ops="and+bcnt", barrier=False, lds=-1, spread=False):
     """one k-row: 64 (AND, BCNT) pairs; `order` = batch size of ANDs issued before their BCNTs;
     barrier: s_barrier after every AND batch and every BCNT batch (keeps the waves of a SIMD in the same phase)"""
     lines = []
     pairs = [(r, c) for r in range(8) for c in range(8)]
+    if lds >= 0:
+        lines.append("s_waitcnt lgkmcnt(0)")
     for s in range(0, 64, order):
         grp = pairs[s:s + order]
         for i, (r, c) in enumerate(grp):
@@ -30,9 +67,15 @@ def body(order, tmp_bank_shift=0, ops="and+bcnt", barrier=False):
                 lines.append("v_and_b32 v%d, v%d, v%d" % (t, A0 + r, B0 + c))
         if barrier:
             lines.append("s_barrier")
+        rd = lds_reads(lds) if lds >= 0 and s + order >= 64 else []
+        if rd and not spread:
+            lines += rd
+            rd = []
         for i, (r, c) in enumerate(grp):
             t = TMP0 + ((s + i + tmp_bank_shift) % 64)
             acc = ACC0 + 8 * r + c
+            if rd and i % 16 == 0:
+                lines.append(rd.pop(0))
             if ops == "and+bcnt":
                 lines.append("v_bcnt_u32_b32 v%d, v%d, v%d" % (acc, t, acc))
             elif ops == "bcnt":
@@ -61,13 +104,23 @@ VARIANTS = [
     ("batch64_wg512", 64, 0, "and+bcnt", 512, False),
     ("batch64_wg512_bar", 64, 0, "and+bcnt", 512, True),
     ("batch32_wg512_bar", 32, 0, "and+bcnt", 512, True),
+    # ... with the real kernel's LDS operand reads (4 ds_read_b128 per k-row, after the AND batch)
+    ("batch64_lds", 64, 0, "and+bcnt", 256, False, True),
+    ("batch64_wg512_lds", 64, 0, "and+bcnt", 512, False, True),
+    ("batch64_wg512_bar_lds", 64, 0, "and+bcnt", 512, True, True),
+    ("batch64_wg512_bar_ldsspread", 64, 0, "and+bcnt", 512, True, True, True),
+    # carry-save (Harley-Seal, depth 1) over pairs of k-rows: 256 VGPRs, so 2 waves per SIMD at most (wg/CU = 2 lines only)
+    ("csa_b1", 1, 0, "csa"),
+    ("csa_b8", 8, 0, "csa"),
+    ("csa_b16", 16, 0, "csa"),
+    ("csa_b32", 32, 0, "csa"),
 ]
 
 ROWS_PER_ITER = 4  # k-rows per loop iteration (the real kernel unrolls 8)
 
 
-def kernel(name, order, shift, ops, wg=256, barrier=False):
-    clob = ", ".join('"v%d"' % i for i in list(range(A0, B0 + 8)) + list(range(ACC0, ACC0 + 64)) + list(range(TMP0, TMP0 + 64)))
+def kernel(name, order, shift, ops, wg=256, barrier=False, lds=False, spread=False):
+    clob = ", ".join('"v%d"' % i for i in [8, 9] + list(range(A0, B1 + 8)) + list(range(ACC0, ACC0 + 64)) + list(range(TMP0, TMP0 + 64)) + (list(range(ONES0, ONES0 + 64)) if ops == "csa" else []))
     L = []
     # operands from the lane id and a seed (seed 0 -> all-zero data: the low-power arm)
     for r in range(8):
@@ -77,14 +130,29 @@ def kernel(name, order, shift, ops, wg=256, barrier=False):
         L.append("v_mul_lo_u32 v%d, %%[tid], %%[m%d]" % (B0 + r, (r + 1) % 2))
         L.append("v_add_u32 v%d, v%d, %%[seed]" % (B0 + r, B0 + r))
         L.append("v_mul_lo_u32 v%d, v%d, %%[seed]" % (B0 + r, B0 + r))
+    # LDS addresses of the lane's A and B operand slots (as k_pair_counts: 8x8 lane grid, 32 B per lane and operand)
+    L.append("v_lshrrev_b32 v8, 3, %[tid]")
+    L.append("v_and_b32 v8, 7, v8")
+    L.append("v_lshlrev_b32 v8, 5, v8")
+    L.append("v_and_b32 v9, 7, %[tid]")
+    L.append("v_lshlrev_b32 v9, 5, v9")
+    for r in range(8):  # second k-row's operands
+        L.append("v_mul_lo_u32 v%d, v%d, %%[m1]" % (A1 + r, A0 + r))
+        L.append("v_mul_lo_u32 v%d, v%d, %%[m0]" % (B1 + r, B0 + r))
     for i in range(64):
         L.append("v_mov_b32 v%d, 0" % (ACC0 + i))
         L.append("v_mov_b32 v%d, 0" % (TMP0 + i))
+        if ops == "csa":
+            L.append("v_mov_b32 v%d, 0" % (ONES0 + i))
     L.append("s_memtime %[t0]")
     L.append("s_waitcnt lgkmcnt(0)")
     L.append("1:")
-    for _ in range(ROWS_PER_ITER):
-        L += body(order, shift, ops, barrier)
+    if ops == "csa":
+        for _ in range(ROWS_PER_ITER // 2):
+            L += body_csa(order)
+    else:
+        for row in range(ROWS_PER_ITER):
+            L += body(order, shift, ops, barrier, row if lds else -1, spread)
     L.append("s_sub_u32 %[it], %[it], 1")
     L.append("s_cmp_lg_u32 %[it], 0")
     L.append("s_cbranch_scc1 1b")
@@ -93,6 +161,8 @@ def kernel(name, order, shift, ops, wg=256, barrier=False):
     L.append("v_mov_b32 %[res], 0")
     for i in range(64):
         L.append("v_xor_b32 %%[res], %%[res], v%d" % (ACC0 + i))
+        if ops == "csa":
+            L.append("v_xor_b32 %%[res], %%[res], v%d" % (ONES0 + i))
     asm = "\\n\\t".join(L)
     return """
 __global__ __launch_bounds__(%d) void k_%s(uint32_t *out, uint64_t *cyc, uint32_t seed, int iters)
@@ -154,7 +224,13 @@ int main()
             for v in VARIANTS:
                 if seed == 0 and v[0] not in ("batch8", "and_only", "bcnt_only"):
                     continue
-                o.write('    run("%s", k_%s, %d, %du, 64);\n' % (v[0], v[0], wg, seed))
+                if v[3] == "csa" and wg != 2:
+                    continue
+                thr = v[4] if len(v) > 4 else 256
+                if thr == 512 and wg != 2:
+                    continue
+                # 512-thread workgroups: ONE per CU gives the same 2 waves per SIMD as two 256-thread ones
+                o.write('    run("%s", k_%s, %d, %du, 64, %d);\n' % (v[0], v[0], wg * 256 // thr, seed, thr))
     o.write("    return 0;\n}\n")
 
 
