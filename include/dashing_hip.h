@@ -221,10 +221,15 @@ void dsh_free_host(void *p);
 int dsh_set_profiling(dsh_ctx *ctx, int enable);
 int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
                        double *prepare_ms, uint32_t *pair_kernel_launches);
-/* Tunables (tile shape variant etc.); returns DSH_EINVAL for unknown names. */
+/* Tunables; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
+ * byte-identical output over their ranges): "kc" (16|32|64 k-rows per LDS stage), "emax" (exception-list cap, -1 auto),
+ * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
+ * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
+ * "ls_item_chunks", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
+ * "assembler_permille", "shard_c0_x10"; profiling/what-if only: "finalize_stop", "pair_mfma" (never the default). */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
- * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "tiles",
+ * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles",
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.
