@@ -238,7 +238,7 @@ def main():
     # What actually bounds the tile kernel: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
     # Cycles are wall time x 2.4 GHz on 1024 SIMDs, the same convention as profiles/ubench/pair_sched.txt:
     #   nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                                  = 6.0
-    #   each op on its own   2.07 + 4.42  (and_only / bcnt_only rows of pair_sched.txt)             = 6.49
+    #   each op on its own   2.06 + 4.07..4.42  (and_only / bcnt_only rows of pair_sched.txt)       = 6.13 (..6.49)
     #   the mix with the waves of a SIMD phase-locked (all ANDs, barrier, all BCNTs, barrier),
     #     registers only 6.4-6.8, with the LDS operand reads 6.9                                     = 6.9
     #   the mix free-running (waves of a SIMD in different instruction classes), any order/banks    = 8.18
@@ -250,11 +250,11 @@ def main():
         "cycles_per_and_bcnt_pair": round(cyc, 3),
         "frac_of_free_running_mix_ceiling": round(8.18 / cyc, 4) if cyc else 0.0,
         "frac_of_phase_locked_mix_ceiling": round(6.9 / cyc, 4) if cyc else 0.0,
-        "frac_of_isolated_rates": round(6.49 / cyc, 4) if cyc else 0.0,
+        "frac_of_isolated_rates": round(6.13 / cyc, 4) if cyc else 0.0,
         "frac_of_nominal_issue_model": round(6.0 / cyc, 4) if cyc else 0.0,
-        "ceilings_cycles": {"free_running_mix": 8.18, "phase_locked_mix_with_lds_reads": 6.9, "isolated_sum": 6.49, "nominal_2_plus_4": 6.0},
+        "ceilings_cycles": {"free_running_mix": 8.18, "phase_locked_mix_with_lds_reads": 6.9, "isolated_sum": 6.13, "nominal_2_plus_4": 6.0},
         "phase_locked_kernel": lockstep,
-        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.07 cycles and BCNTs at one per 4.42, but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with two s_barrier per k-row. In-kernel s_memtime (profiles/r2k): 955 cycles per k-row of two waves = 850 for the phases and barriers + ~65 LDS operand reads + ~40 DMA arrival, + 40 per-chunk overhead",
+        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.06 cycles and BCNTs at one per 4.07-4.42 (run to run), but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with two s_barrier per k-row. In-kernel s_memtime (profiles/r2k): 955 cycles per k-row of two waves = 850 for the phases and barriers + ~65 LDS operand reads + ~40 DMA arrival, + 40 per-chunk overhead",
     }
     roofline["finalize"] = {
         "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",
