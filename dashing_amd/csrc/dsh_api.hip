@@ -102,7 +102,7 @@ struct dsh_ctx {
     std::vector<uint4> htiles;
     // options
     int kc = 16;  // 16 rows per LDS stage (32 KiB double-buffered): ~1 % faster than 32 in three sweeps (profiles/)
-    int emax_opt = -1;  // -1: min(96 | 192 for p >= 16, 2^p / 128) -- sweeps per precision in profiles/r1k/README.md
+    int emax_opt = -1;  // -1: min(255, 2^p / 128) -- sweeps per precision in profiles/r2m/emax_sweep.txt (r1k: with the slower tile kernel, 96 / 192)
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
@@ -205,7 +205,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
     if (want_rb > want_re) want_rb = want_re;
     const uint64_t n = c->n;
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
-                                          : (int)std::min<uint64_t>(c->p >= 16 ? 192 : 96, (1ull << c->p) >> 7);  // sweeps: profiles/r1k/README.md
+                                          : (int)std::min<uint64_t>(kExcCap - 1, (1ull << c->p) >> 7);  // sweeps: profiles/r2m/emax_sweep.txt
     if (emax_new != c->emax) {  // thresholds and lists (hence planes) depend on it
         c->planes_valid = false;
         c->card_estim = -1;
