@@ -17,6 +17,8 @@ def host():
     lib = C.CDLL(os.path.join(ROOT, "dashing_amd", "libdashing_host.so"))
     vp, cp, sz = C.c_void_p, C.c_char_p, C.c_size_t
     lib.dshh_append_fastx.restype = C.c_long
+    lib.dshh_append_fastx_into.restype = C.c_long
+    lib.dshh_append_fastx_into.argtypes = [cp, vp, sz, C.POINTER(sz)]
     lib.dshh_append_fastx.argtypes = [cp, vp, sz, C.POINTER(sz)]
     lib.dshh_make_fname.argtypes = [cp, C.c_uint, C.c_int, cp, cp, cp, cp, sz]
     lib.dshh_write_hll.argtypes = [cp, vp, C.c_int, C.c_int]
@@ -103,6 +105,33 @@ def test_fastx(host, tmp_path):
     empty.write_text("")
     assert parse(host, str(empty)) == (0, b"")
     assert parse(host, "/nonexistent.fa")[0] == -1
+
+
+def test_fastx_into_caller_memory(host, tmp_path):
+    """append_fastx_into (what the CLI's streaming loader calls): parses straight into caller-owned memory behind what is
+    already there, never grows it, reports an overflow instead of truncating silently"""
+    fa = tmp_path / "a.fa"
+    fa.write_text(">r1\nACGT\nAC\n>r2\nGG\n")
+    buf = np.full(64, ord("x"), np.uint8)
+    n = C.c_size_t(3)  # three bytes already in the buffer
+    assert host.dshh_append_fastx_into(str(fa).encode(), buf.ctypes.data, buf.size, C.byref(n)) == 2
+    assert n.value == 3 + 9 and buf[:12].tobytes() == b"xxxACGTACNGG" and buf[12] == ord("x")
+    # a second file behind the first, as for a multi-file genome
+    assert host.dshh_append_fastx_into(str(fa).encode(), buf.ctypes.data, buf.size, C.byref(n)) == 2
+    assert n.value == 21 and buf[12:21].tobytes() == b"ACGTACNGG"
+    small = np.zeros(8, np.uint8)
+    n = C.c_size_t(0)
+    assert host.dshh_append_fastx_into(str(fa).encode(), small.ctypes.data, small.size, C.byref(n)) == -2
+    assert n.value == 0
+    assert host.dshh_append_fastx_into(b"/nonexistent.fa", small.ctypes.data, small.size, C.byref(n)) == -1
+    # a long single-line record that crosses the parser's 1 MiB read blocks
+    big = tmp_path / "big.fa"
+    seq = (b"ACGT" * 300_000) + b"N" + (b"TTGA" * 50_000)
+    big.write_bytes(b">big\n" + seq + b"\n")
+    out = np.zeros(seq.size if hasattr(seq, "size") else len(seq) + 16, np.uint8)
+    n = C.c_size_t(0)
+    assert host.dshh_append_fastx_into(str(big).encode(), out.ctypes.data, out.size, C.byref(n)) == 1
+    assert n.value == len(seq) and out[: n.value].tobytes() == seq
 
 
 def test_sort_and_split(host, tmp_path):
