@@ -111,6 +111,7 @@ struct dsh_ctx {
     int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
+    int ls_sort_items = 1;
     int ls_item_chunks = 16;  // lockstep kernel: work items of about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
     // (planes of >= 8 chunks, i.e. p >= 12 at kc = 16: tools/lockstep_ab.py -- 4-6 % faster at p = 14/18, 2-3 % at 12,
@@ -511,7 +512,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             chunk_range(T[t], cb, ce);
             maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((ce - cb + piece - 1) / piece));
         }
-        for (uint32_t s = 0; s < maxpieces; ++s)  // piece-major so neighbours in launch order share planes
+        for (uint32_t s = 0; s < maxpieces; ++s) {  // piece-major so neighbours in launch order share planes
+            const size_t g0 = I.size();
             for (size_t t = bd.first; t < bd.second; ++t) {
                 uint32_t cb, ce;
                 chunk_range(T[t], cb, ce);
@@ -519,6 +521,10 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                 if (b0 >= ce) continue;
                 I.push_back(make_uint4((uint32_t)(t - bd.first), (uint32_t)b0, (uint32_t)std::min<uint64_t>(ce, b0 + piece), 0));
             }
+            // the lockstep kernel pairs consecutive items: keep equal lengths together (only a tile's last piece is shorter)
+            if (lockstep && c->ls_sort_items)
+                std::stable_sort(I.begin() + g0, I.end(), [](const uint4 &x, const uint4 &y) { return x.z - x.y > y.z - y.y; });
+        }
         band_items.emplace_back(i0, I.size());
     }
     // tile and item lists travel through page-locked staging, so nothing below needs the host to wait
@@ -1440,6 +1446,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "range_sort_min_rows")) {
         if (v < 1) return fail(c, DSH_EINVAL, "range_sort_min_rows must be >= 1");
         c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "ls_sort_items")) {
+        c->ls_sort_items = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "ls_item_chunks")) {

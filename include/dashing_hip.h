@@ -225,7 +225,7 @@ int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_ke
  * byte-identical output over their ranges): "kc" (16|32|64 k-rows per LDS stage), "emax" (exception-list cap, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
- * "ls_item_chunks", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
+ * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
  * "assembler_permille", "shard_c0_x10"; profiling/what-if only: "finalize_stop", "pair_mfma" (never the default). */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",

@@ -270,13 +270,15 @@ def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
         free = ctx.dist_rows()
         assert ctx.info("lockstep") == 0
         ctx.set_option("pair_lockstep", 1)
-        for kc, ns, chunks in ((16, 0, 16), (32, 0, 16), (16, 3, 16), (16, 0, 1), (16, 0, 100000), (16, 5, 7)):
+        for kc, ns, chunks, srt in ((16, 0, 16, 1), (32, 0, 16, 1), (16, 3, 16, 1), (16, 0, 1, 0), (16, 0, 100000, 1), (16, 5, 7, 0), (16, 0, 16, 0)):
             ctx.set_option("kc", kc)
             ctx.set_option("nsplit", ns)
             ctx.set_option("ls_item_chunks", chunks)
+            ctx.set_option("ls_sort_items", srt)  # equal-length items next to each other (the kernel pairs neighbours)
             got = ctx.dist_rows()
             assert ctx.info("lockstep") == (1 if (1 << p) // 32 >= kc else 0)
-            assert got.tobytes() == free.tobytes(), (kc, ns, chunks)
+            assert got.tobytes() == free.tobytes(), (kc, ns, chunks, srt)
+        ctx.set_option("ls_sort_items", 1)
         # a row range (odd tile counts) and a rectangle through the same kernel
         ctx.set_option("kc", 16)
         ctx.set_option("nsplit", 0)
@@ -291,6 +293,7 @@ def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
         ctx.set_option("kc", 16)
         ctx.set_option("nsplit", 0)
         ctx.set_option("ls_item_chunks", 16)
+        ctx.set_option("ls_sort_items", 1)
 
 
 def test_properties_at_scale(ctx, oracle):

@@ -22,7 +22,7 @@ for n, p in cases:
     ctx.set_profiling(True)
     row = {"n": n, "p": p}
     for vi, (name, opts) in enumerate(variants):
-        for k_, v_ in (("nsplit", 0), ("kc", 16)):
+        for k_, v_ in (("nsplit", 0), ("kc", 16), ("ls_item_chunks", 16), ("ls_sort_items", 1)):
             ctx.set_option(k_, v_)
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
