@@ -83,6 +83,30 @@ def pair_slots(ctx):
     return ctx.info("avg_tile_planes_x100") / 100.0 * ctx.info("words_per_plane") * ctx.info("tiles") * 128 * 128 / 64.0
 
 
+def self_launch(n_gpus, backend):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec under torch.distributed.run, one rank per GPU on
+    this node (the same command line the driver uses).  Fails -- never falls back to fewer GPUs -- when the node shows
+    fewer than N devices (backend gloo = dry run of the N-rank code path with every rank on cuda:0, never reported)."""
+    import socket
+    import subprocess
+
+    import dashing_amd
+
+    have = dashing_amd.device_count()
+    need = 1 if backend == "gloo" else n_gpus
+    if have < need:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible gfx950 device(s), found %d\n" % (n_gpus, need, have))
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(argv, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +116,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary p=10 workload line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args.gpus, backend))  # one rank per GPU under torch.distributed.run; never a silent 1-GPU run
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: launched with WORLD_SIZE=%s but --gpus %d: refusing to report a mislabelled run" % (os.environ["WORLD_SIZE"], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -104,7 +136,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DSH_BENCH_BACKEND=gloo is a dry-run of the N>1 code path on a box with ONE GPU: all ranks share
     # cuda:0 and the spans travel through host memory.  Never used for reported numbers.
-    backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
     # DSH_BENCH_FORCE_DIST=1 runs the distributed code path (process group, exchange) even with one rank --
     # a functional check of the RCCL plumbing on a 1-GPU box, not a reported configuration.
     multi = world > 1 or bool(os.environ.get("DSH_BENCH_FORCE_DIST"))
@@ -119,6 +150,8 @@ def main():
             torch.cuda.set_device(0)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            if torch.cuda.device_count() < world:
+                sys.exit("bench.py: %d ranks but only %d visible GPUs" % (world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -322,7 +355,7 @@ def main():
         }
         if multi:
             line["multi_gpu"] = {
-                "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
+                "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
                 "row_bounds": bounds, "pairs_per_rank": sizes,
                 "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange": round(phases[1], 4),
                                             "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},

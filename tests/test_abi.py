@@ -104,3 +104,25 @@ def test_balance_rows(n, parts):
                    for mid in itertools.combinations_with_replacement(range(nt + 1), parts - 1)
                    for c in [(0,) + mid + (nt,)])
         assert worst <= best + 1e-2
+
+
+def test_bench_gpus_flag_never_falls_back_to_one_gpu():
+    """`bench.py --gpus N` without a launcher re-execs itself under torch.distributed.run; with fewer than N devices
+    (none in the CPU container) it must exit non-zero and print no JSON line."""
+    import subprocess
+    import sys
+
+    import dashing_amd
+
+    if dashing_amd.device_count() >= 2:
+        pytest.skip("a multi-GPU box: covered by the gpu tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, timeout=300)
+    assert r.returncode != 0
+    assert b"needs 2 visible" in r.stderr and not r.stdout.strip()
+    # a launcher that disagrees with --gpus is refused as well
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"refusing" in r.stderr
