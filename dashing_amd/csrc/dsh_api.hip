@@ -74,6 +74,8 @@ struct dsh_ctx {
     bool planes_valid = false;
     int card_estim = -1;
     DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
+    DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
+    uint32_t nbuckets = 0, ent_stride = 0;
     // column layout of the cached plane matrix.  0: identity over all n sketches.  1: the sub-collection
     // {lay_rb .. n-1} -- the rows [lay_rb, lay_re) first, then the rows [lay_re, n), each part in key order
     // (lay_rb = 0, lay_re = n: the whole collection sorted, what full-triangle calls and the shard path use)
@@ -84,11 +86,10 @@ struct dsh_ctx {
     bool hk32_valid = false;
     hipEvent_t ev_perm = nullptr;       // upload of pin_perm done (it is rewritten by the next layout)
     bool perm_in_flight = false;
-    std::vector<uint16_t> hkeys;        // per sketch (T_i << 8) | lo_i
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
     uint32_t *pin_perm = nullptr;       // page-locked copy of hperm: its upload is then truly asynchronous
     size_t pin_perm_cap = 0;
-    std::vector<uint8_t> blk_T, blk_lo; // per 128-column block: max threshold, min register value
+    std::vector<uint8_t> blk_T, blk_lo, blk_L; // per 128-column block: max high threshold, min register value, min low threshold
     std::vector<uint4> hitems;
     PinBuf pin_work;                    // sketch work list of the call in flight
     hipEvent_t ev_work = nullptr;
@@ -97,12 +98,13 @@ struct dsh_ctx {
     hipEvent_t ev_lists = nullptr;      // recorded after their upload; waited on before they are rewritten
     bool lists_in_flight = false;
     uint32_t Npad = 0, W = 0, P = 0, Kpad = 0;
-    int vlo = 0, vhi = 0;
-    int emax = 0, cum_bytes = 4;
+    int vlo = 0, vhi = 0, pbase = 0;  // register value range of the columns; plane pl is the threshold pbase + 1 + pl
+    int emax = 0, elow = 0, cum_bytes = 4;
     std::vector<uint4> htiles;
     // options
     int kc = 16;  // 16 rows per LDS stage (32 KiB double-buffered): ~1 % faster than 32 in three sweeps (profiles/)
-    int emax_opt = -1;  // -1: min(255, 2^p / 128) -- sweeps per precision in profiles/r2m/emax_sweep.txt (r1k: with the slower tile kernel, 96 / 192)
+    int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
+    int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
     uint64_t cum_budget = 2ull << 30;
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
@@ -188,6 +190,34 @@ void invalidate(dsh_ctx *c)
     c->hk32_valid = false;
 }
 
+// fields of a per-sketch key (k_selfhist_card): bad << 31 | hi << 18 | T << 12 | L << 6 | lo
+inline int key_lo(uint32_t k) { return (int)(k & 63u); }
+inline int key_L(uint32_t k) { return (int)((k >> 6) & 63u); }
+inline int key_T(uint32_t k) { return (int)((k >> 12) & 63u); }
+inline int key_hi(uint32_t k) { return (int)((k >> 18) & 63u); }
+
+// default caps of the two listed tails (profiles/r3b/list_cap_sweep.jsonl).  A pair shares cap^2 / 2^p listed positions
+// per side, each one an LDS atomic in k_finalize; every halving of the upper tail (a plane saved) costs twice the
+// entries, while the lower tail of the register law falls off double-exponentially: listing ~200 registers removes
+// the one or two nearly empty planes at the bottom.  Below p = 12 a plane is cheap (<= 64 words per pair) and
+// k_finalize is the hot kernel: short upper lists, no lower ones.
+int auto_list_cap(int p, bool upper)
+{
+    const uint64_t m = 1ull << p;
+    if (p < 12) return upper ? (int)(m >> 7) : 0;
+    return upper ? (int)std::min<uint64_t>(kMaxListSide, m >> 5) : (int)std::min<uint64_t>(200, m >> 6);
+}
+
+// dense plane range of the tile (ti, tj): C(v) is needed for v in (max(larger of the two minima, smaller of the two
+// low thresholds), larger of the two high thresholds] -- below that every C(v) is 0 or comes from the low-list join
+void tile_planes(const dsh_ctx *c, uint32_t ti, uint32_t tj, int &pb, int &pe)
+{
+    const int lo_t = std::max<int>(std::max<int>(c->blk_lo[ti], c->blk_lo[tj]), std::min<int>(c->blk_L[ti], c->blk_L[tj]));
+    const int T_t = std::max<int>(c->blk_T[ti], c->blk_T[tj]);
+    pb = std::max(0, lo_t - c->pbase);
+    pe = std::max(pb, T_t - c->pbase);
+}
+
 // cardinalities + thresholds/exception lists + planes for the current sketch matrix.
 // want_sorted: lay the plane-matrix columns out in (threshold, min value) order so that the
 // 128-column blocks are homogeneous and every tile can use its own narrow plane range.
@@ -205,13 +235,14 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
     if (!want_sorted) want_rb = 0, want_re = c->n;
     if (want_rb > want_re) want_rb = want_re;
     const uint64_t n = c->n;
-    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kExcCap - 1)
-                                          : (int)std::min<uint64_t>(kExcCap - 1, (1ull << c->p) >> 7);  // sweeps: profiles/r2m/emax_sweep.txt
-    if (emax_new != c->emax) {  // thresholds and lists (hence planes) depend on it
+    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kMaxListSide) : auto_list_cap(c->p, true);
+    const int elow_new = c->elow_opt >= 0 ? std::min<int>(c->elow_opt, (int)kMaxListSide) : auto_list_cap(c->p, false);
+    if (emax_new != c->emax || elow_new != c->elow) {  // thresholds and lists (hence planes) depend on them
         c->planes_valid = false;
         c->card_estim = -1;
     }
     c->emax = emax_new;
+    c->elow = elow_new;
     const bool same_layout = c->planes_valid && c->planes_sorted == want_sorted &&
                              (!want_sorted || (c->lay_rb == want_rb && c->lay_re == want_re));
     if (c->card_estim == estim && (card_only || same_layout)) return DSH_OK;
@@ -224,13 +255,13 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
     // the per-sketch pass depends on (registers, estimator, emax) only: a new column layout reuses it
     if (c->card_estim != estim) {
         HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
-        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kExcCap * sizeof(uint32_t) + 256));  // + slack: k_finalize prefetches one step past a list
-        HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kExcCap));
+        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kListCap * (c->p <= 15 ? 2 : 4)));
+        HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kListCap));
         HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->tailhist.ensure(std::max<uint64_t>(n, 1) * 64));
-        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax,
-                                       (double *)c->card.ptr, (uint32_t *)c->exc.ptr, (uint8_t *)c->excv.ptr,
+        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax, c->elow,
+                                       (double *)c->card.ptr, c->exc.ptr, (uint8_t *)c->excv.ptr,
                                        (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
                                        (uint8_t *)c->tailhist.ptr));
         c->card_estim = estim;
@@ -263,7 +294,6 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
             if (k32[i] & 0x80000000u)
                 return fail(c, DSH_EINVAL, "sketch %llu holds a register value above %d (= 64 - p + 1): not an HLL of precision %d (corrupt or foreign .hll?)",
                             (unsigned long long)i, 64 - c->p + 1, c->p);
-        c->hkeys.resize(n);
         // the plane matrix holds the sketches col0 .. n-1 (a row range [rb,re) of the triangle never looks at
         // sketches before rb); value range and thresholds are taken over those only
         const uint64_t col0 = want_sorted ? want_rb : 0;
@@ -271,16 +301,14 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t key = k32[i];
             if (i >= col0) {
-                vr[0] = std::min<int>(vr[0], (int)(key & 0xFF));
-                vr[1] = std::max<int>(vr[1], (int)(key >> 16));
-                vr[2] = std::max<int>(vr[2], (int)((key >> 8) & 0xFF));
+                vr[0] = std::min<int>(vr[0], key_lo(key));
+                vr[1] = std::max<int>(vr[1], key_hi(key));
+                vr[2] = std::max<int>(vr[2], key_T(key));
             }
-            c->hkeys[i] = (uint16_t)(key & 0xFFFF);
         }
         if (ncols == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
         c->vhi = vr[1];
-        c->P = (uint32_t)(vr[2] - vr[0]);  // dense planes cover v in (lo, Tmax]
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
@@ -293,9 +321,9 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         // then the later rows; each part is key-ordered on its own.
         c->hperm.resize(ncols);
         if (want_sorted) {
-            auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each
+            auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each: high threshold, low threshold, max value
                 const uint32_t key = k32[i];
-                return (((key >> 8) & 63u) << 12) | ((key & 63u) << 6) | ((key >> 16) & 63u);
+                return ((uint32_t)key_T(key) << 12) | ((uint32_t)key_L(key) << 6) | (uint32_t)key_hi(key);
             };
             // stable LSD radix sort, three 6-bit digits (a single 2^18-bucket counting sort spends
             // ~0.1 ms clearing and scanning its counters -- a quarter of prepare())
@@ -349,12 +377,19 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         const uint32_t NT = c->Npad / kTile;
         c->blk_T.assign(NT, 0);
         c->blk_lo.assign(NT, 255);
+        c->blk_L.assign(NT, 255);
+        int pbase = vr[2];
         for (uint64_t s = 0; s < ncols; ++s) {
-            const uint16_t key = c->hkeys[c->hperm[s]];
+            const uint32_t key = k32[c->hperm[s]];
             const uint32_t b = (uint32_t)(s / kTile);
-            c->blk_T[b] = std::max<uint8_t>(c->blk_T[b], (uint8_t)(key >> 8));
-            c->blk_lo[b] = std::min<uint8_t>(c->blk_lo[b], (uint8_t)(key & 0xFF));
+            c->blk_T[b] = std::max<uint8_t>(c->blk_T[b], (uint8_t)key_T(key));
+            c->blk_lo[b] = std::min<uint8_t>(c->blk_lo[b], (uint8_t)key_lo(key));
+            c->blk_L[b] = std::min<uint8_t>(c->blk_L[b], (uint8_t)key_L(key));
+            pbase = std::min<int>(pbase, key_L(key));
         }
+        // dense planes cover v in (pbase, Tmax]: below the smallest low threshold every C(v) comes from the list join
+        c->pbase = pbase;
+        c->P = (uint32_t)(vr[2] - pbase);
         const uint64_t K = (uint64_t)c->P * c->W;
         c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
         if (c->Kpad) {
@@ -364,10 +399,18 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
                 HIPCHK(c, hipMemsetAsync((uint32_t *)c->planes.ptr + K * c->Npad, 0,
                                          (size_t)(c->Kpad - K) * c->Npad * sizeof(uint32_t),
                                          c->stream));
-            HIPCHK(c, launch_transform(c->stream, c->regs, ncols, c->p, c->vlo, c->P, c->W, c->Npad,
+            HIPCHK(c, launch_transform(c->stream, c->regs, ncols, c->p, c->pbase, c->P, c->W, c->Npad,
                                        (uint32_t *)c->planes.ptr,
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
         }
+        // position index of every column block (the list joins of k_finalize)
+        c->nbuckets = (uint32_t)std::min<uint64_t>(m, kMaxBuckets);
+        c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
+        HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
+        HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
+        HIPCHK(c, launch_build_colindex(c->stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
+                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, ncols, c->p, NT, c->nbuckets,
+                                        c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
         c->planes_sorted = want_sorted;
         c->lay_rb = want_rb;
         c->lay_re = want_re;
@@ -443,11 +486,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     T.clear();
     const uint32_t NT = c->Npad / kTile;
     auto tile_of = [&](uint32_t ti, uint32_t tj) {
-        const int lo_t = std::max<int>(c->blk_lo[ti], c->blk_lo[tj]);
-        const int T_t = std::max<int>(c->blk_T[ti], c->blk_T[tj]);
-        int pb = lo_t - c->vlo, pe = T_t - c->vlo;
-        if (pb < 0) pb = 0;
-        if (pe < pb) pe = pb;
+        int pb, pe;
+        tile_planes(c, ti, tj, pb, pe);
         return make_uint4(ti, tj, (uint32_t)pb, (uint32_t)pe);
     };
     if (job.rect) {
@@ -578,7 +618,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.cum = c->cum.ptr;
         f.cum_bytes = c->cum_bytes;
         f.vhi = c->vhi;
-        f.exc = (const uint32_t *)c->exc.ptr;
+        f.exc = c->exc.ptr;
         f.exc_n = (const uint32_t *)c->exc_n.ptr;
         f.excv = (const uint8_t *)c->excv.ptr;
         f.keys = (const uint32_t *)c->keys.ptr;
@@ -587,8 +627,12 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.tiles = dt;
         f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
         f.vlo = c->vlo;
+        f.pbase = c->pbase;
+        f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
+        f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
+        f.nbuckets = c->nbuckets;
+        f.ent_stride = c->ent_stride;
         f.p = c->p;
-        f.emax = c->emax;
         f.estim = job.estim;
         f.result_type = job.result_type;
         f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
@@ -695,6 +739,8 @@ void dsh_destroy(dsh_ctx *c)
     if (c->ev_perm) (void)hipEventDestroy(c->ev_perm);
     c->keys.release();
     c->tailhist.release();
+    c->cidx_off.release();
+    c->cidx_ent.release();
     c->perm.release();
     c->items.release();
     c->cum.release();
@@ -1221,9 +1267,9 @@ static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb
     double total = 0;
     for (uint32_t ti = 0; ti < NT; ++ti) {
         for (uint32_t tj = ti; tj < NT; ++tj) {
-            const int lo_t = std::max<int>(c->blk_lo[ti], c->blk_lo[tj]);
-            const int T_t = std::max<int>(c->blk_T[ti], c->blk_T[tj]);
-            rowcost[ti] += std::max(0, T_t - lo_t) + c->shard_c0;
+            int pb, pe;
+            tile_planes(c, ti, tj, pb, pe);
+            rowcost[ti] += (pe - pb) + c->shard_c0;
         }
         total += rowcost[ti];
     }
@@ -1365,6 +1411,7 @@ int dsh_set_profiling(dsh_ctx *c, int enable)
 {
     if (!c) return DSH_EINVAL;
     c->profiling = enable != 0;
+    if (!c->profiling) c->finalize_stop = 0;  // the stop points exist for profiling runs only
     return DSH_OK;
 }
 
@@ -1384,8 +1431,10 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     if (!std::strcmp(name, "planes")) *out = c->P;
     else if (!std::strcmp(name, "vlo")) *out = c->vlo;
     else if (!std::strcmp(name, "vhi")) *out = c->vhi;
-    else if (!std::strcmp(name, "threshold")) *out = c->vlo + (int64_t)c->P;
+    else if (!std::strcmp(name, "threshold")) *out = c->pbase + (int64_t)c->P;
+    else if (!std::strcmp(name, "pbase")) *out = c->pbase;
     else if (!std::strcmp(name, "emax")) *out = c->emax;
+    else if (!std::strcmp(name, "elow")) *out = c->elow;
     else if (!std::strcmp(name, "kc")) *out = c->kc;
     else if (!std::strcmp(name, "tile")) *out = kTile;
     else if (!std::strcmp(name, "npad")) *out = c->Npad;
@@ -1466,7 +1515,9 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->pair_mfma = v != 0;
         return DSH_OK;
     }
-    if (!std::strcmp(name, "finalize_stop")) {
+    if (!std::strcmp(name, "finalize_stop")) {  // profiling only: results are meaningless while it is set
+        if (v < 0 || v > 4) return fail(c, DSH_EINVAL, "finalize_stop must be in [0,4]");
+        if (v && !c->profiling) return fail(c, DSH_ESTATE, "finalize_stop needs dsh_set_profiling(ctx, 1)");
         c->finalize_stop = (int)v;
         return DSH_OK;
     }
@@ -1475,9 +1526,9 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->nsplit = (int)v;
         return DSH_OK;
     }
-    if (!std::strcmp(name, "emax")) {
-        if (v < -1 || v >= (int64_t)kExcCap) return fail(c, DSH_EINVAL, "emax must be in [-1,%u]", kExcCap - 1);
-        c->emax_opt = (int)v;
+    if (!std::strcmp(name, "emax") || !std::strcmp(name, "elow")) {
+        if (v < -1 || v > (int64_t)kMaxListSide) return fail(c, DSH_EINVAL, "%s must be in [-1,%u]", name, kMaxListSide);
+        (name[1] == 'm' ? c->emax_opt : c->elow_opt) = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "xcd_swizzle")) {

@@ -6,11 +6,18 @@
 namespace dsh {
 
 constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
-constexpr uint32_t kExcCap = 256;  // capacity of a sketch's exception list (entries); emax <= 255
+constexpr uint32_t kListCap = 512;  // capacity of a sketch's register list (entries): upper tail (emax <= 255) + lower tail (elow <= 255)
+constexpr uint32_t kMaxListSide = 255;  // cap of either tail (their per-value counts are bytes)
+constexpr uint32_t kMaxBuckets = 1u << 14;  // position buckets of a column block's index
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, uint32_t *exc, uint8_t *excv, uint32_t *exc_n,
+                                int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist);
+// position index of every 128-column block of the plane layout (perm == nullptr: identity): off[nblocks][nbuckets + 2]
+// (uint16), ent[nblocks][ent_stride]
+hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
+                                 const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks, uint32_t nbuckets,
+                                 uint32_t ent_stride, uint16_t *off, uint32_t *ent);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
                             const uint32_t *perm);
@@ -35,12 +42,16 @@ struct FinalizeLaunch {
     uint64_t nslots;
     const uint4 *tiles;
     const uint32_t *perm;
-    int vlo, vhi, p, estim, result_type, emax;
+    int vlo, vhi, pbase, p, estim, result_type;
     double ksinv;
     const double *card;
-    const uint32_t *exc, *exc_n, *keys;
+    const void *exc;
+    const uint32_t *exc_n, *keys;
     const uint8_t *excv;
     const uint8_t *tailhist;
+    const uint16_t *cidx_off;
+    const uint32_t *cidx_ent;
+    uint32_t nbuckets, ent_stride;
     uint64_t n, ncols;  // collection size (output dimension); real columns of the plane matrix
     int rect, sorted_out, square;
     int stop = 0;  // profiling: k_finalize leaves after phase `stop`
@@ -67,7 +78,7 @@ struct SketchWork {
     uint32_t slot;   // row of the resident sketch matrix
 };
 constexpr int kMaxPLds = 17;   // largest p whose registers fit a workgroup's LDS (k_sketch)
-constexpr int kMaxPCompare = 24;  // the compare path takes every p the sketches can have (k_finalize: position bitmap in LDS up to p = 19, hash-only probing above)
+constexpr int kMaxPCompare = 24;  // the compare path takes every p the sketches can have 
 constexpr int kMaxP = 24;      // largest p for sketching / cardinalities / up- and download (positions are 24-bit)
 constexpr uint32_t kSketchSub = 8192;  // bases per sub-chunk (256 threads x 32 start positions)
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,

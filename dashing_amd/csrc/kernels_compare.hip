@@ -39,27 +39,35 @@ namespace dsh {
 // ------------------------------------------------------------------------------------------
 // per-sketch pass.  block = 256 threads = 4 waves, one sketch per wave.
 // PT = type of a listed position: uint16_t for p <= 15, uint32_t above.
+// Per sketch: 64-bin histogram -> cardinality; value range [lo, hi]; the HIGH threshold T (the registers above T,
+// at most emax of them, are listed: the geometric upper tail of the register law) and the LOW threshold L (the
+// registers below L, at most elow of them, are listed too: the lower tail falls off double-exponentially, so two
+// or three nearly empty bit-planes are traded for ~150 list entries); lo <= L <= T <= hi.  The list holds
+// (position, value) in no particular order -- k_finalize joins lists through a position index
+// (k_build_colindex), nothing walks them in order.
+// key = bad << 31 | hi << 18 | T << 12 | L << 6 | lo.
 template <typename PT>
 __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs,
-                                                        uint64_t n, int p, int estim, int emax,
+                                                        uint64_t n, int p, int estim, int emax, int elow,
                                                         double *__restrict__ card,
-                                                        uint32_t *__restrict__ exc,
+                                                        PT *__restrict__ exc,
                                                         uint8_t *__restrict__ excv,
                                                         uint32_t *__restrict__ exc_n,
                                                         uint32_t *__restrict__ keys,
                                                         uint8_t *__restrict__ tailhist)
 {
-    __shared__ uint32_t cursor[4][64];
+    __shared__ uint32_t cursor[4];
     __shared__ uint32_t hist[4][64];
     __shared__ uint32_t sub[4][8][65];  // 8 privatised copies per wave: the register values pile up in ~8 bins, so
                                         // one copy would serialise its LDS atomics; rows padded to 65 words so that
                                         // the same bin of different copies falls into different banks (with a stride
                                         // of 64 every copy's bin b shared bank b and the copies bought nothing)
-    __shared__ int thr[4];
+    __shared__ int thr[4], thrL[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sub[wave][k][lane] = 0;
+    if (lane == 0) cursor[wave] = 0;
     __syncthreads();
     const uint64_t m = 1ull << p;
     const uint4 *src = reinterpret_cast<const uint4 *>(regs + (s < n ? s : 0) * m);
@@ -110,43 +118,40 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         while (lo < 63 && h[lo] == 0) ++lo;
         while (hi > 0 && h[hi] == 0) --hi;
         card[s] = estimate(c, c, p, estim, lo, hi);
-        // threshold: the largest tail that fits the exception list
+        // high threshold: the largest upper tail that fits its list
         int T = hi;
         uint32_t cnt = 0;
         while (T > lo && cnt + h[T] <= (uint32_t)emax) {
             cnt += h[T];
             --T;
         }
+        // low threshold: the largest lower tail (values lo .. L-1) that fits its list, never reaching T
+        int L = lo;
+        uint32_t cntl = 0;
+        while (L < T && cntl + h[L] <= (uint32_t)elow) {
+            cntl += h[L];
+            ++L;
+        }
         thr[wave] = T;
-        exc_n[s] = cnt;
-        // (max value, threshold, min value): the host derives the global value range from these (no
-        // same-address global atomics: 3 x N of them cost ~12 ns each) and sorts columns by the low 16 bits
-        keys[s] = ((uint32_t)hi << 16) | ((uint32_t)T << 8) | (uint32_t)lo;
+        thrL[wave] = L;
+        exc_n[s] = cnt + cntl;
+        // the host derives the global ranges from the keys (no same-address global atomics: 3 x N of them cost
+        // ~12 ns each) and orders the columns by them
+        keys[s] = ((uint32_t)hi << 18) | ((uint32_t)T << 12) | ((uint32_t)L << 6) | (uint32_t)lo;
     }
     if (s < n && __any(bad != 0) && lane == 0) atomicOr(&keys[s], 0x80000000u);  // (after lane 0's plain store above)
     __syncthreads();
     if (s >= n) return;
-    // histogram of the listed registers (values above T_i), one byte per value: k_finalize starts a
-    // pair's tail bins from the two sketches' tail histograms and only corrects shared positions
-    tailhist[s * 64 + lane] = lane > thr[wave] ? (uint8_t)hist[wave][lane] : (uint8_t)0;
-    if (emax == 0) return;
-    // second pass: the registers above T_i as a list ordered by VALUE, largest first (any order within
-    // a value): for a tile threshold T >= T_i the entries that matter (value > T) are then a prefix
-    // whose length is the sum of the tail histogram above T.  Positions and values go to separate
-    // arrays (k_finalize streams positions only).  Slot = start of the value's run + a running counter.
-    const uint32_t T = (uint32_t)thr[wave];
-    {
-        uint32_t start = 0;
-        for (int x = 63; x > lane; --x) start += hist[wave][x];  // entries with a larger value
-        cursor[wave][lane] = start;                              // only read for lane > T
-    }
-    // cursor[wave] is private to this wave (some waves of the block may already have returned)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    PT *dstp = reinterpret_cast<PT *>(exc + s * kExcCap);
-    uint8_t *dstv = excv + s * kExcCap;
-    uint32_t *cur = cursor[wave];
+    // histogram of the listed upper-tail registers, one byte per value: k_finalize starts a pair's tail bins from
+    // the two sketches' tail histograms and only corrects the positions both sketches list
+    const uint32_t T = (uint32_t)thr[wave], L = (uint32_t)thrL[wave];
+    tailhist[s * 64 + lane] = (uint32_t)lane > T ? (uint8_t)hist[wave][lane] : (uint8_t)0;
+    if (emax == 0 && elow == 0) return;
+    // second pass: the listed registers.  cursor[wave] is private to this wave (some waves of the block may
+    // already have returned), slots are handed out by an LDS counter
+    PT *dstp = exc + s * kListCap;
+    uint8_t *dstv = excv + s * kListCap;
+    uint32_t *cur = &cursor[wave];
     auto emit16 = [&](const uint4 x, uint64_t c) {
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const uint32_t v = (w[k] >> (8 * b)) & 0xFFu;
-                if (v > T) {
-                    const uint32_t slot = atomicAdd(&cur[v & 63u], 1u);
+                if (v > T || v < L) {
+                    const uint32_t slot = atomicAdd(cur, 1u);
                     dstp[slot] = (PT)(c * 16 + k * 4 + b);
                     dstv[slot] = (uint8_t)v;
                 }
@@ -167,16 +172,74 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
         if (c < nch) emit16(cache[k], c);
     }
     for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) emit16(src[c], c);
-    // pad to a whole 16-byte piece of positions with the never-listed position 2^p (k_finalize reads
-    // the positions 16 B at a time and tests each against a bitmap that has no bit there)
-    {
-        uint32_t total = 0;
-        for (int x = 63; x > (int)T; --x) total += hist[wave][x];
-        constexpr uint32_t per = 16 / sizeof(PT);
-        const uint32_t end = (total + per - 1) / per * per;
-        if (total + lane < end) {
-            dstp[total + lane] = (PT)(1u << p);
-            dstv[total + lane] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Position index of one 128-column block of the plane matrix: every listed (position, value) of its sketches,
+// bucketed by position.  bucket(pos) = pos >> sh with at most 2^14 buckets; off[b] .. off[b+1] (uint16: a block
+// holds at most 128 x 510 entries) delimit bucket b in ent[]; an entry is (pos & (2^sh - 1)) << 13 | column within the
+// block << 6 | value.  k_finalize looks the row sketch's listed positions up here: the two sketches of a pair list
+// the same position |list_i| x |list_j| / 2^p times -- a sparse join, instead of every pair walking a whole list.
+// One 256-thread workgroup per column block; counting sort through LDS counters (order inside a bucket is whatever
+// the atomics give: every consumer treats a bucket as a set).
+template <typename PT>
+__global__ __launch_bounds__(256) void k_build_colindex(const PT *__restrict__ exc, const uint8_t *__restrict__ excv,
+                                                         const uint32_t *__restrict__ exc_n,
+                                                         const uint32_t *__restrict__ perm, uint64_t ncols, int p,
+                                                         uint32_t nbuckets, uint32_t ent_stride,
+                                                         uint16_t *__restrict__ off, uint32_t *__restrict__ ent)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nbuckets] counters, then cursors
+    __shared__ uint32_t part[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sh = p > 14 ? (uint32_t)(p - 14) : 0u;
+    const uint64_t c0 = (uint64_t)blockIdx.x * kTile;
+    for (uint32_t b = tid; b < nbuckets; b += 256) cnt[b] = 0;
+    __syncthreads();
+    for (uint32_t sl = wave; sl < kTile; sl += 4) {
+        if (c0 + sl >= ncols) break;
+        const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
+        const uint32_t ne = exc_n[s];
+        const PT *ps = exc + s * kListCap;
+        for (uint32_t e = lane; e < ne; e += 64) atomicAdd(&cnt[(uint32_t)ps[e] >> sh], 1u);
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns the buckets [t*per, (t+1)*per)
+    const uint32_t per = (nbuckets + 255) / 256;
+    uint32_t sum = 0;
+    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) sum += cnt[b];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 256; ++t) {
+            const uint32_t x = part[t];
+            part[t] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    uint16_t *myoff = off + (uint64_t)blockIdx.x * (nbuckets + 2);
+    uint32_t run = part[tid];
+    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) {
+        const uint32_t x = cnt[b];
+        myoff[b] = (uint16_t)run;
+        cnt[b] = run;  // becomes the bucket's cursor
+        run += x;
+    }
+    if (tid * per < nbuckets && (tid + 1) * per >= nbuckets) myoff[nbuckets] = (uint16_t)run;  // owner of the last bucket: end mark
+    __syncthreads();
+    uint32_t *myent = ent + (uint64_t)blockIdx.x * ent_stride;
+    for (uint32_t sl = wave; sl < kTile; sl += 4) {
+        if (c0 + sl >= ncols) break;
+        const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
+        const uint32_t ne = exc_n[s];
+        const PT *ps = exc + s * kListCap;
+        const uint8_t *vs = excv + s * kListCap;
+        for (uint32_t e = lane; e < ne; e += 64) {
+            const uint32_t pos = ps[e];
+            const uint32_t slot = atomicAdd(&cnt[pos >> sh], 1u);
+            myent[slot] = ((pos & ((1u << sh) - 1u)) << 13) | (sl << 6) | (uint32_t)vs[e];
         }
     }
 }
@@ -734,18 +797,22 @@ struct FinalizeArgs {
     uint64_t nslots;
     const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile of the band
     const uint32_t *perm;  // plane-matrix column -> sketch index (nullptr: identity)
-    int vlo;    // global: plane pl is threshold v = vlo+1+pl; histogram columns start at vlo
+    int vlo;    // smallest register value of any column: the histogram columns start at bin vlo
     int vhi;    // largest register value present anywhere
+    int pbase;  // plane pl is the threshold v = pbase + 1 + pl
     int p;
     int estim;
     int result_type;
     double ksinv;
     const double *card;
-    const uint32_t *exc;      // [n][kExcCap] 4-byte slots: the listed POSITIONS as PT (uint16 for p <= 15), value-descending
-    const uint8_t *excv;      // [n][kExcCap]: the listed values, same order
-    const uint32_t *exc_n;
-    const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value
-    const uint32_t *keys;     // [n]: (max value << 16) | (T_i << 8) | min value
+    const void *exc;          // [n][kListCap] listed POSITIONS as PT (uint16 for p <= 15, else uint32)
+    const uint8_t *excv;      // [n][kListCap]: the listed values, same order
+    const uint32_t *exc_n;    // [n] entries listed
+    const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value above its T
+    const uint32_t *keys;     // [n]: hi << 18 | T << 12 | L << 6 | lo
+    const uint16_t *cidx_off; // position index of the column blocks: [blocks][nbuckets + 2]
+    const uint32_t *cidx_ent; // [blocks][ent_stride]
+    uint32_t nbuckets, ent_stride;
     uint64_t n;      // sketches in the collection = dimension of the output matrix
     uint64_t ncols;  // real columns of the plane matrix (a sub-collection when only a row range is wanted)
     // triangle mode: rows [row_begin,row_end) (original indices), out index = tri(i,j) - base_index
@@ -758,40 +825,34 @@ struct FinalizeArgs {
     // square != 0 (triangle tiles, all rows): every pair is written at BOTH out[i*n+j] and
     // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
     int square;
-    uint32_t hash_slots;  // power of two >= 2 * emax: LDS hash of the row sketch's tail entries
-    int use_bitmap;       // p <= 19: position bitmap of the row sketch in LDS as a prefilter; above: every entry probes the hash
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
 };
 
-// Exception handling without a sequential merge: the block's 128 lanes share sketch i (one tile
-// row).  A lane's tail bins (values > T) start as i's tail histogram + sketch j's (tailhist, one
-// byte per value) -- that counts a position listed by BOTH sketches twice.  To find those, i's live
-// entries (value > T: a prefix of its value-ordered list) are put into a position bitmap and a
-// small open-addressing hash in LDS; each lane streams the positions of j's live prefix against the
-// bitmap (16-B loads, one LDS read + one shift per entry) and, for the few shared positions
-// (|list_i| * |list_j| / 2^p per pair), removes the smaller of the two values.  Exact, order-independent.
+// The two sparse tails of a pair's histogram without walking lists.  The block's 128 lanes share sketch i (one tile
+// row); the tile has the dense planes v in (Lp, T].
+//   upper tail (x > T): a lane's bins start as i's tail histogram + sketch j's (tailhist, one byte per value) -- that
+//     counts a position listed by BOTH sketches twice; at each such position the smaller value is taken out again.
+//   lower tail (x < Lp): max(a_t, b_t) = x < Lp needs both registers below Lp <= min(L_i, L_j), i.e. the position in
+//     both low lists: the bins below Lp are exactly the positions both sketches list, at the larger of the two values
+//     (if Lp comes from the value minima instead, no register pair lies below it and the join finds nothing).
+// The shared positions are found through the column block's position index (k_build_colindex): lane e takes the row
+// sketch's e-th listed register and visits the bucket of its position -- |list_i| lookups per tile row instead of
+// 128 list walks -- and applies what it finds to the owning lane's histogram column with LDS atomics.  Exact and
+// order-independent.  C(Lp) = number of low joins, so c[Lp] = C(Lp+1) - C(Lp) and c[T] = m - |union above T| - C(T).
 template <typename CT>
 __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
 {
     // histogram columns hold counts <= 2^p: CT (uint16 when p <= 15) halves the LDS footprint and
     // doubles the resident waves of this latency-sensitive kernel
-    // dynamic LDS: bitA = one bit per register position, set where the row sketch lists a value > T (the
-    // prefilter every list entry of a column sketch is tested against; first, so its address is a
-    // constant), the hash with the row sketch's values, then the histogram columns [(vhi-vlo+1)][128]
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
-    const uint32_t kHashSlots = a.hash_slots;
-    // + one word that stays zero: position 2^p pads the lists.  Without the bitmap (p > 19: 2^p bits do not fit LDS
-    // next to the columns) a single dummy word keeps the layout
-    const uint32_t bit_words = a.use_bitmap ? ((1u << a.p) >> 5) + 1u : 1u;
-    uint32_t *bitA = reinterpret_cast<uint32_t *>(hs_raw);
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)hs_raw != 0u) __builtin_trap();  // see probe_piece
-    uint32_t *hashA = bitA + bit_words;
-    uint32_t *histA = hashA + kHashSlots;  // [64] + the live length of the row sketch's list (no static LDS:
-    uint32_t &naLive = histA[64];          // the bitmap then sits at LDS address 0 and needs no base add)
-    CT *hs = reinterpret_cast<CT *>(hs_raw + ((((size_t)bit_words + kHashSlots + 65) * 4 + 15) & ~(size_t)15));
+    uint32_t *histA = reinterpret_cast<uint32_t *>(hs_raw);  // [64] row sketch's tail histogram above T
+    uint32_t *corr = histA + 64;                              // [128] per column: upper-tail positions shared with the row sketch
+    uint32_t *lowc = corr + 128;                              // [128] per column: lower-tail joins = C(Lp)
+    uint32_t *actm = lowc + 128;                              // [4] lanes whose column is live (bit per lane) + naLive
+    CT *hs = reinterpret_cast<CT *>(hs_raw + (64 + 128 + 128 + 8) * 4);
     using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
@@ -802,37 +863,23 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
     if (si >= a.ncols) return;  // padding row (uniform)
     const uint64_t i = a.perm ? a.perm[si] : si;
-    // this tile's own plane range: C(v) = 0 for v <= vlo_t, exceptions above T
     const int vlo = a.vlo, vhi = a.vhi;
-    const int vlo_t = vlo + (int)tile.z, T = vlo + (int)tile.w;
+    // this tile's own plane range: dense C(v) for v in (Lp, T]
+    const int Lp = a.pbase + (int)tile.z, T = a.pbase + (int)tile.w;
     // block-level skip (uniform) when the row sketch cannot be wanted
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
-    for (uint32_t t = tid; t < kHashSlots; t += 128) hashA[t] = 0xFFFFFFFFu;
-    for (uint32_t t = tid; t < bit_words; t += 128) bitA[t] = 0;
-    if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = live prefix length
+    corr[tid] = 0;
+    lowc[tid] = 0;
+    if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = its live upper entries
         const uint32_t h = tid > T ? a.tailhist[i * 64 + tid] : 0u;
         histA[tid] = h;
         uint32_t tot = h;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
-        if (tid == 0) naLive = tot;
+        if (tid == 0) actm[4] = tot;
     }
-    __syncthreads();
-    {
-        const uint32_t na = naLive;
-        const PT *ap = reinterpret_cast<const PT *>(a.exc + i * kExcCap);
-        const uint8_t *av = a.excv + i * kExcCap;
-        for (uint32_t t = tid; t < na; t += 128) {
-            const uint32_t pos = ap[t];
-            const uint32_t e = (pos << 8) | av[t];
-            if (a.use_bitmap) atomicOr(&bitA[pos >> 5], 1u << (pos & 31u));
-            uint32_t h = pos & (kHashSlots - 1);
-            while (atomicCAS(&hashA[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1) & (kHashSlots - 1);
-        }
-    }
-    __syncthreads();
-    if (sj >= a.ncols) return;
-    const uint64_t j = a.perm ? a.perm[sj] : sj;
+    const bool col_ok = sj < a.ncols;
+    const uint64_t j = col_ok ? (a.perm ? a.perm[sj] : sj) : 0;
     uint64_t oi = i, oj = j;
     bool active;
     if (a.rect) {
@@ -851,49 +898,64 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         }
         active = si < sj && oi >= a.row_begin && oi < a.row_end;
     }
-    if (!active) return;
+    active = active && col_ok;
+    {
+        const unsigned long long bal = __ballot(active);
+        if ((tid & 63) == 0) {
+            actm[(tid >> 6) * 2] = (uint32_t)bal;
+            actm[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+    uint64_t oidx = 0;
+    if (active) oidx = a.rect ? (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin)
+                              : oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     if (a.stop == 1) {
-        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)naLive;
+        if (active) a.out[oidx] = (float)T;
         return;
     }
     const uint32_t m = 1u << a.p;
     CT *col = hs + tid;
+    uint32_t prev = 0, nb = 0, keyj = 0, keyi = 0;
     // All global loads of this lane's inputs are issued together, before anything waits on them: the
     // C(v) of up to 16 planes, 48 bins of sketch j's tail histogram, the two keys (one round trip
     // instead of one per plane / per bin -- with dependent loads this part was half of the kernel).
     const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
     constexpr int kBatch = 16;
     uint32_t cvv[kBatch];
-#pragma unroll
-    for (int t = 0; t < kBatch; ++t) {
-        const uint32_t pl = tile.z + (uint32_t)t;
-        cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
-    }
     const int w0 = (T + 1) >> 4;  // first 16-byte word of the tail histogram that holds a bin > T (uniform)
-    const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
     uint4 tq[3];
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
-    const uint32_t keyj = a.keys[j], keyi = a.keys[i];
-    // bins below the tile's range are empty; dense part: c[x] = C(x+1) - C(x), x in [vlo_t, T)
-    for (int x = vlo; x < vlo_t; ++x) col[(x - vlo) * 128] = 0;
-    uint32_t prev = 0;
-#pragma unroll
-    for (int t = 0; t < kBatch; ++t) {
-        const uint32_t pl = tile.z + (uint32_t)t;
-        if (pl < tile.w) {  // uniform
-            col[pl * 128] = (CT)(cvv[t] - prev);
-            prev = cvv[t];
+        for (int t = 0; t < kBatch; ++t) {
+            const uint32_t pl = tile.z + (uint32_t)t;
+            cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
         }
+        const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
+        keyj = a.keys[j];
+        keyi = a.keys[i];
     }
-    for (uint32_t pl = tile.z + kBatch; pl < tile.w; ++pl) {  // wide plane ranges (heterogeneous tiles)
-        const uint32_t cv = cum[(uint64_t)pl * a.nslots];
-        col[pl * 128] = (CT)(cv - prev);
-        prev = cv;
-    }
-    // tail bins: histogram of i's listed values + histogram of j's listed values (both > T) ...
-    uint32_t nb = 0;  // sketch j's entries above T = the live prefix of its list
-    {
+    __syncthreads();  // histA, corr, lowc, actm are set
+    if (active) {
+        // bins below the dense range start empty (the lower-tail join fills them); dense part: c[x] = C(x+1) - C(x),
+        // x in [Lp, T), written as if C(Lp) were 0 -- corrected after the join
+        for (int x = vlo; x < Lp; ++x) col[(x - vlo) * 128] = 0;
+        CT *dcol = col + (a.pbase - vlo) * 128;  // bin pbase + pl lives at dcol + pl * 128
+#pragma unroll
+        for (int t = 0; t < kBatch; ++t) {
+            const uint32_t pl = tile.z + (uint32_t)t;
+            if (pl < tile.w) {  // uniform
+                dcol[pl * 128] = (CT)(cvv[t] - prev);
+                prev = cvv[t];
+            }
+        }
+        for (uint32_t pl = tile.z + kBatch; pl < tile.w; ++pl) {  // wide plane ranges (heterogeneous tiles)
+            const uint32_t cv = cum[(uint64_t)pl * a.nslots];
+            dcol[pl * 128] = (CT)(cv - prev);
+            prev = cv;
+        }
+        // tail bins: histogram of i's listed values + histogram of j's listed values (both > T)
         const uint32_t qw[12] = {tq[0].x, tq[0].y, tq[0].z, tq[0].w, tq[1].x, tq[1].y, tq[1].z, tq[1].w,
                                  tq[2].x, tq[2].y, tq[2].z, tq[2].w};
         const int x0 = w0 * 16;
@@ -913,121 +975,74 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
             col[(x - vlo) * 128] = (CT)(histA[x] + qj);
         }
     }
-    uint32_t ucnt = naLive + nb;  // |list_i above T| + |list_j above T|, shared positions still counted twice
+    __syncthreads();
     if (a.stop == 2) {
-        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)(ucnt + prev + keyj);
+        if (active) a.out[oidx] = (float)(nb + prev + keyj);
         return;
     }
-    // largest bin that can be non-empty (a scan bound for the estimator): the larger of the two maxima
-    const int maxj = (int)(keyj >> 16), maxi = (int)(keyi >> 16);
+    // ---- the join: lane e takes the row sketch's e-th listed register
+    {
+        const uint32_t ni = a.exc_n[i];
+        const PT *ap = reinterpret_cast<const PT *>(a.exc) + i * kListCap;
+        const uint8_t *av = a.excv + i * kListCap;
+        const uint32_t sh = a.p > 14 ? (uint32_t)(a.p - 14) : 0u;
+        const uint16_t *boff = a.cidx_off + (uint64_t)tile.y * (a.nbuckets + 2);
+        const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
+        uint32_t *hw = reinterpret_cast<uint32_t *>(hs);
+        for (uint32_t e = tid; e < ni; e += 128) {
+            const int va = (int)av[e];
+            const bool up = va > T, down = va < Lp;
+            if (!(up || down)) continue;
+            const uint32_t pos = ap[e];
+            const uint32_t b = pos >> sh, plow = pos & ((1u << sh) - 1u);
+            const uint32_t q0 = boff[b], q1 = boff[b + 1];
+            for (uint32_t q = q0; q < q1; ++q) {
+                const uint32_t x = bent[q];
+                if ((x >> 13) != plow) continue;
+                const uint32_t jl = (x >> 6) & 127u;
+                const int vb = (int)(x & 63u);
+                if (!((actm[jl >> 5] >> (jl & 31u)) & 1u)) continue;  // that lane has no pair (diagonal tile, range, padding)
+                int bin;
+                if (up && vb > T) {  // shared upper-tail position: keep only the larger value
+                    bin = va < vb ? va : vb;
+                    atomicAdd(&corr[jl], 1u);
+                    const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
+                    if (sizeof(CT) == 2) atomicSub(&hw[cell >> 1], 1u << (16u * (cell & 1u)));  // (the half holds >= 1: no borrow)
+                    else atomicSub(&hw[cell], 1u);
+                } else if (down && vb < Lp) {  // both registers below the dense range: max(a_t, b_t) is the larger
+                    bin = va > vb ? va : vb;
+                    atomicAdd(&lowc[jl], 1u);
+                    const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
+                    if (sizeof(CT) == 2) atomicAdd(&hw[cell >> 1], 1u << (16u * (cell & 1u)));
+                    else atomicAdd(&hw[cell], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint32_t ucnt = actm[4] + nb - corr[tid];  // |list_i above T| + |list_j above T| - shared positions
+    const uint32_t clow = lowc[tid];                 // C(Lp)
+    if (tile.w > tile.z) col[(Lp - vlo) * 128] -= (CT)clow;  // c[Lp] = C(Lp+1) - C(Lp)
+    else prev = clow;                                         // no dense plane: C(T) = C(Lp)
+    col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union above T|
+    if (a.stop == 3) {
+        a.out[oidx] = (float)(ucnt + clow);
+        return;
+    }
+    // scan bounds for the estimator: no bin below the larger of the two minima, none above the larger of the maxima
+    const int loj = (int)(keyj & 63u), loi = (int)(keyi & 63u);
+    const int minv = loi > loj ? loi : loj;
+    const int maxj = (int)((keyj >> 18) & 63u), maxi = (int)((keyi >> 18) & 63u);
     int maxv = maxi > maxj ? maxi : maxj;
     if (maxv < T) maxv = T;
-    // ... minus the smaller value at every position both sketches list (counted twice above).
-    // Sketch j's positions are streamed 16 B at a time (8 or 4 per load) and each is tested against the
-    // row sketch's position bitmap: one LDS read + one bit extract per entry, nothing else.  Entries past
-    // the live prefix inside the last piece (values <= T, or the 2^p padding) can at worst raise a false
-    // candidate; the rare candidate path checks the entry's value and fetches the row sketch's from the hash.
-    const uint4 *eb = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(a.exc + j * kExcCap, 16));
-    const uint8_t *bv = a.excv + j * kExcCap;
-    constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    constexpr uint32_t kPer = 16 / sizeof(PT);  // positions per 16-byte piece
-    auto candidate = [&](uint32_t pos, uint32_t idx) {
-        const int vb = (int)bv[idx];
-        if (vb <= T) return;  // not part of the tail bins (or padding)
-        uint32_t h = pos & (kHashSlots - 1);
-        for (;;) {
-            const uint32_t sv = hashA[h];
-            if (sv == kEmpty) return;
-            if ((sv >> 8) == pos) {  // shared position: keep only the larger value
-                const int va = (int)(sv & 0xFFu);
-                col[((va < vb ? va : vb) - vlo) * 128] -= 1;
-                --ucnt;
-                return;
-            }
-            h = (h + 1) & (kHashSlots - 1);
-        }
-    };
-    // pieces with a possible shared position, up to four numbers (+1) of 8 bits; looked at after the walk
-    uint32_t pending = 0;
-    auto flush = [&]() {
-        while (pending) {
-            const uint32_t pi = (pending & 0xFFu) - 1u;
-            pending >>= 8;
-            const uint4 e4 = eb[pi];
-            const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
-            for (uint32_t t = 0; t < kPer; ++t) {
-                const uint32_t x = ev[sizeof(PT) == 2 ? (t >> 1) : t];
-                const uint32_t pos = sizeof(PT) == 2 ? ((x >> (16 * (t & 1))) & 0xFFFFu) : x;
-                if ((bitA[pos >> 5] >> (pos & 31u)) & 1u) candidate(pos, pi * kPer + t);
-            }
-        }
-    };
-    // fast path: OR of the (shifted) bitmap words of a piece -- bit 0 set iff some entry may be shared.
-    // The bitmap starts at LDS address 0 (checked above), so a word's byte address is computed from the
-    // position alone and the read needs no base add.
-    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    auto bitword = [](uint32_t byte_addr) -> uint32_t { return *(lds_cu32 *)(uintptr_t)byte_addr; };
-    auto probe_piece = [&](const uint4 e4, uint32_t first) {
-        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
-        uint32_t any = 0;
-        if (sizeof(PT) == 2) {
-            uint32_t w[8];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                w[2 * t] = bitword((ev[t] >> 3) & 0x1FFCu);   // ((pos & 0xFFFF) >> 5) * 4, pos < 2^16
-                w[2 * t + 1] = bitword((ev[t] >> 19) & 0x1FFCu);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) any |= (w[2 * t] >> (ev[t] & 31u)) | (w[2 * t + 1] >> ((ev[t] >> 16) & 31u));
-        } else {
-            uint32_t w[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = bitword((ev[t] >> 3) & ~3u);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) any |= w[t] >> (ev[t] & 31u);
-        }
-        // A hit is rare per lane (|list_i| * |list_j| / 2^p per pair) but not per WAVE: some lane of the 64
-        // hits in almost every piece, so the expensive part must not sit here.  Only remember the piece.
-        if (any & 1u) {
-            if (pending >> 24) flush();  // four pieces already waiting (very rare)
-            pending = (pending << 8) | (first / kPer + 1u);
-        }
-    };
-    // 4 pieces per step, the next step's loads issued before this step's probes so the L2 round trip
-    // of the list is not on the critical path.  Loads are unconditional: a sketch's row of the list
-    // array is 1 KiB, so pieces past the live prefix are readable (and never probed).
-    const uint32_t nq = (nb + kPer - 1) / kPer;
-    if (a.use_bitmap) {
-        uint4 cur[4], nxt[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = eb[u];
-        for (uint32_t q = 0; q < nq; q += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = eb[q + 4 + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (q + u < nq) probe_piece(cur[u], (q + u) * kPer);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-        }
-        flush();
-    } else {  // very large sketches (p 20..24): no prefilter, every live entry of the column sketch probes the hash
-        const PT *plist = reinterpret_cast<const PT *>(eb);
-        for (uint32_t t = 0; t < nb; ++t) candidate((uint32_t)plist[t], t);
-    }
-    // (a bin emptied by a correction can only lower the true maximum; maxv is just a scan bound)
-    col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union|
-    if (a.stop == 3) {
-        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)(ucnt + maxv);
-        return;
-    }
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
-    const double us = estimate(c, raw, a.p, a.estim, vlo_t, maxv);
+    const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv);
     if (a.stop == 4) {
-        a.out[oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index] = (float)us;
+        a.out[oidx] = (float)us;
         return;
     }
     const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
@@ -1037,9 +1052,6 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         a.out[j * a.n + i] = asym ? result_cmp_from(a.card[i], a.card[j], us, a.result_type, a.ksinv) : res;
         return;
     }
-    uint64_t oidx;
-    if (a.rect) oidx = (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin);
-    else oidx = oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     a.out[oidx] = res;
 }
 
@@ -1188,17 +1200,39 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, double *card, uint32_t *exc, uint8_t *excv, uint32_t *exc_n,
+                                int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist)
 {
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 3) / 4);
     if (p <= 15)
-        hipLaunchKernelGGL(k_selfhist_card<uint16_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                           card, exc, excv, exc_n, keys, tailhist);
+        hipLaunchKernelGGL(k_selfhist_card<uint16_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax, elow,
+                           card, (uint16_t *)exc, excv, exc_n, keys, tailhist);
     else
-        hipLaunchKernelGGL(k_selfhist_card<uint32_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax,
-                           card, exc, excv, exc_n, keys, tailhist);
+        hipLaunchKernelGGL(k_selfhist_card<uint32_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax, elow,
+                           card, (uint32_t *)exc, excv, exc_n, keys, tailhist);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
+                                 const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks, uint32_t nbuckets,
+                                 uint32_t ent_stride, uint16_t *off, uint32_t *ent)
+{
+    if (nblocks == 0) return hipSuccess;
+    const size_t lds = (size_t)nbuckets * sizeof(uint32_t);
+    if (p <= 15) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint16_t>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_build_colindex<uint16_t>, dim3(nblocks), dim3(256), lds, st, (const uint16_t *)exc, excv,
+                           exc_n, perm, ncols, p, nbuckets, ent_stride, off, ent);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint32_t>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_build_colindex<uint32_t>, dim3(nblocks), dim3(256), lds, st, (const uint32_t *)exc, excv,
+                           exc_n, perm, ncols, p, nbuckets, ent_stride, off, ent);
+    }
     return hipGetLastError();
 }
 
@@ -1306,25 +1340,15 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
-    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi;
+    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi; a.pbase = f.pbase;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist; a.n = f.n; a.ncols = f.ncols; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
+    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist;
+    a.cidx_off = f.cidx_off; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;
+    a.n = f.n; a.ncols = f.ncols; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
-    uint32_t hs = 16;
-    while (hs < 2u * (uint32_t)f.emax) hs <<= 1;
-    a.hash_slots = hs;
     a.stop = f.stop;
-    a.use_bitmap = f.p <= 19;
-    const size_t bit_words = f.p <= 19 ? (((size_t)1 << f.p) >> 5) + 1 : 1;
-    const size_t lds = (((bit_words + hs + 65) * sizeof(uint32_t) + 15) & ~(size_t)15) +
-                       (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
-    if (lds > (48u << 10)) {  // large p: the position bitmap alone is 2^p / 8 bytes
-        hipError_t e = f.cum_bytes == 2
-                           ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(k_finalize<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    const size_t lds = (64 + 128 + 128 + 8) * sizeof(uint32_t) + (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);

@@ -216,6 +216,11 @@ def test_options_do_not_change_results(ctx):
         for emax in (0, 1, 8, 64, 200, 255, -1):   # dense-only .. full exception lists: same exact histogram
             ctx.set_option("emax", emax)
             assert ctx.dist_rows().tobytes() == base.tobytes()
+        for elow, emax in ((0, -1), (1, 0), (7, 3), (64, 255), (255, 0), (255, 255), (200, 17), (-1, -1)):  # the listed lower tail
+            ctx.set_option("elow", elow)
+            ctx.set_option("emax", emax)
+            assert ctx.dist_rows().tobytes() == base.tobytes()
+            assert ctx.dist_rect(3, 133, 0, 140).tobytes() == ctx.dist_rect(3, 133, 0, 140).tobytes()
         ctx.set_option("xcd_swizzle", 0)
         assert ctx.dist_rows().tobytes() == base.tobytes()
         for sm in (0, 1, -1):   # identity vs (threshold,min)-sorted plane columns
@@ -252,6 +257,7 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("ls_item_chunks", 16)
         ctx.set_option("kc", 16)
         ctx.set_option("emax", -1)
+        ctx.set_option("elow", -1)
         ctx.set_option("sort", -1)
         ctx.set_option("nsplit", 0)
         ctx.set_option("xcd_swizzle", 1)
