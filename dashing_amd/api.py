@@ -24,6 +24,7 @@ SYMBOLS = [
     "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_async", "dsh_sketch_batch_device",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
+    "dsh_event_record", "dsh_event_wait", "dsh_event_query",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
@@ -75,6 +76,9 @@ def load_library():
     lib.dsh_dist_rows_device_async.argtypes = [vp, i32, i32, i32, u64, u64, vp]
     lib.dsh_wait.argtypes = [vp]
     lib.dsh_wait_event.argtypes = [vp, vp]
+    lib.dsh_event_record.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.dsh_event_wait.argtypes = [vp, u64]
+    lib.dsh_event_query.argtypes = [vp, u64, C.POINTER(i32)]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
     lib.dsh_knn.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, C.c_uint32, vp, vp]
     lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
@@ -271,6 +275,20 @@ class Context:
 
     def wait(self):
         self._ck(self._lib.dsh_wait(self._h))
+
+    def event_record(self):
+        """ticket marking everything enqueued on this context so far"""
+        t = C.c_uint64()
+        self._ck(self._lib.dsh_event_record(self._h, C.byref(t)))
+        return int(t.value)
+
+    def event_wait(self, ticket):
+        self._ck(self._lib.dsh_event_wait(self._h, ticket))
+
+    def event_done(self, ticket):
+        d = C.c_int()
+        self._ck(self._lib.dsh_event_query(self._h, ticket, C.byref(d)))
+        return bool(d.value)
 
     def wait_event(self, hip_event):
         """order the ctx stream after a caller event (e.g. torch.cuda.Event().cuda_event, recorded on torch's stream)"""

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -74,6 +75,16 @@ struct dsh_ctx {
     bool planes_valid = false;
     int card_estim = -1;
     DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
+    // copy-out pipeline of dsh_dist_rows_async: results alternate between two device buffers; the copy of call b to the
+    // host runs on its own stream while the kernels of call b+1 fill the other buffer
+    hipStream_t copy_stream = nullptr;
+    DevBuf outbuf2[2];
+    hipEvent_t ev_filled[2] = {nullptr, nullptr};  // kernels of the call that filled outbuf2[b] done (recorded on stream)
+    hipEvent_t ev_drained[2] = {nullptr, nullptr}; // copy out of outbuf2[b] done (recorded on copy_stream)
+    bool drained_pending[2] = {false, false};
+    unsigned out_turn = 0;
+    std::vector<hipEvent_t> tickets;    // dsh_event_record ring: slot t % 64 holds {join on the ctx stream, mark on the copy stream}
+    uint64_t ticket_next = 0;
     DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
     uint32_t nbuckets = 0, ent_stride = 0;
     // column layout of the cached plane matrix.  0: identity over all n sketches.  1: the sub-collection
@@ -366,7 +377,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
                     c->pin_perm_cap = nperm;
                 }
                 std::memcpy(c->pin_perm, c->hperm.data(), nperm * sizeof(uint32_t));
-                HIPCHK(c, hipMemcpyAsync(c->perm.ptr, c->pin_perm, nperm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, launch_upload(c->stream, c->perm.ptr, c->pin_perm, nperm * sizeof(uint32_t)));
                 if (!c->ev_perm) HIPCHK(c, hipEventCreateWithFlags(&c->ev_perm, hipEventDisableTiming));
                 HIPCHK(c, hipEventRecord(c->ev_perm, c->stream));
                 c->perm_in_flight = true;
@@ -404,12 +415,12 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
         }
         // position index of every column block (the list joins of k_finalize)
-        c->nbuckets = (uint32_t)std::min<uint64_t>(m, kMaxBuckets);
+        c->nbuckets = (uint32_t)std::min<uint64_t>(2 * m, kMaxBuckets);  // (position group, upper | lower tail)
         c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
         HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
         HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
         HIPCHK(c, launch_build_colindex(c->stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
-                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, ncols, c->p, NT, c->nbuckets,
+                                        (const uint32_t *)c->keys.ptr, want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, ncols, c->p, NT, c->nbuckets,
                                         c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
         c->planes_sorted = want_sorted;
         c->lay_rb = want_rb;
@@ -577,10 +588,10 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     std::memcpy(pinT, T.data(), T.size() * sizeof(uint4));
     if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
     HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
-    HIPCHK(c, hipMemcpyAsync(c->tiles.ptr, pinT, T.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_upload(c->stream, c->tiles.ptr, pinT, T.size() * sizeof(uint4)));
     HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
     if (!I.empty())
-        HIPCHK(c, hipMemcpyAsync(c->items.ptr, pinI, I.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_upload(c->stream, c->items.ptr, pinI, I.size() * sizeof(uint4)));
     if (!c->ev_lists) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));
     c->lists_in_flight = true;
@@ -683,6 +694,17 @@ void reset_prof(dsh_ctx *c)
 
 }  // namespace
 
+// The copy-out stream gets the highest priority the device offers: on this runtime a device-to-host copy that has to
+// wait for an event of another stream runs as a small blit kernel, which would otherwise queue behind the millions
+// of workgroups of the compare kernels it is meant to overlap with (profiles/r3d).
+static hipError_t create_copy_stream(hipStream_t *s)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+    if (const char *e = std::getenv("DSH_COPY_STREAM_PRIORITY")) greatest = std::atoi(e);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 extern "C" {
 
 const char *dsh_backend_name(void) { return "hip:gfx950"; }
@@ -708,7 +730,9 @@ int dsh_create(int device, dsh_ctx **out)
     if (!c) return DSH_ENOMEM;
     c->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        create_copy_stream(&c->copy_stream) != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return DSH_EIO;
     }
@@ -746,6 +770,16 @@ void dsh_destroy(dsh_ctx *c)
     c->cum.release();
     c->tiles.release();
     c->outbuf.release();
+    for (int b = 0; b < 2; ++b) {
+        c->outbuf2[b].release();
+        if (c->ev_filled[b]) (void)hipEventDestroy(c->ev_filled[b]);
+        if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]);
+    }
+    for (auto e : c->tickets) (void)hipEventDestroy(e);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
     c->seqbuf.release();
     c->workbuf.release();
     delete c;
@@ -759,6 +793,7 @@ int dsh_synchronize(dsh_ctx *c)
     int rc = bind(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return DSH_OK;
 }
 
@@ -886,8 +921,7 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
     HIPCHK(c, c->pin_work.ensure(work.size() * sizeof(SketchWork)));
     std::memcpy(c->pin_work.ptr, work.data(), work.size() * sizeof(SketchWork));
     HIPCHK(c, c->workbuf.ensure(work.size() * sizeof(SketchWork)));
-    HIPCHK(c, hipMemcpyAsync(c->workbuf.ptr, c->pin_work.ptr, work.size() * sizeof(SketchWork),
-                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_upload(c->stream, c->workbuf.ptr, c->pin_work.ptr, work.size() * sizeof(SketchWork)));
     if (!c->ev_work) HIPCHK(c, hipEventCreateWithFlags(&c->ev_work, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_work, c->stream));
     c->work_in_flight = true;
@@ -1096,12 +1130,28 @@ int dsh_dist_rows_async(dsh_ctx *c, int estim, int result_type, int k, uint64_t 
     const uint64_t span = dsh_tri_span(c->n, rb, re);
     if (span == 0) return DSH_OK;
     if (!out) return DSH_EINVAL;
-    // (the stream orders a later call's kernels after this call's copy out of outbuf; growing outbuf frees the
-    // old buffer, which the runtime does only after the work using it has drained)
-    HIPCHK(c, c->outbuf.ensure(span * sizeof(float)));
-    rc = dsh_dist_rows_device_async(c, estim, result_type, k, rb, re, c->outbuf.ptr);
+    // Two device buffers taken in turn: this call's kernels (ctx stream) wait only for the copy that last drained
+    // THEIR buffer, so they run while the previous call's result is still on its way to the host (copy stream) --
+    // the reference overlaps the comparison of one batch of rows with the emission of the previous one the same way
+    // (src/sketch_and_cmp.h:804-816, distmat/distmat.h:475-479,504-508).
+    const unsigned b = c->out_turn++ & 1u;
+    for (int t = 0; t < 2; ++t) {
+        if (!c->ev_filled[t]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_filled[t], hipEventDisableTiming));
+        if (!c->ev_drained[t]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_drained[t], hipEventDisableTiming));
+    }
+    if (c->outbuf2[b].cap < span * sizeof(float)) {  // growing frees the old buffer: let its last copy finish first
+        if (c->drained_pending[b]) HIPCHK(c, hipEventSynchronize(c->ev_drained[b]));
+        c->drained_pending[b] = false;
+        HIPCHK(c, c->outbuf2[b].ensure(span * sizeof(float)));
+    }
+    if (c->drained_pending[b]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_drained[b], 0));
+    rc = dsh_dist_rows_device_async(c, estim, result_type, k, rb, re, c->outbuf2[b].ptr);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->outbuf.ptr, span * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_filled[b], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_filled[b], 0));
+    HIPCHK(c, hipMemcpyAsync(out, c->outbuf2[b].ptr, span * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_drained[b], c->copy_stream));
+    c->drained_pending[b] = true;
     return DSH_OK;
 }
 
@@ -1110,10 +1160,71 @@ int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, ui
     int rc = dsh_dist_rows_async(c, estim, result_type, k, rb, re, out);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return DSH_OK;
 }
 
 int dsh_wait(dsh_ctx *c) { return dsh_synchronize(c); }
+
+// A ticket marks "everything enqueued on this ctx so far" (kernels on the ctx stream and the copies of
+// dsh_dist_rows_async on the copy stream); waiting for it does not wait for work enqueued afterwards.
+int dsh_event_record(dsh_ctx *c, uint64_t *ticket)
+{
+    if (!c || !ticket) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    constexpr size_t kRing = 64;
+    if (c->tickets.size() < 2 * kRing) {
+        hipEvent_t e = nullptr, j = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&j, hipEventDisableTiming));
+        c->tickets.push_back(j);
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->tickets.push_back(e);
+    }
+    const uint64_t t = c->ticket_next++;
+    hipEvent_t j = c->tickets[2 * (t % kRing)], e = c->tickets[2 * (t % kRing) + 1];
+    if (t >= kRing) HIPCHK(c, hipEventSynchronize(e));  // the ticket that used this slot 64 records ago
+    // the copy stream joins the ctx stream's present position, then the event marks both
+    HIPCHK(c, hipEventRecord(j, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, j, 0));
+    HIPCHK(c, hipEventRecord(e, c->copy_stream));
+    *ticket = t;
+    return DSH_OK;
+}
+
+static int ticket_event(dsh_ctx *c, uint64_t ticket, hipEvent_t *e)
+{
+    if (ticket >= c->ticket_next) return fail(c, DSH_EINVAL, "ticket %llu was never recorded", (unsigned long long)ticket);
+    *e = c->ticket_next - ticket > 64 ? nullptr : c->tickets[2 * (ticket % 64) + 1];  // older than the ring: waited for at its slot's reuse
+    return DSH_OK;
+}
+
+int dsh_event_wait(dsh_ctx *c, uint64_t ticket)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    hipEvent_t e = nullptr;
+    if ((rc = ticket_event(c, ticket, &e))) return rc;
+    if (e) HIPCHK(c, hipEventSynchronize(e));
+    return DSH_OK;
+}
+
+int dsh_event_query(dsh_ctx *c, uint64_t ticket, int *done)
+{
+    if (!c || !done) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    hipEvent_t e = nullptr;
+    if ((rc = ticket_event(c, ticket, &e))) return rc;
+    *done = 1;
+    if (e) {
+        const hipError_t q = hipEventQuery(e);
+        if (q == hipErrorNotReady) *done = 0;
+        else if (q != hipSuccess) return fail(c, DSH_EIO, "hipEventQuery: %s", hipGetErrorString(q));
+    }
+    return DSH_OK;
+}
 
 int dsh_wait_event(dsh_ctx *c, void *hip_event)
 {

@@ -771,7 +771,7 @@ static int dist_main(int argc, char **argv)
                 }
                 // as below: large row blocks (each one a range the library lays its planes out for), two
                 // page-locked buffers, block b+1 enqueued before block b is written at its file offset
-                const uint64_t block_vals = (uint64_t)512 << 20;
+                const uint64_t block_vals = (uint64_t)256 << 20;
                 std::vector<uint64_t> cuts{bounds[d]};
                 while (cuts.back() < bounds[d + 1]) {
                     const uint64_t rb = cuts.back();
@@ -785,10 +785,17 @@ static int dist_main(int argc, char **argv)
                 for (int w = 0; w < (cuts.size() > 2 ? 2 : 1); ++w)
                     if (!(bufs[w] = (float *)dsh_alloc_host(cap * sizeof(float)))) die("could not allocate pinned host memory");
                 const size_t nblocks = cuts.size() - 1;
-                if (nblocks) DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[0], cuts[1], bufs[0]));
+                std::vector<uint64_t> ticket(nblocks + 1, 0);
+                if (nblocks) {
+                    DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[0], cuts[1], bufs[0]));
+                    DSH(c, dsh_event_record(c, &ticket[0]));
+                }
                 for (size_t b = 0; b < nblocks; ++b) {
-                    DSH(c, dsh_wait(c));
-                    if (b + 1 < nblocks) DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[b + 1], cuts[b + 2], bufs[(b + 1) & 1]));
+                    if (b + 1 < nblocks) {
+                        DSH(c, dsh_dist_rows_async(c, o.estim, o.result_type, o.k, cuts[b + 1], cuts[b + 2], bufs[(b + 1) & 1]));
+                        DSH(c, dsh_event_record(c, &ticket[b + 1]));
+                    }
+                    DSH(c, dsh_event_wait(c, ticket[b]));
                     const uint64_t span = dsh_tri_span(n, cuts[b], cuts[b + 1]);
                     const off_t pos = (off_t)(9 + dsh_tri_span(n, 0, cuts[b]) * sizeof(float));
                     size_t done = 0;
@@ -816,9 +823,9 @@ static int dist_main(int argc, char **argv)
         // Row blocks, two page-locked ping-pong buffers, asynchronous C-ABI calls: block b+1 is enqueued
         // (compute + copy into its buffer) before block b is emitted, so the GPU works while this thread
         // formats / writes -- dist_loop's dps[i & 1] scheme (src/sketch_and_cmp.h:804-816) without the
-        // writer thread.  Blocks are large (<= 512 Mi values) so that each one is a row range the library
+        // writer thread.  Blocks are large (<= 256 Mi values) so that each one is a row range the library
         // lays its plane matrix out for (few planes per tile, values at their final positions).
-        const uint64_t block_vals = (uint64_t)512 << 20;
+        const uint64_t block_vals = (uint64_t)256 << 20;
         std::vector<uint64_t> cuts{0};
         while (cuts.back() < n) {
             const uint64_t rb = cuts.back();
@@ -835,10 +842,19 @@ static int dist_main(int argc, char **argv)
             DSH(ctx, dsh_dist_rows_async(ctx, o.estim, o.result_type, o.k, cuts[b], cuts[b + 1], bufs[b & 1]));
         };
         const size_t nblocks = cuts.size() - 1;
-        if (nblocks) enqueue(0);
+        std::vector<uint64_t> ticket(nblocks + 1, 0);
+        if (nblocks) {
+            enqueue(0);
+            DSH(ctx, dsh_event_record(ctx, &ticket[0]));
+        }
         for (size_t b = 0; b < nblocks; ++b) {
-            DSH(ctx, dsh_wait(ctx));                 // block b has arrived in bufs[b & 1]
-            if (b + 1 < nblocks) enqueue(b + 1);     // the other buffer was emitted in the previous iteration
+            // block b+1 goes in first (its host buffer was emitted in the previous iteration): its kernels fill the
+            // library's other device buffer while block b is still being copied out, and only block b is awaited
+            if (b + 1 < nblocks) {
+                enqueue(b + 1);
+                DSH(ctx, dsh_event_record(ctx, &ticket[b + 1]));
+            }
+            DSH(ctx, dsh_event_wait(ctx, ticket[b]));  // block b has arrived in bufs[b & 1]
             const uint64_t rb = cuts[b], re = cuts[b + 1], span = dsh_tri_span(n, rb, re);
             const float *buf = bufs[b & 1];
             if (o.fmt == BINARY) {

@@ -8,7 +8,7 @@ namespace dsh {
 constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
 constexpr uint32_t kListCap = 512;  // capacity of a sketch's register list (entries): upper tail (emax <= 255) + lower tail (elow <= 255)
 constexpr uint32_t kMaxListSide = 255;  // cap of either tail (their per-value counts are bytes)
-constexpr uint32_t kMaxBuckets = 1u << 14;  // position buckets of a column block's index
+constexpr uint32_t kMaxBuckets = 1u << 15;  // buckets of a column block's index: (position group, tail)
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
@@ -16,8 +16,8 @@ hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n,
 // position index of every 128-column block of the plane layout (perm == nullptr: identity): off[nblocks][nbuckets + 2]
 // (uint16), ent[nblocks][ent_stride]
 hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
-                                 const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks, uint32_t nbuckets,
-                                 uint32_t ent_stride, uint16_t *off, uint32_t *ent);
+                                 const uint32_t *keys, const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks,
+                                 uint32_t nbuckets, uint32_t ent_stride, uint16_t *off, uint32_t *ent);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
                             const uint32_t *perm);
@@ -68,6 +68,9 @@ hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *per
 hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
                        uint64_t row0, uint64_t col0, int descending, uint32_t nn,
                        int exclude_self, uint32_t *idx_out, float *val_out);
+
+// in-order upload of a small page-locked host buffer by a kernel (no runtime copy on the ctx stream)
+hipError_t launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 
 // sketch path
 struct SketchWork {

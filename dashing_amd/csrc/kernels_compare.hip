@@ -176,51 +176,65 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------------
 // Position index of one 128-column block of the plane matrix: every listed (position, value) of its sketches,
-// bucketed by position.  bucket(pos) = pos >> sh with at most 2^14 buckets; off[b] .. off[b+1] (uint16: a block
-// holds at most 128 x 510 entries) delimit bucket b in ent[]; an entry is (pos & (2^sh - 1)) << 13 | column within the
-// block << 6 | value.  k_finalize looks the row sketch's listed positions up here: the two sketches of a pair list
-// the same position |list_i| x |list_j| / 2^p times -- a sparse join, instead of every pair walking a whole list.
-// One 256-thread workgroup per column block; counting sort through LDS counters (order inside a bucket is whatever
-// the atomics give: every consumer treats a bucket as a set).
+// bucketed by (position, tail).  bucket = (pos >> sh) * 2 + (1 for the lower tail), at most 2^14 position groups;
+// off[b] .. off[b+1] (uint16: a block holds at most 128 x 510 entries) delimit bucket b in ent[]; an entry is
+// (pos & (2^sh - 1)) << 13 | column within the block << 6 | value.  k_finalize looks the row sketch's listed positions
+// up here: the two sketches of a pair list the same position |list_i| x |list_j| / 2^p times per tail -- a sparse join
+// instead of every pair walking a whole list.  One 1024-thread workgroup per column block; counting sort through LDS
+// counters (the order inside a bucket is whatever the atomics give: every consumer treats a bucket as a set).  A wave
+// takes 8 sketches; the (up to 510) entries of a sketch are loaded together, 8 per lane, before any is used.
 template <typename PT>
-__global__ __launch_bounds__(256) void k_build_colindex(const PT *__restrict__ exc, const uint8_t *__restrict__ excv,
-                                                         const uint32_t *__restrict__ exc_n,
-                                                         const uint32_t *__restrict__ perm, uint64_t ncols, int p,
-                                                         uint32_t nbuckets, uint32_t ent_stride,
-                                                         uint16_t *__restrict__ off, uint32_t *__restrict__ ent)
+__global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ exc, const uint8_t *__restrict__ excv,
+                                                          const uint32_t *__restrict__ exc_n,
+                                                          const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ perm, uint64_t ncols, int p,
+                                                          uint32_t nbuckets, uint32_t ent_stride,
+                                                          uint16_t *__restrict__ off, uint32_t *__restrict__ ent)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nbuckets] counters, then cursors
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t sh = p > 14 ? (uint32_t)(p - 14) : 0u;
     const uint64_t c0 = (uint64_t)blockIdx.x * kTile;
-    for (uint32_t b = tid; b < nbuckets; b += 256) cnt[b] = 0;
+    for (uint32_t b = tid; b < nbuckets; b += 1024) cnt[b] = 0;
     __syncthreads();
-    for (uint32_t sl = wave; sl < kTile; sl += 4) {
+    constexpr int kPer = (int)(kListCap / 64);  // entries per lane
+    for (uint32_t sl = wave; sl < kTile; sl += 16) {
         if (c0 + sl >= ncols) break;
         const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
         const uint32_t ne = exc_n[s];
+        const uint32_t T = (keys[s] >> 12) & 63u;
         const PT *ps = exc + s * kListCap;
-        for (uint32_t e = lane; e < ne; e += 64) atomicAdd(&cnt[(uint32_t)ps[e] >> sh], 1u);
+        const uint8_t *vs = excv + s * kListCap;
+        uint32_t pos[kPer], val[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t e = lane + 64u * (uint32_t)u;
+            pos[u] = e < ne ? (uint32_t)ps[e] : 0u;
+            val[u] = e < ne ? (uint32_t)vs[e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+            if (lane + 64u * (uint32_t)u < ne) atomicAdd(&cnt[((pos[u] >> sh) << 1) | (val[u] > T ? 0u : 1u)], 1u);
     }
     __syncthreads();
     // exclusive scan: thread t owns the buckets [t*per, (t+1)*per)
-    const uint32_t per = (nbuckets + 255) / 256;
+    const uint32_t per = (nbuckets + 1023) / 1024;
     uint32_t sum = 0;
     for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) sum += cnt[b];
-    part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < 256; ++t) {
-            const uint32_t x = part[t];
-            part[t] = run;
-            run += x;
-        }
+    // block scan of the 1024 partial sums: within a wave by shuffles, across the 16 waves through part[]
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
     }
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wave; ++w) wbase += part[w];
+    uint32_t run = wbase + incl - sum;
     uint16_t *myoff = off + (uint64_t)blockIdx.x * (nbuckets + 2);
-    uint32_t run = part[tid];
     for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) {
         const uint32_t x = cnt[b];
         myoff[b] = (uint16_t)run;
@@ -230,17 +244,26 @@ __global__ __launch_bounds__(256) void k_build_colindex(const PT *__restrict__ e
     if (tid * per < nbuckets && (tid + 1) * per >= nbuckets) myoff[nbuckets] = (uint16_t)run;  // owner of the last bucket: end mark
     __syncthreads();
     uint32_t *myent = ent + (uint64_t)blockIdx.x * ent_stride;
-    for (uint32_t sl = wave; sl < kTile; sl += 4) {
+    for (uint32_t sl = wave; sl < kTile; sl += 16) {
         if (c0 + sl >= ncols) break;
         const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
         const uint32_t ne = exc_n[s];
+        const uint32_t T = (keys[s] >> 12) & 63u;
         const PT *ps = exc + s * kListCap;
         const uint8_t *vs = excv + s * kListCap;
-        for (uint32_t e = lane; e < ne; e += 64) {
-            const uint32_t pos = ps[e];
-            const uint32_t slot = atomicAdd(&cnt[pos >> sh], 1u);
-            myent[slot] = ((pos & ((1u << sh) - 1u)) << 13) | (sl << 6) | (uint32_t)vs[e];
+        uint32_t pos[kPer], val[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t e = lane + 64u * (uint32_t)u;
+            pos[u] = e < ne ? (uint32_t)ps[e] : 0u;
+            val[u] = e < ne ? (uint32_t)vs[e] : 0u;
         }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+            if (lane + 64u * (uint32_t)u < ne) {
+                const uint32_t slot = atomicAdd(&cnt[((pos[u] >> sh) << 1) | (val[u] > T ? 0u : 1u)], 1u);
+                myent[slot] = ((pos[u] & ((1u << sh) - 1u)) << 13) | (sl << 6) | val[u];
+            }
     }
 }
 
@@ -850,9 +873,8 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
     uint32_t *histA = reinterpret_cast<uint32_t *>(hs_raw);  // [64] row sketch's tail histogram above T
     uint32_t *corr = histA + 64;                              // [128] per column: upper-tail positions shared with the row sketch
-    uint32_t *lowc = corr + 128;                              // [128] per column: lower-tail joins = C(Lp)
-    uint32_t *actm = lowc + 128;                              // [4] lanes whose column is live (bit per lane) + naLive
-    CT *hs = reinterpret_cast<CT *>(hs_raw + (64 + 128 + 128 + 8) * 4);
+    uint32_t *actm = corr + 128;                              // [4] lanes whose column is live (bit per lane) + naLive
+    CT *hs = reinterpret_cast<CT *>(hs_raw + (64 + 128 + 8) * 4);
     using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
     const int tid = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
@@ -869,7 +891,6 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     // block-level skip (uniform) when the row sketch cannot be wanted
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
     corr[tid] = 0;
-    lowc[tid] = 0;
     if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = its live upper entries
         const uint32_t h = tid > T ? a.tailhist[i * 64 + tid] : 0u;
         histA[tid] = h;
@@ -936,7 +957,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         keyj = a.keys[j];
         keyi = a.keys[i];
     }
-    __syncthreads();  // histA, corr, lowc, actm are set
+    __syncthreads();  // histA, corr, actm are set
     if (active) {
         // bins below the dense range start empty (the lower-tail join fills them); dense part: c[x] = C(x+1) - C(x),
         // x in [Lp, T), written as if C(Lp) were 0 -- corrected after the join
@@ -994,27 +1015,26 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
             const bool up = va > T, down = va < Lp;
             if (!(up || down)) continue;
             const uint32_t pos = ap[e];
-            const uint32_t b = pos >> sh, plow = pos & ((1u << sh) - 1u);
+            const uint32_t b = ((pos >> sh) << 1) | (up ? 0u : 1u), plow = pos & ((1u << sh) - 1u);
             const uint32_t q0 = boff[b], q1 = boff[b + 1];
             for (uint32_t q = q0; q < q1; ++q) {
                 const uint32_t x = bent[q];
-                if ((x >> 13) != plow) continue;
                 const uint32_t jl = (x >> 6) & 127u;
                 const int vb = (int)(x & 63u);
-                if (!((actm[jl >> 5] >> (jl & 31u)) & 1u)) continue;  // that lane has no pair (diagonal tile, range, padding)
-                int bin;
-                if (up && vb > T) {  // shared upper-tail position: keep only the larger value
-                    bin = va < vb ? va : vb;
+                // same position, a live value on the column's side too, and a lane that owns a pair (diagonal tile,
+                // row range, padding)
+                if ((x >> 13) != plow || !(up ? vb > T : vb < Lp) || !((actm[jl >> 5] >> (jl & 31u)) & 1u)) continue;
+                // upper tail: the position was counted in both tail histograms, take the smaller value out again;
+                // lower tail: both registers are below the dense range, max(a_t, b_t) is the larger one
+                const int bin = up ? (va < vb ? va : vb) : (va > vb ? va : vb);
+                const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
+                const uint32_t one = sizeof(CT) == 2 ? 1u << (16u * (cell & 1u)) : 1u;
+                uint32_t *w = &hw[sizeof(CT) == 2 ? cell >> 1 : cell];
+                if (up) {
                     atomicAdd(&corr[jl], 1u);
-                    const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
-                    if (sizeof(CT) == 2) atomicSub(&hw[cell >> 1], 1u << (16u * (cell & 1u)));  // (the half holds >= 1: no borrow)
-                    else atomicSub(&hw[cell], 1u);
-                } else if (down && vb < Lp) {  // both registers below the dense range: max(a_t, b_t) is the larger
-                    bin = va > vb ? va : vb;
-                    atomicAdd(&lowc[jl], 1u);
-                    const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
-                    if (sizeof(CT) == 2) atomicAdd(&hw[cell >> 1], 1u << (16u * (cell & 1u)));
-                    else atomicAdd(&hw[cell], 1u);
+                    atomicSub(w, one);  // (the 16-bit half holds >= 1: no borrow into its neighbour)
+                } else {
+                    atomicAdd(w, one);
                 }
             }
         }
@@ -1022,7 +1042,8 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     __syncthreads();
     if (!active) return;
     const uint32_t ucnt = actm[4] + nb - corr[tid];  // |list_i above T| + |list_j above T| - shared positions
-    const uint32_t clow = lowc[tid];                 // C(Lp)
+    uint32_t clow = 0;                                // C(Lp) = the lower-tail joins = the bins below the dense range
+    for (int x = vlo; x < Lp; ++x) clow += col[(x - vlo) * 128];
     if (tile.w > tile.z) col[(Lp - vlo) * 128] -= (CT)clow;  // c[Lp] = C(Lp+1) - C(Lp)
     else prev = clow;                                         // no dense plane: C(T) = C(Lp)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union above T|
@@ -1198,6 +1219,27 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
 }
 
 // ------------------------------------------------------------------------------------------
+// Small host -> device uploads (column permutation, tile / item / work lists) as a KERNEL that reads the page-locked
+// staging buffer over PCIe: in order on the ctx stream like everything else.  A hipMemcpyAsync here goes through the
+// runtime's copy path, and a copy queued on the ctx stream while the copy stream is moving a result to the host made
+// the following kernels wait for that transfer in about half of the cases (profiles/r3d) -- the overlap of
+// dsh_dist_rows_async needs the ctx stream free of runtime copies.
+__global__ __launch_bounds__(256) void k_upload(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t nwords)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += stride) dst[w] = src[w];
+}
+
+hipError_t launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    const uint64_t nwords = (bytes + 3) / 4;  // (every list here is a whole number of 32-bit words)
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(256, (nwords + 255) / 256);
+    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src_pinned, nwords);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
                                 int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
@@ -1215,8 +1257,8 @@ hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n,
 }
 
 hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
-                                 const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks, uint32_t nbuckets,
-                                 uint32_t ent_stride, uint16_t *off, uint32_t *ent)
+                                 const uint32_t *keys, const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks,
+                                 uint32_t nbuckets, uint32_t ent_stride, uint16_t *off, uint32_t *ent)
 {
     if (nblocks == 0) return hipSuccess;
     const size_t lds = (size_t)nbuckets * sizeof(uint32_t);
@@ -1224,14 +1266,14 @@ hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint16_t>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_build_colindex<uint16_t>, dim3(nblocks), dim3(256), lds, st, (const uint16_t *)exc, excv,
-                           exc_n, perm, ncols, p, nbuckets, ent_stride, off, ent);
+        hipLaunchKernelGGL(k_build_colindex<uint16_t>, dim3(nblocks), dim3(1024), lds, st, (const uint16_t *)exc, excv,
+                           exc_n, keys, perm, ncols, p, nbuckets, ent_stride, off, ent);
     } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint32_t>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_build_colindex<uint32_t>, dim3(nblocks), dim3(256), lds, st, (const uint32_t *)exc, excv,
-                           exc_n, perm, ncols, p, nbuckets, ent_stride, off, ent);
+        hipLaunchKernelGGL(k_build_colindex<uint32_t>, dim3(nblocks), dim3(1024), lds, st, (const uint32_t *)exc, excv,
+                           exc_n, keys, perm, ncols, p, nbuckets, ent_stride, off, ent);
     }
     return hipGetLastError();
 }
@@ -1348,7 +1390,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;
-    const size_t lds = (64 + 128 + 128 + 8) * sizeof(uint32_t) + (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
+    const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);

@@ -124,11 +124,16 @@ int dsh_dist_rows_device(dsh_ctx *ctx, int estim, int result_type, int k, uint64
 /* Asynchronous forms -- the reference overlaps the comparison of one batch of rows with the emission of
  * the previous one through two ping-pong buffers (dist_loop's dps[i & 1] + std::async writer,
  * src/sketch_and_cmp.h:804-816; parallel_fill's writer thread, distmat/distmat.h:475-479,504-508).  These
- * calls ENQUEUE the whole computation (and, for the host form, the copy into `out`) on the ctx stream and
- * return; dsh_wait(ctx) blocks until everything enqueued on the ctx has completed.  Calls may be issued
- * back to back (they execute in order).  `out` must stay valid until dsh_wait and should come from
- * dsh_alloc_host: the copy into pageable memory is staged by the runtime and is not asynchronous.
- * Typical use: async(block b+1 -> buf[(b+1)&1]); emit block b from buf[b&1]; dsh_wait; ... (the CLI does this).
+ * calls ENQUEUE the whole computation on the ctx stream and return.  For the host form the result goes to one of
+ * two device buffers taken in turn and is copied to `out` on a second (copy) stream, so the kernels of the next call
+ * run while the previous result is still travelling to the host; a call only waits for the copy that last drained
+ * the buffer it is about to fill.  Calls may be issued back to back (their kernels execute in order).
+ * Completion: dsh_wait(ctx) blocks until everything enqueued on the ctx (both streams) has completed;
+ * dsh_event_record / dsh_event_wait mark and await one point of the sequence without draining what was enqueued
+ * after it.  `out` must stay valid until then and should come from dsh_alloc_host: the copy into pageable memory is
+ * staged by the runtime and is not asynchronous.
+ * Typical use (the CLI does this):  async(block 0); t0 = record;  loop b: async(block b+1 -> buf[(b+1)&1]);
+ * t(b+1) = record; event_wait(t(b)); emit block b from buf[b&1].
  * The call itself may still block briefly at its start while a new column layout is built on the host
  * (only the first call after the sketches changed touches the device for that). */
 int dsh_dist_rows_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
@@ -136,6 +141,13 @@ int dsh_dist_rows_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_
 int dsh_dist_rows_device_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin,
                                uint64_t row_end, void *d_out);
 int dsh_wait(dsh_ctx *ctx);
+/* Per-call completion.  dsh_event_record: *ticket marks everything enqueued on the ctx so far (kernels, sketch
+ * batches, and the host copies of dsh_dist_rows_async).  dsh_event_wait blocks the calling host thread until that
+ * point has completed; work enqueued after the record keeps running.  dsh_event_query: *done = 1/0 without blocking.
+ * Tickets are cheap (a ring of 64 event pairs; a ticket more than 64 records old counts as complete). */
+int dsh_event_record(dsh_ctx *ctx, uint64_t *ticket);
+int dsh_event_wait(dsh_ctx *ctx, uint64_t ticket);
+int dsh_event_query(dsh_ctx *ctx, uint64_t ticket, int *done);
 /* Make all work enqueued on the ctx stream AFTER this call wait for `hip_event` (a hipEvent_t recorded by
  * the caller on its own stream, e.g. torch.cuda.Event.cuda_event after producing d_regs / a gathered
  * staging buffer) -- the device-side alternative to synchronising the host before a *_device call. */
@@ -222,14 +234,16 @@ int dsh_set_profiling(dsh_ctx *ctx, int enable);
 int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
                        double *prepare_ms, uint32_t *pair_kernel_launches);
 /* Tunables; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
- * byte-identical output over their ranges): "kc" (16|32|64 k-rows per LDS stage), "emax" (exception-list cap, -1 auto),
+ * byte-identical output over their ranges): "kc" (16|32|64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
  * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
- * "assembler_permille", "shard_c0_x10"; profiling/what-if only: "finalize_stop", "pair_mfma" (never the default). */
+ * "assembler_permille", "shard_c0_x10"; what-if only: "pair_mfma" (never the default).
+ * "finalize_stop" (1..4) is a profiling aid that DOES change results (k_finalize leaves after a phase and stores a dummy):
+ * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
- * "vhi", "threshold", "emax", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles",
+ * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles",
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.

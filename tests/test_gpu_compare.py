@@ -161,6 +161,35 @@ def test_async_rows_and_wait(ctx):
             ctx.dist_rows_async(two[(i + 1) & 1].array, cuts[i + 1], cuts[i + 2])
         out.append(two[i & 1].array[: dashing_amd.tri_span(n, cuts[i], cuts[i + 1])].copy())
     assert np.concatenate(out).tobytes() == ctx.dist_rows().tobytes()
+    # per-call completion (dsh_event_record / dsh_event_wait): block b+1 and b+2 are already enqueued -- their kernels
+    # fill the OTHER device buffer while block b is copied out on the copy stream -- when block b is consumed; every host
+    # buffer is poisoned as soon as it has been read, so a copy that lands late or twice would show
+    n2, p2 = 2600, 12
+    regs2 = synth.synthetic_sketches(n2, p2, seed=777)
+    ctx.set_sketches(regs2)
+    want = ctx.dist_rows(result_type=dashing_amd.JI)
+    cuts2 = dashing_amd.partition_rows(n2, 9, 1)
+    spans = [dashing_amd.tri_span(n2, cuts2[i], cuts2[i + 1]) for i in range(9)]
+    three = [dashing_amd.PinnedArray(max(spans)) for _ in range(3)]
+    tickets, got = {}, []
+
+    def enqueue(i):
+        ctx.dist_rows_async(three[i % 3].array, cuts2[i], cuts2[i + 1])
+        tickets[i] = ctx.event_record()
+
+    enqueue(0)
+    enqueue(1)
+    for i in range(9):
+        if i + 2 < 9:
+            enqueue(i + 2)
+        ctx.event_wait(tickets[i])
+        assert ctx.event_done(tickets[i])
+        got.append(three[i % 3].array[: spans[i]].copy())
+        three[i % 3].array[:] = np.float32(-7.0)
+    assert np.concatenate(got).tobytes() == want.tobytes()
+    ctx.wait()
+    with pytest.raises(dashing_amd.DshError):
+        ctx.event_wait(10_000_000)  # never recorded
 
 
 def test_device_async_and_wait_event(ctx):
