@@ -463,6 +463,9 @@ struct PairJob {
     int rect;
     int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
     int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
+    int knn = 0;          // band of the key-ordered triangle for the nearest-neighbour selection: d_out = V, d_out2 = Vt
+    float *d_out2 = nullptr;
+    uint64_t knn_ld = 0, knn_rows = 0;
     int ksinv_double = 0; // 1./k as a double (nndist_loop, src/sketch_and_cmp.h:729) instead of the float of dist_loop (:797)
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
@@ -654,6 +657,10 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         f.rect = job.rect;
         f.sorted_out = job.sorted_rows;
         f.square = job.square;
+        f.knn = job.knn;
+        f.out2 = job.d_out2;
+        f.knn_ld = job.knn_ld;
+        f.knn_rows = job.knn_rows;
         f.row_begin = job.row_begin;
         f.row_end = job.row_end;
         f.col_begin = job.col_begin;
@@ -1321,6 +1328,69 @@ int dsh_knn(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, uint64_t
                 rc = fail(c, DSH_EIO, "copy of neighbours failed");
         } while (0);
         sq.release();
+        didx.release();
+        dval.release();
+        return rc;
+    }
+    if (qb == 0 && rb == 0 && qe == c->n && re == c->n && c->n > 1 && nn <= 1024) {
+        // all-vs-all beyond the n x n budget: the triangle ONCE, in bands of tile rows of the key-ordered layout.  A band
+        // leaves its values twice (V: band rows x columns, Vt: columns x band rows -- each pair is a candidate of both its
+        // sketches) and two selection passes fold them into the running lists of the n sketches; nothing of size n x n
+        // exists (nndist_loop, src/sketch_and_cmp.h:712-783, keeps n heaps the same way).
+        const uint64_t n = c->n;
+        if ((rc = prepare(c, estim, 1))) return rc;
+        const uint64_t npad = c->Npad;
+        const uint64_t budget = std::max<uint64_t>(std::min<uint64_t>(c->knn_square_budget, (uint64_t)16 << 30), 2 * kTile * npad * sizeof(float));
+        const uint64_t band = std::min<uint64_t>(npad, budget / (2 * npad * sizeof(float)) / kTile * kTile);
+        DevBuf V, Vt, didx, dval;
+        rc = DSH_OK;
+        do {
+            if (V.ensure(band * npad * sizeof(float)) != hipSuccess || Vt.ensure(npad * band * sizeof(float)) != hipSuccess ||
+                didx.ensure(n * nn * sizeof(uint32_t)) != hipSuccess || dval.ensure(n * nn * sizeof(float)) != hipSuccess) {
+                rc = fail(c, DSH_ENOMEM, "device allocation failed");
+                break;
+            }
+            hipError_t e = launch_knn_state_init(c->stream, (uint32_t *)didx.ptr, (float *)dval.ptr, n * nn, descending);
+            if (e != hipSuccess) {
+                rc = fail(c, DSH_EIO, "k_fill_knn_state: %s", hipGetErrorString(e));
+                break;
+            }
+            for (uint64_t b0 = 0; b0 < n && rc == DSH_OK; b0 += band) {
+                const uint64_t b1 = std::min<uint64_t>(n, b0 + band);
+                PairJob j;
+                j.estim = estim;
+                j.result_type = result_type;
+                j.k = k;
+                j.rect = 0;
+                j.sorted_rows = 1;
+                j.knn = 1;
+                j.ksinv_double = 1;
+                j.row_begin = b0;
+                j.row_end = b1;
+                j.col_begin = j.col_end = 0;
+                j.base_index = 0;
+                j.d_out = (float *)V.ptr;
+                j.d_out2 = (float *)Vt.ptr;
+                j.knn_ld = npad;
+                j.knn_rows = band;
+                if ((rc = run_pairs(c, j))) break;
+                const uint32_t *perm = (const uint32_t *)c->perm.ptr;
+                e = launch_topk_merge(c->stream, (const float *)V.ptr, npad, 0, b0, b1 - b0, n, perm, descending, nn,
+                                      (uint32_t *)didx.ptr, (float *)dval.ptr);
+                if (e == hipSuccess)
+                    e = launch_topk_merge(c->stream, (const float *)Vt.ptr, band, 1, b0, b1 - b0, n, perm, descending, nn,
+                                          (uint32_t *)didx.ptr, (float *)dval.ptr);
+                if (e != hipSuccess) rc = fail(c, DSH_EIO, "k_topk_merge: %s", hipGetErrorString(e));
+            }
+            if (rc) break;
+            if (hipMemcpyAsync(idx_out, didx.ptr, n * nn * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(val_out, dval.ptr, n * nn * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess)
+                rc = fail(c, DSH_EIO, "copy of neighbours failed");
+        } while (0);
+        (void)hipStreamSynchronize(c->stream);
+        V.release();
+        Vt.release();
         didx.release();
         dval.release();
         return rc;

@@ -54,6 +54,9 @@ struct FinalizeLaunch {
     uint32_t nbuckets, ent_stride;
     uint64_t n, ncols;  // collection size (output dimension); real columns of the plane matrix
     int rect, sorted_out, square;
+    int knn = 0;          // band-wise nearest neighbours: out = V[band rows][knn_ld], out2 = Vt[columns][knn_rows]
+    float *out2 = nullptr;
+    uint64_t knn_ld = 0, knn_rows = 0;
     int stop = 0;  // profiling: k_finalize leaves after phase `stop`
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
@@ -68,6 +71,12 @@ hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *per
 hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
                        uint64_t row0, uint64_t col0, int descending, uint32_t nn,
                        int exclude_self, uint32_t *idx_out, float *val_out);
+
+// band-wise nearest neighbours (no n x n matrix): running lists idx/val[n][nn] by sketch index
+hipError_t launch_knn_state_init(hipStream_t st, uint32_t *idx, float *val, uint64_t cnt, int descending);
+hipError_t launch_topk_merge(hipStream_t st, const float *vals, uint64_t ld, int mode, uint64_t b0, uint64_t rows,
+                             uint64_t ncols, const uint32_t *perm, int descending, uint32_t nn, uint32_t *st_idx,
+                             float *st_val);
 
 // in-order upload of a small page-locked host buffer by a kernel (no runtime copy on the ctx stream)
 hipError_t launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);

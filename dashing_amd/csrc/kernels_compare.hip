@@ -848,6 +848,12 @@ struct FinalizeArgs {
     // square != 0 (triangle tiles, all rows): every pair is written at BOTH out[i*n+j] and
     // out[j*n+i] of an n x n matrix (the all-vs-all nearest-neighbour path: each pair computed once)
     int square;
+    // knn != 0 (whole key-ordered layout, rows = plane columns [row_begin,row_end) like sorted_out): the pair (si, sj),
+    // si < sj, is written twice -- out[(si - row_begin) * knn_ld + sj] is a candidate of row si, out2[sj * knn_rows +
+    // (si - row_begin)] a candidate of row sj -- for the band-wise nearest-neighbour selection (k_topk_merge)
+    int knn;
+    float *out2;
+    uint64_t knn_ld, knn_rows;
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         active = j >= a.col_begin && j < a.col_end;
     } else if (a.square) {
         active = si < sj;
-    } else if (a.sorted_out) {
+    } else if (a.sorted_out || a.knn) {
         oi = si;
         oj = sj;
         active = si < sj && si >= a.row_begin && si < a.row_end;
@@ -928,8 +934,9 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         }
     }
     uint64_t oidx = 0;
-    if (active) oidx = a.rect ? (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin)
-                              : oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
+    if (active) oidx = a.rect  ? (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin)
+                       : a.knn ? (si - a.row_begin) * a.knn_ld + sj
+                               : oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     if (a.stop == 1) {
         if (active) a.out[oidx] = (float)T;
         return;
@@ -1067,10 +1074,16 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
         return;
     }
     const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
-    if (a.square) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
-        a.out[i * a.n + j] = res;
+    if (a.square || a.knn) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
         const bool asym = a.result_type == 4 || a.result_type == 5 || a.result_type == 6;
-        a.out[j * a.n + i] = asym ? result_cmp_from(a.card[i], a.card[j], us, a.result_type, a.ksinv) : res;
+        const float rev = asym ? result_cmp_from(a.card[i], a.card[j], us, a.result_type, a.ksinv) : res;
+        if (a.square) {
+            a.out[i * a.n + j] = res;
+            a.out[j * a.n + i] = rev;
+        } else {
+            a.out[oidx] = res;
+            a.out2[sj * a.knn_rows + (si - a.row_begin)] = rev;
+        }
         return;
     }
     a.out[oidx] = res;
@@ -1215,6 +1228,131 @@ hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_
     if (rows == 0 || nn == 0) return hipSuccess;
     hipLaunchKernelGGL(k_topk, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, st, vals, rows,
                        ncols, row0, col0, descending, nn, exclude_self, idx_out, val_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Nearest neighbours without the n x n matrix (perform_nns, src/sketch_and_cmp.h:642-697, whose heaps take every pair
+// as it is computed): the triangle is computed in bands of tile rows of the key-ordered layout; k_finalize leaves a
+// band's values twice -- V[r][t] (row = band row r, column = plane column t > b0 + r) and Vt[t][r] (row = plane column
+// t, column = band row r with b0 + r < t) -- and this kernel folds each row's new candidates into the running list of
+// that row's sketch: one wave per row, nn selection passes over (running list) U (candidates) in the total order of
+// k_topk (value best-first, then sketch index ascending; NaN last), every candidate carrying its ORIGINAL sketch index.
+//   mode 0: rows r in [0, rows) of V (leading dimension ld): sketch perm[b0 + r], candidates t in (b0 + r, ncols)
+//   mode 1: rows t in (b0, ncols) of Vt (leading dimension = band rows): sketch perm[t], candidates r in [0, min(rows, t - b0))
+// state: idx[n][nn] / val[n][nn] by original sketch index, initialised to (0xFFFFFFFF, worst).
+__global__ __launch_bounds__(256) void k_topk_merge(const float *__restrict__ vals, uint64_t ld, int mode, uint64_t b0,
+                                                     uint64_t rows, uint64_t ncols, const uint32_t *__restrict__ perm,
+                                                     int descending, uint32_t nn, uint32_t *__restrict__ st_idx,
+                                                     float *__restrict__ st_val)
+{
+    extern __shared__ __attribute__((aligned(8))) unsigned char tk_raw[];  // per wave: nn x (idx, val) of the running list
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *ri = reinterpret_cast<uint32_t *>(tk_raw) + (size_t)wave * 2 * nn;
+    float *rv = reinterpret_cast<float *>(ri + nn);
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+    uint64_t srow, c_begin, c_end;  // plane column of the row's sketch; candidate columns of this row
+    const float *v;
+    if (mode == 0) {
+        if (w >= rows) return;
+        srow = b0 + w;
+        c_begin = srow + 1;
+        c_end = ncols;
+        v = vals + w * ld;
+    } else {
+        srow = b0 + 1 + w;
+        if (srow >= ncols) return;
+        c_begin = 0;
+        c_end = srow - b0 < rows ? srow - b0 : rows;
+        v = vals + srow * ld;
+    }
+    const uint32_t self = perm ? perm[srow] : (uint32_t)srow;
+    const float worst = descending ? -__builtin_huge_valf() : __builtin_huge_valf();
+    for (uint32_t t = lane; t < nn; t += 64) {
+        ri[t] = st_idx[(uint64_t)self * nn + t];
+        rv[t] = st_val[(uint64_t)self * nn + t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto before = [descending](float av, uint32_t ai, float bv, uint32_t bi) {
+        if (av != bv) return descending ? av > bv : av < bv;
+        return ai < bi;
+    };
+    float pv = descending ? __builtin_huge_valf() : -__builtin_huge_valf();
+    uint32_t pi = 0;
+    bool first = true;
+    for (uint32_t t = 0; t < nn; ++t) {
+        float bv = worst;
+        uint32_t bi = 0xFFFFFFFFu;
+        auto offer = [&](float x, uint32_t id) {
+            if (x != x) x = worst;
+            if (!first && !before(pv, pi, x, id)) return;  // not after the previous pick
+            if (bi == 0xFFFFFFFFu || before(x, id, bv, bi)) {
+                bv = x;
+                bi = id;
+            }
+        };
+        for (uint32_t u = lane; u < nn; u += 64)
+            if (ri[u] != 0xFFFFFFFFu) offer(rv[u], ri[u]);
+        for (uint64_t c = c_begin + lane; c < c_end; c += 64) {
+            const uint64_t sc = mode == 0 ? c : b0 + c;  // plane column of the candidate
+            offer(v[c], perm ? perm[sc] : (uint32_t)sc);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const uint32_t oi = __shfl_xor(bi, d, 64);
+            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || before(ov, oi, bv, bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            st_idx[(uint64_t)self * nn + t] = bi;
+            st_val[(uint64_t)self * nn + t] = bi == 0xFFFFFFFFu ? worst : bv;
+        }
+        pv = bv;
+        pi = bi;
+        first = false;
+        if (bi == 0xFFFFFFFFu) {  // fewer candidates than nn: the rest stays empty
+            for (uint32_t u = t + 1 + lane; u < nn; u += 64) {
+                st_idx[(uint64_t)self * nn + u] = 0xFFFFFFFFu;
+                st_val[(uint64_t)self * nn + u] = worst;
+            }
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_knn_state(uint32_t *__restrict__ idx, float *__restrict__ val, uint64_t cnt, float worst)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < cnt) {
+        idx[t] = 0xFFFFFFFFu;
+        val[t] = worst;
+    }
+}
+
+hipError_t launch_knn_state_init(hipStream_t st, uint32_t *idx, float *val, uint64_t cnt, int descending)
+{
+    if (cnt == 0) return hipSuccess;
+    const float worst = descending ? -__builtin_huge_valf() : __builtin_huge_valf();
+    hipLaunchKernelGGL(k_fill_knn_state, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, st, idx, val, cnt, worst);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_merge(hipStream_t st, const float *vals, uint64_t ld, int mode, uint64_t b0, uint64_t rows,
+                             uint64_t ncols, const uint32_t *perm, int descending, uint32_t nn, uint32_t *st_idx,
+                             float *st_val)
+{
+    const uint64_t nrows = mode == 0 ? rows : (ncols > b0 + 1 ? ncols - b0 - 1 : 0);
+    if (nrows == 0 || nn == 0) return hipSuccess;
+    const size_t lds = (size_t)4 * 2 * nn * sizeof(uint32_t);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_topk_merge, dim3((uint32_t)((nrows + 3) / 4)), dim3(256), lds, st, vals, ld, mode, b0, rows, ncols,
+                       perm, descending, nn, st_idx, st_val);
     return hipGetLastError();
 }
 
@@ -1387,6 +1525,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist;
     a.cidx_off = f.cidx_off; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;
     a.n = f.n; a.ncols = f.ncols; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
+    a.knn = f.knn; a.out2 = f.out2; a.knn_ld = f.knn_ld; a.knn_rows = f.knn_rows;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;

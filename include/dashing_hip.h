@@ -170,9 +170,12 @@ int dsh_dist_rect(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_be
  * src/dashing.h:268-280) -- best first; a query is never its own neighbour.  Ties are broken by the
  * lower slot index (the reference's heap/thread order is unspecified).  idx_out/val_out: host
  * arrays [q_end-q_begin][nn]; missing neighbours (nn larger than the candidates) get idx 0xFFFFFFFF.
- * All-vs-all (nq == 0 in dashing): q = r = [0,n) -- every pair is then computed once and kept
- * in an n x n float matrix in HBM for the selection (option "knn_square_budget_bytes", default
- * 96 GiB; larger problems fall back to query blocks x all references). */
+ * All-vs-all (nq == 0 in dashing): q = r = [0,n) -- every pair is computed ONCE.  Up to "knn_square_budget_bytes"
+ * (option, default 96 GiB) both orientations go into an n x n float matrix in HBM and one selection pass per row
+ * follows; beyond it (configs[4]: n x n would be 360 GB) the triangle is computed in bands of tile rows, every band
+ * leaves its values as candidates of both sketches of each pair and is folded into the n running lists, so nothing of
+ * size n x n exists (300 000 x p=14, nn=10: 14.7 s on one MI355X, one triangle pass).  nn > 1024 or q != r: blocks of
+ * queries x all references. */
 int dsh_knn(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t q_begin, uint64_t q_end,
             uint64_t r_begin, uint64_t r_end, uint32_t nn, uint32_t *idx_out, float *val_out);
 

@@ -512,6 +512,39 @@ def test_knn_all_vs_all_paths_agree(ctx, oracle, rt):
     assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("rt", [dashing_amd.JI, dashing_amd.CONTAINMENT_INDEX, dashing_amd.MASH_DIST])
+def test_knn_bands_match_square_at_c3_size(ctx, rt):
+    """The band-wise all-vs-all kNN (triangle computed once, no n x n matrix: dsh_knn beyond its square budget) selects
+    exactly what the n x n path selects -- BASELINE configs[2] size, with exact ties from duplicated sketches."""
+    n, p = 10_000, 14
+    regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
+    regs[5] = regs[6] = regs[7]
+    regs[9000] = regs[123]
+    ctx.set_sketches(regs)
+    si, sv = ctx.knn(10, result_type=rt, k=31)
+    ctx.set_option("knn_square_budget_bytes", 256 << 20)  # bands of 3 200 rows: four of them
+    try:
+        bi, bv = ctx.knn(10, result_type=rt, k=31)
+    finally:
+        ctx.set_option("knn_square_budget_bytes", 96 << 30)
+    assert (si == bi).all() and (sv.view(np.uint32) == bv.view(np.uint32)).all()
+    assert si[5, 0] == 6 and si[6, 0] == 5 and si[7, 0] == 5 and si[5, 1] == 7  # ties go to the lower index
+
+
+def test_knn_more_neighbours_than_the_band_path_takes(ctx, oracle):
+    """nn > 1024 (the band path keeps a sketch's running list in LDS) falls back to query blocks"""
+    n, p = 1100, 10
+    regs = synth.synthetic_sketches(n, p, seed=5)
+    ctx.set_sketches(regs)
+    ctx.set_option("knn_square_budget_bytes", 0)
+    try:
+        gi, gv = ctx.knn(1050, k=21)
+    finally:
+        ctx.set_option("knn_square_budget_bytes", 96 << 30)
+    wi, wv = oracle.knn(regs, 1050, k=21)
+    assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
+
+
 def test_out_of_range_registers_are_refused(ctx):
     """uploaded registers above 64 - p + 1 (corrupt / foreign sketches) make the compare entry points fail loudly
     instead of aliasing into wrong histogram bins"""

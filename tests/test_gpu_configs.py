@@ -378,3 +378,30 @@ def test_config4_full_300k_p14_eight_ranges(ctx, oracle):
         second.update(_checksums(torch, buf, offs2[r + 1] - offs2[r], offs2[r], edges))
     assert first.keys() == second.keys() and len(first) == len(edges) - 1
     assert first == second
+
+
+def test_config4_knn_300k_without_the_square_matrix(ctx, oracle):
+    """SURVEY 8f-2 at configs[4] size: 10 nearest neighbours of each of 300 000 sketches (p = 14).  The n x n matrix
+    would be 360 GB; dsh_knn computes the triangle once in bands and keeps only the running lists
+    (src/sketch_and_cmp.h:642-783).  Sampled queries against the oracle (ties by the lower index: the collection
+    holds exact duplicates), every list complete, sorted, and free of the query itself."""
+    import time
+
+    import torch
+
+    n, p, nn = 300_000, 14, 10
+    dev = torch.device("cuda", 0)
+    regs_d = derived_collection(torch, dev, n, p, 4_000, seed=0x5EED3000)
+    ctx.attach_device(regs_d.data_ptr(), n, p)
+    t0 = time.perf_counter()
+    gi, gv = ctx.knn(nn)
+    dt = time.perf_counter() - t0
+    assert (gi != 0xFFFFFFFF).all() and (gi != np.arange(n, dtype=np.uint32)[:, None]).all()
+    assert (np.diff(gv.astype(np.float64), axis=1) <= 0).all()  # Jaccard: best first
+    regs_h = regs_d.cpu().numpy()
+    for q in (0, 3_999, 4_000, 123_456, 299_999):
+        wi, wv = oracle.knn(regs_h, nn, qb=q, qe=q + 1, rb=0, re=n)
+        assert (gi[q] == wi[0]).all(), (q, gi[q], wi[0])
+        assert np.allclose(gv[q], wv[0], rtol=1e-6, atol=1e-12)
+    print("knn 300k x p14 x nn=10: %.1f s" % dt)
+    assert dt < 60.0  # about one triangle pass (~15 s); the query-block fallback computes every pair twice
