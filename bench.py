@@ -169,6 +169,23 @@ def main():
         ctx.set_option(k_, int(v_))
     ctx.attach_device(regs_d.data_ptr(), n, p)
 
+    # The exchange of the spans: through the C-ABI (dsh_comm_init / dsh_collect_spans: RCCL inside libdashing_hip.so, on
+    # the library's stream -- what a C++ host calls) unless DSH_BENCH_EXCHANGE=torch; if the library's communicator
+    # cannot be brought up, torch.distributed's RCCL does the same point-to-point transfers (recorded in the line).
+    exchange = "none"
+    if multi:
+        exchange = "torch.distributed" if backend == "nccl" else "gloo (host staged)"
+        if backend == "nccl" and os.environ.get("DSH_BENCH_EXCHANGE", "cabi") == "cabi":
+            try:
+                multigpu.cabi_comm_init(ctx, rank, world)
+                exchange = "c-abi rccl (dsh_collect_spans)"
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench.py: rank %d: C-ABI communicator unavailable (%s): torch.distributed exchange\n" % (rank, e))
+            flag = torch.tensor([1 if exchange.startswith("c-abi") else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+            if int(flag.item()) == 0:
+                exchange = "torch.distributed"
+    use_cabi = exchange.startswith("c-abi")
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
     offs = [0]
@@ -192,7 +209,9 @@ def main():
         ctx.synchronize()
         t1 = time.perf_counter()
         if multi:
-            if host_stage:
+            if use_cabi:
+                multigpu.collect_row_spans_cabi(ctx, local, final, n, bounds, rank, 0)
+            elif host_stage:
                 lh = local[: max(my_pairs, 1)].cpu()
                 if rank == 0:
                     final_h[: sizes[0]] = lh[: sizes[0]]
@@ -355,7 +374,7 @@ def main():
         }
         if multi:
             line["multi_gpu"] = {
-                "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
+                "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend, "exchange": exchange,
                 "row_bounds": bounds, "pairs_per_rank": sizes,
                 "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange": round(phases[1], 4),
                                             "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},

@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     SYMMETRIC_CONTAINMENT_INDEX,
     SYMMETRIC_CONTAINMENT_DIST,
     device_count,
+    comm_unique_id,
     backend_name,
     lib_path,
     load_library,

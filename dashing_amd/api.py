@@ -25,6 +25,8 @@ SYMBOLS = [
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
+    "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
+    "dsh_allgather_device", "dsh_dist_collect",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
@@ -79,6 +81,14 @@ def load_library():
     lib.dsh_event_record.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.dsh_event_wait.argtypes = [vp, u64]
     lib.dsh_event_query.argtypes = [vp, u64, C.POINTER(i32)]
+    lib.dsh_comm_unique_id.argtypes = [vp]
+    lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.dsh_comm_destroy.argtypes = [vp]
+    lib.dsh_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.dsh_collect_spans.argtypes = [vp, u64, vp, vp, vp, i32]
+    lib.dsh_collect_spans_async.argtypes = [vp, u64, vp, vp, vp, i32]
+    lib.dsh_allgather_device.argtypes = [vp, vp, u64, vp]
+    lib.dsh_dist_collect.argtypes = [vp, i32, i32, i32, vp, i32, vp]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
     lib.dsh_knn.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, C.c_uint32, vp, vp]
     lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
@@ -112,6 +122,16 @@ def backend_name():
 
 def device_count():
     return int(load_library().dsh_device_count())
+
+
+def comm_unique_id():
+    """128 bytes (an ncclUniqueId) created by RCCL inside the library: rank 0 makes it, every rank passes it to
+    Context.comm_init.  Raises if RCCL cannot be loaded."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().dsh_comm_unique_id(buf)
+    if rc:
+        raise DshError(rc, "dsh_comm_unique_id (RCCL not available?)")
+    return buf.raw
 
 
 def tri_span(n, rb, re):
@@ -329,6 +349,37 @@ class Context:
     def unpermute_blocks_device(self, stage_ptr, block_off, out_ptr):
         off = np.ascontiguousarray(block_off, np.uint64)
         self._ck(self._lib.dsh_unpermute_blocks_device(self._h, C.c_void_p(stage_ptr), off.ctypes.data, off.size, C.c_void_p(out_ptr)))
+
+    # ---- multi-GPU exchange over RCCL inside the library (all traffic on the ctx stream)
+    def comm_init(self, unique_id, rank, world):
+        self._ck(self._lib.dsh_comm_init(self._h, unique_id, rank, world))
+
+    def comm_destroy(self):
+        self._ck(self._lib.dsh_comm_destroy(self._h))
+
+    def comm_rank(self):
+        r, w = C.c_int(), C.c_int()
+        rc = self._lib.dsh_comm_rank(self._h, C.byref(r), C.byref(w))
+        return (r.value, w.value) if rc == 0 else None
+
+    def collect_spans(self, n, bounds, local_ptr, final_ptr, dst=0, wait=True):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        f = self._lib.dsh_collect_spans if wait else self._lib.dsh_collect_spans_async
+        self._ck(f(self._h, n, b.ctypes.data, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
+
+    def allgather_device(self, send_ptr, bytes_per_rank, recv_ptr):
+        self._ck(self._lib.dsh_allgather_device(self._h, C.c_void_p(send_ptr), bytes_per_rank, C.c_void_p(recv_ptr)))
+
+    def dist_collect(self, bounds, dst=0, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        """this rank's rows computed, every span delivered to `dst`; returns the packed matrix there, None elsewhere"""
+        b = np.ascontiguousarray(bounds, np.uint64)
+        me = self.comm_rank()
+        out = None
+        if me is None or me[0] == dst:
+            out = np.zeros(max(tri_span(self.n, 0, self.n), 1), np.float32)
+        self._ck(self._lib.dsh_dist_collect(self._h, estim, result_type, k, b.ctypes.data, dst,
+                                            out.ctypes.data if out is not None else None))
+        return None if out is None else out[: tri_span(self.n, 0, self.n)]
 
     # ---- misc
     def synchronize(self):

@@ -1,6 +1,8 @@
 // dsh_api.hip -- the C-ABI of libdashing_hip.so (include/dashing_hip.h) over the gfx950 kernels.
 // No CPU fallback lives here: without a HIP device dsh_create fails with DSH_ENODEV.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen'ed at dsh_comm_init (single-GPU users never load it)
 
 #include <algorithm>
 #include <cstdarg>
@@ -85,6 +87,10 @@ struct dsh_ctx {
     unsigned out_turn = 0;
     std::vector<hipEvent_t> tickets;    // dsh_event_record ring: slot t % 64 holds {join on the ctx stream, mark on the copy stream}
     uint64_t ticket_next = 0;
+    // multi-GPU exchange (dsh_comm_*): an RCCL communicator over the ranks' contexts; all traffic on `stream`
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
     DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
     uint32_t nbuckets = 0, ent_stride = 0;
     // column layout of the cached plane matrix.  0: identity over all n sketches.  1: the sub-collection
@@ -162,6 +168,64 @@ int fail(dsh_ctx *c, int code, const char *fmt, ...)
         if (e_ != hipSuccess)                                                             \
             return fail((c), e_ == hipErrorOutOfMemory ? DSH_ENOMEM : DSH_EIO, "%s: %s",  \
                         #expr, hipGetErrorString(e_));                                    \
+    } while (0)
+
+// RCCL, loaded on first use.  The library must be the one built against the HIP runtime this file links to (the
+// streams handed to it are ours): librccl.so.1 through this library's RUNPATH (/opt/rocm/lib), or DSH_RCCL_LIB.
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    const char *names[3] = {std::getenv("DSH_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (r.h) break;
+        r.err = dlerror();
+    }
+    if (!r.h) return &r;
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(r.h, name);
+        if (!p) r.err = std::string("librccl: missing symbol ") + name;
+        return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv ||
+        !r.AllGather || !r.GetErrorString) {
+        dlclose(r.h);
+        r.h = nullptr;
+    }
+    return &r;
+}
+
+#define NCCLCHK(c, expr)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return fail((c), DSH_EIO, "%s: %s", #expr, rccl()->GetErrorString(r_));     \
     } while (0)
 
 int bind(dsh_ctx *c)
@@ -755,6 +819,9 @@ void dsh_destroy(dsh_ctx *c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    if (c->comm && rccl()->h) (void)rccl()->CommDestroy(c->comm);
+    c->gather_full.release();
+    c->gather_local.release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->regs_own.release();
     c->card.release();
@@ -1717,6 +1784,159 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         return DSH_OK;
     }
     return fail(c, DSH_EINVAL, "unknown option %s", name);
+}
+
+
+/* ---- multi-GPU exchange through RCCL (one context per rank; ranks may be processes or threads) ------------------ */
+int dsh_comm_unique_id(void *id_out)
+{
+    if (!id_out) return DSH_EINVAL;
+    Rccl *r = rccl();
+    if (!r->h) return DSH_ENODEV;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return DSH_EIO;
+    std::memcpy(id_out, &id, sizeof id);
+    return DSH_OK;
+}
+
+int dsh_comm_init(dsh_ctx *c, const void *unique_id, int rank, int world)
+{
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    Rccl *r = rccl();
+    if (!r->h) return fail(c, DSH_ENODEV, "RCCL is not available (%s)", r->err.c_str());
+    if (c->comm) {
+        NCCLCHK(c, r->CommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    NCCLCHK(c, r->CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return DSH_OK;
+}
+
+int dsh_comm_destroy(dsh_ctx *c)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (c->comm) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        NCCLCHK(c, rccl()->CommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return DSH_OK;
+}
+
+int dsh_comm_rank(const dsh_ctx *c, int *rank, int *world)
+{
+    if (!c) return DSH_EINVAL;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm ? c->comm_world : 1;
+    return c->comm ? DSH_OK : DSH_ESTATE;
+}
+
+static int collect_spans(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    if (!bounds || dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad bounds / destination rank");
+    if (bounds[0] != 0 || bounds[world] != n) return fail(c, DSH_EINVAL, "bounds must run from 0 to n over the %d ranks", world);
+    for (int r = 0; r < world; ++r)
+        if (bounds[r] > bounds[r + 1]) return fail(c, DSH_EINVAL, "bounds not monotone at rank %d", r);
+    const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+    if (rank == dst) {
+        if (!d_final) return DSH_EINVAL;
+        float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[rank]);
+        if (mine && d_local && d_local != (const void *)own)  // computed elsewhere: put it into place
+            HIPCHK(c, hipMemcpyAsync(own, d_local, mine * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else if (mine && !d_local) {
+        return DSH_EINVAL;
+    }
+    if (world == 1) return DSH_OK;
+    Rccl *r = rccl();
+    // one message per peer, all of them in one group: the destination's links are busy at once, every span lands
+    // at its final place (the ranks' row ranges are contiguous spans of the packed triangle)
+    NCCLCHK(c, r->GroupStart());
+    if (rank == dst) {
+        for (int src = 0; src < world; ++src) {
+            const uint64_t cnt = dsh_tri_span(n, bounds[src], bounds[src + 1]);
+            if (src == dst || cnt == 0) continue;
+            ncclResult_t e = r->Recv((float *)d_final + dsh_tri_span(n, 0, bounds[src]), cnt, ncclFloat32, src, c->comm, c->stream);
+            if (e != ncclSuccess) {
+                (void)r->GroupEnd();
+                return fail(c, DSH_EIO, "ncclRecv: %s", r->GetErrorString(e));
+            }
+        }
+    } else if (mine) {
+        ncclResult_t e = r->Send(d_local, mine, ncclFloat32, dst, c->comm, c->stream);
+        if (e != ncclSuccess) {
+            (void)r->GroupEnd();
+            return fail(c, DSH_EIO, "ncclSend: %s", r->GetErrorString(e));
+        }
+    }
+    NCCLCHK(c, r->GroupEnd());
+    return DSH_OK;
+}
+
+int dsh_collect_spans_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->comm && !(bounds && bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    return collect_spans(c, n, bounds, d_local, d_final, dst);
+}
+
+int dsh_collect_spans(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    int rc = dsh_collect_spans_async(c, n, bounds, d_local, d_final, dst);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_allgather_device(dsh_ctx *c, const void *d_send, uint64_t bytes_per_rank, void *d_recv)
+{
+    if (!c || (bytes_per_rank && (!d_send || !d_recv))) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->comm) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if (bytes_per_rank) NCCLCHK(c, rccl()->AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_dist_collect(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *bounds, int dst, float *out)
+{
+    if (!c || !bounds) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d", dst);
+    const uint64_t n = c->n, total = dsh_tri_span(n, 0, n);
+    if (bounds[0] != 0 || bounds[world] != n) return fail(c, DSH_EINVAL, "bounds must run from 0 to n over the %d ranks", world);
+    const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+    void *d_local = nullptr;
+    if (rank == dst) {
+        if (total && !out) return DSH_EINVAL;
+        HIPCHK(c, c->gather_full.ensure(std::max<uint64_t>(total, 1) * sizeof(float)));
+        d_local = (float *)c->gather_full.ptr + dsh_tri_span(n, 0, bounds[rank]);  // computed in place
+    } else {
+        HIPCHK(c, c->gather_local.ensure(std::max<uint64_t>(mine, 1) * sizeof(float)));
+        d_local = c->gather_local.ptr;
+    }
+    if (mine && (rc = dsh_dist_rows_device_async(c, estim, result_type, k, bounds[rank], bounds[rank + 1], d_local))) return rc;
+    if ((rc = collect_spans(c, n, bounds, d_local, rank == dst ? c->gather_full.ptr : nullptr, dst))) return rc;
+    if (rank == dst && total)
+        HIPCHK(c, hipMemcpyAsync(out, c->gather_full.ptr, total * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
 }
 
 }  // extern "C"

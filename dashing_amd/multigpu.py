@@ -54,6 +54,24 @@ def max_span(n, bounds):
     return max(span_sizes(n, bounds))
 
 
+def cabi_comm_init(ctx, rank, world):
+    """Give `ctx` an RCCL communicator of its own INSIDE libdashing_hip.so (dsh_comm_init): the exchange then runs on
+    the library's stream, ordered with its kernels, and a C++ host gets the same call sequence without torch.
+    torch.distributed only carries the 128-byte id from rank 0 to the others (any backend)."""
+    ids = [api.comm_unique_id() if rank == 0 else None]
+    if dist.is_initialized():
+        dist.broadcast_object_list(ids, src=0)
+    ctx.comm_init(ids[0], rank, world)
+
+
+def collect_row_spans_cabi(ctx, local, final, n, bounds, rank, dst=0, wait=True):
+    """collect_row_spans through the C-ABI (dsh_collect_spans): grouped ncclSend/ncclRecv on the ctx stream, every span
+    received at its final place on `dst`.  `final` is only needed on dst, whose own span is expected to be there
+    already (computed in place), exactly as with collect_row_spans."""
+    ctx.collect_spans(n, bounds, 0 if rank == dst else local.data_ptr(), final.data_ptr() if rank == dst else 0, dst, wait=wait)
+    return final if rank == dst else None
+
+
 def collect_row_spans(local, final, n, bounds, rank, world, dst=0):
     """The multi-GPU exchange of the distance matrix: rank r has computed the rows [bounds[r], bounds[r+1])
     (Context.dist_rows_device), i.e. ONE contiguous span of the packed triangle already in its final

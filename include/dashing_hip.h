@@ -206,6 +206,35 @@ int dsh_unpermute_staged_device(dsh_ctx *ctx, const void *d_stage, uint64_t stri
 int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_t *block_off,
                                 uint32_t nshards, void *d_out_tri);
 
+/* ---- multi-GPU exchange over RCCL / xGMI ------------------------------------------------------
+ * One dsh_ctx per GPU; the ranks may be processes (one per GPU, the bench) or threads of one process (the CLI).
+ * The compare needs no collective -- every rank holds all sketches and computes a row range whose result is ONE
+ * contiguous span of dashing's packed matrix (dsh_balance_rows) -- so the only exchange is the delivery of the spans
+ * to the rank that emits the matrix, as in dashing where one process writes it (src/sketch_and_cmp.h:838-849), and,
+ * when sketching is shared out, the all-gather of the register arrays.  RCCL is loaded on first use (librccl.so.1
+ * next to the HIP runtime this library links to; DSH_RCCL_LIB overrides); all traffic is enqueued on the ctx stream,
+ * so it is ordered with the kernels without any host synchronisation.
+ *   dsh_comm_unique_id   rank 0: 128 bytes (an ncclUniqueId) to hand to every rank (file, pipe, MPI, shared memory ...)
+ *   dsh_comm_init        collective (blocks until all `world` ranks called it with the same id)
+ *   dsh_collect_spans    after rank r computed rows [bounds[r], bounds[r+1]) into d_local (device, its span): grouped
+ *                        ncclSend/ncclRecv, one message per peer, every span received at its final place in d_final
+ *                        (device, n(n-1)/2 floats, only read on `dst`; dst's own span is copied there unless d_local
+ *                        already points at it).  The _async form returns after enqueueing (dsh_wait / a ticket).
+ *   dsh_allgather_device ncclAllGather of equal-sized byte blocks (d_recv: world x bytes_per_rank), e.g. the register
+ *                        arrays after sharded sketching (dsh_copy_sketches_device gives the block)
+ *   dsh_dist_collect     the whole multi-GPU dist step for a host without device pointers: computes this rank's row
+ *                        range, delivers the spans to `dst`, which gets the full packed matrix in `out` (host,
+ *                        n(n-1)/2 floats; ignored on other ranks).  Without a communicator (world = 1) it is dsh_dist_rows. */
+#define DSH_UNIQUE_ID_BYTES 128
+int dsh_comm_unique_id(void *id_out);
+int dsh_comm_init(dsh_ctx *ctx, const void *unique_id, int rank, int world);
+int dsh_comm_destroy(dsh_ctx *ctx);
+int dsh_comm_rank(const dsh_ctx *ctx, int *rank, int *world);
+int dsh_collect_spans(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst);
+int dsh_collect_spans_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst);
+int dsh_allgather_device(dsh_ctx *ctx, const void *d_send, uint64_t bytes_per_rank, void *d_recv);
+int dsh_dist_collect(dsh_ctx *ctx, int estim, int result_type, int k, const uint64_t *bounds, int dst, float *out);
+
 /* ---- helpers shared by every host (C++ CLI, Python, a patched dashing) -------------------- */
 /* number of packed elements of rows [row_begin,row_end) of an n x n upper triangle */
 uint64_t dsh_tri_span(uint64_t n, uint64_t row_begin, uint64_t row_end);

@@ -80,6 +80,15 @@ def main():
             fh = final_r.cpu() if rank == 0 else None
             multigpu.collect_row_spans(my.cpu(), fh, n, bounds, rank, world, 0)
             full = fh.to(dev) if rank == 0 else None
+        elif os.environ.get("E2E_CABI"):  # the exchange inside libdashing_hip.so (dsh_comm_init / dsh_collect_spans)
+            multigpu.cabi_comm_init(ctx, rank, world)
+            assert ctx.comm_rank() == (rank, world)
+            full = multigpu.collect_row_spans_cabi(ctx, my, final_r, n, bounds, rank, 0)
+            # the all-gather of the register arrays through the same communicator gives what torch's gave
+            allr = torch.empty((world, per, m), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ctx.allgather_device(local.data_ptr(), per * m, allr.data_ptr())
+            assert torch.equal(allr.permute(1, 0, 2).reshape(per * world, m)[:n], regs_d)
         else:
             full = multigpu.collect_row_spans(my, final_r, n, bounds, rank, world, 0)
     elif pieces == 1:

@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 WORKER = os.path.join(ROOT, "tests", "e2e_multigpu_worker.py")
 
 
@@ -34,6 +35,62 @@ def test_end_to_end_ranks(backend, world, pieces):
     out = r.stdout.decode() + r.stderr.decode()
     assert r.returncode == 0, out[-3000:]
     assert "E2E_OK world=%d backend=%s pieces=%d" % (world, backend, pieces) in out, out[-3000:]
+
+
+def test_end_to_end_cabi_exchange_single_rank_rccl():
+    """the same path with the exchange done by the library's own RCCL communicator (dsh_comm_init, dsh_collect_spans,
+    dsh_allgather_device) next to torch.distributed's: both RCCL instances come up on the one GPU"""
+    env = dict(os.environ, E2E_BACKEND="nccl", E2E_PIECES="0", E2E_CABI="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=600, cwd=ROOT)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0 and "E2E_OK world=1 backend=nccl pieces=0" in out, out[-3000:]
+
+
+def test_cabi_comm_in_process(ctx):
+    """dsh_comm_* without torch.distributed (what the C++ CLI does): unique id -> communicator of one rank ->
+    dsh_dist_collect == dsh_dist_rows; spans computed out of place land in the final buffer; a second init replaces the
+    communicator; calls before dsh_comm_init fail with DSH_ESTATE"""
+    import numpy as np
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    n, p = 500, 12
+    regs = synth.synthetic_sketches(n, p, seed=8)
+    ctx.set_sketches(regs)
+    want = ctx.dist_rows()
+    assert ctx.comm_rank() is None
+    with pytest.raises(dashing_amd.DshError):
+        ctx.allgather_device(0, 0, 0)
+    uid = dashing_amd.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    try:
+        assert ctx.comm_rank() == (0, 1)
+        assert ctx.dist_collect([0, n]).tobytes() == want.tobytes()
+        dev = torch.device("cuda", 0)
+        local = torch.empty(want.size, dtype=torch.float32, device=dev)
+        final = torch.full((want.size,), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        ctx.dist_rows_device_async(local.data_ptr(), 0, n)
+        ctx.collect_spans(n, [0, n], local.data_ptr(), final.data_ptr(), 0, wait=False)  # enqueued behind the kernels
+        ctx.wait()
+        assert final.cpu().numpy().tobytes() == want.tobytes()
+        blk = torch.arange(4096, dtype=torch.uint8, device=dev)
+        got = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.allgather_device(blk.data_ptr(), 4096, got.data_ptr())
+        assert torch.equal(blk, got)
+        with pytest.raises(dashing_amd.DshError):
+            ctx.collect_spans(n, [0, n - 1], local.data_ptr(), final.data_ptr(), 0)  # bounds must end at n
+        ctx.comm_init(dashing_amd.comm_unique_id(), 0, 1)  # re-initialisation replaces the communicator
+        assert ctx.dist_collect([0, n]).tobytes() == want.tobytes()
+    finally:
+        ctx.comm_destroy()
+    assert ctx.comm_rank() is None and np.isfinite(ctx.dist_rows()).all()
 
 
 def _bench(args, env_extra, timeout=900):
