@@ -61,7 +61,8 @@ static void usage(const char *sub)
         "  -P, --prefix DIR / -x, --suffix STR   sketch cache location / name suffix\n"
         "  -C, --no-canon           do not canonicalise k-mers\n"
         "  --device INT             GPU ordinal [0]\n"
-        "  --ngpus INT | --devices a,b,..  (dist, -b only) share the rows of the matrix between several GPUs\n", kVersion, sub);
+        "  --ngpus INT | --devices a,b,..  (dist) share the rows of the matrix between several GPUs: -b to a file is written\n"
+        "                           by every GPU at its own offsets, other outputs are gathered to the first GPU over RCCL\n", kVersion, sub);
     if (!std::strcmp(sub, "sketch")) {
         std::fprintf(stderr, "  -c, --skip-cached        skip genomes whose .hll already exists\n"
                              "  -o FILE                  write all sketches into one file (+ FILE.labels.gz) instead of one .hll per genome\n");
@@ -84,12 +85,13 @@ struct Opts {
     int estim = ERTL_MLE, result_type = JI, fmt = UT_TSV;
     int cache = 0, presketched = 0, avoid_sorting = 0, skip_cached = 0;
     unsigned nneighbors = 0;  // --nearest-neighbors
+    int rccl = 0;             // --rccl: deliver the rows through the RCCL exchange of the C-ABI even with one device
     std::vector<int> devices;  // --devices a,b,... / --ngpus G: GPUs sharing the all-pairs rows (binary output)
     std::string paths_file, prefix, suffix, spacing, out_sizes, out_dists;
     std::vector<std::string> inpaths, querypaths;
 };
 
-enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_NN, OPT_NGPUS, OPT_DEVICES, OPT_UNSUPPORTED };
+enum { OPT_PRESKETCHED = 1000, OPT_AVOID_SORT, OPT_DEVICE, OPT_NPERBATCH, OPT_NN, OPT_NGPUS, OPT_DEVICES, OPT_RCCL, OPT_UNSUPPORTED };
 
 static Opts parse(int argc, char **argv, bool is_dist)
 {
@@ -109,6 +111,7 @@ static Opts parse(int argc, char **argv, bool is_dist)
         {"presketched", no_argument, nullptr, OPT_PRESKETCHED}, {"avoid-sorting", no_argument, nullptr, OPT_AVOID_SORT},
         {"skip-cached", no_argument, nullptr, 'c'}, {"device", required_argument, nullptr, OPT_DEVICE},
         {"ngpus", required_argument, nullptr, OPT_NGPUS}, {"devices", required_argument, nullptr, OPT_DEVICES},
+        {"rccl", no_argument, nullptr, OPT_RCCL},
         {"nperbatch", required_argument, nullptr, OPT_NPERBATCH}, {"spacing", required_argument, nullptr, 's'},
         {"window-size", required_argument, nullptr, 'w'}, {"help", no_argument, nullptr, 'h'},
         {"use-bb-minhash", no_argument, nullptr, OPT_UNSUPPORTED}, {"use-range-minhash", no_argument, nullptr, OPT_UNSUPPORTED},
@@ -163,6 +166,7 @@ static Opts parse(int argc, char **argv, bool is_dist)
             }
             break;
         }
+        case OPT_RCCL: o.rccl = 1; break;
         case OPT_NPERBATCH: case 'e': break;  // accepted, no effect here
         case 's': if (optarg && *optarg) die("spaced seeds are out of scope (HLL hot path only)"); break;
         case 'w': if (std::atoi(optarg) > 0) die("minimizer windows are out of scope (HLL hot path only)"); break;
@@ -809,6 +813,48 @@ static int dist_main(int argc, char **argv)
                 if (d > 0) dsh_destroy(c);
             });
         for (auto &w : workers) w.join();
+    } else if (o.devices.size() > 1 || o.rccl) {
+        // Several GPUs, output that one writer has to emit in order (text formats, or -b to a pipe): every device
+        // computes its row range (dsh_balance_rows: one contiguous span of the packed matrix each) and the spans are
+        // delivered to the first device over RCCL / xGMI inside the library (dsh_dist_collect: grouped ncclSend/ncclRecv
+        // straight into place), which hands the whole matrix to this process -- dashing's single writer
+        // (src/sketch_and_cmp.h:804-849) fed by G GPUs.  One thread per device, as RCCL wants for one process.
+        const size_t G = std::max<size_t>(o.devices.size(), 1), m = (size_t)1 << o.S;
+        uint8_t uid[DSH_UNIQUE_ID_BYTES];
+        if (int rc = dsh_comm_unique_id(uid)) die("[dashing-amd] RCCL is not available (dsh_comm_unique_id = %d)", rc);
+        std::vector<uint8_t> all;
+        if (G > 1) {
+            all.resize(n * m);
+            DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
+        }
+        std::vector<uint64_t> bounds(G + 1);
+        if (dsh_balance_rows(n, (uint32_t)G, bounds.data())) die("dsh_balance_rows failed");
+        std::vector<float> tri(std::max<uint64_t>(total, 1));
+        std::vector<std::thread> workers;
+        for (size_t d = 0; d < G; ++d)
+            workers.emplace_back([&, d]() {
+                dsh_ctx *c = ctx;
+                if (d > 0) {
+                    if (int rc = dsh_create(o.devices[d], &c)) die("[dashing-amd] dsh_create(device %d) = %d", o.devices[d], rc);
+                    DSH(c, dsh_sketches_alloc(c, n, o.S));
+                    DSH(c, dsh_upload_sketches(c, all.data(), 0, n));
+                }
+                DSH(c, dsh_comm_init(c, uid, (int)d, (int)G));
+                DSH(c, dsh_dist_collect(c, o.estim, o.result_type, o.k, bounds.data(), 0, d == 0 ? tri.data() : nullptr));
+                DSH(c, dsh_comm_destroy(c));
+                if (d > 0) dsh_destroy(c);
+            });
+        for (auto &w : workers) w.join();
+        if (o.fmt == BINARY) {
+            if (write_binary_header(pairofp, n)) die("Failure");
+            if (total && std::fwrite(tri.data(), sizeof(float), total, pairofp) != total) die("Failed to write rows to disk");
+        } else if (o.fmt == FULL_TSV) {
+            emit_full_header(pairofp, o.inpaths);
+            for (size_t i = 0; i < n; ++i) emit_full_row(pairofp, o.inpaths, i, tri.data());
+        } else {
+            emit_header(pairofp, o.fmt, o.inpaths);
+            for (size_t i = 0; i < n; ++i) emit_ut_row(pairofp, o.fmt, o.inpaths, i, tri.data() + dsh_tri_span(n, 0, i));
+        }
     } else if (o.fmt == FULL_TSV) {
         std::vector<float> tri(std::max<uint64_t>(total, 1));
         DSH(ctx, dsh_dist_rows(ctx, o.estim, o.result_type, o.k, 0, n, tri.data()));

@@ -236,6 +236,21 @@ def test_multi_device_binary_matches_single(genomes, tmp_path):
     assert len(c.read_bytes()) == len(a.read_bytes())
 
 
+def test_rccl_collect_path_matches_plain(genomes, tmp_path):
+    """`dist --ngpus G` with an output that one writer emits in order goes through dsh_comm_init + dsh_dist_collect
+    (RCCL inside the library).  A one-GPU box can only run it with one rank (--rccl forces the path; RCCL refuses two
+    ranks on one device): every format must equal the plain run byte for byte."""
+    d, paths, seqs = genomes
+    for flags in ([], ["-U", "-M"], ["-T"], ["-b"]):
+        a, b = tmp_path / "plain.out", tmp_path / "rccl.out"
+        run("dist", "--avoid-sorting", *flags, "-O", a, "-o", os.devnull, *paths)
+        run("dist", "--avoid-sorting", "--rccl", *flags, "-O", b, "-o", os.devnull, *paths)
+        assert a.read_bytes() == b.read_bytes(), flags
+    r = subprocess.run([CLI, "dist", "--avoid-sorting", "--devices", "0,0", "-O", str(tmp_path / "x.tsv"), "-o", os.devnull, *paths],
+                       capture_output=True, timeout=300)
+    assert r.returncode != 0  # two ranks on one GPU: RCCL refuses, the CLI reports it instead of hanging
+
+
 def test_multi_device_presketched_large(oracle, tmp_path):
     """700 presketched sketches (several 128-row tile rows per device): 3 contexts vs 1, and vs the oracle."""
     import ctypes as C
