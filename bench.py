@@ -186,6 +186,9 @@ def main():
             if int(flag.item()) == 0:
                 exchange = "torch.distributed"
     use_cabi = exchange.startswith("c-abi")
+    NPARTS = int(os.environ.get("DSH_BENCH_PARTS", "8"))
+    if use_cabi:
+        exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_dist_rows_parts_device_async + dsh_collect_parts_async)" % NPARTS
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
     offs = [0]
@@ -205,13 +208,25 @@ def main():
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
         t0 = time.perf_counter()
         ctx.attach_device(regs_d.data_ptr(), n, p)
+        if use_cabi:
+            # pipelined: the rank's rows in NPARTS parts; part q travels to rank 0 (copy stream, grouped ncclSend/ncclRecv
+            # behind the part's event) while the later parts are still being finalized on the ctx stream
+            ctx.dist_rows_parts_device_async(local.data_ptr(), bounds[rank], bounds[rank + 1], NPARTS, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            computed = ctx.event_record()
+            ctx.collect_parts_async(n, bounds, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
+            ctx.event_wait(computed)
+            t1 = time.perf_counter()
+            ctx.wait()
+            t2 = time.perf_counter()
+            if timed:
+                phase["compute"] += t1 - t0
+                phase["exchange"] += t2 - t1  # what is left of the exchange after the last kernel
+            return final
         ctx.dist_rows_device(local.data_ptr(), bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
         t1 = time.perf_counter()
         if multi:
-            if use_cabi:
-                multigpu.collect_row_spans_cabi(ctx, local, final, n, bounds, rank, 0)
-            elif host_stage:
+            if host_stage:
                 lh = local[: max(my_pairs, 1)].cpu()
                 if rank == 0:
                     final_h[: sizes[0]] = lh[: sizes[0]]
@@ -376,7 +391,7 @@ def main():
             line["multi_gpu"] = {
                 "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend, "exchange": exchange,
                 "row_bounds": bounds, "pairs_per_rank": sizes,
-                "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange": round(phases[1], 4),
+                "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange" if not use_cabi else "exchange_exposed_after_last_kernel": round(phases[1], 4),
                                             "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},
                 "exchange_bytes_into_rank0": 4 * (total_pairs - sizes[0]),
             }

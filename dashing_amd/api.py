@@ -26,7 +26,7 @@ SYMBOLS = [
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
     "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
-    "dsh_allgather_device", "dsh_dist_collect",
+    "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
@@ -89,6 +89,9 @@ def load_library():
     lib.dsh_collect_spans_async.argtypes = [vp, u64, vp, vp, vp, i32]
     lib.dsh_allgather_device.argtypes = [vp, vp, u64, vp]
     lib.dsh_dist_collect.argtypes = [vp, i32, i32, i32, vp, i32, vp]
+    lib.dsh_range_parts.argtypes = [u64, u64, u64, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+    lib.dsh_dist_rows_parts_device_async.argtypes = [vp, i32, i32, i32, u64, u64, vp, C.c_uint32]
+    lib.dsh_collect_parts_async.argtypes = [vp, u64, vp, C.c_uint32, vp, vp, i32]
     lib.dsh_dist_rect.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, vp]
     lib.dsh_knn.argtypes = [vp, i32, i32, i32, u64, u64, u64, u64, C.c_uint32, vp, vp]
     lib.dsh_shard_plan.argtypes = [vp, i32, C.c_uint32, vp]
@@ -132,6 +135,16 @@ def comm_unique_id():
     if rc:
         raise DshError(rc, "dsh_comm_unique_id (RCCL not available?)")
     return buf.raw
+
+
+def range_parts(n, rb, re, nparts):
+    """row boundaries of the parts dsh_dist_rows_parts_device_async cuts [rb, re) into (may be fewer than nparts)"""
+    b = np.zeros(nparts + 1, np.uint64)
+    k = C.c_uint32()
+    rc = load_library().dsh_range_parts(n, rb, re, nparts, b.ctypes.data, C.byref(k))
+    if rc:
+        raise DshError(rc, "dsh_range_parts")
+    return [int(x) for x in b[: k.value + 1]]
 
 
 def tri_span(n, rb, re):
@@ -366,6 +379,13 @@ class Context:
         b = np.ascontiguousarray(bounds, np.uint64)
         f = self._lib.dsh_collect_spans if wait else self._lib.dsh_collect_spans_async
         self._ck(f(self._h, n, b.ctypes.data, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
+
+    def dist_rows_parts_device_async(self, out_ptr, row_begin, row_end, nparts, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        self._ck(self._lib.dsh_dist_rows_parts_device_async(self._h, estim, result_type, k, row_begin, row_end, C.c_void_p(out_ptr), nparts))
+
+    def collect_parts_async(self, n, bounds, nparts, local_ptr, final_ptr, dst=0):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        self._ck(self._lib.dsh_collect_parts_async(self._h, n, b.ctypes.data, nparts, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
 
     def allgather_device(self, send_ptr, bytes_per_rank, recv_ptr):
         self._ck(self._lib.dsh_allgather_device(self._h, C.c_void_p(send_ptr), bytes_per_rank, C.c_void_p(recv_ptr)))

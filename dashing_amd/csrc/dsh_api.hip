@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -76,10 +77,14 @@ struct dsh_ctx {
     // derived state
     bool planes_valid = false;
     int card_estim = -1;
+    uint64_t card_from = 0;             // the per-sketch pass (cardinalities, lists, keys) covers the sketches [card_from, n)
     DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
     // copy-out pipeline of dsh_dist_rows_async: results alternate between two device buffers; the copy of call b to the
     // host runs on its own stream while the kernels of call b+1 fill the other buffer
     hipStream_t copy_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // prepare(): the column index is built next to the bit-plane transform
+    hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    bool aux_join_pending = false;
     DevBuf outbuf2[2];
     hipEvent_t ev_filled[2] = {nullptr, nullptr};  // kernels of the call that filled outbuf2[b] done (recorded on stream)
     hipEvent_t ev_drained[2] = {nullptr, nullptr}; // copy out of outbuf2[b] done (recorded on copy_stream)
@@ -91,6 +96,8 @@ struct dsh_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
+    DevBuf hist;                        // [n][64] per-sketch register histograms (k_selfhist_card -> k_card_from_hist)
+    hipEvent_t ev_keys = nullptr;       // the keys have reached the host
     DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
     uint32_t nbuckets = 0, ent_stride = 0;
     // column layout of the cached plane matrix.  0: identity over all n sketches.  1: the sub-collection
@@ -98,11 +105,21 @@ struct dsh_ctx {
     // (lay_rb = 0, lay_re = n: the whole collection sorted, what full-triangle calls and the shard path use)
     int planes_sorted = 0;
     uint64_t lay_rb = 0, lay_re = 0;
+    // a row-range layout may keep its wanted rows in several PARTS (consecutive sub-ranges, each key-ordered on its
+    // own, each a whole number of 128-row tile rows except the last): a part's tiles are finished -- and its span of
+    // the packed matrix complete -- before the next part starts, so it can travel while the rest is computed
+    std::vector<uint64_t> lay_parts;    // row boundaries, lay_parts.front() = lay_rb, .back() = lay_re
+    std::vector<hipEvent_t> ev_part;    // part q complete (recorded on the ctx stream by the last call with parts)
+    uint32_t parts_done = 0;            // parts of the last dsh_dist_rows_parts_device_async call
     uint64_t ncols = 0;                 // real columns (sketches) of the plane matrix; Npad = ncols padded to 128
-    std::vector<uint32_t> hk32;         // host copy of the per-sketch keys (valid while the per-sketch pass is)
+    PinBuf pin_keys;                    // host copy of the per-sketch keys (valid while the per-sketch pass is), page-locked:
+    const uint32_t *hk32 = nullptr;     // the copy is a direct DMA and the host only waits for ev_keys
     bool hk32_valid = false;
     hipEvent_t ev_perm = nullptr;       // upload of pin_perm done (it is rewritten by the next layout)
     bool perm_in_flight = false;
+    std::vector<uint32_t> sort_a, sort_b, sort_keys;  // scratch of the column sort
+    std::vector<uint2> tile_chunks;     // scratch of run_pairs: chunk range per tile
+    double host_layout_us = 0, host_lists_us = 0, host_keys_wait_us = 0;  // host time of the last call (dsh_get_info)
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
     uint32_t *pin_perm = nullptr;       // page-locked copy of hperm: its upload is then truly asynchronous
     size_t pin_perm_cap = 0;
@@ -296,8 +313,28 @@ void tile_planes(const dsh_ctx *c, uint32_t ti, uint32_t tj, int &pb, int &pe)
 // cardinalities + thresholds/exception lists + planes for the current sketch matrix.
 // want_sorted: lay the plane-matrix columns out in (threshold, min value) order so that the
 // 128-column blocks are homogeneous and every tile can use its own narrow plane range.
+// rows [rb, re) cut into nparts consecutive parts of about equal pair counts, every cut a whole number of 128-row
+// tile rows after rb (fewer parts if the range has fewer tile rows); out gets the boundaries
+void range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &out)
+{
+    out.assign(1, rb);
+    if (re > n) re = n;
+    const uint64_t total = dsh_tri_span(n, rb, re);
+    for (uint32_t q = 1; q < nparts && out.back() < re; ++q) {
+        const long double target = (long double)total * q / nparts;
+        uint64_t best = out.back() + kTile;
+        for (uint64_t cand = out.back() + kTile; cand < re; cand += kTile) {
+            best = cand;
+            if ((long double)dsh_tri_span(n, rb, cand) >= target) break;
+        }
+        if (best >= re) break;
+        out.push_back(best);
+    }
+    if (out.back() != re) out.push_back(re);
+}
+
 int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint64_t want_rb = 0,
-            uint64_t want_re = ~0ull)
+            uint64_t want_re = ~0ull, uint32_t nparts = 1)
 {
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
@@ -310,6 +347,8 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
     if (!want_sorted) want_rb = 0, want_re = c->n;
     if (want_rb > want_re) want_rb = want_re;
     const uint64_t n = c->n;
+    std::vector<uint64_t> parts;
+    if (want_sorted) range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kMaxListSide) : auto_list_cap(c->p, true);
     const int elow_new = c->elow_opt >= 0 ? std::min<int>(c->elow_opt, (int)kMaxListSide) : auto_list_cap(c->p, false);
     if (emax_new != c->emax || elow_new != c->elow) {  // thresholds and lists (hence planes) depend on them
@@ -319,8 +358,11 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
     c->emax = emax_new;
     c->elow = elow_new;
     const bool same_layout = c->planes_valid && c->planes_sorted == want_sorted &&
-                             (!want_sorted || (c->lay_rb == want_rb && c->lay_re == want_re));
-    if (c->card_estim == estim && (card_only || same_layout)) return DSH_OK;
+                             (!want_sorted || (c->lay_rb == want_rb && c->lay_re == want_re && c->lay_parts == parts));
+    // sketches the per-sketch pass has to cover: a row range of the triangle never looks at the sketches before it
+    const uint64_t need_from = (card_only || !want_sorted) ? 0 : want_rb;
+    const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
+    if (have_pass && (card_only || same_layout)) return DSH_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
@@ -328,18 +370,31 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
     // the per-sketch pass depends on (registers, estimator, emax) only: a new column layout reuses it
-    if (c->card_estim != estim) {
+    if (!have_pass) {
         HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
         HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kListCap * (c->p <= 15 ? 2 : 4)));
         HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kListCap));
         HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         HIPCHK(c, c->tailhist.ensure(std::max<uint64_t>(n, 1) * 64));
-        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, n, c->p, estim, c->emax, c->elow,
-                                       (double *)c->card.ptr, c->exc.ptr, (uint8_t *)c->excv.ptr,
+        HIPCHK(c, c->hist.ensure(std::max<uint64_t>(n, 1) * 64 * sizeof(uint32_t)));
+        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, need_from, n, c->p, estim, c->emax, c->elow,
+                                       (uint32_t *)c->hist.ptr, c->exc.ptr, (uint8_t *)c->excv.ptr,
                                        (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
                                        (uint8_t *)c->tailhist.ptr));
+        // the keys travel to the host right behind the per-sketch pass (the column order is made there); the
+        // cardinalities follow on the stream while the host sorts
+        HIPCHK(c, c->pin_keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        c->hk32 = (const uint32_t *)c->pin_keys.ptr;
+        if (n > need_from)
+            HIPCHK(c, hipMemcpyAsync((uint32_t *)c->pin_keys.ptr + need_from, (const uint32_t *)c->keys.ptr + need_from,
+                                     (n - need_from) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (!c->ev_keys) HIPCHK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_keys, c->stream));
+        HIPCHK(c, launch_card_from_hist(c->stream, (const uint32_t *)c->hist.ptr, (const uint32_t *)c->keys.ptr, need_from, n,
+                                        c->p, estim, (double *)c->card.ptr));
         c->card_estim = estim;
+        c->card_from = need_from;
         c->hk32_valid = false;
     }
     if (card_only) {  // a cardinality query never builds planes (and leaves stale ones marked so)
@@ -358,14 +413,15 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
         // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no
         // device round trip and so does not wait for the work still queued on the stream
+        const auto t_h0 = std::chrono::steady_clock::now();
         if (!c->hk32_valid) {
-            c->hk32.resize(n);
-            if (n) HIPCHK(c, hipMemcpyAsync(c->hk32.data(), c->keys.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev_keys));
             c->hk32_valid = true;
         }
-        const std::vector<uint32_t> &k32 = c->hk32;
-        for (uint64_t i = 0; i < n; ++i)
+        const auto t_h1 = std::chrono::steady_clock::now();
+        c->host_keys_wait_us = std::chrono::duration<double, std::micro>(t_h1 - t_h0).count();
+        const uint32_t *k32 = c->hk32;
+        for (uint64_t i = c->card_from; i < n; ++i)  // (the sketches the per-sketch pass covered)
             if (k32[i] & 0x80000000u)
                 return fail(c, DSH_EINVAL, "sketch %llu holds a register value above %d (= 64 - p + 1): not an HLL of precision %d (corrupt or foreign .hll?)",
                             (unsigned long long)i, 64 - c->p + 1, c->p);
@@ -373,13 +429,11 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         // sketches before rb); value range and thresholds are taken over those only
         const uint64_t col0 = want_sorted ? want_rb : 0;
         const uint64_t ncols = n - col0;
-        for (uint64_t i = 0; i < n; ++i) {
+        for (uint64_t i = col0; i < n; ++i) {
             const uint32_t key = k32[i];
-            if (i >= col0) {
-                vr[0] = std::min<int>(vr[0], key_lo(key));
-                vr[1] = std::max<int>(vr[1], key_hi(key));
-                vr[2] = std::max<int>(vr[2], key_T(key));
-            }
+            vr[0] = std::min<int>(vr[0], key_lo(key));
+            vr[1] = std::max<int>(vr[1], key_hi(key));
+            vr[2] = std::max<int>(vr[2], key_T(key));
         }
         if (ncols == 0) vr[0] = vr[1] = vr[2] = 0;
         c->vlo = vr[0];
@@ -400,25 +454,27 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
                 const uint32_t key = k32[i];
                 return ((uint32_t)key_T(key) << 12) | ((uint32_t)key_L(key) << 6) | (uint32_t)key_hi(key);
             };
-            // stable LSD radix sort, three 6-bit digits (a single 2^18-bucket counting sort spends
-            // ~0.1 ms clearing and scanning its counters -- a quarter of prepare())
-            std::vector<uint32_t> a, b, keys(n);
+            // stable LSD radix sort, two 9-bit digits (a single 2^18-bucket counting sort spends ~0.1 ms clearing
+            // and scanning its counters); the host sits between the per-sketch pass and the transform, so this is
+            // on the critical path of every layout: scratch is kept on the context
+            std::vector<uint32_t> &a = c->sort_a, &b = c->sort_b, &keys = c->sort_keys;
+            keys.resize(n);
             for (uint64_t i = col0; i < n; ++i) keys[i] = skey(i);
             auto sort_part = [&](uint64_t lo, uint64_t hi, uint32_t *dst) {
                 const uint64_t cnt_ = hi - lo;
-                a.resize(cnt_);
-                b.resize(cnt_);
-                for (uint64_t i = 0; i < cnt_; ++i) a[i] = (uint32_t)(lo + i);
-                for (int shift = 0; shift < 18; shift += 6) {
-                    uint32_t cnt[65] = {0};
-                    for (uint64_t i = 0; i < cnt_; ++i) cnt[((keys[a[i]] >> shift) & 63u) + 1u]++;
-                    for (int k = 1; k < 65; ++k) cnt[k] += cnt[k - 1];
-                    for (uint64_t i = 0; i < cnt_; ++i) b[cnt[(keys[a[i]] >> shift) & 63u]++] = a[i];
-                    a.swap(b);
-                }
-                std::copy(a.begin(), a.end(), dst);
+                if (a.size() < cnt_) a.resize(cnt_);
+                uint32_t cnt[513];
+                std::memset(cnt, 0, sizeof cnt);
+                for (uint64_t i = 0; i < cnt_; ++i) cnt[(keys[lo + i] & 511u) + 1u]++;
+                for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+                for (uint64_t i = 0; i < cnt_; ++i) a[cnt[keys[lo + i] & 511u]++] = (uint32_t)(lo + i);
+                std::memset(cnt, 0, sizeof cnt);
+                for (uint64_t i = 0; i < cnt_; ++i) cnt[((keys[a[i]] >> 9) & 511u) + 1u]++;
+                for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+                for (uint64_t i = 0; i < cnt_; ++i) dst[cnt[(keys[a[i]] >> 9) & 511u]++] = a[i];
+                (void)b;
             };
-            sort_part(want_rb, want_re, c->hperm.data());
+            for (size_t q = 0; q + 1 < parts.size(); ++q) sort_part(parts[q], parts[q + 1], c->hperm.data() + (parts[q] - want_rb));
             sort_part(want_re, n, c->hperm.data() + (want_re - want_rb));
             // perm, then (whole collection only) its inverse for the un-permute of the shard path
             const bool whole = want_rb == 0 && want_re == n;
@@ -465,6 +521,20 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         // dense planes cover v in (pbase, Tmax]: below the smallest low threshold every C(v) comes from the list join
         c->pbase = pbase;
         c->P = (uint32_t)(vr[2] - pbase);
+        // position index of every column block (the list joins of k_finalize): 79 workgroups at C3 -- built on a
+        // second stream next to the bit-plane transform, which fills the chip on its own; both only need the
+        // per-sketch pass and the permutation, the tile kernels wait for both
+        c->nbuckets = (uint32_t)std::min<uint64_t>(2 * m, kMaxBuckets);  // (position group, upper | lower tail)
+        c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
+        HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
+        HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
+        c->host_layout_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h1).count();
+        HIPCHK(c, hipEventRecord(c->ev_aux_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_aux_fork, 0));
+        HIPCHK(c, launch_build_colindex(c->aux_stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
+                                        (const uint32_t *)c->keys.ptr, want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, ncols,
+                                        c->p, NT, c->nbuckets, c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
+        HIPCHK(c, hipEventRecord(c->ev_aux_join, c->aux_stream));
         const uint64_t K = (uint64_t)c->P * c->W;
         c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
         if (c->Kpad) {
@@ -478,17 +548,11 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
                                        (uint32_t *)c->planes.ptr,
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
         }
-        // position index of every column block (the list joins of k_finalize)
-        c->nbuckets = (uint32_t)std::min<uint64_t>(2 * m, kMaxBuckets);  // (position group, upper | lower tail)
-        c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
-        HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
-        HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
-        HIPCHK(c, launch_build_colindex(c->stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
-                                        (const uint32_t *)c->keys.ptr, want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, ncols, c->p, NT, c->nbuckets,
-                                        c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
+        c->aux_join_pending = true;  // only k_finalize reads the index: the tile kernel starts without waiting for it
         c->planes_sorted = want_sorted;
         c->lay_rb = want_rb;
         c->lay_re = want_re;
+        c->lay_parts = parts;
         c->planes_valid = true;
     }
     if (e0 && e1) {
@@ -527,6 +591,7 @@ struct PairJob {
     int rect;
     int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
     int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
+    uint32_t nparts = 1;  // triangle rows in this many parts, an event per part (dsh_dist_rows_parts_device_async)
     int knn = 0;          // band of the key-ordered triangle for the nearest-neighbour selection: d_out = V, d_out2 = Vt
     float *d_out2 = nullptr;
     uint64_t knn_ld = 0, knn_rows = 0;
@@ -553,13 +618,14 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         lrb = job.row_begin;
         lre = jre;
     }
-    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre);
+    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, want_sorted && !job.sorted_rows ? job.nparts : 1);
     if (rc) return rc;
     if (job.result_type < 0 || job.result_type > 8)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
     if (job.k < 1) return fail(c, DSH_EINVAL, "bad k %d", job.k);
     // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes
     // v in (max(min lo of its two blocks), max threshold of its two blocks]
+    const auto t_l0 = std::chrono::steady_clock::now();
     std::vector<uint4> &T = c->htiles;
     T.clear();
     const uint32_t NT = c->Npad / kTile;
@@ -596,8 +662,38 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         bands.emplace_back(b, e);
         b = e;
     }
+    // Parts (dsh_dist_rows_parts_device_async): the tile kernel runs once per band, k_finalize once per SEGMENT -- the
+    // tiles of one part inside one band -- and an event marks the end of a part's last segment: the part's span of the
+    // matrix is final and can travel while the other parts are finalized.  (Cutting the tile kernel as well costs
+    // 0.2-0.3 ms per cut at C3 / 8 ranks: two tails and a pipeline bubble, profiles/r3e.)
+    struct Seg { size_t b, e; int part; };  // tiles [b, e) of T; part completed by this segment or -1
+    std::vector<std::vector<Seg>> segs(bands.size());
+    {
+        const bool with_parts = !job.rect && !job.sorted_rows && c->planes_sorted && c->lay_parts.size() > 2 && job.nparts > 1;
+        // part of a tile = part of its tile row (parts are consecutive runs of whole tile rows of the layout)
+        auto part_of = [&](size_t t) -> size_t {
+            if (!with_parts) return 0;
+            const uint64_t pos = (uint64_t)T[t].x * kTile;
+            size_t q = 0;
+            while (q + 2 < c->lay_parts.size() && pos >= c->lay_parts[q + 1] - c->lay_rb) ++q;
+            return q;
+        };
+        for (size_t bi = 0; bi < bands.size(); ++bi) {
+            size_t b = bands[bi].first;
+            while (b < bands[bi].second) {
+                const size_t q = part_of(b);
+                size_t e = b;
+                while (e < bands[bi].second && part_of(e) == q) ++e;
+                const bool last_of_part = e == T.size() || part_of(e) != q;
+                segs[bi].push_back({b, e, with_parts && last_of_part ? (int)q : -1});
+                b = e;
+            }
+        }
+        c->parts_done = 0;
+    }
     if (c->xcd_swizzle)
-        for (auto &bd : bands) xcd_order(T, bd.first, bd.second, use_lockstep(c) ? 2 : 1);
+        for (auto &sv : segs)
+            for (auto &sg : sv) xcd_order(T, sg.b, sg.e, use_lockstep(c) ? 2 : 1);
     // work items per band: {tile index in band, chunk begin, chunk end}
     const uint32_t KC = (uint32_t)c->kc;
     auto chunk_range = [&](const uint4 &t, uint32_t &cb, uint32_t &ce) {
@@ -609,14 +705,17 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     std::vector<std::pair<size_t, size_t>> band_items;
     const uint32_t cpp = c->W >= KC ? c->W / KC : 1;  // chunks per plane when a plane spans chunks
     const bool lockstep = use_lockstep(c);
+    std::vector<uint2> &CR = c->tile_chunks;  // chunk range of every tile, computed once
+    CR.resize(T.size());
+    for (size_t t = 0; t < T.size(); ++t) {
+        uint32_t cb, ce;
+        chunk_range(T[t], cb, ce);
+        CR[t] = make_uint2(cb, ce);
+    }
     for (auto &bd : bands) {
         const size_t nt = bd.second - bd.first;
         uint64_t tot = 0;
-        for (size_t t = bd.first; t < bd.second; ++t) {
-            uint32_t cb, ce;
-            chunk_range(T[t], cb, ce);
-            tot += ce - cb;
-        }
+        for (size_t t = bd.first; t < bd.second; ++t) tot += CR[t].y - CR[t].x;
         // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
         uint64_t piece = c->nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + c->nsplit - 1) / c->nsplit)
                                        : std::max<uint64_t>(1, tot / (16 * 512));
@@ -625,22 +724,22 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         piece = (piece + cpp - 1) / cpp * cpp;
         const size_t i0 = I.size();
         uint32_t maxpieces = 0;
-        for (size_t t = bd.first; t < bd.second; ++t) {
-            uint32_t cb, ce;
-            chunk_range(T[t], cb, ce);
-            maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((ce - cb + piece - 1) / piece));
-        }
+        for (size_t t = bd.first; t < bd.second; ++t)
+            maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((CR[t].y - CR[t].x + piece - 1) / piece));
         for (uint32_t s = 0; s < maxpieces; ++s) {  // piece-major so neighbours in launch order share planes
             const size_t g0 = I.size();
+            uint32_t lmin = ~0u, lmax = 0;
             for (size_t t = bd.first; t < bd.second; ++t) {
-                uint32_t cb, ce;
-                chunk_range(T[t], cb, ce);
-                const uint64_t b0 = cb + (uint64_t)s * piece;
-                if (b0 >= ce) continue;
-                I.push_back(make_uint4((uint32_t)(t - bd.first), (uint32_t)b0, (uint32_t)std::min<uint64_t>(ce, b0 + piece), 0));
+                const uint64_t b0 = CR[t].x + (uint64_t)s * piece;
+                if (b0 >= CR[t].y) continue;
+                const uint32_t e0 = (uint32_t)std::min<uint64_t>(CR[t].y, b0 + piece);
+                I.push_back(make_uint4((uint32_t)(t - bd.first), (uint32_t)b0, e0, 0));
+                lmin = std::min<uint32_t>(lmin, e0 - (uint32_t)b0);
+                lmax = std::max<uint32_t>(lmax, e0 - (uint32_t)b0);
             }
-            // the lockstep kernel pairs consecutive items: keep equal lengths together (only a tile's last piece is shorter)
-            if (lockstep && c->ls_sort_items)
+            // the lockstep kernel pairs consecutive items: keep equal lengths together (only a tile's last piece can be
+            // shorter; with whole-plane pieces every item of the group is the same length and there is nothing to do)
+            if (lockstep && c->ls_sort_items && lmin != lmax)
                 std::stable_sort(I.begin() + g0, I.end(), [](const uint4 &x, const uint4 &y) { return x.z - x.y > y.z - y.y; });
         }
         band_items.emplace_back(i0, I.size());
@@ -654,6 +753,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     uint4 *pinT = (uint4 *)c->pin_lists.ptr, *pinI = pinT + T.size();
     std::memcpy(pinT, T.data(), T.size() * sizeof(uint4));
     if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
+    c->host_lists_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();
     HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
     HIPCHK(c, launch_upload(c->stream, c->tiles.ptr, pinT, T.size() * sizeof(uint4)));
     HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
@@ -692,46 +792,64 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                          c->Npad, c->Kpad, c->W, c->P, dt, di, ni, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
-        FinalizeLaunch f;
-        f.cum = c->cum.ptr;
-        f.cum_bytes = c->cum_bytes;
-        f.vhi = c->vhi;
-        f.exc = c->exc.ptr;
-        f.exc_n = (const uint32_t *)c->exc_n.ptr;
-        f.excv = (const uint8_t *)c->excv.ptr;
-        f.keys = (const uint32_t *)c->keys.ptr;
-        f.tailhist = (const uint8_t *)c->tailhist.ptr;
-        f.nslots = nslots;
-        f.tiles = dt;
-        f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
-        f.vlo = c->vlo;
-        f.pbase = c->pbase;
-        f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
-        f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
-        f.nbuckets = c->nbuckets;
-        f.ent_stride = c->ent_stride;
-        f.p = c->p;
-        f.estim = job.estim;
-        f.result_type = job.result_type;
-        f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
-        f.card = (const double *)c->card.ptr;
-        f.n = c->n;
-        f.ncols = c->ncols;
-        f.stop = c->finalize_stop;
-        f.rect = job.rect;
-        f.sorted_out = job.sorted_rows;
-        f.square = job.square;
-        f.knn = job.knn;
-        f.out2 = job.d_out2;
-        f.knn_ld = job.knn_ld;
-        f.knn_rows = job.knn_rows;
-        f.row_begin = job.row_begin;
-        f.row_end = job.row_end;
-        f.col_begin = job.col_begin;
-        f.col_end = job.col_end;
-        f.base_index = job.base_index;
-        f.out = job.d_out;
-        HIPCHK(c, launch_finalize(c->stream, f));
+        for (const Seg &sg : segs[bi]) {
+            FinalizeLaunch f;
+            const uint64_t seg_off = (uint64_t)(sg.b - bd.first) * kTile * kTile;  // first pair slot of the segment in the band
+            f.cum = (const char *)c->cum.ptr + seg_off * (uint64_t)c->cum_bytes;
+            f.cum_bytes = c->cum_bytes;
+            f.cum_stride = nslots;
+            f.vhi = c->vhi;
+            f.exc = c->exc.ptr;
+            f.exc_n = (const uint32_t *)c->exc_n.ptr;
+            f.excv = (const uint8_t *)c->excv.ptr;
+            f.keys = (const uint32_t *)c->keys.ptr;
+            f.tailhist = (const uint8_t *)c->tailhist.ptr;
+            f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
+            f.tiles = (const uint4 *)c->tiles.ptr + sg.b;
+            f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
+            f.vlo = c->vlo;
+            f.pbase = c->pbase;
+            f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
+            f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
+            f.nbuckets = c->nbuckets;
+            f.ent_stride = c->ent_stride;
+            f.p = c->p;
+            f.estim = job.estim;
+            f.result_type = job.result_type;
+            f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
+            f.card = (const double *)c->card.ptr;
+            f.n = c->n;
+            f.ncols = c->ncols;
+            f.stop = c->finalize_stop;
+            f.rect = job.rect;
+            f.sorted_out = job.sorted_rows;
+            f.square = job.square;
+            f.knn = job.knn;
+            f.out2 = job.d_out2;
+            f.knn_ld = job.knn_ld;
+            f.knn_rows = job.knn_rows;
+            f.row_begin = job.row_begin;
+            f.row_end = job.row_end;
+            f.col_begin = job.col_begin;
+            f.col_end = job.col_end;
+            f.base_index = job.base_index;
+            f.out = job.d_out;
+            if (c->aux_join_pending) {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
+                c->aux_join_pending = false;
+            }
+            HIPCHK(c, launch_finalize(c->stream, f));
+            if (sg.part >= 0) {  // this segment completes a part: its span of the matrix is final
+                const size_t q = (size_t)sg.part;
+                while (c->ev_part.size() <= q) {
+                    hipEvent_t e = nullptr;
+                    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->ev_part.push_back(e);
+                }
+                HIPCHK(c, hipEventRecord(c->ev_part[q], c->stream));
+                c->parts_done = (uint32_t)q + 1;
+            }
+        }
         if (d) (void)hipEventRecord(d, c->stream);
         if (a && b && d) {
             evp.emplace_back(a, b);
@@ -802,7 +920,10 @@ int dsh_create(int device, dsh_ctx **out)
     c->device = device;
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        create_copy_stream(&c->copy_stream) != hipSuccess) {
+        create_copy_stream(&c->copy_stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return DSH_EIO;
@@ -832,11 +953,14 @@ void dsh_destroy(dsh_ctx *c)
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
     c->pin_lists.release();
     c->pin_work.release();
+    c->pin_keys.release();
     if (c->ev_work) (void)hipEventDestroy(c->ev_work);
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
     if (c->ev_perm) (void)hipEventDestroy(c->ev_perm);
     c->keys.release();
     c->tailhist.release();
+    c->hist.release();
+    if (c->ev_keys) (void)hipEventDestroy(c->ev_keys);
     c->cidx_off.release();
     c->cidx_ent.release();
     c->perm.release();
@@ -850,10 +974,17 @@ void dsh_destroy(dsh_ctx *c)
         if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]);
     }
     for (auto e : c->tickets) (void)hipEventDestroy(e);
+    for (auto e : c->ev_part) (void)hipEventDestroy(e);
     if (c->copy_stream) {
         (void)hipStreamSynchronize(c->copy_stream);
         (void)hipStreamDestroy(c->copy_stream);
     }
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+    }
+    if (c->ev_aux_fork) (void)hipEventDestroy(c->ev_aux_fork);
+    if (c->ev_aux_join) (void)hipEventDestroy(c->ev_aux_join);
     c->seqbuf.release();
     c->workbuf.release();
     delete c;
@@ -1073,7 +1204,7 @@ int dsh_cardinalities(dsh_ctx *c, int estim, double *out)
     if (rc) return rc;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
-    if (c->card_estim != estim) {
+    if (c->card_estim != estim || c->card_from != 0) {
         // same per-sketch pass as prepare() (thresholds/exception lists come out identical)
         rc = prepare(c, estim, -1, /*card_only=*/true);
         if (rc) return rc;
@@ -1178,6 +1309,44 @@ int dsh_dist_rows_device_async(dsh_ctx *c, int estim, int result_type, int k, ui
     j.result_type = result_type;
     j.k = k;
     j.rect = 0;
+    j.row_begin = rb;
+    j.row_end = re;
+    j.col_begin = j.col_end = 0;
+    j.base_index = dsh_tri_span(c->n, 0, rb);
+    j.d_out = (float *)d_out;
+    return run_pairs(c, j);
+}
+
+int dsh_range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, uint64_t *part_rows, uint32_t *nparts_out)
+{
+    if (!part_rows || !nparts_out || nparts == 0) return DSH_EINVAL;
+    if (re > n) re = n;
+    if (rb > re) rb = re;
+    std::vector<uint64_t> parts;
+    range_parts(n, rb, re, nparts, parts);
+    for (size_t q = 0; q < parts.size(); ++q) part_rows[q] = parts[q];
+    *nparts_out = (uint32_t)parts.size() - 1;
+    return DSH_OK;
+}
+
+int dsh_dist_rows_parts_device_async(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, uint64_t re, void *d_out,
+                                     uint32_t nparts)
+{
+    if (!c || nparts == 0) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    reset_prof(c);
+    c->parts_done = 0;
+    if (re > c->n) re = c->n;
+    if (rb >= re || c->n < 2) return DSH_OK;
+    if (!d_out) return DSH_EINVAL;
+    PairJob j;
+    j.estim = estim;
+    j.result_type = result_type;
+    j.k = k;
+    j.rect = 0;
+    j.nparts = nparts;
     j.row_begin = rb;
     j.row_end = re;
     j.col_begin = j.col_end = 0;
@@ -1681,6 +1850,9 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "vhi")) *out = c->vhi;
     else if (!std::strcmp(name, "threshold")) *out = c->pbase + (int64_t)c->P;
     else if (!std::strcmp(name, "pbase")) *out = c->pbase;
+    else if (!std::strcmp(name, "host_layout_us")) *out = (int64_t)c->host_layout_us;
+    else if (!std::strcmp(name, "host_lists_us")) *out = (int64_t)c->host_lists_us;
+    else if (!std::strcmp(name, "host_keys_wait_us")) *out = (int64_t)c->host_keys_wait_us;
     else if (!std::strcmp(name, "emax")) *out = c->emax;
     else if (!std::strcmp(name, "elow")) *out = c->elow;
     else if (!std::strcmp(name, "kc")) *out = c->kc;
@@ -1897,6 +2069,65 @@ int dsh_collect_spans(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void
     int rc = dsh_collect_spans_async(c, n, bounds, d_local, d_final, dst);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
+                            void *d_final, int dst)
+{
+    if (!c || !bounds || nparts == 0) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    if (!c->comm && !(bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d", dst);
+    if (bounds[0] != 0 || bounds[world] != n) return fail(c, DSH_EINVAL, "bounds must run from 0 to n over the %d ranks", world);
+    if (rank == dst && !d_final) return DSH_EINVAL;
+    // every rank's parts, from the same function the compute used (dsh_range_parts): both sides of a message agree
+    std::vector<std::vector<uint64_t>> parts((size_t)world);
+    size_t maxparts = 0;
+    for (int r = 0; r < world; ++r) {
+        range_parts(n, bounds[r], bounds[r + 1], nparts, parts[r]);
+        maxparts = std::max(maxparts, parts[r].size() - 1);
+    }
+    const size_t myparts = parts[rank].size() - 1;
+    const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+    if (mine && c->parts_done != myparts)
+        return fail(c, DSH_ESTATE, "dsh_dist_rows_parts_device_async(%u parts) of this rank's rows must come first", nparts);
+    Rccl *rc_ = world > 1 ? rccl() : nullptr;
+    const uint64_t my_off = dsh_tri_span(n, 0, bounds[rank]);
+    for (size_t q = 0; q < maxparts; ++q) {
+        // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
+        // there while the ctx stream computes part q+1
+        if (q < myparts && mine) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+        if (rank == dst && q < myparts && mine && d_local) {
+            const uint64_t o0 = dsh_tri_span(n, 0, parts[rank][q]) - my_off, cnt = dsh_tri_span(n, parts[rank][q], parts[rank][q + 1]);
+            float *own = (float *)d_final + my_off + o0;
+            if (cnt && (const float *)d_local + o0 != own)
+                HIPCHK(c, hipMemcpyAsync(own, (const float *)d_local + o0, cnt * sizeof(float), hipMemcpyDeviceToDevice, c->copy_stream));
+        }
+        if (world == 1) continue;
+        NCCLCHK(c, rc_->GroupStart());
+        ncclResult_t e = ncclSuccess;
+        if (rank == dst) {
+            for (int src = 0; src < world && e == ncclSuccess; ++src) {
+                if (src == dst || q >= parts[src].size() - 1) continue;
+                const uint64_t cnt = dsh_tri_span(n, parts[src][q], parts[src][q + 1]);
+                if (cnt) e = rc_->Recv((float *)d_final + dsh_tri_span(n, 0, parts[src][q]), cnt, ncclFloat32, src, c->comm, c->copy_stream);
+            }
+        } else if (q < myparts) {
+            const uint64_t o0 = dsh_tri_span(n, 0, parts[rank][q]) - my_off, cnt = dsh_tri_span(n, parts[rank][q], parts[rank][q + 1]);
+            if (cnt) {
+                if (!d_local) e = ncclInvalidArgument;
+                else e = rc_->Send((const float *)d_local + o0, cnt, ncclFloat32, dst, c->comm, c->copy_stream);
+            }
+        }
+        if (e != ncclSuccess) {
+            (void)rc_->GroupEnd();
+            return fail(c, DSH_EIO, "ncclSend/ncclRecv: %s", rc_->GetErrorString(e));
+        }
+        NCCLCHK(c, rc_->GroupEnd());
+    }
     return DSH_OK;
 }
 

@@ -10,9 +10,11 @@ constexpr uint32_t kListCap = 512;  // capacity of a sketch's register list (ent
 constexpr uint32_t kMaxListSide = 255;  // cap of either tail (their per-value counts are bytes)
 constexpr uint32_t kMaxBuckets = 1u << 15;  // buckets of a column block's index: (position group, tail)
 
-hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
+hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t first, uint64_t n, int p, int estim,
+                                int emax, int elow, uint32_t *hist, void *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist);
+hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uint32_t *keys, uint64_t first, uint64_t n, int p,
+                                 int estim, double *card);
 // position index of every 128-column block of the plane layout (perm == nullptr: identity): off[nblocks][nbuckets + 2]
 // (uint16), ent[nblocks][ent_stride]
 hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
@@ -39,7 +41,8 @@ hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const 
 struct FinalizeLaunch {
     const void *cum;
     int cum_bytes;  // 2 or 4
-    uint64_t nslots;
+    uint64_t cum_stride;  // pair slots of the whole band (distance between two planes of cum)
+    uint64_t nslots;      // pair slots to finalize (a band, or a segment of it: cum/tiles point at its first tile)
     const uint4 *tiles;
     const uint32_t *perm;
     int vlo, vhi, pbase, p, estim, result_type;

@@ -47,16 +47,15 @@ namespace dsh {
 // (k_build_colindex), nothing walks them in order.
 // key = bad << 31 | hi << 18 | T << 12 | L << 6 | lo.
 template <typename PT>
-__global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs,
+__global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs, uint64_t first,
                                                         uint64_t n, int p, int estim, int emax, int elow,
-                                                        double *__restrict__ card,
+                                                        uint32_t *__restrict__ hist_out,
                                                         PT *__restrict__ exc,
                                                         uint8_t *__restrict__ excv,
                                                         uint32_t *__restrict__ exc_n,
                                                         uint32_t *__restrict__ keys,
                                                         uint8_t *__restrict__ tailhist)
 {
-    __shared__ uint32_t cursor[4];
     __shared__ uint32_t hist[4][64];
     __shared__ uint32_t sub[4][8][65];  // 8 privatised copies per wave: the register values pile up in ~8 bins, so
                                         // one copy would serialise its LDS atomics; rows padded to 65 words so that
@@ -64,10 +63,9 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                                         // of 64 every copy's bin b shared bank b and the copies bought nothing)
     __shared__ int thr[4], thrL[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t s = first + (uint64_t)blockIdx.x * 4 + wave;  // sketches [first, n)
 #pragma unroll
     for (int k = 0; k < 8; ++k) sub[wave][k][lane] = 0;
-    if (lane == 0) cursor[wave] = 0;
     __syncthreads();
     const uint64_t m = 1ull << p;
     const uint4 *src = reinterpret_cast<const uint4 *>(regs + (s < n ? s : 0) * m);
@@ -113,11 +111,11 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     __syncthreads();
     if (s < n && lane == 0) {
         const uint32_t *h = hist[wave];
-        auto c = [h](int v) -> uint32_t { return h[v]; };
         int lo = 0, hi = 63;
         while (lo < 63 && h[lo] == 0) ++lo;
         while (hi > 0 && h[hi] == 0) --hi;
-        card[s] = estimate(c, c, p, estim, lo, hi);
+        // (the cardinality is estimated by k_card_from_hist, one LANE per sketch: here a whole wave would idle
+        // behind lane 0's fp64 recurrence -- half of this kernel's instruction issue)
         // high threshold: the largest upper tail that fits its list
         int T = hi;
         uint32_t cnt = 0;
@@ -146,32 +144,79 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     // the two sketches' tail histograms and only corrects the positions both sketches list
     const uint32_t T = (uint32_t)thr[wave], L = (uint32_t)thrL[wave];
     tailhist[s * 64 + lane] = (uint32_t)lane > T ? (uint8_t)hist[wave][lane] : (uint8_t)0;
+    hist_out[s * 64 + lane] = hist[wave][lane];
     if (emax == 0 && elow == 0) return;
-    // second pass: the listed registers.  cursor[wave] is private to this wave (some waves of the block may
-    // already have returned), slots are handed out by an LDS counter
+    // second pass: the listed registers.  A lane first counts its own hits (SWAR: 4 registers per step), one wave
+    // prefix sum gives every lane its first slot, then it writes its hits there -- a few hundred instructions per
+    // wave instead of a decision (ballot or LDS counter) per register byte, which was two thirds of this kernel.
     PT *dstp = exc + s * kListCap;
     uint8_t *dstv = excv + s * kListCap;
-    uint32_t *cur = &cursor[wave];
-    auto emit16 = [&](const uint4 x, uint64_t c) {
-        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    const uint32_t trep = (T + 1) * 0x01010101u, lrep = L * 0x01010101u;
+    auto hits = [trep, lrep](uint32_t x) -> uint32_t {  // bit 7 of byte b set iff register b is > T or < L (bytes are < 128)
+        const uint32_t ge = ((x | 0x80808080u) - trep) & 0x80808080u;          // >= T + 1
+        const uint32_t lt = ~((x | 0x80808080u) - lrep) & 0x80808080u;         // < L
+        return ge | lt;
+    };
+    uint32_t mine = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kRegCache; ++k)
+        if ((uint64_t)k * 64 + lane < nch) {
+            const uint32_t w[4] = {cache[k].x, cache[k].y, cache[k].z, cache[k].w};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t v = (w[k] >> (8 * b)) & 0xFFu;
-                if (v > T || v < L) {
-                    const uint32_t slot = atomicAdd(cur, 1u);
-                    dstp[slot] = (PT)(c * 16 + k * 4 + b);
-                    dstv[slot] = (uint8_t)v;
-                }
+            for (int q = 0; q < 4; ++q) mine += (uint32_t)__popc(hits(w[q]));
+        }
+    for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) {
+        const uint4 x = src[c];
+        mine += (uint32_t)(__popc(hits(x.x)) + __popc(hits(x.y)) + __popc(hits(x.z)) + __popc(hits(x.w)));
+    }
+    uint32_t slot = mine;  // inclusive prefix sum over the wave, then exclusive
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(slot, d, 64);
+        if (lane >= d) slot += o;
+    }
+    slot -= mine;
+    auto emit4 = [&](uint32_t x, uint32_t pos0) {
+        uint32_t h = hits(x);
+        while (h) {
+            const uint32_t b = (uint32_t)__builtin_ctz(h) >> 3;  // byte index of the lowest hit
+            h &= h - 1;
+            if (slot < kListCap) {  // (only a sketch with out-of-range registers -- refused later -- can list more than planned)
+                dstp[slot] = (PT)(pos0 + b);
+                dstv[slot] = (uint8_t)((x >> (8 * b)) & 0xFFu);
             }
+            ++slot;
+        }
     };
 #pragma unroll
     for (int k = 0; k < kRegCache; ++k) {
         const uint64_t c = (uint64_t)k * 64 + lane;
-        if (c < nch) emit16(cache[k], c);
+        if (c < nch) {
+            const uint32_t w[4] = {cache[k].x, cache[k].y, cache[k].z, cache[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) emit4(w[q], (uint32_t)(c * 16 + q * 4));
+        }
     }
-    for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) emit16(src[c], c);
+    for (uint64_t c = (uint64_t)kRegCache * 64 + lane; c < nch; c += 64) {
+        const uint4 x = src[c];
+        emit4(x.x, (uint32_t)(c * 16));
+        emit4(x.y, (uint32_t)(c * 16 + 4));
+        emit4(x.z, (uint32_t)(c * 16 + 8));
+        emit4(x.w, (uint32_t)(c * 16 + 12));
+    }
+}
+
+// cardinality_estimate(hll_t&) = h.report() (src/dashing.h:492) from the 64-bin histograms of k_selfhist_card: one
+// lane per sketch (the estimators are sequential recurrences over the bins).
+__global__ __launch_bounds__(64) void k_card_from_hist(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ keys,
+                                                       uint64_t first, uint64_t n, int p, int estim, double *__restrict__ card)
+{
+    const uint64_t s = first + (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t *h = hist + s * 64;
+    auto c = [h](int v) -> uint32_t { return h[v & 63]; };
+    const uint32_t key = keys[s];
+    card[s] = estimate(c, c, p, estim, (int)(key & 63u), (int)((key >> 18) & 63u));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -198,25 +243,40 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
     const uint64_t c0 = (uint64_t)blockIdx.x * kTile;
     for (uint32_t b = tid; b < nbuckets; b += 1024) cnt[b] = 0;
     __syncthreads();
-    constexpr int kPer = (int)(kListCap / 64);  // entries per lane
-    for (uint32_t sl = wave; sl < kTile; sl += 16) {
-        if (c0 + sl >= ncols) break;
-        const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
-        const uint32_t ne = exc_n[s];
-        const uint32_t T = (keys[s] >> 12) & 63u;
-        const PT *ps = exc + s * kListCap;
-        const uint8_t *vs = excv + s * kListCap;
-        uint32_t pos[kPer], val[kPer];
+    // a wave's 8 sketches x 8 entries per lane are loaded ONCE, all loads in flight together (bucket << 13 | column
+    // << 6 | value; 0xFFFFFFFF = none): both passes run from registers -- the kernel is one workgroup per column
+    // block, i.e. latency, not throughput
+    constexpr int kPer = (int)(kListCap / 64);  // entries per lane and sketch
+    constexpr int kSk = (int)(kTile / 16);      // sketches per wave
+    uint32_t ne[kSk], Ts[kSk];
+    const PT *ps[kSk];
+    const uint8_t *vs[kSk];
+#pragma unroll
+    for (int q = 0; q < kSk; ++q) {
+        const uint32_t sl = wave + 16u * (uint32_t)q;
+        const bool ok = c0 + sl < ncols;
+        const uint64_t s = ok ? (perm ? perm[c0 + sl] : c0 + sl) : 0;
+        ne[q] = ok ? exc_n[s] : 0u;
+        Ts[q] = (keys[s] >> 12) & 63u;
+        ps[q] = exc + s * kListCap;
+        vs[q] = excv + s * kListCap;
+    }
+    uint32_t bk[kSk][kPer], pv[kSk][kPer];
+#pragma unroll
+    for (int q = 0; q < kSk; ++q)
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
             const uint32_t e = lane + 64u * (uint32_t)u;
-            pos[u] = e < ne ? (uint32_t)ps[e] : 0u;
-            val[u] = e < ne ? (uint32_t)vs[e] : 0u;
+            const uint32_t pos = e < ne[q] ? (uint32_t)ps[q][e] : 0u;
+            const uint32_t val = e < ne[q] ? (uint32_t)vs[q][e] : 0u;
+            bk[q][u] = e < ne[q] ? (((pos >> sh) << 1) | (val > Ts[q] ? 0u : 1u)) : 0xFFFFFFFFu;
+            pv[q][u] = ((pos & ((1u << sh) - 1u)) << 13) | ((wave + 16u * (uint32_t)q) << 6) | val;
         }
 #pragma unroll
+    for (int q = 0; q < kSk; ++q)
+#pragma unroll
         for (int u = 0; u < kPer; ++u)
-            if (lane + 64u * (uint32_t)u < ne) atomicAdd(&cnt[((pos[u] >> sh) << 1) | (val[u] > T ? 0u : 1u)], 1u);
-    }
+            if (bk[q][u] != 0xFFFFFFFFu) atomicAdd(&cnt[bk[q][u]], 1u);
     __syncthreads();
     // exclusive scan: thread t owns the buckets [t*per, (t+1)*per)
     const uint32_t per = (nbuckets + 1023) / 1024;
@@ -244,27 +304,11 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
     if (tid * per < nbuckets && (tid + 1) * per >= nbuckets) myoff[nbuckets] = (uint16_t)run;  // owner of the last bucket: end mark
     __syncthreads();
     uint32_t *myent = ent + (uint64_t)blockIdx.x * ent_stride;
-    for (uint32_t sl = wave; sl < kTile; sl += 16) {
-        if (c0 + sl >= ncols) break;
-        const uint64_t s = perm ? perm[c0 + sl] : c0 + sl;
-        const uint32_t ne = exc_n[s];
-        const uint32_t T = (keys[s] >> 12) & 63u;
-        const PT *ps = exc + s * kListCap;
-        const uint8_t *vs = excv + s * kListCap;
-        uint32_t pos[kPer], val[kPer];
 #pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-            const uint32_t e = lane + 64u * (uint32_t)u;
-            pos[u] = e < ne ? (uint32_t)ps[e] : 0u;
-            val[u] = e < ne ? (uint32_t)vs[e] : 0u;
-        }
+    for (int q = 0; q < kSk; ++q)
 #pragma unroll
         for (int u = 0; u < kPer; ++u)
-            if (lane + 64u * (uint32_t)u < ne) {
-                const uint32_t slot = atomicAdd(&cnt[((pos[u] >> sh) << 1) | (val[u] > T ? 0u : 1u)], 1u);
-                myent[slot] = ((pos[u] & ((1u << sh) - 1u)) << 13) | (sl << 6) | val[u];
-            }
-    }
+            if (bk[q][u] != 0xFFFFFFFFu) myent[atomicAdd(&cnt[bk[q][u]], 1u)] = pv[q][u];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -817,8 +861,8 @@ hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const 
 // (consecutive lanes = consecutive j: coalesced cum reads and output writes).
 struct FinalizeArgs {
     const void *cum;
-    uint64_t nslots;
-    const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile of the band
+    uint64_t nslots;       // distance between two planes of cum (pair slots of the band)
+    const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile
     const uint32_t *perm;  // plane-matrix column -> sketch index (nullptr: identity)
     int vlo;    // smallest register value of any column: the histogram columns start at bin vlo
     int vhi;    // largest register value present anywhere
@@ -1379,18 +1423,26 @@ hipError_t launch_upload(hipStream_t st, void *dst, const void *src_pinned, size
 
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
-hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int estim,
-                                int emax, int elow, double *card, void *exc, uint8_t *excv, uint32_t *exc_n,
+hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t first, uint64_t n, int p, int estim,
+                                int emax, int elow, uint32_t *hist, void *exc, uint8_t *excv, uint32_t *exc_n,
                                 uint32_t *keys, uint8_t *tailhist)
 {
-    if (n == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)((n + 3) / 4);
+    if (n <= first) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n - first + 3) / 4);
     if (p <= 15)
-        hipLaunchKernelGGL(k_selfhist_card<uint16_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax, elow,
-                           card, (uint16_t *)exc, excv, exc_n, keys, tailhist);
+        hipLaunchKernelGGL(k_selfhist_card<uint16_t>, dim3(blocks), dim3(256), 0, st, regs, first, n, p, estim, emax, elow,
+                           hist, (uint16_t *)exc, excv, exc_n, keys, tailhist);
     else
-        hipLaunchKernelGGL(k_selfhist_card<uint32_t>, dim3(blocks), dim3(256), 0, st, regs, n, p, estim, emax, elow,
-                           card, (uint32_t *)exc, excv, exc_n, keys, tailhist);
+        hipLaunchKernelGGL(k_selfhist_card<uint32_t>, dim3(blocks), dim3(256), 0, st, regs, first, n, p, estim, emax, elow,
+                           hist, (uint32_t *)exc, excv, exc_n, keys, tailhist);
+    return hipGetLastError();
+}
+
+hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uint32_t *keys, uint64_t first, uint64_t n, int p,
+                                 int estim, double *card)
+{
+    if (n <= first) return hipSuccess;
+    hipLaunchKernelGGL(k_card_from_hist, dim3((uint32_t)((n - first + 63) / 64)), dim3(64), 0, st, hist, keys, first, n, p, estim, card);
     return hipGetLastError();
 }
 
@@ -1520,7 +1572,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
-    a.cum = f.cum; a.nslots = f.nslots; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi; a.pbase = f.pbase;
+    a.cum = f.cum; a.nslots = f.cum_stride; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi; a.pbase = f.pbase;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
     a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist;
     a.cidx_off = f.cidx_off; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;

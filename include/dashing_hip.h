@@ -224,8 +224,20 @@ int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_
  *                        arrays after sharded sketching (dsh_copy_sketches_device gives the block)
  *   dsh_dist_collect     the whole multi-GPU dist step for a host without device pointers: computes this rank's row
  *                        range, delivers the spans to `dst`, which gets the full packed matrix in `out` (host,
- *                        n(n-1)/2 floats; ignored on other ranks).  Without a communicator (world = 1) it is dsh_dist_rows. */
+ *                        n(n-1)/2 floats; ignored on other ranks).  Without a communicator (world = 1) it is dsh_dist_rows.
+ * Pipelined form (the exchange hidden behind the compute): dsh_dist_rows_parts_device_async computes a row range in
+ * `nparts` consecutive parts (dsh_range_parts: about equal pair counts, cuts on whole 128-row tile rows; the plane
+ * matrix keeps every part key-ordered on its own) and marks the completion of each part on the ctx stream;
+ * dsh_collect_parts_async then enqueues, on the copy stream, one round of grouped ncclSend/ncclRecv per part, each
+ * round waiting only for its own part -- part q travels over xGMI while part q+1 is computed.  Every rank calls both
+ * with the same bounds / nparts; dsh_wait (or a ticket) completes them. */
 #define DSH_UNIQUE_ID_BYTES 128
+int dsh_range_parts(uint64_t n, uint64_t row_begin, uint64_t row_end, uint32_t nparts, uint64_t *part_rows, /* [nparts + 1] */
+                    uint32_t *nparts_out);
+int dsh_dist_rows_parts_device_async(dsh_ctx *ctx, int estim, int result_type, int k, uint64_t row_begin, uint64_t row_end,
+                                     void *d_out, uint32_t nparts);
+int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
+                            void *d_final, int dst);
 int dsh_comm_unique_id(void *id_out);
 int dsh_comm_init(dsh_ctx *ctx, const void *unique_id, int rank, int world);
 int dsh_comm_destroy(dsh_ctx *ctx);

@@ -74,9 +74,19 @@ def main():
         my = torch.zeros(max(sizes[rank], 1), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         dst_ptr = final_r.data_ptr() if rank == 0 else my.data_ptr()  # rank 0 computes in place
-        ctx.dist_rows_device(dst_ptr, bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, rt, k)
-        ctx.synchronize()
-        if backend == "gloo":
+        if backend == "nccl" and os.environ.get("E2E_CABI") == "parts":
+            # the pipelined form: rows in parts, each part sent behind its event while the next is finalized
+            multigpu.cabi_comm_init(ctx, rank, world)
+            ctx.dist_rows_parts_device_async(dst_ptr, bounds[rank], bounds[rank + 1], 3, dashing_amd.ESTIM_ERTL_MLE, rt, k)
+            ctx.collect_parts_async(n, bounds, 3, 0 if rank == 0 else my.data_ptr(), final_r.data_ptr() if rank == 0 else 0, 0)
+            ctx.wait()
+            full = final_r
+        else:
+            ctx.dist_rows_device(dst_ptr, bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, rt, k)
+            ctx.synchronize()
+        if backend == "nccl" and os.environ.get("E2E_CABI") == "parts":
+            pass
+        elif backend == "gloo":
             fh = final_r.cpu() if rank == 0 else None
             multigpu.collect_row_spans(my.cpu(), fh, n, bounds, rank, world, 0)
             full = fh.to(dev) if rank == 0 else None

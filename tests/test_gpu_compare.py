@@ -134,6 +134,46 @@ def test_row_ranges_key_ordered_layout(ctx, oracle, n, p):
         ctx.set_option("range_sort_min_rows", 1024)
 
 
+@pytest.mark.parametrize("n,p", [(1500, 12), (2100, 10)])
+def test_row_range_in_parts_and_pipelined_collect(ctx, n, p):
+    """dsh_dist_rows_parts_device_async: a row range computed in parts (each key-ordered on its own, cuts on tile
+    rows) is the byte-identical span; dsh_collect_parts_async (here one rank: the copy-into-place rounds, each behind
+    its part's event on the copy stream) assembles it in the final buffer."""
+    import torch
+
+    parts_h = []
+    for k, card in enumerate((60_000, 900_000, 7_000_000)):
+        parts_h += [synth.hll_registers(77 * k + g, card * (1 + g % 3), p) for g in range(n // 3 + 1)]
+    regs = np.stack(parts_h)[:n]
+    regs = regs[np.random.default_rng(5).permutation(n)]
+    ctx.set_sketches(regs)
+    full = ctx.dist_rows(result_type=dashing_amd.MASH_DIST, k=21)
+    dev = torch.device("cuda", 0)
+    for rb, re in ((0, n), (256, n), (300, 1400), (0, 130)):
+        span = dashing_amd.tri_span(n, rb, re)
+        lo = dashing_amd.tri_span(n, 0, rb)
+        for nparts in (1, 2, 3, 7):
+            pr = dashing_amd.range_parts(n, rb, re, nparts)
+            assert pr[0] == rb and pr[-1] == re and all((x - rb) % 128 == 0 for x in pr[1:-1]) and sorted(set(pr)) == pr
+            out = torch.full((span,), -3.0, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            ctx.dist_rows_parts_device_async(out.data_ptr(), rb, re, nparts, result_type=dashing_amd.MASH_DIST, k=21)
+            ctx.wait()
+            assert out.cpu().numpy().tobytes() == full[lo : lo + span].tobytes(), (rb, re, nparts)
+    # one rank, whole triangle in 4 parts, delivered into a separate final buffer part by part
+    total = full.size
+    local = torch.full((total,), -1.0, dtype=torch.float32, device=dev)
+    final = torch.full((total,), -2.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.dist_rows_parts_device_async(local.data_ptr(), 0, n, 4, result_type=dashing_amd.MASH_DIST, k=21)
+    ctx.collect_parts_async(n, [0, n], 4, local.data_ptr(), final.data_ptr(), 0)
+    ctx.wait()
+    assert final.cpu().numpy().tobytes() == full.tobytes()
+    with pytest.raises(dashing_amd.DshError):  # the parts of the exchange must be the parts that were computed
+        ctx.collect_parts_async(n, [0, n], 2, local.data_ptr(), final.data_ptr(), 0)
+    ctx.wait()
+
+
 def test_async_rows_and_wait(ctx):
     """dsh_dist_rows_async / dsh_wait (the reference's ping-pong buffers, src/sketch_and_cmp.h:804-816): calls
     return before the work is done, may be issued back to back, and deliver the blocking call's bytes."""

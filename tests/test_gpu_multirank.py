@@ -37,10 +37,11 @@ def test_end_to_end_ranks(backend, world, pieces):
     assert "E2E_OK world=%d backend=%s pieces=%d" % (world, backend, pieces) in out, out[-3000:]
 
 
-def test_end_to_end_cabi_exchange_single_rank_rccl():
-    """the same path with the exchange done by the library's own RCCL communicator (dsh_comm_init, dsh_collect_spans,
-    dsh_allgather_device) next to torch.distributed's: both RCCL instances come up on the one GPU"""
-    env = dict(os.environ, E2E_BACKEND="nccl", E2E_PIECES="0", E2E_CABI="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("mode", ["1", "parts"])
+def test_end_to_end_cabi_exchange_single_rank_rccl(mode):
+    """the same path with the exchange done by the library's own RCCL communicator (dsh_comm_init, dsh_collect_spans or the
+    pipelined dsh_dist_rows_parts_device_async + dsh_collect_parts_async, dsh_allgather_device) next to torch.distributed"""
+    env = dict(os.environ, E2E_BACKEND="nccl", E2E_PIECES="0", E2E_CABI=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER]
     r = subprocess.run(cmd, env=env, capture_output=True, timeout=600, cwd=ROOT)

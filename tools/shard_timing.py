@@ -36,6 +36,24 @@ for G in (1, 2, 4, 8):
             best = min(best, time.perf_counter() - t0)
         rows.append(round(best * 1e3, 3))
     print(json.dumps({"G": G, "range_ms": rows, "max_ms": max(rows), "row_bounds": b, "planes_per_tile_last_rank": ctx.info("avg_tile_planes_x100") / 100}))
+# the same ranges computed in parts (what the pipelined exchange needs): cost of the extra launches / tails
+for nparts in (2, 4):
+    G = 8
+    b = dashing_amd.balance_rows(n, G)
+    mx = max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(G))
+    out = torch.empty(mx, dtype=torch.float32, device="cuda")
+    rows = []
+    for r in range(G):
+        best = 1e9
+        for _ in range(3):
+            ctx.attach_device(regs.data_ptr(), n, p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.dist_rows_parts_device_async(out.data_ptr(), b[r], b[r + 1], nparts)
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        rows.append(round(best * 1e3, 3))
+    print(json.dumps({"G": G, "nparts": nparts, "range_ms": rows, "max_ms": max(rows), "parts_rank0": dashing_amd.range_parts(n, b[0], b[1], nparts)}))
 for G in (1, 2, 4, 8):
     ctx.attach_device(regs.data_ptr(), n, p)
     off = ctx.shard_plan(G)
