@@ -202,8 +202,10 @@ __device__ __forceinline__ float result_from_ji(double ji, int result_type, doub
 
 // Second arm of result_cmp (src/dashing.h:577-588): measures on set_triple(lhs, rhs) =
 // lhs.full_set_comparison(rhs) = {max(mys-is,0), max(os-is,0), is}, is = max(mys+os-us, 0)
-// (the triple is restated from the absent sketch submodule, SURVEY.md A.6, medium confidence;
-// the formulas on it are in-tree).  EmissionType values: SIZES 2, FULL_CONTAINMENT_DIST 4,
+// (hll_t's own full_set_comparison is in the absent sketch submodule; the order of the triple --
+// {mine - is, other - is, is} -- and J = is / (sum of the three) are corroborated in-tree by the exact-set sketch,
+// src/khset64.h:129-141,146-149, and the intersection max(0, creport(a) + creport(b) - union_size) by
+// src/dashing.h:550-552; the formulas ON the triple are in-tree: tests/test_reference_anchors.py).  EmissionType values: SIZES 2, FULL_CONTAINMENT_DIST 4,
 // CONTAINMENT_INDEX 5, CONTAINMENT_DIST 6, SYMMETRIC_CONTAINMENT_INDEX 7, _DIST 8.
 __device__ __forceinline__ double max0(double x) { return x < 0. ? 0. : x; }
 __device__ inline float result_from_triple(double mys, double os, double us, int result_type, double ksinv)
