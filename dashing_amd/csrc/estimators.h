@@ -83,11 +83,13 @@ __device__ inline double estimate_improved(const Hist &c, int p)
     return m * divinv * m / z;
 }
 
-// IEEE-754 double division for operands whose quotient and intermediates stay in the normal
-// range (here: numerator and denominator both in (2^-70, 2^2)): reciprocal estimate, two Newton
-// steps, quotient, one residual correction -- the same fma sequence hipcc emits for `/` minus
-// its v_div_scale/v_div_fixup special-case handling (3 of 11 instructions).  Correctly rounded,
-// so results stay identical to a CPU `/` (checked on every pair of the bench sample).
+// IEEE-754 double division for NORMAL, NON-ZERO, POSITIVE operands whose quotient, reciprocal and residual stay in
+// the normal range: reciprocal estimate, two Newton steps, quotient, one residual correction -- the same fma
+// sequence hipcc emits for `/` minus its v_div_scale/v_div_fixup special-case handling (3 of 11 instructions).
+// Correctly rounded under that precondition, so results stay identical to a CPU `/`.  Used ONLY where the
+// precondition holds by construction: the step of the inner recurrence (both operands in [x', 2), x' = x 2^-s >=
+// 2^-130) and the two constant divisors of the series start (x'^2 / 3, x'^2 / 472.5).  The once-per-iteration
+// divisions (start value, secant step: operands may be zero, negative or huge) use the plain `/`.
 __device__ __forceinline__ double div_normal(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
@@ -132,7 +134,7 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     const double a = z + (double)c0;
     const double mPrime = (double)(int)(m - c0);
     double gprev = z + ldexp((double)cq1, -q);
-    double x = gprev <= 1.5 * a ? div_normal(mPrime, 0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
+    double x = gprev <= 1.5 * a ? mPrime / (0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
     gprev = 0.;
     double deltaX = x;
     // sqrt(2^p) without the sqrt sequence: 2^(p/2), times the correctly rounded sqrt(2) for odd p (a power-of-two
@@ -163,7 +165,7 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
             g += ck * h;
         }
         g += x * a;
-        if (gprev < g && g <= mPrime) deltaX *= div_normal(g - mPrime, gprev - g);
+        if (gprev < g && g <= mPrime) deltaX *= (g - mPrime) / (gprev - g);
         else deltaX = 0.;
         x += deltaX;
         gprev = g;

@@ -311,7 +311,9 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         std::vector<int> cached(nb, 0), gz(nb, 0);
         std::vector<std::string> fnames(nb);
         std::vector<std::vector<std::string>> files(nb);
-        std::vector<std::vector<uint8_t>> zseq(nb);  // gzip'ed genomes only: their size is not known from the file
+        std::vector<std::vector<uint8_t>> zseq(nb);  // genomes whose sequence length the file size does not bound: compressed
+                                                     // files, FIFOs, /dev/stdin, process substitutions (parsed growably)
+        std::vector<std::pair<size_t, std::vector<uint8_t>>> late;  // (slot, sequence): a plain file that outgrew its region
 #pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
         for (long i = 0; i < (long)nb; ++i) {
             const std::string &entry = o.inpaths[g + i];
@@ -376,7 +378,17 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
                     if (len) dst[len++] = 'N';
                     const long rc = append_fastx_into(f, dst, cap, len);
                     if (rc == -1) die("Could not open %s", f.c_str());
-                    if (rc == -2) die("%s grew while it was being read", f.c_str());
+                    if (rc == -2) {  // the file grew after its region was sized: read the whole genome growably instead and
+                                     // sketch it on its own after the batch (what is staged is a prefix of it: harmless)
+                        std::vector<uint8_t> whole;
+                        for (const auto &f2 : files[i]) {
+                            if (!whole.empty()) whole.push_back('N');
+                            if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
+                        }
+#pragma omp critical
+                        late.emplace_back(slot_of[t], std::move(whole));
+                        break;
+                    }
                 }
             }
             std::memset(dst + len, 'N', cap - len);  // invalid bases close every span: no k-mer, harmless
@@ -398,6 +410,11 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
             DSH(ctx, dsh_sketch_batch_async(ctx, buf, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon));
             r0 = r1;
+        }
+        for (auto &lg : late) {  // (max-merged into their slots: a genome may be fed in several calls)
+            lg.second.push_back('N');
+            const uint64_t loff[2] = {0, lg.second.size()};
+            DSH(ctx, dsh_sketch_batch(ctx, lg.second.data(), loff, 1, lg.first, o.k, o.canon, nullptr));
         }
         for (size_t t = 0; t < slot_of.size(); ++t) {
             pending.slots.push_back(slot_of[t]);
@@ -935,9 +952,13 @@ static int dist_main(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
-    // idle OpenMP workers sleep instead of spinning: between the parallel regions the HIP runtime's own threads
-    // (start-up, copies) need the cores (must be set before the OpenMP runtime starts)
-    ::setenv("OMP_WAIT_POLICY", "passive", 0);
+    // idle OpenMP workers should sleep instead of spinning: between the parallel regions the HIP runtime's own threads
+    // (start-up, copies) need the cores.  libgomp reads OMP_WAIT_POLICY in a constructor that runs before main(), so
+    // setting it here would be too late: re-exec once with it in the environment.
+    if (!std::getenv("OMP_WAIT_POLICY") && !std::getenv("GOMP_SPINCOUNT")) {
+        ::setenv("OMP_WAIT_POLICY", "passive", 1);
+        ::execv("/proc/self/exe", argv);  // (on failure just carry on with the default policy)
+    }
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
         std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  printmat              (binary distance matrix -> text)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;

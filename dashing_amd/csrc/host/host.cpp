@@ -110,36 +110,59 @@ struct ZstdApi {
 
 class InStream {
 public:
-    enum Kind { CLOSED, PLAIN, GZIP, ZSTD };
-    // 0 on success, -ENOENT if the file cannot be opened, -ENOSYS for a zstd file on a host without libzstd
+    enum Kind { CLOSED, PLAIN, GZIP, GZPIPE, ZSTD };
+    // 0 on success, -ENOENT if the file cannot be opened, -ENOSYS for a zstd file on a host without libzstd,
+    // -ENOMEM / -EIO if a decoder cannot be set up.
+    // The format is sniffed from the first bytes actually READ (kept and replayed), never with pread or a second
+    // open: the path may be a FIFO, /dev/stdin or a `<(zcat x.gz)` process substitution, as dashing's gz* reader
+    // accepts (bonsai's Encoder::for_each opens every input with gzopen).
     int open(const std::string &path)
     {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) return -ENOENT;
-        unsigned char magic[4] = {0, 0, 0, 0};
-        const ssize_t got = ::pread(fd_, magic, 4, 0);
-        if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-            gz_ = gzdopen(fd_, "rb");
-            if (!gz_) {
-                ::close(fd_);
-                fd_ = -1;
-                return -ENOENT;
+        prelen_ = prepos_ = 0;
+        while (prelen_ < 4) {
+            const ssize_t r = ::read(fd_, pre_ + prelen_, 4 - prelen_);
+            if (r <= 0) break;
+            prelen_ += (size_t)r;
+        }
+        const unsigned char *magic = pre_;
+        if (prelen_ >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            if (::lseek(fd_, 0, SEEK_SET) == 0) {  // a regular file: zlib's own reader from the start
+                prelen_ = 0;
+                gz_ = gzdopen(fd_, "rb");
+                if (!gz_) return fail_open(-ENOMEM);
+                gzbuffer(gz_, 1 << 20);
+                kind_ = GZIP;
+            } else {  // a pipe: inflate by hand, starting with the bytes already taken
+                std::memset(&zl_, 0, sizeof zl_);
+                if (inflateInit2(&zl_, 16 + MAX_WBITS) != Z_OK) return fail_open(-ENOMEM);
+                zin_.resize(1 << 17);
+                std::memcpy(zin_.data(), pre_, prelen_);
+                zlen_ = prelen_;
+                zpos_ = 0;
+                prelen_ = 0;
+                zframe_done_ = false;
+                kind_ = GZPIPE;
             }
-            gzbuffer(gz_, 1 << 20);
-            kind_ = GZIP;
-        } else if (got == 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD) {
+        } else if (prelen_ == 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD) {
             const ZstdApi &z = ZstdApi::get();
-            if (!z.ok) {
-                ::close(fd_);
-                fd_ = -1;
-                return -ENOSYS;
-            }
+            if (!z.ok) return fail_open(-ENOSYS);
             zs_ = z.createDStream();
-            z.initDStream(zs_);
+            if (!zs_) return fail_open(-ENOMEM);
+            if (z.isError(z.initDStream(zs_))) {
+                z.freeDStream(zs_);
+                zs_ = nullptr;
+                return fail_open(-EIO);
+            }
             zin_.resize(1 << 17);
+            std::memcpy(zin_.data(), pre_, prelen_);  // the magic belongs to the stream
+            zlen_ = prelen_;
+            zpos_ = 0;
+            prelen_ = 0;
             kind_ = ZSTD;
         } else {
-            kind_ = PLAIN;
+            kind_ = PLAIN;  // (pre_ is replayed by read())
         }
         return 0;
     }
@@ -149,6 +172,7 @@ public:
     {
         if (kind_ == PLAIN) {
             size_t done = 0;
+            while (prepos_ < prelen_ && done < n) ((unsigned char *)dst)[done++] = pre_[prepos_++];
             while (done < n) {
                 const ssize_t r = ::read(fd_, (char *)dst + done, n - done);
                 if (r < 0) return -1;
@@ -166,6 +190,41 @@ public:
                 done += (size_t)r;
             }
             return (ssize_t)done;
+        }
+        if (kind_ == GZPIPE) {  // concatenated members are one stream, as for gzread
+            zl_.next_out = (Bytef *)dst;
+            size_t left = n;
+            while (left) {
+                if (zpos_ == zlen_ && !zeof_) {
+                    const ssize_t r = ::read(fd_, zin_.data(), zin_.size());
+                    if (r < 0) return -1;
+                    if (r == 0) zeof_ = true;
+                    zlen_ = (size_t)std::max<ssize_t>(r, 0);
+                    zpos_ = 0;
+                }
+                if (zpos_ == zlen_ && zeof_) {
+                    if (!zframe_done_) return -1;  // truncated member
+                    break;
+                }
+                if (zframe_done_) {  // more input after a finished member: the next member
+                    if (gz_members_ && inflateReset(&zl_) != Z_OK) return -1;
+                    zframe_done_ = false;
+                }
+                zl_.next_in = (Bytef *)zin_.data() + zpos_;
+                zl_.avail_in = (uInt)(zlen_ - zpos_);
+                zl_.avail_out = (uInt)std::min<size_t>(left, 1u << 30);
+                const uInt out0 = zl_.avail_out;
+                const int rc = inflate(&zl_, Z_NO_FLUSH);
+                zpos_ = zlen_ - zl_.avail_in;
+                left -= out0 - zl_.avail_out;
+                if (rc == Z_STREAM_END) {
+                    zframe_done_ = true;
+                    ++gz_members_;
+                } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                    return -1;
+                }
+            }
+            return (ssize_t)(n - left);
         }
         if (kind_ == ZSTD) {
             const ZstdApi &z = ZstdApi::get();
@@ -201,6 +260,7 @@ public:
     {
         if (kind_ == GZIP) gzclose(gz_);  // closes fd_ too
         else if (fd_ >= 0) ::close(fd_);
+        if (kind_ == GZPIPE) inflateEnd(&zl_);
         if (zs_) ZstdApi::get().freeDStream(zs_);
         zs_ = nullptr;
         fd_ = -1;
@@ -212,8 +272,18 @@ public:
     }
 
 private:
+    int fail_open(int rc)
+    {
+        if (fd_ >= 0) ::close(fd_);
+        fd_ = -1;
+        return rc;
+    }
     Kind kind_ = CLOSED;
     int fd_ = -1;
+    unsigned char pre_[4] = {0, 0, 0, 0};  // the bytes the format was sniffed from
+    size_t prelen_ = 0, prepos_ = 0;
+    z_stream zl_;
+    unsigned gz_members_ = 0;
     gzFile gz_ = nullptr;
     void *zs_ = nullptr;
     std::vector<char> zin_;
@@ -353,6 +423,12 @@ long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t
 
 bool is_gzip_file(const std::string &path)
 {
+    // "its sequence length cannot be bounded by its size": compressed (gzip / zstd magic), or not a regular file at
+    // all -- a FIFO, /dev/stdin, a process substitution -- which must not be opened here (reading the magic would eat
+    // it, closing would end the writer): such inputs take the growable parse path
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return false;
+    if (!S_ISREG(st.st_mode) || st.st_size == 0) return true;
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
     unsigned char magic[4] = {0, 0, 0, 0};
@@ -414,6 +490,7 @@ int read_hll(const std::string &path, std::vector<uint8_t> &regs, int &p)
     ssize_t n;
     while ((n = fp.read(buf, sizeof buf)) > 0) all.insert(all.end(), buf, buf + n);
     fp.close();
+    if (n < 0) return -EIO;  // read or decode error (truncated / corrupt gzip or zstd stream), not a layout question
     auto try_layout = [&](size_t hdr, size_t np_off) -> bool {
         if (all.size() <= hdr) return false;
         const size_t m = all.size() - hdr;
@@ -471,13 +548,17 @@ int read_hll_multi(const std::string &path, std::vector<uint8_t> &regs, int &p, 
         uint8_t hdr[28];
         const ssize_t got = fp.read(hdr, sizeof hdr);
         if (got == 0) break;
+        if (got < 0) return -EIO;
+        if (got != (ssize_t)sizeof hdr) return -EINVAL;  // (before any field of the header is looked at)
         uint32_t np;
         std::memcpy(&np, hdr + 16, 4);
-        if (got != (ssize_t)sizeof hdr || np < 4 || np > 30 || (p >= 0 && (int)np != p)) return -EINVAL;
+        if (np < 4 || np > 30 || (p >= 0 && (int)np != p)) return -EINVAL;
         p = (int)np;
         const size_t m = (size_t)1 << p, at = regs.size();
         regs.resize(at + m);
-        if (fp.read(regs.data() + at, m) != (ssize_t)m) return -EINVAL;
+        const ssize_t gotr = fp.read(regs.data() + at, m);
+        if (gotr < 0) return -EIO;
+        if (gotr != (ssize_t)m) return -EINVAL;
         ++n;
     }
     return n ? 0 : -EINVAL;

@@ -236,6 +236,33 @@ def test_multi_device_binary_matches_single(genomes, tmp_path):
     assert len(c.read_bytes()) == len(a.read_bytes())
 
 
+def test_inputs_that_are_not_regular_files(genomes, tmp_path):
+    """FIFOs / stdin / process substitutions as genome paths (dashing's gz* reader takes them): a plain FASTA
+    through /dev/stdin and a gzip stream through a FIFO give the matrix of the regular files."""
+    import threading
+
+    d, paths, seqs = genomes
+    sub = paths[:4]
+    a = tmp_path / "regular.bin"
+    run("dist", "-b", "--avoid-sorting", "-O", a, "-o", os.devnull, *sub)
+    fifo = str(tmp_path / "g1.fifo")
+    os.mkfifo(fifo)
+    payload = gzip.compress(open(sub[1], "rb").read())
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(payload)
+
+    t = threading.Thread(target=feed)
+    t.start()
+    b = tmp_path / "piped.bin"
+    r = subprocess.run([CLI, "dist", "-b", "--avoid-sorting", "-O", str(b), "-o", os.devnull, "/dev/stdin", fifo, sub[2], sub[3]],
+                       input=open(sub[0], "rb").read(), capture_output=True, timeout=300)  # stdin is a pipe
+    t.join()
+    assert r.returncode == 0, r.stderr.decode()
+    assert a.read_bytes() == b.read_bytes()
+
+
 def test_rccl_collect_path_matches_plain(genomes, tmp_path):
     """`dist --ngpus G` with an output that one writer emits in order goes through dsh_comm_init + dsh_dist_collect
     (RCCL inside the library).  A one-GPU box can only run it with one rank (--rccl forces the path; RCCL refuses two

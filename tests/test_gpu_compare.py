@@ -585,6 +585,36 @@ def test_knn_more_neighbours_than_the_band_path_takes(ctx, oracle):
     assert (gi == wi).all() and np.allclose(gv, wv, rtol=1e-6, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("p", [4, 24])
+def test_extreme_histograms_smallest_and_largest_precision(ctx, oracle, p):
+    """the estimator's divisions at the edges of their operand range -- all-zero sketches (c0 = m), one
+    non-zero register (c0 = m - 1), saturated sketches (every register q + 1: the MLE returns +inf), identical pairs --
+    at the smallest and the largest precision the library takes; all three estimators, vs the oracle."""
+    m, q = 1 << p, 64 - p
+    rng = np.random.default_rng(p)
+    regs = np.zeros((7, m), np.uint8)
+    regs[1, m // 3] = 1                       # c0 = m - 1
+    regs[2, :] = q + 1                        # saturated
+    regs[3] = synth.hll_registers(5, 3 * m, p)
+    regs[4] = regs[3]                         # identical pair
+    regs[5] = rng.integers(0, q + 2, m).astype(np.uint8)   # uniform over the whole value range
+    regs[6, : m // 2] = q + 1                 # half saturated, half empty
+    ctx.set_sketches(regs)
+    for estim in (0, 1, 2):
+        want_c = oracle.cardinalities(regs, estim)
+        got_c = ctx.cardinalities(estim)
+        fin = np.isfinite(want_c)
+        assert (np.isfinite(got_c) == fin).all() and np.allclose(got_c[fin], want_c[fin], rtol=1e-12)
+        for rt in (dashing_amd.JI, dashing_amd.MASH_DIST, dashing_amd.SIZES):
+            want = oracle.dist_tri(regs, estim, rt, 31).astype(np.float64)
+            got = ctx.dist_rows(estim=estim, result_type=rt, k=31).astype(np.float64)
+            fin = np.isfinite(want)
+            assert (np.isfinite(got) == fin).all(), (estim, rt)
+            assert (np.isnan(got) == np.isnan(want)).all(), (estim, rt)
+            err = np.abs(got[fin] - want[fin])
+            assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9)).all(), (estim, rt, err.max())
+
+
 def test_out_of_range_registers_are_refused(ctx):
     """uploaded registers above 64 - p + 1 (corrupt / foreign sketches) make the compare entry points fail loudly
     instead of aliasing into wrong histogram bins"""

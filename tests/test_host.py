@@ -405,3 +405,57 @@ def test_zstd_inputs_are_transparent(host, tmp_path):
     bad = tmp_path / "bad.fa.zst"
     bad.write_bytes(frame[:4] + b"\xff" * 64)
     assert parse(host, str(bad), 1 << 20)[0] == -1
+
+
+def _feed_fifo(path, data):
+    import threading
+
+    def w():
+        with open(path, "wb") as f:
+            f.write(data)
+
+    t = threading.Thread(target=w)
+    t.start()
+    return t
+
+
+def test_fastx_from_pipes(host, tmp_path):
+    """Inputs that are not regular files -- a FIFO, as /dev/stdin or `<(zcat x.gz)` are: the format is
+    sniffed from the first bytes READ, nothing is pread or opened twice; plain, gzip (two concatenated members) and zstd."""
+    import ctypes as C2
+
+    text = b">r1\nACGTACGTAC\nGGTT\n>r2\nTTTTGGGGCCCCAAAA\n" * 400
+    want = parse(host, _write(tmp_path / "ref.fa", text), cap=1 << 20)
+    assert want[0] == 800
+    half = len(text) // 2
+    cut = text.rfind(b">", 0, half)
+    streams = {"plain": text, "gzip": gzip.compress(text[:cut]) + gzip.compress(text[cut:])}
+    try:
+        z = C2.CDLL("libzstd.so.1")
+        z.ZSTD_compressBound.restype = C2.c_size_t
+        z.ZSTD_compressBound.argtypes = [C2.c_size_t]
+        z.ZSTD_compress.restype = C2.c_size_t
+        z.ZSTD_compress.argtypes = [C2.c_void_p, C2.c_size_t, C2.c_void_p, C2.c_size_t, C2.c_int]
+        dst = C2.create_string_buffer(z.ZSTD_compressBound(len(text)))
+        nz = z.ZSTD_compress(dst, len(dst), text, len(text), 3)
+        streams["zstd"] = dst.raw[:nz]
+    except OSError:
+        pass
+    for name, data in streams.items():
+        fifo = str(tmp_path / ("in_%s.fifo" % name))
+        os.mkfifo(fifo)
+        t = _feed_fifo(fifo, data)
+        got = parse(host, fifo, cap=1 << 20)
+        t.join()
+        assert got == want, name
+    # a truncated gzip member on a pipe is an error, not a silent short read
+    fifo = str(tmp_path / "trunc.fifo")
+    os.mkfifo(fifo)
+    t = _feed_fifo(fifo, gzip.compress(text)[:-20])
+    assert parse(host, fifo, cap=1 << 20)[0] == -1
+    t.join()
+
+
+def _write(path, data):
+    path.write_bytes(data)
+    return str(path)
