@@ -123,7 +123,7 @@ struct dsh_ctx {
     std::vector<uint32_t> hperm;        // plane-matrix column -> sketch
     uint32_t *pin_perm = nullptr;       // page-locked copy of hperm: its upload is then truly asynchronous
     size_t pin_perm_cap = 0;
-    std::vector<uint8_t> blk_T, blk_lo, blk_L; // per 128-column block: max high threshold, min register value, min low threshold
+    std::vector<uint8_t> blk_T, blk_lo, blk_L, blk_hi; // per 128-column block: max high threshold, min register value, min low threshold, max register value
     std::vector<uint4> hitems;
     PinBuf pin_work;                    // sketch work list of the call in flight
     hipEvent_t ev_work = nullptr;
@@ -136,7 +136,9 @@ struct dsh_ctx {
     int emax = 0, elow = 0, cum_bytes = 4;
     std::vector<uint4> htiles;
     // options
-    int kc = 16;  // 16 rows per LDS stage (32 KiB double-buffered): ~1 % faster than 32 in three sweeps (profiles/)
+    int kc = 16;      // k-rows per LDS stage in effect (set by prepare from kc_opt)
+    int kc_opt = 0;   // 0 auto: 32 where a plane spans >= 8 such chunks (p >= 13: the unrolled lockstep kernel, -1.3 % on C3,
+                      // profiles/r3f), else 16
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
     uint64_t cum_budget = 2ull << 30;
@@ -148,7 +150,7 @@ struct dsh_ctx {
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int ls_sort_items = 1;
-    int ls_item_chunks = 16;  // lockstep kernel: work items of about this many K-chunks (whole planes)
+    int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
     // (planes of >= 8 chunks, i.e. p >= 12 at kc = 16: tools/lockstep_ab.py -- 4-6 % faster at p = 14/18, 2-3 % at 12,
     // 5 % SLOWER at p = 10 where a plane is two chunks), 0 never (the free-running k_pair_counts), 1 wherever W >= kc
@@ -441,6 +443,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
+        c->kc = c->kc_opt ? c->kc_opt : (c->W >= 256 ? 32 : 16);
         c->ncols = ncols;
         c->Npad = (uint32_t)((ncols + kTile - 1) / kTile * kTile);
         // column order: identity, or a counting sort by (threshold, min value, max value): the first
@@ -509,6 +512,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         c->blk_T.assign(NT, 0);
         c->blk_lo.assign(NT, 255);
         c->blk_L.assign(NT, 255);
+        c->blk_hi.assign(NT, 0);
         int pbase = vr[2];
         for (uint64_t s = 0; s < ncols; ++s) {
             const uint32_t key = k32[c->hperm[s]];
@@ -516,6 +520,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
             c->blk_T[b] = std::max<uint8_t>(c->blk_T[b], (uint8_t)key_T(key));
             c->blk_lo[b] = std::min<uint8_t>(c->blk_lo[b], (uint8_t)key_lo(key));
             c->blk_L[b] = std::min<uint8_t>(c->blk_L[b], (uint8_t)key_L(key));
+            c->blk_hi[b] = std::max<uint8_t>(c->blk_hi[b], (uint8_t)key_hi(key));
             pbase = std::min<int>(pbase, key_L(key));
         }
         // dense planes cover v in (pbase, Tmax]: below the smallest low threshold every C(v) comes from the list join
@@ -751,7 +756,18 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     }
     HIPCHK(c, c->pin_lists.ensure((T.size() + std::max<size_t>(I.size(), 1)) * sizeof(uint4)));
     uint4 *pinT = (uint4 *)c->pin_lists.ptr, *pinI = pinT + T.size();
-    std::memcpy(pinT, T.data(), T.size() * sizeof(uint4));
+    // device form of a tile: {row block, column block, plane begin | plane end << 8, smallest | largest << 8 register
+    // value of its two blocks} -- k_finalize's histogram columns only span the values the tile's sketches can hold
+    auto tile_vrange = [&](const uint4 &t, int &lo, int &hi) {
+        lo = std::min<int>(c->blk_lo[t.x], c->blk_lo[t.y]);
+        hi = std::max<int>(c->blk_hi[t.x], c->blk_hi[t.y]);
+        if (hi < lo) hi = lo;  // (blocks of padding only)
+    };
+    for (size_t t = 0; t < T.size(); ++t) {
+        int lo, hi;
+        tile_vrange(T[t], lo, hi);
+        pinT[t] = make_uint4(T[t].x, T[t].y, T[t].z | (T[t].w << 8), (uint32_t)lo | ((uint32_t)hi << 8));
+    }
     if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
     c->host_lists_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();
     HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
@@ -798,7 +814,12 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.cum = (const char *)c->cum.ptr + seg_off * (uint64_t)c->cum_bytes;
             f.cum_bytes = c->cum_bytes;
             f.cum_stride = nslots;
-            f.vhi = c->vhi;
+            f.hist_bins = 1;
+            for (size_t t = sg.b; t < sg.e; ++t) {
+                int lo, hi;
+                tile_vrange(T[t], lo, hi);
+                f.hist_bins = std::max(f.hist_bins, hi - lo + 1);
+            }
             f.exc = c->exc.ptr;
             f.exc_n = (const uint32_t *)c->exc_n.ptr;
             f.excv = (const uint8_t *)c->excv.ptr;
@@ -807,7 +828,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
             f.tiles = (const uint4 *)c->tiles.ptr + sg.b;
             f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
-            f.vlo = c->vlo;
             f.pbase = c->pbase;
             f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
             f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
@@ -1878,8 +1898,8 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
 {
     if (!c || !name) return DSH_EINVAL;
     if (!std::strcmp(name, "kc")) {
-        if (v != 16 && v != 32 && v != 64) return fail(c, DSH_EINVAL, "kc must be 16, 32 or 64");
-        c->kc = (int)v;
+        if (v != 0 && v != 16 && v != 32 && v != 64) return fail(c, DSH_EINVAL, "kc must be 0 (auto), 16, 32 or 64");
+        c->kc_opt = (int)v;
         c->planes_valid = false;  // Kpad depends on kc
         return DSH_OK;
     }

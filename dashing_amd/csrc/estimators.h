@@ -89,7 +89,7 @@ __device__ inline double estimate_improved(const Hist &c, int p)
 // Correctly rounded under that precondition, so results stay identical to a CPU `/`.  Used ONLY where the
 // precondition holds by construction: the step of the inner recurrence (both operands in [x', 2), x' = x 2^-s >=
 // 2^-130) and the two constant divisors of the series start (x'^2 / 3, x'^2 / 472.5).  The once-per-iteration
-// divisions (start value, secant step: operands may be zero, negative or huge) use the plain `/`.
+// divisions (start value, secant step: operands may be zero or negative) go through div_guarded below.
 __device__ __forceinline__ double div_normal(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
@@ -100,6 +100,18 @@ __device__ __forceinline__ double div_normal(double num, double den)
     const double q = num * r;
     const double rem = __builtin_fma(-den, q, num);
     return __builtin_fma(rem, r, q);
+}
+
+// The same for operands that are only KNOWN to be finite: the fast sequence when both magnitudes lie in [2^-500, 2^500]
+// (or the numerator is zero) -- then the reciprocal, the quotient (in [2^-1000, 2^1000]) and the residual (>= 2^-553)
+// are all normal and the result is the correctly rounded quotient, signs included -- and the plain `/` otherwise.
+// The estimator's once-per-iteration divisions go through here: their operands are differences of sums of counts
+// (|x| in [2^-60, 2^24] or zero), so the slow branch is never taken in practice, but nothing depends on that.
+__device__ __forceinline__ double div_guarded(double num, double den)
+{
+    const double an = __builtin_fabs(num), ad = __builtin_fabs(den);
+    if (ad >= 0x1p-500 && ad <= 0x1p500 && an <= 0x1p500 && (an >= 0x1p-500 || an == 0.)) return div_normal(num, den);
+    return num / den;
 }
 
 // x + x for a positive normal double far from overflow (the iteration's x' = x * 2^-s, doubled at most ~60
@@ -134,7 +146,7 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     const double a = z + (double)c0;
     const double mPrime = (double)(int)(m - c0);
     double gprev = z + ldexp((double)cq1, -q);
-    double x = gprev <= 1.5 * a ? mPrime / (0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
+    double x = gprev <= 1.5 * a ? div_guarded(mPrime, 0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
     gprev = 0.;
     double deltaX = x;
     // sqrt(2^p) without the sqrt sequence: 2^(p/2), times the correctly rounded sqrt(2) for odd p (a power-of-two
@@ -165,7 +177,7 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
             g += ck * h;
         }
         g += x * a;
-        if (gprev < g && g <= mPrime) deltaX *= (g - mPrime) / (gprev - g);
+        if (gprev < g && g <= mPrime) deltaX *= div_guarded(g - mPrime, gprev - g);
         else deltaX = 0.;
         x += deltaX;
         gprev = g;

@@ -45,7 +45,7 @@ struct FinalizeLaunch {
     uint64_t nslots;      // pair slots to finalize (a band, or a segment of it: cum/tiles point at its first tile)
     const uint4 *tiles;
     const uint32_t *perm;
-    int vlo, vhi, pbase, p, estim, result_type;
+    int hist_bins, pbase, p, estim, result_type;  // hist_bins: max over the launch's tiles of (largest - smallest value + 1)
     double ksinv;
     const double *card;
     const void *exc;

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 // instead of 6.49, whatever the order, batch size or register banks inside a wave (profiles/ubench/pair_sched.txt:
 // batch64 8.0, batch64_wg512_bar 6.4-6.8, ..._bar_ldsspread 6.9).  Independent workgroups drift apart; here ONE
 // 512-thread workgroup per CU (8 waves = 2 per SIMD) takes TWO work items (waves 0-3 item 2b, waves 4-7 item 2b+1, each
-// with its own LDS staging) and every k-row is: 64 ANDs into temporaries | s_barrier | 64 BCNTs | s_barrier.  The
+// with its own LDS staging) and every k-row is: 64 ANDs into temporaries | 64 BCNTs | s_barrier (round 2 also had a
+// barrier between the two batches; it is not needed -- see the k loop -- and costs 4 %).  The
 // operands of the next k-row are read from LDS during the BCNT phase (the AND phase was their last use), one 16-byte
 // read per quarter of the phase (all 8 waves arrive together: 32 ds_read_b128 at once back up the LDS queue).
 // With a single workgroup per CU nothing hides a stall, so the plane-boundary flush (16 stores per lane) is deferred
@@ -631,7 +632,11 @@ __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restri
         const uint32_t *Bs = hsm + (ch & 1) * (2 * KC * 128) + KC * 128 + jj;
         uint4 a0 = *reinterpret_cast<const uint4 *>(As), a1 = *reinterpret_cast<const uint4 *>(As + 4);
         uint4 b0 = *reinterpret_cast<const uint4 *>(Bs), b1 = *reinterpret_cast<const uint4 *>(Bs + 4);
-#pragma unroll 4
+        // fully unrolled: the LDS read offsets become immediates (no address arithmetic in the row), and ONE barrier per
+        // k-row, after the BCNT batch.  Measured on C3 (profiles/r3f): barrier after both batches 11.40 ms; after the BCNT
+        // batch only 10.91 (both waves of a SIMD start their ANDs together and are still together when the BCNTs begin);
+        // after the AND batch only 14.2; every second row 12.3; + full unroll 10.55; + KC = 32 10.41.
+#pragma unroll
         for (uint32_t kk = 0; kk < (uint32_t)KC; ++kk) {
             {
                 const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -641,8 +646,6 @@ __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restri
 #pragma unroll
                     for (int c = 0; c < 8; ++c) tmp[r][c] = av[r] & bv[c];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t kn = kk + 1 < (uint32_t)KC ? kk + 1 : kk;  // (the last row is simply read again)
 #pragma unroll
@@ -864,8 +867,7 @@ struct FinalizeArgs {
     uint64_t nslots;       // distance between two planes of cum (pair slots of the band)
     const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile
     const uint32_t *perm;  // plane-matrix column -> sketch index (nullptr: identity)
-    int vlo;    // smallest register value of any column: the histogram columns start at bin vlo
-    int vhi;    // largest register value present anywhere
+    int hist_bins;  // histogram columns allocated per lane (>= the value span of any tile of the launch)
     int pbase;  // plane pl is the threshold v = pbase + 1 + pl
     int p;
     int estim;
@@ -916,7 +918,8 @@ struct FinalizeArgs {
 // 128 list walks -- and applies what it finds to the owning lane's histogram column with LDS atomics.  Exact and
 // order-independent.  C(Lp) = number of low joins, so c[Lp] = C(Lp+1) - C(Lp) and c[T] = m - |union above T| - C(T).
 template <typename CT>
-__global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
+// 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_finalize(FinalizeArgs a)
 {
     // histogram columns hold counts <= 2^p: CT (uint16 when p <= 15) halves the LDS footprint and
     // doubles the resident waves of this latency-sensitive kernel
@@ -930,12 +933,16 @@ __global__ __launch_bounds__(128) void k_finalize(FinalizeArgs a)
     const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
     // one block = one row of a 128 x 128 tile: everything derived from the tile is block-uniform and is
     // written so that the compiler sees it (scalar loads, SGPR compares, scalar branches)
-    const uint4 tile = a.tiles[blockIdx.x >> 7];
+    // tile descriptor: {row block, column block, plane begin | plane end << 8, smallest | largest << 8 register value of
+    // the two blocks' sketches}: the histogram columns of a block only span the values its own sketches can hold
+    uint4 tile = a.tiles[blockIdx.x >> 7];
+    const int vlo = (int)(tile.w & 0xFFu), vhi = (int)(tile.w >> 8);
+    tile.w = tile.z >> 8;
+    tile.z &= 0xFFu;
     const uint64_t si = (uint64_t)tile.x * kTile + (blockIdx.x & 127u);
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
     if (si >= a.ncols) return;  // padding row (uniform)
     const uint64_t i = a.perm ? a.perm[si] : si;
-    const int vlo = a.vlo, vhi = a.vhi;
     // this tile's own plane range: dense C(v) for v in (Lp, T]
     const int Lp = a.pbase + (int)tile.z, T = a.pbase + (int)tile.w;
     // block-level skip (uniform) when the row sketch cannot be wanted
@@ -1572,7 +1579,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
-    a.cum = f.cum; a.nslots = f.cum_stride; a.tiles = f.tiles; a.perm = f.perm; a.vlo = f.vlo; a.vhi = f.vhi; a.pbase = f.pbase;
+    a.cum = f.cum; a.nslots = f.cum_stride; a.tiles = f.tiles; a.perm = f.perm; a.hist_bins = f.hist_bins; a.pbase = f.pbase;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
     a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist;
     a.cidx_off = f.cidx_off; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;
@@ -1581,7 +1588,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;
-    const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)(f.vhi - f.vlo + 1) * 128 * (f.cum_bytes == 2 ? 2 : 4);
+    const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);

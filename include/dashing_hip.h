@@ -278,7 +278,7 @@ int dsh_set_profiling(dsh_ctx *ctx, int enable);
 int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
                        double *prepare_ms, uint32_t *pair_kernel_launches);
 /* Tunables; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
- * byte-identical output over their ranges): "kc" (16|32|64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
+ * byte-identical output over their ranges): "kc" (0 auto | 16 | 32 | 64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
  * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",

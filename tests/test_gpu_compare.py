@@ -324,7 +324,7 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("pair_mfma", 0)
         ctx.set_option("pair_lockstep", -1)
         ctx.set_option("ls_item_chunks", 16)
-        ctx.set_option("kc", 16)
+        ctx.set_option("kc", 0)
         ctx.set_option("emax", -1)
         ctx.set_option("elow", -1)
         ctx.set_option("sort", -1)
@@ -355,7 +355,7 @@ def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
             assert got.tobytes() == free.tobytes(), (kc, ns, chunks, srt)
         ctx.set_option("ls_sort_items", 1)
         # a row range (odd tile counts) and a rectangle through the same kernel
-        ctx.set_option("kc", 16)
+        ctx.set_option("kc", 0)
         ctx.set_option("nsplit", 0)
         ctx.set_option("ls_item_chunks", 16)
         part = ctx.dist_rows(5, n - 3)
@@ -365,7 +365,7 @@ def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
         assert ctx.dist_rect(0, n // 2, n // 3, n).tobytes() == rect.tobytes()
     finally:
         ctx.set_option("pair_lockstep", -1)
-        ctx.set_option("kc", 16)
+        ctx.set_option("kc", 0)
         ctx.set_option("nsplit", 0)
         ctx.set_option("ls_item_chunks", 16)
         ctx.set_option("ls_sort_items", 1)
