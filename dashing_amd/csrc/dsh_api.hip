@@ -137,11 +137,10 @@ struct dsh_ctx {
     std::vector<uint4> htiles;
     // options
     int kc = 16;      // k-rows per LDS stage in effect (set by prepare from kc_opt)
-    int kc_opt = 0;   // 0 auto: 32 where a plane spans >= 8 such chunks (p >= 13: the unrolled lockstep kernel, -1.3 % on C3,
-                      // profiles/r3f), else 16
+    int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
-    uint64_t cum_budget = 2ull << 30;
+    uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
     int range_sort_min_rows = 1024;  // smaller row ranges keep the cached identity layout (a rebuild costs more than it saves)
@@ -152,8 +151,7 @@ struct dsh_ctx {
     int ls_sort_items = 1;
     int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
-    // (planes of >= 8 chunks, i.e. p >= 12 at kc = 16: tools/lockstep_ab.py -- 4-6 % faster at p = 14/18, 2-3 % at 12,
-    // 5 % SLOWER at p = 10 where a plane is two chunks), 0 never (the free-running k_pair_counts), 1 wherever W >= kc
+    // = 1 = wherever a plane is at least one chunk (W >= kc), 0 never (the free-running k_pair_counts)
     int pair_lockstep = -1;
     int pair_mfma = 0;  // WHAT-IF only: 1 = the AND+popcount tile kernel on the matrix cores (never the default)
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
@@ -268,8 +266,9 @@ bool slots_ok(uint64_t first, uint64_t cnt, uint64_t total) { return first <= to
 
 bool use_lockstep(const dsh_ctx *c)
 {
-    if (c->pair_mfma || c->kc > 32 || c->W < (uint32_t)c->kc || c->pair_lockstep == 0) return false;
-    return c->pair_lockstep > 0 || c->W >= 8u * (uint32_t)c->kc;
+    // wherever a plane is at least one chunk (p >= 9): since the kernel needs one barrier per k-row it beats the
+    // free-running one at every precision (profiles/r3f/lockstep_ab.jsonl: -5 % at p = 10 ... -17 % at p = 16)
+    return !(c->pair_mfma || c->kc > 32 || c->W < (uint32_t)c->kc || c->pair_lockstep == 0);
 }
 
 bool whole_sorted(const dsh_ctx *c)
@@ -290,16 +289,15 @@ inline int key_L(uint32_t k) { return (int)((k >> 6) & 63u); }
 inline int key_T(uint32_t k) { return (int)((k >> 12) & 63u); }
 inline int key_hi(uint32_t k) { return (int)((k >> 18) & 63u); }
 
-// default caps of the two listed tails (profiles/r3b/list_cap_sweep.jsonl).  A pair shares cap^2 / 2^p listed positions
+// default caps of the two listed tails (profiles/r3f/list_cap_sweep.jsonl).  A pair shares cap^2 / 2^p listed positions
 // per side, each one an LDS atomic in k_finalize; every halving of the upper tail (a plane saved) costs twice the
 // entries, while the lower tail of the register law falls off double-exponentially: listing ~200 registers removes
-// the one or two nearly empty planes at the bottom.  Below p = 12 a plane is cheap (<= 64 words per pair) and
-// k_finalize is the hot kernel: short upper lists, no lower ones.
+// the one or two nearly empty planes at the bottom.  2^p / 32 entries per side = one shared position per pair and
+// side on average: 32/32 at p = 10, 128/128 at p = 12, the caps 255/200 from p = 13.
 int auto_list_cap(int p, bool upper)
 {
     const uint64_t m = 1ull << p;
-    if (p < 12) return upper ? (int)(m >> 7) : 0;
-    return upper ? (int)std::min<uint64_t>(kMaxListSide, m >> 5) : (int)std::min<uint64_t>(200, m >> 6);
+    return (int)std::min<uint64_t>(upper ? kMaxListSide : 200, m >> 5);
 }
 
 // dense plane range of the tile (ti, tj): C(v) is needed for v in (max(larger of the two minima, smaller of the two
@@ -443,7 +441,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
-        c->kc = c->kc_opt ? c->kc_opt : (c->W >= 256 ? 32 : 16);
+        c->kc = c->kc_opt ? c->kc_opt : (c->W >= 32 ? 32 : 16);
         c->ncols = ncols;
         c->Npad = (uint32_t)((ncols + kTile - 1) / kTile * kTile);
         // column order: identity, or a counting sort by (threshold, min value, max value): the first

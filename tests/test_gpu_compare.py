@@ -301,7 +301,7 @@ def test_options_do_not_change_results(ctx):
             assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
-        ctx.set_option("cum_budget_bytes", 2 << 30)
+        ctx.set_option("cum_budget_bytes", 8 << 30)
         # the r1 tile kernel (256-thread workgroups, no phase-locking) vs the default lockstep kernel: same integers
         ctx.set_option("pair_lockstep", 0)
         for kc, ns in ((16, 0), (32, 0), (16, 3), (16, 64)):
@@ -330,7 +330,7 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("sort", -1)
         ctx.set_option("nsplit", 0)
         ctx.set_option("xcd_swizzle", 1)
-        ctx.set_option("cum_budget_bytes", 2 << 30)
+        ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
 @pytest.mark.parametrize("p,n", [(8, 300), (9, 300), (10, 700), (11, 300), (12, 260), (13, 300), (15, 200), (16, 150), (18, 40)])
