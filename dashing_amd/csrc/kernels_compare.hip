@@ -1068,33 +1068,59 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint16_t *boff = a.cidx_off + (uint64_t)tile.y * (a.nbuckets + 2);
         const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
         uint32_t *hw = reinterpret_cast<uint32_t *>(hs);
-        for (uint32_t e = tid; e < ni; e += 128) {
-            const int va = (int)av[e];
-            const bool up = va > T, down = va < Lp;
-            if (!(up || down)) continue;
-            const uint32_t pos = ap[e];
-            const uint32_t b = ((pos >> sh) << 1) | (up ? 0u : 1u), plow = pos & ((1u << sh) - 1u);
-            const uint32_t q0 = boff[b], q1 = boff[b + 1];
-            for (uint32_t q = q0; q < q1; ++q) {
-                const uint32_t x = bent[q];
-                const uint32_t jl = (x >> 6) & 127u;
-                const int vb = (int)(x & 63u);
-                // same position, a live value on the column's side too, and a lane that owns a pair (diagonal tile,
-                // row range, padding)
-                if ((x >> 13) != plow || !(up ? vb > T : vb < Lp) || !((actm[jl >> 5] >> (jl & 31u)) & 1u)) continue;
-                // upper tail: the position was counted in both tail histograms, take the smaller value out again;
-                // lower tail: both registers are below the dense range, max(a_t, b_t) is the larger one
-                const int bin = up ? (va < vb ? va : vb) : (va > vb ? va : vb);
-                const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
-                const uint32_t one = sizeof(CT) == 2 ? 1u << (16u * (cell & 1u)) : 1u;
-                uint32_t *w = &hw[sizeof(CT) == 2 ? cell >> 1 : cell];
-                if (up) {
-                    atomicAdd(&corr[jl], 1u);
-                    atomicSub(w, one);  // (the 16-bit half holds >= 1: no borrow into its neighbour)
-                } else {
-                    atomicAdd(w, one);
-                }
+        // The look-ups are three levels of dependent global loads (list entry -> bucket bounds -> bucket entries): the
+        // up to 4 entries a lane takes (|list| <= 510 over 128 lanes) go through each level TOGETHER, and the first two
+        // entries of every bucket (1.8 on average at C3) are fetched unconditionally -- three round trips per block
+        // instead of a dozen one after the other.
+        constexpr int kR = (int)(kListCap / 128);
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        int va[kR];
+        uint32_t pos[kR], q0[kR], q1[kR], x0[kR], x1[kR];
+        bool up[kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const uint32_t e = (uint32_t)tid + 128u * (uint32_t)r;
+            va[r] = e < ni ? (int)av[e] : T;  // (T itself is never listed: neither tail)
+            pos[r] = e < ni ? (uint32_t)ap[e] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            up[r] = va[r] > T;
+            const bool use = up[r] || va[r] < Lp;
+            const uint32_t bk = ((pos[r] >> sh) << 1) | (up[r] ? 0u : 1u);
+            q0[r] = use ? (uint32_t)boff[bk] : 0u;
+            q1[r] = use ? (uint32_t)boff[bk + 1] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            x0[r] = q0[r] < q1[r] ? bent[q0[r]] : kNone;
+            x1[r] = q0[r] + 1 < q1[r] ? bent[q0[r] + 1] : kNone;
+        }
+        auto apply = [&](uint32_t x, int var, bool upr, uint32_t plow) {
+            const uint32_t jl = (x >> 6) & 127u;
+            const int vb = (int)(x & 63u);
+            // same position, a live value on the column's side too, and a lane that owns a pair (diagonal tile, row
+            // range, padding)
+            if (x == kNone || (x >> 13) != plow || !(upr ? vb > T : vb < Lp) || !((actm[jl >> 5] >> (jl & 31u)) & 1u)) return;
+            // upper tail: the position was counted in both tail histograms, take the smaller value out again;
+            // lower tail: both registers are below the dense range, max(a_t, b_t) is the larger one
+            const int bin = upr ? (var < vb ? var : vb) : (var > vb ? var : vb);
+            const uint32_t cell = (uint32_t)(bin - vlo) * 128u + jl;
+            const uint32_t one = sizeof(CT) == 2 ? 1u << (16u * (cell & 1u)) : 1u;
+            uint32_t *w = &hw[sizeof(CT) == 2 ? cell >> 1 : cell];
+            if (upr) {
+                atomicAdd(&corr[jl], 1u);
+                atomicSub(w, one);  // (the 16-bit half holds >= 1: no borrow into its neighbour)
+            } else {
+                atomicAdd(w, one);
             }
+        };
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const uint32_t plow = pos[r] & ((1u << sh) - 1u);
+            apply(x0[r], va[r], up[r], plow);
+            apply(x1[r], va[r], up[r], plow);
+            for (uint32_t q = q0[r] + 2; q < q1[r]; ++q) apply(bent[q], va[r], up[r], plow);
         }
     }
     __syncthreads();
