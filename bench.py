@@ -10,7 +10,9 @@ N>1 (strong scaling, the matrix is fixed): rank r computes the rows [b_r, b_{r+1
 (tile-aligned bounds balanced by tile count, dsh_balance_rows; the plane matrix is laid out for that range, so the rank's result is ONE
 contiguous span of the final packed matrix) and the only exchange is point-to-point: every rank
 sends its span straight into its place on rank 0 (RCCL over xGMI) -- no collective inside the
-compare, no un-permute.
+compare, no un-permute.  The exchange runs through the library's own C-ABI (dsh_comm_init + the pipelined
+dsh_dist_rows_parts_device_async / dsh_collect_parts_async: part q of a rank's rows travels on the copy stream
+while the later parts are still being finalized); `python bench.py --gpus N` launches its N ranks itself.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_pair_counts_ls / k_pair_counts), timed
 with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement of the
@@ -295,7 +297,7 @@ def main():
         "avg_launch_ms": round(avg_launch_ms, 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
         "dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
-        "exception_list_cap": ctx.info("emax"), "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
+        "listed_tail_caps": {"upper": ctx.info("emax"), "lower": ctx.info("elow")}, "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
         "key_ordered_columns": bool(ctx.info("sorted")),
         "note": "SURVEY 8d streaming-model bytes (2*2^p+4 per pair, the reference's own traffic): frac > 1 only says the LDS-tiled kernel is not HBM-bound (each staged sketch is reused 128x); the binding resource is integer VALU issue, see valu_int; physical HBM is physical_hbm_gbs",
         "physical_hbm_gbs": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
@@ -321,13 +323,13 @@ def main():
         "frac_of_nominal_issue_model": round(6.0 / cyc, 4) if cyc else 0.0,
         "ceilings_cycles": {"free_running_mix": 8.18, "phase_locked_mix_with_lds_reads": 6.9, "isolated_sum": 6.13, "nominal_2_plus_4": 6.0},
         "phase_locked_kernel": lockstep,
-        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.06 cycles and BCNTs at one per 4.07-4.42 (run to run), but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with two s_barrier per k-row. In-kernel s_memtime (profiles/r2k): 955 cycles per k-row of two waves = 850 for the phases and barriers + ~65 LDS operand reads + ~40 DMA arrival, + 40 per-chunk overhead",
+        "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.06 cycles and BCNTs at one per 4.07-4.42 (run to run), but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with ONE s_barrier per k-row (after the BCNT batch; round 2 had two: profiles/r3f), the k loop fully unrolled: a k-row is 64 v_and_b32 + 64 v_bcnt_u32_b32 + 4 ds_read_b128 + 1 s_barrier. The chip holds 2.30-2.39 GHz under this mix, so 6.9 shader cycles of the micro-benchmark twin are ~7.1 of the wall cycles quoted here",
     }
     roofline["finalize"] = {
         "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",
         "pairs_per_s": round(my_pairs / (kphase[1] * 1e-3), 1) if kphase[1] > 0 else 0.0,
         "cycles_per_wave64_of_pairs": round(kphase[1] * 1e-3 * CLOCK_HZ * N_SIMD / (my_pairs / 64.0), 1) if kphase[1] > 0 and my_pairs else 0.0,
-        "note": "VALU-issue bound (VALU busy ~80 %); ~75 % of its VALU instructions are the Ertl-MLE estimator (~3 secant iterations x ~17 bins = ~51 steps x 19 instructions, 15 of them dependent fp64 operations, plus fp64 divisions per iteration) that must be reproduced bit for bit -- PMC per phase in profiles/r2g, DESIGN.md 3.2",
+        "note": "VALU-issue bound; most of its VALU instructions are the Ertl-MLE estimator (~3 secant iterations x ~17 bins = ~51 steps x 19 instructions, 15 of them dependent fp64 operations, plus fp64 divisions per iteration) that must be reproduced bit for bit; the sparse tails of the histogram come from a position-index join (k_build_colindex) instead of round 2's per-pair list walk -- profiles/r3a (before), r3b, r3f, DESIGN.md 3.5",
     }
     roofline["step"] = {
         "ms": {"prepare": round(kphase[2], 4), "pair_counts": round(kphase[0], 4), "finalize": round(kphase[1], 4)},
@@ -353,6 +355,7 @@ def main():
         # kernel): the same tile kernel with the AND+popcount done as a 0/1 i8 MFMA (option pair_mfma), same inputs
         ref = full[:total_pairs].clone()
         ctx.set_option("pair_mfma", 1)
+        ctx.set_option("kc", 16)  # (the what-if kernel was tuned at 16 rows per stage: two workgroups per CU)
         ts = []
         for _ in range(3):
             ctx.attach_device(regs_d.data_ptr(), n, p)
@@ -363,6 +366,7 @@ def main():
         same = bool(torch.equal(ref, local[:total_pairs]))
         kw = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), 0, n)], 1)
         ctx.set_option("pair_mfma", 0)
+        ctx.set_option("kc", 0)
         what_if = {"label": "WHAT-IF ONLY, not the shipped path and not `value`: v_mfma_i32_32x32x32_i8 on 0/1 bytes expanded from the bit-planes in registers (option pair_mfma=1, default 0)",
                    "ms_per_step": round(min(ts) * 1e3, 3), "pairs_per_s": total_pairs / min(ts),
                    "k_pair_counts_mfma_ms": round(kw["pair_ms"], 3), "output_identical_to_valu_path": same}

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import dashing_amd  # noqa: E402
 from dashing_amd import synth  # noqa: E402
 
-n, p = 10000, 14
+n, p = int(os.environ.get("N", "10000")), int(os.environ.get("P", "14"))
 regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
 ctx = dashing_amd.Context(0)
 if os.environ.get("C0"):
