@@ -375,6 +375,10 @@ def main():
     if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
         secondary = secondary_p10(ctx, torch, dev, synth, dashing_amd)
 
+    dependence = None
+    if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
+        dependence = data_dependence(ctx, torch, dev, dashing_amd, n, p)
+
     line = None
     if rank == 0:
         line = {
@@ -401,6 +405,8 @@ def main():
             }
         if secondary:
             line["secondary"] = secondary
+        if dependence:
+            line["data_dependence"] = dependence
         if what_if:
             line["what_if_mfma"] = what_if
     ctx.close()
@@ -423,6 +429,40 @@ def main():
     if line is not None:
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+
+
+def data_dependence(ctx, torch, dev, dashing_amd, n, p):
+    """The headline workload is friendly (cardinalities within a factor of 4: few planes per tile).  The same pass on
+    two collections it is NOT -- time is proportional to planes per tile -- so the line carries the spread:
+    (a) cardinalities log-uniform over 1e4 .. 1e8 (a RefSeq-like spread), registers from the register law;
+    (b) registers uniform over [0, q+1]: not the sketch of anything, the adversary of thermometer planes."""
+    m, q1 = 1 << p, 64 - p + 1
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    total = n * (n - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    res = {}
+    cards = torch.exp(torch.empty(n, 1, device=dev, dtype=torch.float64).uniform_(float(np.log(1e4)), float(np.log(1e8)), generator=g))
+    u = torch.rand((n, m), generator=g, device=dev, dtype=torch.float64).clamp_(1e-300, 1.0 - 1e-16)
+    regs_a = torch.ceil(torch.log2((cards / m) / -torch.log(u))).clamp_(0, q1).to(torch.uint8)
+    del u
+    regs_b = torch.randint(0, q1 + 1, (n, m), generator=g, device=dev, dtype=torch.uint8)
+    for name, regs in (("log_uniform_cardinalities_1e4_1e8", regs_a), ("uniform_registers_adversary", regs_b)):
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            ctx.attach_device(regs.data_ptr(), n, p)
+            t0 = time.perf_counter()
+            ctx.dist_rows_device(out.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        res[name] = {"ms_per_step": round(best * 1e3, 3), "pairs_per_s": total / best,
+                     "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0, "dense_planes_global": ctx.info("planes"),
+                     "all_finite": bool(torch.isfinite(out[: 1 << 24]).all())}
+    res["note"] = "same N, p, estimator as the headline; correctness on such inputs is covered by tests/test_gpu_compare.py (adversarial registers, heterogeneous collections) and tests/test_gpu_fuzz.py"
+    del out, regs_a, regs_b
+    torch.cuda.empty_cache()
+    return res
 
 
 def secondary_p10(ctx, torch, dev, synth, dashing_amd, n=100_000, p=10):

@@ -952,13 +952,10 @@ static int dist_main(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
-    // idle OpenMP workers should sleep instead of spinning: between the parallel regions the HIP runtime's own threads
-    // (start-up, copies) need the cores.  libgomp reads OMP_WAIT_POLICY in a constructor that runs before main(), so
-    // setting it here would be too late: re-exec once with it in the environment.
-    if (!std::getenv("OMP_WAIT_POLICY") && !std::getenv("GOMP_SPINCOUNT")) {
-        ::setenv("OMP_WAIT_POLICY", "passive", 1);
-        ::execv("/proc/self/exe", argv);  // (on failure just carry on with the default policy)
-    }
+    // (Round 2 called setenv("OMP_WAIT_POLICY", "passive") here; libgomp reads its environment in a constructor that runs
+    // before main(), so that never took effect -- ADVICE r2 -- and a re-exec with the variable set costs more process
+    // start-up than the few milliseconds idle workers spin by default.  Set OMP_WAIT_POLICY=passive in the environment
+    // if the host threads are needed elsewhere between the parallel regions.)
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
         std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  printmat              (binary distance matrix -> text)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;

@@ -11,6 +11,7 @@ import tempfile
 import time
 
 import numpy as np
+import torch  # noqa: F401  (before dashing_amd: its HIP runtime must be the first one this process loads)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
