@@ -42,6 +42,31 @@ def lib_path():
     return os.path.join(_HERE, "libdashing_hip.so")
 
 
+def _preload_torch_hip_runtime():
+    """A process must hold ONE HIP runtime.  The PyTorch wheel brings its own libamdhip64.so (SONAME libamdhip64.so.7, the
+    name libdashing_hip.so asks for); if this library were loaded first it would pull in /opt/rocm's copy and a later
+    `import torch` would add the wheel's next to it -- torch then finds no GPU.  So when a torch installation exists and
+    is not loaded yet, its runtime is loaded first (tests and bench.py use torch for device buffers; a C++ host never
+    comes here)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Load libdashing_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
     global _LIB
@@ -52,6 +77,7 @@ def load_library():
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C dashing_amd/csrc` (there is no CPU fallback)" % path)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     u64, i32, vp = C.c_uint64, C.c_int, C.c_void_p
     lib.dsh_backend_name.restype = C.c_char_p
