@@ -172,6 +172,17 @@ def test_row_range_in_parts_and_pipelined_collect(ctx, n, p):
     with pytest.raises(dashing_amd.DshError):  # the parts of the exchange must be the parts that were computed
         ctx.collect_parts_async(n, [0, n], 2, local.data_ptr(), final.data_ptr(), 0)
     ctx.wait()
+    # parts that span several bands of the C(v) scratch (a part's event comes after its LAST segment)
+    ctx.set_option("cum_budget_bytes", 1 << 21)
+    try:
+        final.fill_(-2.0)
+        torch.cuda.synchronize()
+        ctx.dist_rows_parts_device_async(local.data_ptr(), 0, n, 3, result_type=dashing_amd.MASH_DIST, k=21)
+        ctx.collect_parts_async(n, [0, n], 3, local.data_ptr(), final.data_ptr(), 0)
+        ctx.wait()
+        assert final.cpu().numpy().tobytes() == full.tobytes()
+    finally:
+        ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
 def test_async_rows_and_wait(ctx):
