@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""configs[3] shape (100 000 x p=10) on one GPU: kernel times with the phase-locked vs the free-running tile kernel and with 2 / 8 GiB
+of C(v) scratch (number of bands)."""
 import sys, json
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, dashing_amd
 from dashing_amd import synth
 n, p = 100000, 10

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Host-side share of a dist call (dsh_get_info host_keys_wait_us / host_layout_us / host_lists_us) for the full C3 triangle and
+for the first and last of 8 ranks' row ranges: what sits between the per-sketch pass and the tile kernel (profiles/r3f)."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, dashing_amd
 from dashing_amd import synth
 n, p = 10000, 14
