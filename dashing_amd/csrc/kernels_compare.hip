@@ -5,27 +5,31 @@
 // -> hll_t::jaccard_index -> union_size = estimate(histogram(max(a,b))).
 //
 // Formulation.  Per pair the reference needs the exact histogram
-// c[x] = #{t : max(a_t,b_t) = x}.  It is assembled from two exact pieces:
-//  (1) dense part, x < T: thermometer bit-planes A_v[t] = (a_t < v), v in (lo, T]:
+// c[x] = #{t : max(a_t,b_t) = x}.  For a tile with the dense value range (Lp, T] it is assembled from three exact pieces:
+//  (1) dense part, Lp <= x < T: thermometer bit-planes A_v[t] = (a_t < v), v in (Lp, T]:
 //        C(v) = #{t : max(a_t,b_t) < v} = popcount(A_v & B_v),   c[x] = C(x+1) - C(x)
-//      -- the O(N^2 * 2^p) work: v_and_b32 + v_bcnt_u32_b32 over LDS-staged planes (integer
-//      work, no MFMA);
-//  (2) sparse tail, x > T: every sketch keeps the (position,value) list of its <= emax
-//      registers above its own threshold T_i <= T (the geometric tail of the register law);
-//      max(a_t,b_t) > T iff t is in one of the two lists, so the union of the two lists
-//      (LDS hash of list i, walk of list j) gives c[x] for x > T and |union| = m - C(T+1),
-//      hence c[T] as well.
+//      -- the O(N^2 * 2^p) work: v_and_b32 + v_bcnt_u32_b32 over LDS-staged planes (integer work, no MFMA);
+//  (2) upper tail, x > T: every sketch lists the (position, value) of its <= emax registers above its own T_i <= T (the
+//      geometric tail of the register law); the tail bins are the sum of the two sketches' tail histograms minus, at
+//      every position BOTH list, the smaller value; C(T+1) = m - |union| gives c[T];
+//  (3) lower tail, x < Lp: every sketch also lists its <= elow registers below its L_i (the lower tail falls off
+//      double-exponentially: the bottom planes are nearly empty); the bins below Lp are exactly the positions both
+//      sketches list there, at the larger value; their number is C(Lp).
+// The positions two sketches share are found by a sparse join through a per-column-block position index, not by walks.
 // The estimator then runs once per pair in fp64.
 //
 // Kernels:
-//   k_selfhist_card  per sketch: 64-bin histogram (LDS atomics) -> cardinality, value range,
-//                    threshold T_i, sorted exception list
-//   k_transform      uint8 registers [N][m] -> bit-plane matrix planes[K][Npad] (u32 words,
-//                    row kk = plane*W + word, sketch index fastest)
-//   k_pair_counts    128x128-sketch tiles: plane rows streamed through double-buffered LDS by
-//                    LDS-DMA, each lane owns an 8x8 block of pairs; writes C(v) per pair
-//   k_finalize       one lane per pair: C(v) differences + exception union -> histogram (LDS
-//                    column) -> estimator -> J -> Mash transform -> float at the packed index
+//   k_selfhist_card   per sketch: 64-bin histogram (LDS atomics) -> value range, thresholds T_i / L_i, key, the list
+//   k_card_from_hist  one lane per sketch: cardinality from the histogram
+//   k_build_colindex  per 128-column block: its sketches' listed registers bucketed by (position, tail)
+//   k_transform(_t)   uint8 registers [N][m] -> bit-plane matrix planes[K][Npad] (u32 words, row kk = plane*W + word,
+//                     sketch index fastest)
+//   k_pair_counts_ls  128x128-sketch tiles, two per 512-thread workgroup, AND and BCNT batches phase-locked across the waves
+//                     of a SIMD (one barrier per k-row); plane rows streamed through double-buffered LDS by LDS-DMA, each
+//                     lane owns an 8x8 block of pairs; writes C(v) per pair.  (k_pair_counts: the free-running form, p < 9)
+//   k_finalize        one lane per pair: C(v) differences + the two tail joins -> histogram (LDS column) -> estimator -> J
+//                     -> Mash transform -> float at the packed index
+//   k_topk(_merge)    nearest neighbours;  k_unpermute*  the older shard scheme;  k_upload  in-order list uploads
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
