@@ -1364,13 +1364,14 @@ __global__ __launch_bounds__(256) void k_topk_merge(const float *__restrict__ va
     uint32_t pi = 0;
     bool first = true;
     for (uint32_t t = 0; t < nn; ++t) {
-        float bv = worst;
+        float bv = worst, braw = worst;  // bv: the value the order uses (NaN ranks as the worst), braw: what is reported
         uint32_t bi = 0xFFFFFFFFu;
-        auto offer = [&](float x, uint32_t id) {
-            if (x != x) x = worst;
+        auto offer = [&](float raw, uint32_t id) {
+            const float x = raw != raw ? worst : raw;
             if (!first && !before(pv, pi, x, id)) return;  // not after the previous pick
             if (bi == 0xFFFFFFFFu || before(x, id, bv, bi)) {
                 bv = x;
+                braw = raw;
                 bi = id;
             }
         };
@@ -1382,16 +1383,17 @@ __global__ __launch_bounds__(256) void k_topk_merge(const float *__restrict__ va
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            const float ov = __shfl_xor(bv, d, 64);
+            const float ov = __shfl_xor(bv, d, 64), oraw = __shfl_xor(braw, d, 64);
             const uint32_t oi = __shfl_xor(bi, d, 64);
             if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || before(ov, oi, bv, bi))) {
                 bv = ov;
+                braw = oraw;
                 bi = oi;
             }
         }
         if (lane == 0) {
             st_idx[(uint64_t)self * nn + t] = bi;
-            st_val[(uint64_t)self * nn + t] = bi == 0xFFFFFFFFu ? worst : bv;
+            st_val[(uint64_t)self * nn + t] = bi == 0xFFFFFFFFu ? worst : braw;  // (a NaN stays a NaN, as k_topk reports it)
         }
         pv = bv;
         pi = bi;

@@ -63,8 +63,10 @@ def test_random_case(ctx, oracle, case):
         a, b = rng.choice(n, 2, replace=False)
         regs[a] = regs[b]
     ctx.set_sketches(regs)
-    emax = int(rng.choice([-1, -1, 0, 3, 17, 255]))  # exception-list length: a speed knob, never a result knob
+    emax = int(rng.choice([-1, -1, 0, 3, 17, 255]))  # caps of the two listed tails: speed knobs, never result knobs
+    elow = int(rng.choice([-1, -1, 0, 2, 40, 255]))
     ctx.set_option("emax", emax)
+    ctx.set_option("elow", elow)
     want = oracle.dist_tri(regs, estim, rt, k)
     ig = iw = None
     if rt in INDEX_OF:
@@ -118,4 +120,27 @@ def test_random_case(ctx, oracle, case):
     ctx.unpermute_device(sf.data_ptr(), fin.data_ptr())
     ctx.synchronize()
     _close(fin.cpu().numpy()[:total], want, ig, iw)
+    # the same rows in parts (each key-ordered on its own, an event per part): byte-identical to the plain range
+    if part.size:
+        nparts = int(rng.integers(2, 6))
+        pd = torch.full((part.size,), -9.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.set_option("range_sort_min_rows", 1)
+        try:
+            ctx.dist_rows_parts_device_async(pd.data_ptr(), rb, re, nparts, estim=estim, result_type=rt, k=k)
+            ctx.wait()
+        finally:
+            ctx.set_option("range_sort_min_rows", 1024)
+        assert pd.cpu().numpy().tobytes() == part.tobytes()
+    # nearest neighbours: the band path (no n x n matrix) selects what the square path selects
+    if n > 3 and case % 4 == 0:
+        nn = int(rng.integers(1, min(n, 9)))
+        si, sv = ctx.knn(nn, estim=estim, result_type=rt, k=k)
+        ctx.set_option("knn_square_budget_bytes", 0)
+        try:
+            bi, bv = ctx.knn(nn, estim=estim, result_type=rt, k=k)
+        finally:
+            ctx.set_option("knn_square_budget_bytes", 96 << 30)
+        assert (si == bi).all() and (sv.view(np.uint32) == bv.view(np.uint32)).all()
     ctx.set_option("emax", -1)
+    ctx.set_option("elow", -1)
