@@ -16,18 +16,32 @@ import dashing_amd  # noqa: E402
 from dashing_amd import synth  # noqa: E402
 
 n, p = int(os.environ.get("N", "10000")), int(os.environ.get("P", "14"))
-regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
+if n <= 100000:
+    regs = torch.from_numpy(synth.survey_sketches(n, p)[0]).cuda()
+else:  # sketch g = max(base[a_g], base[b_g]): unions of two base sets, built on the device (as tests/test_gpu_configs.py)
+    nbase = 4000
+    bd = torch.from_numpy(synth.survey_sketches(nbase, p)[0]).cuda()
+    regs = torch.empty((n, 1 << p), dtype=torch.uint8, device="cuda")
+    regs[:nbase] = bd
+    g = torch.arange(nbase, n, device="cuda", dtype=torch.int64)
+    a, b2 = g % nbase, (g * 2654435761 + 12345) % nbase
+    for s0 in range(0, n - nbase, 1 << 14):
+        e0 = min(n - nbase, s0 + (1 << 14))
+        regs[nbase + s0 : nbase + e0] = torch.maximum(bd[a[s0:e0]], bd[b2[s0:e0]])
+    torch.cuda.synchronize()
 ctx = dashing_amd.Context(0)
 if os.environ.get("C0"):
     ctx.set_option("shard_c0_x10", int(os.environ["C0"]))
-for G in (1, 2, 4, 8):
+GS = tuple(int(x) for x in os.environ.get("GS", "1,2,4,8").split(","))
+REPS = int(os.environ.get("REPS", "3"))
+for G in GS:
     b = dashing_amd.balance_rows(n, G)
     mx = max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(G))
     out = torch.empty(mx, dtype=torch.float32, device="cuda")
     rows = []
     for r in range(G):
         best = 1e9
-        for _ in range(3):
+        for _ in range(REPS):
             ctx.attach_device(regs.data_ptr(), n, p)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -37,7 +51,7 @@ for G in (1, 2, 4, 8):
         rows.append(round(best * 1e3, 3))
     print(json.dumps({"G": G, "range_ms": rows, "max_ms": max(rows), "row_bounds": b, "planes_per_tile_last_rank": ctx.info("avg_tile_planes_x100") / 100}))
 # the same ranges computed in parts (what the pipelined exchange needs): cost of the extra launches / tails
-for nparts in (2, 4):
+for nparts in (() if os.environ.get("NO_PARTS") else (2, 4)):
     G = 8
     b = dashing_amd.balance_rows(n, G)
     mx = max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(G))
@@ -54,7 +68,7 @@ for nparts in (2, 4):
             best = min(best, time.perf_counter() - t0)
         rows.append(round(best * 1e3, 3))
     print(json.dumps({"G": G, "nparts": nparts, "range_ms": rows, "max_ms": max(rows), "parts_rank0": dashing_amd.range_parts(n, b[0], b[1], nparts)}))
-for G in (1, 2, 4, 8):
+for G in (() if os.environ.get("NO_SHARDS") else (1, 2, 4, 8)):
     ctx.attach_device(regs.data_ptr(), n, p)
     off = ctx.shard_plan(G)
     mx = max(off[r + 1] - off[r] for r in range(G))
@@ -71,6 +85,8 @@ for G in (1, 2, 4, 8):
             best = min(best, time.perf_counter() - t0)
         rows.append(round(best * 1e3, 3))
     print(json.dumps({"G": G, "shard_ms": rows, "max_ms": max(rows), "pairs_share": [round((off[r + 1] - off[r]) / off[-1], 3) for r in range(G)]}))
+if os.environ.get("NO_SHARDS"):
+    sys.exit(0)
 # unpermute cost
 full = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device="cuda")
 fin = torch.empty_like(full)
