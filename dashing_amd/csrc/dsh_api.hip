@@ -140,6 +140,7 @@ struct dsh_ctx {
     int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
+    size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call
     uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
     int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
@@ -660,27 +661,42 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     const uint64_t per_tile = (uint64_t)kTile * kTile * c->cum_bytes * std::max<uint32_t>(c->P, 1);
     const uint64_t max_tiles = std::max<uint64_t>(1, c->cum_budget / per_tile);
     std::vector<std::pair<size_t, size_t>> bands;
+    // Parts (dsh_dist_rows_parts_device_async): k_finalize runs once per SEGMENT -- the tiles of one part inside one
+    // band -- and an event marks the end of a part's last segment: the part's span of the matrix is final and can travel
+    // while the other parts are computed.  The tile kernel runs once per band; a band is also cut at a part boundary
+    // when the part is large (>= kPartBandTiles tiles: a cut costs 0.2-0.3 ms -- two tails and a pipeline bubble,
+    // profiles/r3g -- nothing against the ~1 ms per 1 000 tiles the part takes, and the first part can leave after 1/nparts of
+    // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
+    constexpr size_t kPartBandTiles = 2048;
+    const bool parts_on = !job.rect && !job.sorted_rows && c->planes_sorted && c->lay_parts.size() > 2 && job.nparts > 1;
+    auto part_of_tile = [&](size_t t) -> size_t {
+        if (!parts_on) return 0;
+        const uint64_t pos = (uint64_t)T[t].x * kTile;
+        size_t q = 0;
+        while (q + 2 < c->lay_parts.size() && pos >= c->lay_parts[q + 1] - c->lay_rb) ++q;
+        return q;
+    };
     for (size_t b = 0; b < T.size();) {
-        const size_t e = std::min<size_t>(T.size(), b + max_tiles);
+        size_t e = std::min<size_t>(T.size(), b + max_tiles);
+        if (parts_on) {  // end of the part b belongs to, if that part is large
+            const size_t q = part_of_tile(b);
+            size_t pe_ = b;
+            while (pe_ < e && part_of_tile(pe_) == q) ++pe_;
+            size_t pb_ = b;
+            while (pb_ > 0 && part_of_tile(pb_ - 1) == q) --pb_;
+            size_t pend = pe_;
+            while (pend < T.size() && part_of_tile(pend) == q) ++pend;
+            if (pend - pb_ >= kPartBandTiles) e = pe_;
+        }
         bands.emplace_back(b, e);
         b = e;
     }
-    // Parts (dsh_dist_rows_parts_device_async): the tile kernel runs once per band, k_finalize once per SEGMENT -- the
-    // tiles of one part inside one band -- and an event marks the end of a part's last segment: the part's span of the
-    // matrix is final and can travel while the other parts are finalized.  (Cutting the tile kernel as well costs
-    // 0.2-0.3 ms per cut at C3 / 8 ranks: two tails and a pipeline bubble, profiles/r3e.)
     struct Seg { size_t b, e; int part; };  // tiles [b, e) of T; part completed by this segment or -1
+    c->last_bands = bands.size();
     std::vector<std::vector<Seg>> segs(bands.size());
     {
-        const bool with_parts = !job.rect && !job.sorted_rows && c->planes_sorted && c->lay_parts.size() > 2 && job.nparts > 1;
-        // part of a tile = part of its tile row (parts are consecutive runs of whole tile rows of the layout)
-        auto part_of = [&](size_t t) -> size_t {
-            if (!with_parts) return 0;
-            const uint64_t pos = (uint64_t)T[t].x * kTile;
-            size_t q = 0;
-            while (q + 2 < c->lay_parts.size() && pos >= c->lay_parts[q + 1] - c->lay_rb) ++q;
-            return q;
-        };
+        const bool with_parts = parts_on;
+        auto part_of = part_of_tile;  // part of a tile = part of its tile row (parts are runs of whole tile rows of the layout)
         for (size_t bi = 0; bi < bands.size(); ++bi) {
             size_t b = bands[bi].first;
             while (b < bands[bi].second) {
@@ -1428,7 +1444,8 @@ int dsh_dist_rows(dsh_ctx *c, int estim, int result_type, int k, uint64_t rb, ui
 int dsh_wait(dsh_ctx *c) { return dsh_synchronize(c); }
 
 // A ticket marks "everything enqueued on this ctx so far" (kernels on the ctx stream and the copies of
-// dsh_dist_rows_async on the copy stream); waiting for it does not wait for work enqueued afterwards.
+// dsh_dist_rows_async / transfers of dsh_collect_parts_async on the copy stream); waiting for it does not wait for work
+// enqueued afterwards, and recording it orders nothing between the two streams.
 int dsh_event_record(dsh_ctx *c, uint64_t *ticket)
 {
     if (!c || !ticket) return DSH_EINVAL;
@@ -1465,9 +1482,10 @@ int dsh_event_wait(dsh_ctx *c, uint64_t ticket)
     if (!c) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    hipEvent_t e = nullptr;
-    if ((rc = ticket_event(c, ticket, &e))) return rc;
-    if (e) HIPCHK(c, hipEventSynchronize(e));
+    hipEvent_t e[2] = {nullptr, nullptr};
+    if ((rc = ticket_event(c, ticket, e))) return rc;
+    for (hipEvent_t x : e)
+        if (x) HIPCHK(c, hipEventSynchronize(x));
     return DSH_OK;
 }
 
@@ -1476,11 +1494,12 @@ int dsh_event_query(dsh_ctx *c, uint64_t ticket, int *done)
     if (!c || !done) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    hipEvent_t e = nullptr;
-    if ((rc = ticket_event(c, ticket, &e))) return rc;
+    hipEvent_t e[2] = {nullptr, nullptr};
+    if ((rc = ticket_event(c, ticket, e))) return rc;
     *done = 1;
-    if (e) {
-        const hipError_t q = hipEventQuery(e);
+    for (hipEvent_t x : e) {
+        if (!x) continue;
+        const hipError_t q = hipEventQuery(x);
         if (q == hipErrorNotReady) *done = 0;
         else if (q != hipSuccess) return fail(c, DSH_EIO, "hipEventQuery: %s", hipGetErrorString(q));
     }
@@ -1882,6 +1901,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "ncols")) *out = (int64_t)c->ncols;
     else if (!std::strcmp(name, "lockstep")) *out = c->planes_valid && use_lockstep(c) ? 1 : 0;
     else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->htiles.size();
+    else if (!std::strcmp(name, "bands")) *out = (int64_t)c->last_bands;
     else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
         uint64_t tot = 0;
@@ -1996,7 +2016,9 @@ int dsh_comm_init(dsh_ctx *c, const void *unique_id, int rank, int world)
     if (rc) return rc;
     Rccl *r = rccl();
     if (!r->h) return fail(c, DSH_ENODEV, "RCCL is not available (%s)", r->err.c_str());
-    if (c->comm) {
+    if (c->comm) {  // re-initialisation: nothing of the old communicator may still be in flight on either stream
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
         NCCLCHK(c, r->CommDestroy(c->comm));
         c->comm = nullptr;
     }
@@ -2015,6 +2037,7 @@ int dsh_comm_destroy(dsh_ctx *c)
     if (rc) return rc;
     if (c->comm) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));  // dsh_collect_parts_async sends there
         NCCLCHK(c, rccl()->CommDestroy(c->comm));
         c->comm = nullptr;
     }
@@ -2100,6 +2123,8 @@ int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint
     if (!c->comm && !(bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
     if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d", dst);
     if (bounds[0] != 0 || bounds[world] != n) return fail(c, DSH_EINVAL, "bounds must run from 0 to n over the %d ranks", world);
+    for (int r = 0; r < world; ++r)
+        if (bounds[r] > bounds[r + 1]) return fail(c, DSH_EINVAL, "bounds not monotone at rank %d", r);
     if (rank == dst && !d_final) return DSH_EINVAL;
     // every rank's parts, from the same function the compute used (dsh_range_parts): both sides of a message agree
     std::vector<std::vector<uint64_t>> parts((size_t)world);

@@ -1047,7 +1047,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int s_ = 0; s_ < 48; ++s_) {
             const int x = x0 + s_;
-            if (x <= T || x > vhi) continue;  // uniform
+            if (x > vhi) break;  // uniform
+            if (x <= T) continue;
             const uint32_t qj = (qw[s_ >> 2] >> (8 * (s_ & 3))) & 0xFFu;
             nb += qj;
             dst[s_ * 128] = (CT)(hA[s_] + qj);
@@ -1065,7 +1066,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     // ---- the join: lane e takes the row sketch's e-th listed register
     {
-        const uint32_t ni = a.exc_n[i];
+        const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.exc_n[i]);
+        const int nr = (int)((ni + 127u) >> 7);  // rounds that hold an entry (uniform): 1 at p <= 11, up to 4 at p = 14
         const PT *ap = reinterpret_cast<const PT *>(a.exc) + i * kListCap;
         const uint8_t *av = a.excv + i * kListCap;
         const uint32_t sh = a.p > 14 ? (uint32_t)(a.p - 14) : 0u;
@@ -1083,12 +1085,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         bool up[kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
+            if (r >= nr) break;
             const uint32_t e = (uint32_t)tid + 128u * (uint32_t)r;
             va[r] = e < ni ? (int)av[e] : T;  // (T itself is never listed: neither tail)
             pos[r] = e < ni ? (uint32_t)ap[e] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
+            if (r >= nr) break;
             up[r] = va[r] > T;
             const bool use = up[r] || va[r] < Lp;
             const uint32_t bk = ((pos[r] >> sh) << 1) | (up[r] ? 0u : 1u);
@@ -1097,6 +1101,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
+            if (r >= nr) break;
             x0[r] = q0[r] < q1[r] ? bent[q0[r]] : kNone;
             x1[r] = q0[r] + 1 < q1[r] ? bent[q0[r] + 1] : kNone;
         }
@@ -1121,6 +1126,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         };
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
+            if (r >= nr) break;
             const uint32_t plow = pos[r] & ((1u << sh) - 1u);
             apply(x0[r], va[r], up[r], plow);
             apply(x1[r], va[r], up[r], plow);

@@ -287,7 +287,7 @@ int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_ke
  * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
- * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles",
+ * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands",
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.

@@ -185,6 +185,40 @@ def test_row_range_in_parts_and_pipelined_collect(ctx, n, p):
         ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
+def test_large_parts_cut_the_tile_kernel(ctx):
+    """parts of >= 2 048 tiles also end a band of the tile kernel (run_pairs, kPartBandTiles): the span stays the
+    byte-identical one and every part's event still follows its last segment (pipelined collect into a second buffer)"""
+    import torch
+
+    n, p = 24000, 10
+    regs = torch.from_numpy(synth.survey_sketches(n, p, seed=0xBA4D)[0]).cuda()
+    dev = torch.device("cuda", 0)
+    total = n * (n - 1) // 2
+    ref = torch.empty(total, dtype=torch.float32, device=dev)
+    ctx.attach_device(regs.data_ptr(), n, p)
+    ctx.dist_rows_device(ref.data_ptr(), 0, n)
+    ctx.synchronize()
+    for rb, re in ((0, n), (4096, 20000)):
+        for nparts in (2, 3):
+            span, lo = dashing_amd.tri_span(n, rb, re), dashing_amd.tri_span(n, 0, rb)
+            local = torch.full((span,), -1.0, dtype=torch.float32, device=dev)
+            final = torch.full((span,), -2.0, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            ctx.attach_device(regs.data_ptr(), n, p)
+            ctx.dist_rows_parts_device_async(local.data_ptr(), rb, re, nparts)
+            ctx.wait()
+            assert ctx.info("bands") == nparts  # one band per (large) part
+            assert torch.equal(local.view(torch.int32), ref[lo : lo + span].view(torch.int32)), (rb, re, nparts)
+            del local, final
+    local = torch.full((total,), -1.0, dtype=torch.float32, device=dev)
+    final = torch.full((total,), -2.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.dist_rows_parts_device_async(local.data_ptr(), 0, n, 4)
+    ctx.collect_parts_async(n, [0, n], 4, local.data_ptr(), final.data_ptr(), 0)
+    ctx.wait()
+    assert torch.equal(final.view(torch.int32), ref.view(torch.int32))
+
+
 def test_async_rows_and_wait(ctx):
     """dsh_dist_rows_async / dsh_wait (the reference's ping-pong buffers, src/sketch_and_cmp.h:804-816): calls
     return before the work is done, may be issued back to back, and deliver the blocking call's bytes."""

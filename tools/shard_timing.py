@@ -51,7 +51,7 @@ for G in GS:
         rows.append(round(best * 1e3, 3))
     print(json.dumps({"G": G, "range_ms": rows, "max_ms": max(rows), "row_bounds": b, "planes_per_tile_last_rank": ctx.info("avg_tile_planes_x100") / 100}))
 # the same ranges computed in parts (what the pipelined exchange needs): cost of the extra launches / tails
-for nparts in (() if os.environ.get("NO_PARTS") else (2, 4)):
+for nparts in (() if os.environ.get("NO_PARTS") else (2, 4, 8)):
     G = 8
     b = dashing_amd.balance_rows(n, G)
     mx = max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(G))
@@ -67,7 +67,25 @@ for nparts in (() if os.environ.get("NO_PARTS") else (2, 4)):
             ctx.synchronize()
             best = min(best, time.perf_counter() - t0)
         rows.append(round(best * 1e3, 3))
-    print(json.dumps({"G": G, "nparts": nparts, "range_ms": rows, "max_ms": max(rows), "parts_rank0": dashing_amd.range_parts(n, b[0], b[1], nparts)}))
+    # exchange model (NOT measured: one GPU here): rank 0 receives every other rank's span over that rank's own xGMI link,
+    # all links at once, at 45 GB/s per link (about what RCCL point-to-point reaches on one link) + 20 us per round of
+    # grouped send/recv.  Part q of a rank can leave when its last k_finalize segment is done (~ (q+1)/nparts of the rank's
+    # time when the tile kernel is cut per part -- large parts -- else after the whole tile kernel); a link carries one
+    # part at a time: done_q = max(ready_q, done_{q-1}) + bytes_q / link.  step = max over ranks of done_last.
+    LINK = 45e9
+    step, worst = max(rows), 0
+    for r in range(1, G):
+        pr = dashing_amd.range_parts(n, b[r], b[r + 1], nparts)
+        done = 0.0
+        for q in range(len(pr) - 1):
+            by = dashing_amd.tri_span(n, pr[q], pr[q + 1]) * 4
+            ready = rows[r] * (q + 1) / (len(pr) - 1)
+            done = max(ready, done) + by / LINK * 1e3 + 0.02
+        if done > step:
+            step, worst = done, r
+    print(json.dumps({"G": G, "nparts": nparts, "range_ms": rows, "max_ms": max(rows), "parts_rank0": dashing_amd.range_parts(n, b[0], b[1], nparts),
+                      "exchange_model": {"assumed_link_GBs": 45, "span_bytes_per_link_max": max(dashing_amd.tri_span(n, b[r], b[r + 1]) for r in range(1, G)) * 4,
+                                         "step_model_ms": round(step, 3), "bound_by": "link of rank %d" % worst if worst else "compute"}}))
 for G in (() if os.environ.get("NO_SHARDS") else (1, 2, 4, 8)):
     ctx.attach_device(regs.data_ptr(), n, p)
     off = ctx.shard_plan(G)
