@@ -140,6 +140,8 @@ struct dsh_ctx {
     int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
+    std::vector<uint32_t> tile_rank;  // scratch of run_pairs
+    int finalize_rowmajor = 1;        // k_finalize walks every segment's tiles in row-major order (option, A/B only)
     size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call
     uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
     int xcd_swizzle = 1;
@@ -572,11 +574,12 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint
 // Order the tiles of a band so that workgroups that run on the same XCD (block b -> XCD b % 8,
 // observed dispatch behaviour; speed only, never correctness) walk one tile row together and
 // share its A panel in that XCD's L2.
-void xcd_order(std::vector<uint4> &t, size_t b, size_t e, size_t group)
+void xcd_order(std::vector<uint4> &t, std::vector<uint32_t> &rank, size_t b, size_t e, size_t group)
 {
     const size_t cnt = e - b;
     if (cnt < 16) return;
     std::vector<uint4> tmp(cnt);
+    std::vector<uint32_t> rtmp(cnt);
     const size_t nx = 8, per = (cnt + nx - 1) / nx;
     // `group` consecutive positions of the launch order share a workgroup (2 with the lockstep kernel); workgroup w
     // runs on XCD w % 8; give XCD x the contiguous range [x*per, (x+1)*per) of the row-major list
@@ -585,9 +588,13 @@ void xcd_order(std::vector<uint4> &t, size_t b, size_t e, size_t group)
         for (size_t x = 0; x < nx; ++x)
             for (size_t u = 0; u < group && r + u < per; ++u) {
                 const size_t src = x * per + r + u;
-                if (src < cnt) tmp[q++] = t[b + src];
+                if (src < cnt) {
+                    rtmp[q] = rank[b + src];
+                    tmp[q++] = t[b + src];
+                }
             }
     std::copy(tmp.begin(), tmp.begin() + q, t.begin() + b);
+    std::copy(rtmp.begin(), rtmp.begin() + q, rank.begin() + b);
 }
 
 struct PairJob {
@@ -710,9 +717,15 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         }
         c->parts_done = 0;
     }
+    // rank[t] = position of tile t in the row-major order of its segment (the order k_finalize walks, see below)
+    std::vector<uint32_t> &rank = c->tile_rank;
+    rank.resize(T.size());
+    for (auto &sv : segs)
+        for (auto &sg : sv)
+            for (size_t t = sg.b; t < sg.e; ++t) rank[t] = (uint32_t)(t - sg.b);
     if (c->xcd_swizzle)
         for (auto &sv : segs)
-            for (auto &sg : sv) xcd_order(T, sg.b, sg.e, use_lockstep(c) ? 2 : 1);
+            for (auto &sg : sv) xcd_order(T, rank, sg.b, sg.e, use_lockstep(c) ? 2 : 1);
     // work items per band: {tile index in band, chunk begin, chunk end}
     const uint32_t KC = (uint32_t)c->kc;
     auto chunk_range = [&](const uint4 &t, uint32_t &cb, uint32_t &ce) {
@@ -768,10 +781,17 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         HIPCHK(c, hipEventSynchronize(c->ev_lists));
         c->lists_in_flight = false;
     }
-    HIPCHK(c, c->pin_lists.ensure((T.size() + std::max<size_t>(I.size(), 1)) * sizeof(uint4)));
-    uint4 *pinT = (uint4 *)c->pin_lists.ptr, *pinI = pinT + T.size();
-    // device form of a tile: {row block, column block, plane begin | plane end << 8, smallest | largest << 8 register
-    // value of its two blocks} -- k_finalize's histogram columns only span the values the tile's sketches can hold
+    HIPCHK(c, c->pin_lists.ensure((2 * T.size() + std::max<size_t>(I.size(), 1)) * sizeof(uint4)));
+    uint4 *pinT = (uint4 *)c->pin_lists.ptr, *pinF = pinT + T.size(), *pinI = pinF + T.size();
+    // The tile kernel's list (launch order: XCD-interleaved, see xcd_order) holds {row block, column block, ..}.
+    // k_finalize has its own list, every segment in ROW-MAJOR order: {row block, column block, plane begin | plane end
+    // << 8 | smallest << 16 | largest << 24 register value of the two blocks' sketches (its histogram columns only span
+    // the values the tile's sketches can hold), index of the tile's C(v) block in the band}.  A block of k_finalize
+    // writes one row of a tile into row perm[si] of the packed matrix, scattered over the row (the columns are
+    // key-ordered); block b runs on XCD b % 8 = tile row % 8, so a given output row is always written through the same
+    // L2.  Walking a tile row's tiles one after the other keeps that row's lines in L2 until they are complete (the 128
+    // rows of a tile row are 5 MB at C3, spread over the 8 L2s); in the tile kernel's interleaved order 8 tile rows were
+    // in flight at once, lines left the L2 partly written and WRITE_SIZE was 6x the output (profiles/r3a, r3i).
     auto tile_vrange = [&](const uint4 &t, int &lo, int &hi) {
         lo = std::min<int>(c->blk_lo[t.x], c->blk_lo[t.y]);
         hi = std::max<int>(c->blk_hi[t.x], c->blk_hi[t.y]);
@@ -782,10 +802,19 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         tile_vrange(T[t], lo, hi);
         pinT[t] = make_uint4(T[t].x, T[t].y, T[t].z | (T[t].w << 8), (uint32_t)lo | ((uint32_t)hi << 8));
     }
+    for (size_t bi = 0; bi < bands.size(); ++bi)
+        for (const Seg &sg : segs[bi])
+            for (size_t t = sg.b; t < sg.e; ++t) {
+                int lo, hi;
+                tile_vrange(T[t], lo, hi);
+                const size_t at = c->finalize_rowmajor ? sg.b + rank[t] : t;
+                pinF[at] = make_uint4(T[t].x, T[t].y, T[t].z | (T[t].w << 8) | ((uint32_t)lo << 16) | ((uint32_t)hi << 24),
+                                      (uint32_t)(t - bands[bi].first));
+            }
     if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
     c->host_lists_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();
-    HIPCHK(c, c->tiles.ensure(T.size() * sizeof(uint4)));
-    HIPCHK(c, launch_upload(c->stream, c->tiles.ptr, pinT, T.size() * sizeof(uint4)));
+    HIPCHK(c, c->tiles.ensure(2 * T.size() * sizeof(uint4)));  // [tile kernel's list | k_finalize's list]
+    HIPCHK(c, launch_upload(c->stream, c->tiles.ptr, pinT, 2 * T.size() * sizeof(uint4)));
     HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
     if (!I.empty())
         HIPCHK(c, launch_upload(c->stream, c->items.ptr, pinI, I.size() * sizeof(uint4)));
@@ -824,8 +853,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         if (b) (void)hipEventRecord(b, c->stream);
         for (const Seg &sg : segs[bi]) {
             FinalizeLaunch f;
-            const uint64_t seg_off = (uint64_t)(sg.b - bd.first) * kTile * kTile;  // first pair slot of the segment in the band
-            f.cum = (const char *)c->cum.ptr + seg_off * (uint64_t)c->cum_bytes;
+            f.cum = c->cum.ptr;  // the band's C(v); a tile's block is named by its descriptor
             f.cum_bytes = c->cum_bytes;
             f.cum_stride = nslots;
             f.hist_bins = 1;
@@ -840,7 +868,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.keys = (const uint32_t *)c->keys.ptr;
             f.tailhist = (const uint8_t *)c->tailhist.ptr;
             f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
-            f.tiles = (const uint4 *)c->tiles.ptr + sg.b;
+            f.tiles = (const uint4 *)c->tiles.ptr + T.size() + sg.b;
             f.perm = c->planes_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
             f.pbase = c->pbase;
             f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
@@ -1987,6 +2015,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "emax") || !std::strcmp(name, "elow")) {
         if (v < -1 || v > (int64_t)kMaxListSide) return fail(c, DSH_EINVAL, "%s must be in [-1,%u]", name, kMaxListSide);
         (name[1] == 'm' ? c->emax_opt : c->elow_opt) = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_rowmajor")) {
+        c->finalize_rowmajor = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "xcd_swizzle")) {

@@ -934,14 +934,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     CT *hs = reinterpret_cast<CT *>(hs_raw + (64 + 128 + 8) * 4);
     using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
     const int tid = threadIdx.x;
-    const uint64_t slot = (uint64_t)blockIdx.x * 128 + tid;  // nslots is a multiple of 128
     // one block = one row of a 128 x 128 tile: everything derived from the tile is block-uniform and is
     // written so that the compiler sees it (scalar loads, SGPR compares, scalar branches)
-    // tile descriptor: {row block, column block, plane begin | plane end << 8, smallest | largest << 8 register value of
-    // the two blocks' sketches}: the histogram columns of a block only span the values its own sketches can hold
+    // k_finalize's tile descriptor (its own list, row-major per segment -- run_pairs): {row block, column block, plane
+    // begin | plane end << 8 | smallest << 16 | largest << 24 register value of the two blocks' sketches, index of the
+    // tile's C(v) block in the band}: the histogram columns of a block only span the values its own sketches can hold
     uint4 tile = a.tiles[blockIdx.x >> 7];
-    const int vlo = (int)(tile.w & 0xFFu), vhi = (int)(tile.w >> 8);
-    tile.w = tile.z >> 8;
+    const int vlo = (int)((tile.z >> 16) & 0xFFu), vhi = (int)(tile.z >> 24);
+    // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column
+    const uint64_t slot = ((uint64_t)tile.w * 128 + (blockIdx.x & 127u)) * 128 + (uint32_t)tid;
+    tile.w = (tile.z >> 8) & 0xFFu;
     tile.z &= 0xFFu;
     const uint64_t si = (uint64_t)tile.x * kTile + (blockIdx.x & 127u);
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;

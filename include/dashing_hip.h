@@ -281,7 +281,7 @@ int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_ke
  * byte-identical output over their ranges): "kc" (0 auto | 16 | 32 | 64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
- * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
+ * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
  * "assembler_permille", "shard_c0_x10"; what-if only: "pair_mfma" (never the default).
  * "finalize_stop" (1..4) is a profiling aid that DOES change results (k_finalize leaves after a phase and stores a dummy):
  * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */

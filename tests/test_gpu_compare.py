@@ -185,6 +185,42 @@ def test_row_range_in_parts_and_pipelined_collect(ctx, n, p):
         ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
+def test_finalize_tile_order_does_not_change_results(ctx):
+    """k_finalize walks its own row-major tile list while the tile kernel's launch order is XCD-interleaved (run_pairs):
+    with hundreds of tiles per segment, every combination of the two orders, a row range, parts and several bands gives
+    the same bytes"""
+    import torch
+
+    n, p = 3300, 10
+    regs = synth.survey_sketches(n, p, seed=0xF1A7)[0]
+    ctx.set_sketches(regs)
+    base = ctx.dist_rows()
+    dev = torch.device("cuda", 0)
+    try:
+        for rm, xs in ((0, 1), (1, 0), (0, 0), (1, 1)):
+            ctx.set_option("finalize_rowmajor", rm)
+            ctx.set_option("xcd_swizzle", xs)
+            assert ctx.dist_rows().tobytes() == base.tobytes(), (rm, xs)
+            lo, span = dashing_amd.tri_span(n, 0, 640), dashing_amd.tri_span(n, 640, 2100)
+            assert ctx.dist_rows(640, 2100).tobytes() == base[lo : lo + span].tobytes(), (rm, xs)
+        out = torch.full((base.size,), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        ctx.dist_rows_parts_device_async(out.data_ptr(), 0, n, 3)
+        ctx.wait()
+        assert out.cpu().numpy().tobytes() == base.tobytes()
+        ctx.set_option("cum_budget_bytes", 1 << 24)  # several bands
+        assert ctx.dist_rows().tobytes() == base.tobytes()
+        out.fill_(-1.0)
+        torch.cuda.synchronize()
+        ctx.dist_rows_parts_device_async(out.data_ptr(), 0, n, 3)
+        ctx.wait()
+        assert out.cpu().numpy().tobytes() == base.tobytes()
+    finally:
+        ctx.set_option("finalize_rowmajor", 1)
+        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("cum_budget_bytes", 8 << 30)
+
+
 def test_large_parts_cut_the_tile_kernel(ctx):
     """parts of >= 2 048 tiles also end a band of the tile kernel (run_pairs, kPartBandTiles): the span stays the
     byte-identical one and every part's event still follows its last segment (pipelined collect into a second buffer)"""
@@ -358,7 +394,7 @@ def test_options_do_not_change_results(ctx):
         for chunks in (1, 16, 64, 100000):  # item size of the lockstep kernel
             ctx.set_option("ls_item_chunks", chunks)
             assert ctx.dist_rows().tobytes() == base.tobytes()
-        ctx.set_option("ls_item_chunks", 16)
+        ctx.set_option("ls_item_chunks", 64)
         ctx.set_option("pair_lockstep", -1)
         # the what-if variant of the tile kernel on the matrix cores (never the default): same integers
         ctx.set_option("pair_mfma", 1)
@@ -368,7 +404,7 @@ def test_options_do_not_change_results(ctx):
     finally:
         ctx.set_option("pair_mfma", 0)
         ctx.set_option("pair_lockstep", -1)
-        ctx.set_option("ls_item_chunks", 16)
+        ctx.set_option("ls_item_chunks", 64)
         ctx.set_option("kc", 0)
         ctx.set_option("emax", -1)
         ctx.set_option("elow", -1)

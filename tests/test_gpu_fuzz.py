@@ -48,7 +48,10 @@ def _close(got, want, index_got=None, index_want=None):
     assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9) + 1e-12 * max(scale, 1.0)).all(), err.max()
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_CASES", "100"))))  # e.g. DSH_FUZZ_CASES=400 for a long soak
+_FIRST = int(os.environ.get("DSH_FUZZ_FIRST", "0"))  # e.g. DSH_FUZZ_FIRST=2500 DSH_FUZZ_CASES=2500 for a long soak on fresh seeds
+
+
+@pytest.mark.parametrize("case", range(_FIRST, _FIRST + int(os.environ.get("DSH_FUZZ_CASES", "100"))))
 def test_random_case(ctx, oracle, case):
     rng = np.random.default_rng(1000 + case)
     p = int(rng.choice([4, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20]))
@@ -144,3 +147,44 @@ def test_random_case(ctx, oracle, case):
         assert (si == bi).all() and (sv.view(np.uint32) == bv.view(np.uint32)).all()
     ctx.set_option("emax", -1)
     ctx.set_option("elow", -1)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("DSH_FUZZ_BIG_CASES", "6"))))
+def test_random_case_many_tiles(ctx, oracle, case):
+    """the same sweep at sizes with hundreds of tiles per launch (XCD-interleaved tile order for the tile kernel, row-major
+    for k_finalize, several bands, parts that cut the tile kernel): whole triangle vs the oracle; a row range, parts and
+    the band-wise nearest neighbours vs the triangle"""
+    import torch
+
+    rng = np.random.default_rng(77000 + case)
+    p = int(rng.choice([9, 10, 11]))
+    n = int(rng.integers(2100, 3600))
+    kind = str(rng.choice(["law", "related", "narrow"]))
+    estim = int(rng.integers(0, 3))
+    rt = int(rng.choice([1, 1, 5, 7]))  # index measures: no jump at 0
+    k = int(rng.choice([21, 31]))
+    regs = _regs(rng, n, p, kind)
+    ctx.set_sketches(regs)
+    want = oracle.dist_tri(regs, estim, rt, k)
+    try:
+        if case % 2:
+            ctx.set_option("cum_budget_bytes", 1 << int(rng.integers(22, 27)))  # several bands
+        got = ctx.dist_rows(estim=estim, result_type=rt, k=k)
+        _close(got, want)
+        rb = int(rng.integers(0, n - 300))
+        re = int(rng.integers(rb + 200, n + 1))
+        lo, span = dashing_amd.tri_span(n, 0, rb), dashing_amd.tri_span(n, rb, re)
+        assert ctx.dist_rows(rb, re, estim=estim, result_type=rt, k=k).tobytes() == got[lo : lo + span].tobytes()
+        pd = torch.full((span,), -9.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.dist_rows_parts_device_async(pd.data_ptr(), rb, re, int(rng.integers(2, 9)), estim=estim, result_type=rt, k=k)
+        ctx.wait()
+        assert pd.cpu().numpy().tobytes() == got[lo : lo + span].tobytes()
+        nn = int(rng.integers(1, 12))
+        si, sv = ctx.knn(nn, estim=estim, result_type=rt, k=k)
+        ctx.set_option("knn_square_budget_bytes", 0)
+        bi, bv = ctx.knn(nn, estim=estim, result_type=rt, k=k)
+        assert (si == bi).all() and (sv.view(np.uint32) == bv.view(np.uint32)).all()
+    finally:
+        ctx.set_option("knn_square_budget_bytes", 96 << 30)
+        ctx.set_option("cum_budget_bytes", 8 << 30)
