@@ -676,24 +676,27 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
     constexpr size_t kPartBandTiles = 2048;
     const bool parts_on = !job.rect && !job.sorted_rows && c->planes_sorted && c->lay_parts.size() > 2 && job.nparts > 1;
-    auto part_of_tile = [&](size_t t) -> size_t {
-        if (!parts_on) return 0;
-        const uint64_t pos = (uint64_t)T[t].x * kTile;
+    // first tile of every part: T is row-major and a part is a run of whole tile rows, so the part of a tile is monotone
+    std::vector<size_t> pstart{0};
+    if (parts_on) {
         size_t q = 0;
-        while (q + 2 < c->lay_parts.size() && pos >= c->lay_parts[q + 1] - c->lay_rb) ++q;
-        return q;
+        for (size_t t = 0; t < T.size(); ++t) {
+            const uint64_t pos = (uint64_t)T[t].x * kTile;
+            while (q + 2 < c->lay_parts.size() && pos >= c->lay_parts[q + 1] - c->lay_rb) {
+                ++q;
+                pstart.push_back(t);
+            }
+        }
+    }
+    pstart.push_back(T.size());
+    auto part_of_tile = [&](size_t t) -> size_t {
+        return (size_t)(std::upper_bound(pstart.begin(), pstart.end() - 1, t) - pstart.begin()) - 1;
     };
     for (size_t b = 0; b < T.size();) {
         size_t e = std::min<size_t>(T.size(), b + max_tiles);
-        if (parts_on) {  // end of the part b belongs to, if that part is large
+        if (parts_on) {  // a large part also ends the band
             const size_t q = part_of_tile(b);
-            size_t pe_ = b;
-            while (pe_ < e && part_of_tile(pe_) == q) ++pe_;
-            size_t pb_ = b;
-            while (pb_ > 0 && part_of_tile(pb_ - 1) == q) --pb_;
-            size_t pend = pe_;
-            while (pend < T.size() && part_of_tile(pend) == q) ++pend;
-            if (pend - pb_ >= kPartBandTiles) e = pe_;
+            if (pstart[q + 1] - pstart[q] >= kPartBandTiles) e = std::min(e, pstart[q + 1]);
         }
         bands.emplace_back(b, e);
         b = e;
@@ -708,9 +711,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             size_t b = bands[bi].first;
             while (b < bands[bi].second) {
                 const size_t q = part_of(b);
-                size_t e = b;
-                while (e < bands[bi].second && part_of(e) == q) ++e;
-                const bool last_of_part = e == T.size() || part_of(e) != q;
+                const size_t e = std::min(bands[bi].second, pstart[q + 1]);
+                const bool last_of_part = e == pstart[q + 1];
                 segs[bi].push_back({b, e, with_parts && last_of_part ? (int)q : -1});
                 b = e;
             }
