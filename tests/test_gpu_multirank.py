@@ -130,3 +130,28 @@ def test_bench_gpus_flag_refuses_missing_devices():
     assert r.returncode != 0
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert "needs %d visible" % want in r.stderr.decode()
+
+
+def test_bench_measures_hbm_traffic_itself():
+    """roofline.traffic of the default bench line comes from two rocprofv3 --pmc child passes of the run itself (not only
+    from the committed profiles/pmc_pair_kernel.json): non-null, of the size the tile kernel is known to move, and within
+    a few percent of the algorithm-independent floor-to-ceiling window (compulsory bytes .. streaming-model bytes)"""
+    import json
+    import shutil
+
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not installed")
+    r = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"], {"DSH_BENCH_N": "4000"})
+    out = r.stdout.decode()
+    assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    rf = line["roofline"]
+    assert rf["traffic"] is not None and "measured in this run" in rf["traffic_note"], rf["traffic_note"]
+    n, p = 4000, 14
+    compulsory = n * (1 << p)                       # every register read once
+    streaming = (n * (n - 1) // 2) * (2 * (1 << p) + 4)
+    assert compulsory < rf["traffic"] < streaming
+    # --no-pmc: the hash-checked file or null, never a child pass
+    r = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-pmc"], {"DSH_BENCH_N": "4000"})
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert "measured in this run" not in line["roofline"]["traffic_note"]

@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--env", action="append", default=[])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--passes", default="kt,fetch,write,sq1,sq2")
-    ap.add_argument("--cmd", default="python %s --no-cpu-baseline --no-secondary" % os.path.join(ROOT, "bench.py"))
+    ap.add_argument("--cmd", default="python %s --no-cpu-baseline --no-secondary --no-pmc" % os.path.join(ROOT, "bench.py"))
     args = ap.parse_args()
     env = dict(kv.split("=", 1) for kv in args.env)
     outdir = os.path.join(ROOT, "gpurun_out", args.tag)
