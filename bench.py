@@ -93,6 +93,10 @@ def live_pmc_traffic(n, p):
 
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    # never nest: when this process is itself being profiled (rocprofv3 / rocprof preload their tool library and export
+    # ROCPROF* / ROCP_TOOL* variables) a second profiler in a child would inherit that environment
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled"
     vals = {}
     work = tempfile.mkdtemp(prefix="dsh_pmc_", dir="/tmp")
     try:
@@ -105,7 +109,7 @@ def live_pmc_traffic(n, p):
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
                 env.pop(k, None)
             try:
-                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
             except (OSError, subprocess.TimeoutExpired) as e:
                 return None, "rocprofv3 --pmc %s pass did not finish (%s)" % (counter, type(e).__name__)
             got = []
