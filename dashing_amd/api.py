@@ -25,7 +25,7 @@ SYMBOLS = [
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
-    "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
+    "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
@@ -108,6 +108,9 @@ def load_library():
     lib.dsh_event_wait.argtypes = [vp, u64]
     lib.dsh_event_query.argtypes = [vp, u64, C.POINTER(i32)]
     lib.dsh_comm_unique_id.argtypes = [vp]
+    lib.dsh_comm_available.argtypes = []
+    lib.dsh_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i32)]
+    lib.dsh_comm_wait.argtypes = [vp]
     lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.dsh_comm_destroy.argtypes = [vp]
     lib.dsh_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
@@ -161,6 +164,19 @@ def comm_unique_id():
     if rc:
         raise DshError(rc, "dsh_comm_unique_id (RCCL not available?)")
     return buf.raw
+
+
+def comm_available():
+    """True if librccl can be loaded by the library in this process (local check, no communication)"""
+    return load_library().dsh_comm_available() == 0
+
+
+def comm_library():
+    """(resolved path of the loaded librccl -- or the loader's error text --, ncclGetVersion code or 0)"""
+    buf = C.create_string_buffer(1024)
+    v = C.c_int(0)
+    load_library().dsh_comm_library(buf, len(buf), C.byref(v))
+    return buf.value.decode(errors="replace"), int(v.value)
 
 
 def range_parts(n, rb, re, nparts):
@@ -395,6 +411,10 @@ class Context:
 
     def comm_destroy(self):
         self._ck(self._lib.dsh_comm_destroy(self._h))
+
+    def comm_wait(self):
+        """dsh_wait with a deadline on the RCCL traffic (DSH_COMM_TIMEOUT_S): an error instead of a hang"""
+        self._ck(self._lib.dsh_comm_wait(self._h))
 
     def comm_rank(self):
         r, w = C.c_int(), C.c_int()

@@ -1,0 +1,244 @@
+// ctx.h -- the per-GPU context behind the opaque dsh_ctx of include/dashing_hip.h, and the internal entry points the
+// translation units of libdashing_hip.so share:
+//   abi.hip       context, resident sketches, sketch waist, cardinalities, compare entry points, tickets, options
+//   engine.hip    prepare() (per-sketch pass, layout, bit-planes, position index) and run_pairs() (tile kernel + k_finalize)
+//   knn.hip       dsh_knn
+//   exchange.hip  RCCL: dsh_comm_*, dsh_collect_*, dsh_allgather_device, dsh_dist_collect
+//   plan.cpp      the pure-host planner (layout, tiles, bands, parts, work items, row partitions)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen'ed at dsh_comm_init (single-GPU users never load it)
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dashing_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+// page-locked host staging: a hipMemcpyAsync from it is a true asynchronous DMA, so the call that filled it
+// may return before the copy has run (the event says when it may be rewritten)
+struct PinBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2;
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct dsh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // resident sketch matrix
+    DevBuf regs_own;
+    const uint8_t *regs = nullptr;  // device
+    uint64_t n = 0;
+    int p = 0;
+    bool have_sketches = false;
+    // derived state
+    bool planes_valid = false;
+    int card_estim = -1;
+    uint64_t card_from = 0;             // the per-sketch pass (cardinalities, lists, keys) covers the sketches [card_from, n)
+    DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
+    // copy-out pipeline of dsh_dist_rows_async: results alternate between two device buffers; the copy of call b to the
+    // host runs on its own stream while the kernels of call b+1 fill the other buffer
+    hipStream_t copy_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // prepare(): the column index is built next to the bit-plane transform
+    hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    bool aux_join_pending = false;
+    DevBuf outbuf2[2];
+    hipEvent_t ev_filled[2] = {nullptr, nullptr};  // kernels of the call that filled outbuf2[b] done (recorded on stream)
+    hipEvent_t ev_drained[2] = {nullptr, nullptr}; // copy out of outbuf2[b] done (recorded on copy_stream)
+    bool drained_pending[2] = {false, false};
+    unsigned out_turn = 0;
+    std::vector<hipEvent_t> tickets;    // dsh_event_record ring: slot t % 64 holds {mark on the ctx stream, mark on the copy stream}
+    uint64_t ticket_next = 0;
+    // multi-GPU exchange (dsh_comm_*): an RCCL communicator over the ranks' contexts
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
+    DevBuf hist;                        // [n][64] per-sketch register histograms (k_selfhist_card -> k_card_from_hist)
+    hipEvent_t ev_keys = nullptr;       // the keys have reached the host
+    DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
+    uint32_t nbuckets = 0, ent_stride = 0;
+    // column layout of the cached plane matrix (plan.h) and the plan of the last compare call
+    dsh::plan::Layout lay;
+    dsh::plan::PairPlan pp;
+    std::vector<hipEvent_t> ev_part;    // part q complete (recorded on the ctx stream by the last call with parts)
+    uint32_t parts_done = 0;            // parts of the last dsh_dist_rows_parts_device_async call
+    PinBuf pin_keys;                    // host copy of the per-sketch keys (valid while the per-sketch pass is), page-locked:
+    const uint32_t *hk32 = nullptr;     // the copy is a direct DMA and the host only waits for ev_keys
+    bool hk32_valid = false;
+    hipEvent_t ev_perm = nullptr;       // upload of pin_perm done (it is rewritten by the next layout)
+    bool perm_in_flight = false;
+    double host_layout_us = 0, host_lists_us = 0, host_keys_wait_us = 0;  // host time of the last call (dsh_get_info)
+    uint32_t *pin_perm = nullptr;       // page-locked copy of lay.perm: its upload is then truly asynchronous
+    size_t pin_perm_cap = 0;
+    PinBuf pin_work;                    // sketch work list of the call in flight
+    hipEvent_t ev_work = nullptr;
+    bool work_in_flight = false;
+    PinBuf pin_lists;                   // tiles then items of the call in flight
+    hipEvent_t ev_lists = nullptr;      // recorded after their upload; waited on before they are rewritten
+    bool lists_in_flight = false;
+    uint32_t W = 0, Kpad = 0;           // words per plane; plane rows padded to whole LDS stages
+    int emax = 0, elow = 0, cum_bytes = 4;
+    // options
+    int kc = 16;      // k-rows per LDS stage in effect (set by prepare from kc_opt)
+    int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
+    int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
+    int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
+    int finalize_rowmajor = 1;        // k_finalize walks every segment's tiles in row-major order (option, A/B only)
+    size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call
+    uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
+    int xcd_swizzle = 1;
+    int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
+    int range_sort_min_rows = 1024;  // smaller row ranges keep the cached identity layout (a rebuild costs more than it saves)
+    int assembler_permille = 21;  // the un-permute (0.42 ms) on rank 0 of a 19.9 ms pass (profiles/r1k)
+    int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
+    uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
+    double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
+    int ls_sort_items = 1;
+    int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
+    // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
+    // = 1 = wherever a plane is at least one chunk (W >= kc), 0 never (the free-running k_pair_counts)
+    int pair_lockstep = -1;
+    int pair_mfma = 0;  // WHAT-IF only (built with `make WHATIF=1`): 1 = the AND+popcount tile kernel on the matrix cores
+    int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
+    int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
+    // profiling
+    bool profiling = false;
+    double pair_ms = 0, fin_ms = 0, prep_ms = 0;
+    uint32_t pair_launches = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace dsh {
+
+inline int fail(dsh_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return dsh::fail((c), e_ == hipErrorOutOfMemory ? DSH_ENOMEM : DSH_EIO, "%s: %s",  \
+                             #expr, hipGetErrorString(e_));                                    \
+    } while (0)
+
+inline int bind(dsh_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return DSH_OK;
+}
+
+inline hipEvent_t next_event(dsh_ctx *c)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+// slots [first, first + cnt) inside [0, total) -- written so that first + cnt cannot wrap
+inline bool slots_ok(uint64_t first, uint64_t cnt, uint64_t total) { return first <= total && cnt <= total - first; }
+
+inline bool use_lockstep(const dsh_ctx *c)
+{
+    // wherever a plane is at least one chunk (p >= 9): since the kernel needs one barrier per k-row it beats the
+    // free-running one at every precision (profiles/r3f/lockstep_ab.jsonl: -5 % at p = 10 ... -17 % at p = 16)
+    return !(c->pair_mfma || c->kc > 32 || c->W < (uint32_t)c->kc || c->pair_lockstep == 0);
+}
+
+inline bool whole_sorted(const dsh_ctx *c) { return c->planes_valid && c->lay.whole; }
+
+inline void invalidate(dsh_ctx *c)
+{
+    c->planes_valid = false;
+    c->card_estim = -1;
+    c->hk32_valid = false;
+}
+
+inline void reset_prof(dsh_ctx *c)
+{
+    c->pair_ms = c->fin_ms = c->prep_ms = 0;
+    c->pair_launches = 0;
+    c->ev_used = 0;
+}
+
+// one pass of the compare path over a set of pairs (engine.hip)
+struct PairJob {
+    int estim, result_type, k;
+    int rect;
+    int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
+    int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
+    uint32_t nparts = 0;  // > 0: triangle rows in (at most) this many parts of a key-ordered layout, an event per part
+    int knn = 0;          // band of the key-ordered triangle for the nearest-neighbour selection: d_out = V, d_out2 = Vt
+    float *d_out2 = nullptr;
+    uint64_t knn_ld = 0, knn_rows = 0;
+    int ksinv_double = 0; // 1./k as a double (nndist_loop, src/sketch_and_cmp.h:729) instead of the float of dist_loop (:797)
+    uint64_t row_begin, row_end, col_begin, col_end;
+    uint64_t base_index;
+    float *d_out;
+};
+
+// cardinalities + thresholds/lists + planes + position index for the current sketch matrix.  want_sorted < 0: whatever
+// is cached.  card_only: the per-sketch pass alone.
+int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint64_t want_rb = 0,
+            uint64_t want_re = ~0ull, uint32_t nparts = 1);
+int run_pairs(dsh_ctx *c, const PairJob &job);
+
+// exchange.hip: waits for both streams of the communicator's traffic and destroys it (no-op without one)
+int comm_release(dsh_ctx *c);
+
+}  // namespace dsh

@@ -1,0 +1,355 @@
+// engine.hip -- the device side of a compare pass: prepare() builds what a layout needs (per-sketch pass, key-ordered
+// columns, bit-planes, position index), run_pairs() launches the tile kernel and k_finalize over the plan of plan.cpp.
+// Together they replace dist_loop / perform_core_op (src/sketch_and_cmp.h:785-880, :699-710) and the compare side of
+// dm::parallel_fill (distmat/distmat.h:459-512).
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "ctx.h"
+
+namespace dsh {
+
+int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t want_rb, uint64_t want_re, uint32_t nparts)
+{
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
+    if (want_sorted < 0) {  // "whatever is cached"
+        want_sorted = c->lay.sorted;
+        want_rb = c->lay.rb;
+        want_re = c->lay.re;
+    }
+    if (want_re > c->n) want_re = c->n;
+    if (!want_sorted) want_rb = 0, want_re = c->n;
+    if (want_rb > want_re) want_rb = want_re;
+    const uint64_t n = c->n;
+    std::vector<uint64_t> parts;
+    if (want_sorted) plan::range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
+    const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, true);
+    const int elow_new = c->elow_opt >= 0 ? std::min<int>(c->elow_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, false);
+    if (emax_new != c->emax || elow_new != c->elow) {  // thresholds and lists (hence planes) depend on them
+        c->planes_valid = false;
+        c->card_estim = -1;
+    }
+    c->emax = emax_new;
+    c->elow = elow_new;
+    const bool same_layout = c->planes_valid && c->lay.sorted == want_sorted &&
+                             (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.parts == parts));
+    // sketches the per-sketch pass has to cover: a row range of the triangle never looks at the sketches before it
+    const uint64_t need_from = (card_only || !want_sorted) ? 0 : want_rb;
+    const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
+    if (have_pass && (card_only || same_layout)) return DSH_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = next_event(c);
+        e1 = next_event(c);
+        if (e0) (void)hipEventRecord(e0, c->stream);
+    }
+    // the per-sketch pass depends on (registers, estimator, emax) only: a new column layout reuses it
+    if (!have_pass) {
+        HIPCHK(c, c->card.ensure(std::max<uint64_t>(n, 1) * sizeof(double)));
+        HIPCHK(c, c->exc.ensure(std::max<uint64_t>(n, 1) * kListCap * (c->p <= 15 ? 2 : 4)));
+        HIPCHK(c, c->excv.ensure(std::max<uint64_t>(n, 1) * kListCap));
+        HIPCHK(c, c->exc_n.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->tailhist.ensure(std::max<uint64_t>(n, 1) * 64));
+        HIPCHK(c, c->hist.ensure(std::max<uint64_t>(n, 1) * 64 * sizeof(uint32_t)));
+        HIPCHK(c, launch_selfhist_card(c->stream, c->regs, need_from, n, c->p, estim, c->emax, c->elow,
+                                       (uint32_t *)c->hist.ptr, c->exc.ptr, (uint8_t *)c->excv.ptr,
+                                       (uint32_t *)c->exc_n.ptr, (uint32_t *)c->keys.ptr,
+                                       (uint8_t *)c->tailhist.ptr));
+        // the keys travel to the host right behind the per-sketch pass (the column order is made there); the
+        // cardinalities follow on the stream while the host sorts
+        HIPCHK(c, c->pin_keys.ensure(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        c->hk32 = (const uint32_t *)c->pin_keys.ptr;
+        if (n > need_from)
+            HIPCHK(c, hipMemcpyAsync((uint32_t *)c->pin_keys.ptr + need_from, (const uint32_t *)c->keys.ptr + need_from,
+                                     (n - need_from) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (!c->ev_keys) HIPCHK(c, hipEventCreateWithFlags(&c->ev_keys, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_keys, c->stream));
+        HIPCHK(c, launch_card_from_hist(c->stream, (const uint32_t *)c->hist.ptr, (const uint32_t *)c->keys.ptr, need_from, n,
+                                        c->p, estim, (double *)c->card.ptr));
+        c->card_estim = estim;
+        c->card_from = need_from;
+        c->hk32_valid = false;
+    }
+    if (card_only) {  // a cardinality query never builds planes (and leaves stale ones marked so)
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, c->stream);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            c->prep_ms += ms;
+        }
+        return DSH_OK;
+    }
+    if (!same_layout) {
+        if (c->p > kMaxPCompare)
+            return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPCompare, c->p);
+        // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no
+        // device round trip and so does not wait for the work still queued on the stream
+        const auto t_h0 = std::chrono::steady_clock::now();
+        if (!c->hk32_valid) {
+            HIPCHK(c, hipEventSynchronize(c->ev_keys));
+            c->hk32_valid = true;
+        }
+        const auto t_h1 = std::chrono::steady_clock::now();
+        c->host_keys_wait_us = std::chrono::duration<double, std::micro>(t_h1 - t_h0).count();
+        const uint32_t *k32 = c->hk32;
+        for (uint64_t i = c->card_from; i < n; ++i)  // (the sketches the per-sketch pass covered)
+            if (plan::key_bad(k32[i]))
+                return fail(c, DSH_EINVAL, "sketch %llu holds a register value above %d (= 64 - p + 1): not an HLL of precision %d (corrupt or foreign .hll?)",
+                            (unsigned long long)i, 64 - c->p + 1, c->p);
+        c->planes_valid = false;  // (the cached layout is overwritten from here on)
+        plan::Layout &L = c->lay;
+        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L);
+        c->cum_bytes = c->p <= 15 ? 2 : 4;
+        const uint64_t m = 1ull << c->p;
+        c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
+        c->kc = c->kc_opt ? c->kc_opt : (c->W >= 32 ? 32 : 16);
+        if (want_sorted) {
+            // perm, then (whole collection only) its inverse for the un-permute of the shard path
+            const uint64_t nperm = L.perm.size();
+            HIPCHK(c, c->perm.ensure(std::max<uint64_t>(nperm, 1) * sizeof(uint32_t)));
+            if (nperm) {
+                if (c->perm_in_flight) {  // the previous layout's upload from pin_perm
+                    HIPCHK(c, hipEventSynchronize(c->ev_perm));
+                    c->perm_in_flight = false;
+                }
+                if (nperm > c->pin_perm_cap) {
+                    if (c->pin_perm) (void)hipHostFree(c->pin_perm);
+                    c->pin_perm = nullptr;
+                    c->pin_perm_cap = 0;
+                    HIPCHK(c, hipHostMalloc((void **)&c->pin_perm, nperm * sizeof(uint32_t), hipHostMallocDefault));
+                    c->pin_perm_cap = nperm;
+                }
+                std::memcpy(c->pin_perm, L.perm.data(), nperm * sizeof(uint32_t));
+                HIPCHK(c, launch_upload(c->stream, c->perm.ptr, c->pin_perm, nperm * sizeof(uint32_t)));
+                if (!c->ev_perm) HIPCHK(c, hipEventCreateWithFlags(&c->ev_perm, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->ev_perm, c->stream));
+                c->perm_in_flight = true;
+            }
+        }
+        const uint32_t NT = L.Npad / kTile;
+        // position index of every column block (the list joins of k_finalize): 79 workgroups at C3 -- built on a
+        // second stream next to the bit-plane transform, which fills the chip on its own; both only need the
+        // per-sketch pass and the permutation, the tile kernels wait for both
+        c->nbuckets = (uint32_t)std::min<uint64_t>(2 * m, kMaxBuckets);  // (position group, upper | lower tail)
+        c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
+        HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
+        HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
+        c->host_layout_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h1).count();
+        HIPCHK(c, hipEventRecord(c->ev_aux_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_aux_fork, 0));
+        HIPCHK(c, launch_build_colindex(c->aux_stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
+                                        (const uint32_t *)c->keys.ptr, want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, L.ncols,
+                                        c->p, NT, c->nbuckets, c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
+        HIPCHK(c, hipEventRecord(c->ev_aux_join, c->aux_stream));
+        const uint64_t K = (uint64_t)L.P * c->W;
+        c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
+        if (c->Kpad) {
+            const size_t bytes = (size_t)c->Kpad * L.Npad * sizeof(uint32_t);
+            HIPCHK(c, c->planes.ensure(bytes));
+            if (c->Kpad > K)
+                HIPCHK(c, hipMemsetAsync((uint32_t *)c->planes.ptr + K * L.Npad, 0,
+                                         (size_t)(c->Kpad - K) * L.Npad * sizeof(uint32_t),
+                                         c->stream));
+            HIPCHK(c, launch_transform(c->stream, c->regs, L.ncols, c->p, L.pbase, L.P, c->W, L.Npad,
+                                       (uint32_t *)c->planes.ptr,
+                                       want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
+        }
+        c->aux_join_pending = true;  // only k_finalize reads the index: the tile kernel starts without waiting for it
+        c->planes_valid = true;
+    }
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        c->prep_ms += ms;
+    }
+    return DSH_OK;
+}
+
+int run_pairs(dsh_ctx *c, const PairJob &job)
+{
+    // Triangle rows [rb,re): the plane matrix is laid out for exactly that range (wanted rows first, both
+    // parts key-ordered), so every tile is homogeneous and the result lands at its final packed position --
+    // whatever the range (a full triangle, one rank's rows, a row block of the CLI).  Tiny ranges and
+    // rectangles keep the identity layout, which stays cached across calls; a call with parts (an event per part:
+    // the pipelined exchange) always gets the key-ordered layout of its range, however short, so that its parts
+    // are the ones dsh_range_parts reports to the other ranks.
+    const uint64_t jre = std::min<uint64_t>(job.row_end, c->n);
+    const bool full_tri = !job.rect && job.row_begin == 0 && jre >= c->n;
+    const bool with_parts = job.nparts > 0 && !job.rect && !job.sorted_rows;
+    int want_sorted = 0;
+    uint64_t lrb = 0, lre = c->n;
+    if (job.sorted_rows) want_sorted = 1;
+    else if (!job.rect && jre > job.row_begin &&
+             (with_parts || (c->sort_mode != 0 && (full_tri || jre - job.row_begin >= (uint64_t)c->range_sort_min_rows)))) {
+        want_sorted = 1;
+        lrb = job.row_begin;
+        lre = jre;
+    }
+    c->parts_done = 0;
+    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, with_parts ? job.nparts : 1);
+    if (rc) return rc;
+    if (job.result_type < 0 || job.result_type > 8)
+        return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
+    if (job.k < 1) return fail(c, DSH_EINVAL, "bad k %d", job.k);
+    const auto t_l0 = std::chrono::steady_clock::now();
+    const plan::Layout &L = c->lay;
+    plan::PairPlan &pp = c->pp;
+    plan::PairQuery q;
+    q.rect = job.rect;
+    q.sorted_rows = job.sorted_rows;
+    q.want_parts = with_parts;
+    q.row_begin = job.row_begin;
+    q.row_end = job.row_end;
+    q.col_begin = job.col_begin;
+    q.col_end = job.col_end;
+    plan::Tuning tu;
+    tu.W = c->W;
+    tu.kc = c->kc;
+    tu.cum_bytes = c->cum_bytes;
+    tu.cum_budget = c->cum_budget;
+    tu.nsplit = c->nsplit;
+    tu.lockstep = use_lockstep(c);
+    tu.ls_item_chunks = c->ls_item_chunks;
+    tu.ls_sort_items = c->ls_sort_items;
+    tu.xcd_swizzle = c->xcd_swizzle;
+    tu.finalize_rowmajor = c->finalize_rowmajor;
+    if (!plan::build_pairs(L, q, tu, pp)) {
+        pp.T.clear();
+        return DSH_OK;
+    }
+    const std::vector<plan::U4> &T = pp.T, &I = pp.items;
+    c->last_bands = pp.bands.size();
+    // tile and item lists travel through page-locked staging, so nothing below needs the host to wait
+    if (c->lists_in_flight) {  // the previous call's upload (long done unless calls are issued back to back)
+        HIPCHK(c, hipEventSynchronize(c->ev_lists));
+        c->lists_in_flight = false;
+    }
+    static_assert(sizeof(plan::U4) == sizeof(uint4), "plan::U4 must have the layout of uint4");
+    HIPCHK(c, c->pin_lists.ensure((2 * T.size() + std::max<size_t>(I.size(), 1)) * sizeof(uint4)));
+    plan::U4 *pinT = (plan::U4 *)c->pin_lists.ptr, *pinF = pinT + T.size(), *pinI = pinF + T.size();
+    plan::emit_tile_lists(L, pp, pinT, pinF);
+    if (!I.empty()) std::memcpy(pinI, I.data(), I.size() * sizeof(uint4));
+    c->host_lists_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();
+    HIPCHK(c, c->tiles.ensure(2 * T.size() * sizeof(uint4)));  // [tile kernel's list | k_finalize's list]
+    HIPCHK(c, launch_upload(c->stream, c->tiles.ptr, pinT, 2 * T.size() * sizeof(uint4)));
+    HIPCHK(c, c->items.ensure(std::max<size_t>(I.size(), 1) * sizeof(uint4)));
+    if (!I.empty())
+        HIPCHK(c, launch_upload(c->stream, c->items.ptr, pinI, I.size() * sizeof(uint4)));
+    if (!c->ev_lists) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));
+    c->lists_in_flight = true;
+    HIPCHK(c, c->cum.ensure(std::max<uint64_t>(pp.per_tile_bytes * pp.max_band, 256)));
+
+    const float ksinv_f = (float)(1. / (double)job.k);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evp, evf;
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi) {
+        const auto &bd = pp.bands[bi];
+        const uint32_t nt = (uint32_t)(bd.second - bd.first);
+        const uint64_t nslots = (uint64_t)nt * kTile * kTile;
+        const uint4 *dt = (const uint4 *)c->tiles.ptr + bd.first;
+        const uint4 *di = (const uint4 *)c->items.ptr + pp.band_items[bi].first;
+        const uint32_t ni = (uint32_t)(pp.band_items[bi].second - pp.band_items[bi].first);
+        hipEvent_t a = nullptr, b = nullptr, d = nullptr;
+        if (c->profiling) {
+            a = next_event(c);
+            b = next_event(c);
+            d = next_event(c);
+            if (a) (void)hipEventRecord(a, c->stream);
+        }
+        if (c->pair_mfma)
+            HIPCHK(c, launch_pair_counts_mfma(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                              L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
+        else if (use_lockstep(c))
+            HIPCHK(c, launch_pair_counts_lockstep(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                                  L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
+        else
+            HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
+                                         L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
+        if (b) (void)hipEventRecord(b, c->stream);
+        for (const plan::Seg &sg : pp.segs[bi]) {
+            FinalizeLaunch f;
+            f.cum = c->cum.ptr;  // the band's C(v); a tile's block is named by its descriptor
+            f.cum_bytes = c->cum_bytes;
+            f.cum_stride = nslots;
+            f.hist_bins = sg.hist_bins;
+            f.exc = c->exc.ptr;
+            f.exc_n = (const uint32_t *)c->exc_n.ptr;
+            f.excv = (const uint8_t *)c->excv.ptr;
+            f.keys = (const uint32_t *)c->keys.ptr;
+            f.tailhist = (const uint8_t *)c->tailhist.ptr;
+            f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
+            f.tiles = (const uint4 *)c->tiles.ptr + T.size() + sg.b;
+            f.perm = L.sorted ? (const uint32_t *)c->perm.ptr : nullptr;
+            f.pbase = L.pbase;
+            f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
+            f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
+            f.nbuckets = c->nbuckets;
+            f.ent_stride = c->ent_stride;
+            f.p = c->p;
+            f.estim = job.estim;
+            f.result_type = job.result_type;
+            f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
+            f.card = (const double *)c->card.ptr;
+            f.n = c->n;
+            f.ncols = L.ncols;
+            f.stop = c->finalize_stop;
+            f.rect = job.rect;
+            f.sorted_out = job.sorted_rows;
+            f.square = job.square;
+            f.knn = job.knn;
+            f.out2 = job.d_out2;
+            f.knn_ld = job.knn_ld;
+            f.knn_rows = job.knn_rows;
+            f.row_begin = job.row_begin;
+            f.row_end = job.row_end;
+            f.col_begin = job.col_begin;
+            f.col_end = job.col_end;
+            f.base_index = job.base_index;
+            f.out = job.d_out;
+            if (c->aux_join_pending) {
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
+                c->aux_join_pending = false;
+            }
+            HIPCHK(c, launch_finalize(c->stream, f));
+            if (sg.part >= 0) {  // this segment completes a part: its span of the matrix is final
+                const size_t qp = (size_t)sg.part;
+                while (c->ev_part.size() <= qp) {
+                    hipEvent_t e = nullptr;
+                    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->ev_part.push_back(e);
+                }
+                HIPCHK(c, hipEventRecord(c->ev_part[qp], c->stream));
+                c->parts_done = (uint32_t)qp + 1;
+            }
+        }
+        if (d) (void)hipEventRecord(d, c->stream);
+        if (a && b && d) {
+            evp.emplace_back(a, b);
+            evf.emplace_back(b, d);
+        }
+    }
+    // everything is enqueued; the blocking entry points synchronise, the *_async ones return here
+    if (c->profiling) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &e : evp) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            c->pair_ms += ms;
+            if (c->Kpad) c->pair_launches++;
+        }
+        for (auto &e : evf) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e.first, e.second);
+            c->fin_ms += ms;
+        }
+    }
+    return DSH_OK;
+}
+
+}  // namespace dsh

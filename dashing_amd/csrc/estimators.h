@@ -47,19 +47,21 @@ __device__ inline double ertl_tau(double x)
     return z / 3.;
 }
 
-template <class Hist>
-__device__ inline double estimate_original(const Hist &c, int p)
+// lo_hint/hi_hint: a range known to contain every non-empty bin (see estimate_mle); `raw(v)` skips the bounds test of
+// `c(v)` and may be called for v in [lo_hint, hi_hint] only.  The sum runs over the live range alone: the bins outside
+// it are zero and adding +0.0 changes nothing, so the additions that remain are the same, in the same ascending order,
+// as the reference loop over 1 .. q (-E / --original, src/distmain.cpp:59) -- bit-identical.
+template <class Hist, class Raw>
+__device__ inline double estimate_original(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint)
 {
     const int q = 64 - p;
     const double m = (double)(1ull << p);
-    double sum = (double)c(0);
-    for (int i = 1; i < q + 1; ++i) {
-        const uint32_t ci = c(i);
-        if (ci) sum += ldexp((double)ci, -i);
-    }
+    const uint32_t c0 = c(0);
+    double sum = (double)c0;
+    const int lo = lo_hint > 1 ? lo_hint : 1, hi = hi_hint < q ? hi_hint : q;
+    for (int i = lo; i <= hi; ++i) sum += ldexp((double)raw(i), -i);
     double value = alpha_m(1ull << p) * m * m / sum;
     if (value < 2.5 * m) {
-        const uint32_t c0 = c(0);
         if (c0) value = m * log(m / (double)c0);
     } else if (value > 4294967296. / 30.) {
         const double corr = -4294967296. * log1p(-ldexp(value, -32));
@@ -190,7 +192,7 @@ __device__ inline double estimate(const Hist &c, const Raw &raw, int p, int esti
                                   int hi_hint)
 {
     switch (estim) {
-    case 0: return estimate_original(c, p);
+    case 0: return estimate_original(c, raw, p, lo_hint, hi_hint);
     case 1: return estimate_improved(c, p);
     default: return estimate_mle(c, raw, p, lo_hint, hi_hint);
     }

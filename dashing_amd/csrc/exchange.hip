@@ -1,0 +1,411 @@
+// exchange.hip -- the multi-GPU exchange behind the C-ABI: an RCCL communicator per context (librccl is dlopen'ed on
+// first use), point-to-point collection of the ranks' spans of dashing's packed triangle on one destination rank
+// (one message per peer or, pipelined, per part), the all-gather of register arrays after sharded sketching.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "ctx.h"
+
+using namespace dsh;
+
+namespace {
+
+// RCCL, loaded on first use (std::call_once: the CLI's one-thread-per-device path may get here from several threads).
+// The library must be the one built against the HIP runtime this file links to (the streams handed to it are ours):
+// librccl.so.1 through this library's RUNPATH (/opt/rocm/lib), or DSH_RCCL_LIB.
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err, path;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[3] = {std::getenv("DSH_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+            r.err = dlerror();
+            if (nm == names[0]) return;  // an explicit DSH_RCCL_LIB that does not load is an error, not a hint
+        }
+        if (!r.h) return;
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(r.h, name);
+            if (!p) r.err = std::string("librccl: missing symbol ") + name;
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
+        r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommAbort || !r.GetVersion || !r.GroupStart ||
+            !r.GroupEnd || !r.Send || !r.Recv || !r.AllGather || !r.GetErrorString) {
+            dlclose(r.h);
+            r.h = nullptr;
+            return;
+        }
+        Dl_info di;
+        if (dladdr((void *)r.GetUniqueId, &di) && di.dli_fname) r.path = di.dli_fname;
+    });
+    return &r;
+}
+
+#define NCCLCHK(c, expr)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return fail((c), DSH_EIO, "%s: %s", #expr, rccl()->GetErrorString(r_));     \
+    } while (0)
+
+double env_seconds(const char *name, double dflt)
+{
+    const char *e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    const double v = std::atof(e);
+    return v > 0 ? v : dflt;
+}
+
+// Wait for a stream that carries RCCL traffic, with a deadline: a peer that never posts its side of a grouped
+// send/recv would otherwise block this rank for ever.  On expiry the communicator is aborted (its kernels leave the
+// stream) and the call fails with a message; DSH_COMM_TIMEOUT_S (default 120) sets the deadline.
+int sync_guarded(dsh_ctx *c, hipStream_t st, const char *what)
+{
+    if (!c->comm || c->comm_world == 1) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        return DSH_OK;
+    }
+    const double limit = env_seconds("DSH_COMM_TIMEOUT_S", 120.0);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return DSH_OK;
+        if (q != hipErrorNotReady) return fail(c, DSH_EIO, "%s: %s", what, hipGetErrorString(q));
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 1023u) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            (void)rccl()->CommAbort(c->comm);
+            c->comm = nullptr;
+            c->comm_rank = 0;
+            c->comm_world = 1;
+            return fail(c, DSH_EIO, "%s: the RCCL exchange did not complete within %.0f s (DSH_COMM_TIMEOUT_S): a peer "
+                                    "is missing or stuck; the communicator was aborted", what, limit);
+        }
+    }
+}
+
+// bounds of `world` row ranges over n rows (dsh_balance_rows / dsh_partition_rows) and a destination rank: ONE check
+// for every entry point that takes them
+int validate_bounds(dsh_ctx *c, uint64_t n, const uint64_t *bounds, int world, int dst)
+{
+    if (!bounds) return fail(c, DSH_EINVAL, "bounds is NULL");
+    if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d (world %d)", dst, world);
+    if (bounds[0] != 0 || bounds[world] != n) return fail(c, DSH_EINVAL, "bounds must run from 0 to n over the %d ranks", world);
+    for (int r = 0; r < world; ++r)
+        if (bounds[r] > bounds[r + 1]) return fail(c, DSH_EINVAL, "bounds not monotone at rank %d", r);
+    return DSH_OK;
+}
+
+}  // namespace
+
+namespace dsh {
+
+int comm_release(dsh_ctx *c)
+{
+    if (!c->comm) return DSH_OK;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // dsh_collect_parts_async sends there
+    const ncclResult_t e = rccl()->CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return e == ncclSuccess ? DSH_OK : fail(c, DSH_EIO, "ncclCommDestroy: %s", rccl()->GetErrorString(e));
+}
+
+}  // namespace dsh
+
+extern "C" {
+
+/* ---- multi-GPU exchange through RCCL (one context per rank; ranks may be processes or threads) ------------------ */
+int dsh_comm_available(void) { return rccl()->h ? DSH_OK : DSH_ENODEV; }
+
+int dsh_comm_library(char *path_out, size_t cap, int *version_out)
+{
+    Rccl *r = rccl();
+    if (!r->h) {
+        if (path_out && cap) std::snprintf(path_out, cap, "%s", r->err.c_str());  // why it is not there
+        return DSH_ENODEV;
+    }
+    if (path_out && cap) std::snprintf(path_out, cap, "%s", r->path.c_str());
+    if (version_out) {
+        int v = 0;
+        if (r->GetVersion(&v) != ncclSuccess) v = 0;
+        *version_out = v;
+    }
+    return DSH_OK;
+}
+
+int dsh_comm_unique_id(void *id_out)
+{
+    if (!id_out) return DSH_EINVAL;
+    Rccl *r = rccl();
+    if (!r->h) return DSH_ENODEV;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return DSH_EIO;
+    std::memcpy(id_out, &id, sizeof id);
+    return DSH_OK;
+}
+
+int dsh_comm_init(dsh_ctx *c, const void *unique_id, int rank, int world)
+{
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    Rccl *r = rccl();
+    if (!r->h) return fail(c, DSH_ENODEV, "RCCL is not available (%s)", r->err.c_str());
+    if ((rc = comm_release(c))) return rc;  // re-initialisation: nothing of the old communicator is in flight any more
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    // ncclCommInitRank blocks until every rank has joined.  It runs on a helper thread so that a rank that never
+    // arrives costs this one DSH_COMM_INIT_TIMEOUT_S (default 90 s) and an error, not a hang.  (On expiry the helper
+    // stays blocked inside RCCL and is left behind; the context works on without a communicator.)
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t res = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto sh = std::make_shared<Shared>();
+    const int device = c->device;
+    auto init = r->CommInitRank;
+    std::thread([sh, device, init, world, id, rank] {
+        ncclComm_t comm = nullptr;
+        ncclResult_t res = hipSetDevice(device) == hipSuccess ? init(&comm, world, id, rank) : ncclUnhandledCudaError;
+        std::lock_guard<std::mutex> lk(sh->mu);
+        sh->res = res;
+        sh->comm = comm;
+        sh->done = true;
+        sh->cv.notify_all();
+    }).detach();
+    const double limit = env_seconds("DSH_COMM_INIT_TIMEOUT_S", 90.0);
+    {
+        std::unique_lock<std::mutex> lk(sh->mu);
+        if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; }))
+            return fail(c, DSH_EIO, "ncclCommInitRank(rank %d of %d) did not return within %.0f s (DSH_COMM_INIT_TIMEOUT_S): "
+                                    "not every rank joined", rank, world, limit);
+        if (sh->res != ncclSuccess) return fail(c, DSH_EIO, "ncclCommInitRank: %s", r->GetErrorString(sh->res));
+        c->comm = sh->comm;
+    }
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return DSH_OK;
+}
+
+int dsh_comm_destroy(dsh_ctx *c)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    return comm_release(c);
+}
+
+int dsh_comm_rank(const dsh_ctx *c, int *rank, int *world)
+{
+    if (!c) return DSH_EINVAL;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm ? c->comm_world : 1;
+    return c->comm ? DSH_OK : DSH_ESTATE;
+}
+
+int dsh_comm_wait(dsh_ctx *c)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = sync_guarded(c, c->stream, "dsh_comm_wait (ctx stream)"))) return rc;
+    return sync_guarded(c, c->copy_stream, "dsh_comm_wait (copy stream)");
+}
+
+static int collect_spans(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    int rc = validate_bounds(c, n, bounds, world, dst);
+    if (rc) return rc;
+    const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+    if (rank == dst) {
+        if (!d_final) return DSH_EINVAL;
+        float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[rank]);
+        if (mine && d_local && d_local != (const void *)own)  // computed elsewhere: put it into place
+            HIPCHK(c, hipMemcpyAsync(own, d_local, mine * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else if (mine && !d_local) {
+        return DSH_EINVAL;
+    }
+    if (world == 1) return DSH_OK;
+    Rccl *r = rccl();
+    // one message per peer, all of them in one group: the destination's links are busy at once, every span lands
+    // at its final place (the ranks' row ranges are contiguous spans of the packed triangle)
+    NCCLCHK(c, r->GroupStart());
+    if (rank == dst) {
+        for (int src = 0; src < world; ++src) {
+            const uint64_t cnt = dsh_tri_span(n, bounds[src], bounds[src + 1]);
+            if (src == dst || cnt == 0) continue;
+            ncclResult_t e = r->Recv((float *)d_final + dsh_tri_span(n, 0, bounds[src]), cnt, ncclFloat32, src, c->comm, c->stream);
+            if (e != ncclSuccess) {
+                (void)r->GroupEnd();
+                return fail(c, DSH_EIO, "ncclRecv: %s", r->GetErrorString(e));
+            }
+        }
+    } else if (mine) {
+        ncclResult_t e = r->Send(d_local, mine, ncclFloat32, dst, c->comm, c->stream);
+        if (e != ncclSuccess) {
+            (void)r->GroupEnd();
+            return fail(c, DSH_EIO, "ncclSend: %s", r->GetErrorString(e));
+        }
+    }
+    NCCLCHK(c, r->GroupEnd());
+    return DSH_OK;
+}
+
+int dsh_collect_spans_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->comm && !(bounds && bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    return collect_spans(c, n, bounds, d_local, d_final, dst);
+}
+
+int dsh_collect_spans(dsh_ctx *c, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst)
+{
+    int rc = dsh_collect_spans_async(c, n, bounds, d_local, d_final, dst);
+    if (rc) return rc;
+    return sync_guarded(c, c->stream, "dsh_collect_spans");
+}
+
+int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
+                            void *d_final, int dst)
+{
+    if (!c || !bounds || nparts == 0) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    if (!c->comm && !(bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;
+    if (rank == dst && !d_final) return DSH_EINVAL;
+    // every rank's parts, from the same function the compute used (dsh_range_parts): both sides of a message agree.
+    // dsh_dist_rows_parts_device_async lays ANY non-empty range out in exactly these parts (a short range: one part) and
+    // records an event for each, so a rank with few rows takes part in the rounds like every other.
+    std::vector<std::vector<uint64_t>> parts((size_t)world);
+    size_t maxparts = 0;
+    for (int r = 0; r < world; ++r) {
+        plan::range_parts(n, bounds[r], bounds[r + 1], nparts, parts[r]);
+        maxparts = std::max(maxparts, parts[r].size() - 1);
+    }
+    const size_t myparts = parts[rank].size() - 1;
+    if (c->parts_done != myparts)
+        return fail(c, DSH_ESTATE, "dsh_dist_rows_parts_device_async(%u parts) of this rank's rows must come first (%u parts computed, %zu expected)",
+                    nparts, c->parts_done, myparts);
+    Rccl *rc_ = world > 1 ? rccl() : nullptr;
+    const uint64_t my_off = dsh_tri_span(n, 0, bounds[rank]);
+    for (size_t q = 0; q < maxparts; ++q) {
+        // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
+        // there while the ctx stream computes part q+1
+        if (q < myparts) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+        if (rank == dst && q < myparts && d_local) {
+            const uint64_t o0 = dsh_tri_span(n, 0, parts[rank][q]) - my_off, cnt = dsh_tri_span(n, parts[rank][q], parts[rank][q + 1]);
+            float *own = (float *)d_final + my_off + o0;
+            if (cnt && (const float *)d_local + o0 != own)
+                HIPCHK(c, hipMemcpyAsync(own, (const float *)d_local + o0, cnt * sizeof(float), hipMemcpyDeviceToDevice, c->copy_stream));
+        }
+        if (world == 1) continue;
+        NCCLCHK(c, rc_->GroupStart());
+        ncclResult_t e = ncclSuccess;
+        if (rank == dst) {
+            for (int src = 0; src < world && e == ncclSuccess; ++src) {
+                if (src == dst || q >= parts[src].size() - 1) continue;
+                const uint64_t cnt = dsh_tri_span(n, parts[src][q], parts[src][q + 1]);
+                if (cnt) e = rc_->Recv((float *)d_final + dsh_tri_span(n, 0, parts[src][q]), cnt, ncclFloat32, src, c->comm, c->copy_stream);
+            }
+        } else if (q < myparts) {
+            const uint64_t o0 = dsh_tri_span(n, 0, parts[rank][q]) - my_off, cnt = dsh_tri_span(n, parts[rank][q], parts[rank][q + 1]);
+            if (cnt) {
+                if (!d_local) e = ncclInvalidArgument;
+                else e = rc_->Send((const float *)d_local + o0, cnt, ncclFloat32, dst, c->comm, c->copy_stream);
+            }
+        }
+        if (e != ncclSuccess) {
+            (void)rc_->GroupEnd();
+            return fail(c, DSH_EIO, "ncclSend/ncclRecv: %s", rc_->GetErrorString(e));
+        }
+        NCCLCHK(c, rc_->GroupEnd());
+    }
+    return DSH_OK;
+}
+
+int dsh_allgather_device(dsh_ctx *c, const void *d_send, uint64_t bytes_per_rank, void *d_recv)
+{
+    if (!c || (bytes_per_rank && (!d_send || !d_recv))) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->comm) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if (bytes_per_rank) NCCLCHK(c, rccl()->AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, c->stream));
+    return sync_guarded(c, c->stream, "dsh_allgather_device");
+}
+
+int dsh_dist_collect(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *bounds, int dst, float *out)
+{
+    if (!c || !bounds) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    const uint64_t n = c->n, total = dsh_tri_span(n, 0, n);
+    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;  // before anything is sized by them
+    const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+    void *d_local = nullptr;
+    if (rank == dst) {
+        if (total && !out) return DSH_EINVAL;
+        HIPCHK(c, c->gather_full.ensure(std::max<uint64_t>(total, 1) * sizeof(float)));
+        d_local = (float *)c->gather_full.ptr + dsh_tri_span(n, 0, bounds[rank]);  // computed in place
+    } else {
+        HIPCHK(c, c->gather_local.ensure(std::max<uint64_t>(mine, 1) * sizeof(float)));
+        d_local = c->gather_local.ptr;
+    }
+    if (mine && (rc = dsh_dist_rows_device_async(c, estim, result_type, k, bounds[rank], bounds[rank + 1], d_local))) return rc;
+    if ((rc = collect_spans(c, n, bounds, d_local, rank == dst ? c->gather_full.ptr : nullptr, dst))) return rc;
+    if (rank == dst && total)
+        HIPCHK(c, hipMemcpyAsync(out, c->gather_full.ptr, total * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return sync_guarded(c, c->stream, "dsh_dist_collect");
+}
+
+}  // extern "C"

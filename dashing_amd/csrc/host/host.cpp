@@ -120,7 +120,12 @@ public:
     {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) return -ENOENT;
+        // a reused object starts from scratch: no decoder state of the previous input survives
         prelen_ = prepos_ = 0;
+        zeof_ = false;
+        zframe_done_ = true;  // (as constructed: an empty stream is a clean end; the gzip-pipe path clears it)
+        gz_members_ = 0;
+        zpos_ = zlen_ = 0;
         while (prelen_ < 4) {
             const ssize_t r = ::read(fd_, pre_ + prelen_, 4 - prelen_);
             if (r <= 0) break;
@@ -128,7 +133,9 @@ public:
         }
         const unsigned char *magic = pre_;
         if (prelen_ >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-            if (::lseek(fd_, 0, SEEK_SET) == 0) {  // a regular file: zlib's own reader from the start
+            // seekable: step back over the sniffed bytes (relative: a /dev/stdin redirected from the middle of a file
+            // must return to where the stream started, not to offset 0) and let zlib's own reader take it from there
+            if (::lseek(fd_, -(off_t)prelen_, SEEK_CUR) != (off_t)-1) {
                 prelen_ = 0;
                 gz_ = gzdopen(fd_, "rb");
                 if (!gz_) return fail_open(-ENOMEM);

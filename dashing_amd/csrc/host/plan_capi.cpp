@@ -1,0 +1,240 @@
+// plan_capi.cpp -- CPU test hook of the pure-host planner (../plan.cpp): builds a layout and a pair plan for given
+// per-sketch keys exactly as engine.hip does and checks the plan against its contract, so the schedule that replaces
+// dist_loop / perform_core_op (src/sketch_and_cmp.h:785-880, :699-710) is unit-tested without a GPU
+// (tests/test_plan.py).  Built into libdashing_host.so; not part of the GPU C-ABI.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../plan.h"
+
+using namespace dsh;
+using namespace dsh::plan;
+
+namespace {
+
+struct Err {
+    char *buf;
+    size_t cap;
+    int fail(const char *fmt, ...)
+    {
+        if (buf && cap) {
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, cap, fmt, ap);
+            va_end(ap);
+        }
+        return -1;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// mode: 0 triangle rows [rb, re) (want_sorted decides the layout), 1 rectangle rows [rb,re) x cols [cb,ce) (identity
+// layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN).
+// stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P.
+int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
+                    uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
+                    int ls_item_chunks, uint64_t *stats, char *err, size_t cap)
+{
+    Err E{err, cap};
+    if (re > n) re = n;
+    if (mode == 1 || !want_sorted) want_sorted = mode == 2 ? 1 : 0;
+    if (mode == 2) want_sorted = 1;
+    std::vector<uint64_t> parts;
+    uint64_t lrb = 0, lre = n;
+    if (want_sorted && mode == 0) lrb = rb, lre = re;
+    if (want_sorted) range_parts(n, lrb, lre, std::max<uint32_t>(want_parts ? nparts : 1, 1), parts);
+    Layout L;
+    build_layout(keys, n, want_sorted, lrb, lre, parts, L);
+    // ---- layout: perm is a permutation of the columns; the parts hold exactly their rows; block stats are right
+    const uint64_t col0 = want_sorted ? lrb : 0;
+    if (L.ncols != n - col0) return E.fail("ncols %llu != %llu", (unsigned long long)L.ncols, (unsigned long long)(n - col0));
+    if (L.Npad % kTile || L.Npad < L.ncols || L.Npad >= L.ncols + kTile) return E.fail("bad Npad %u", L.Npad);
+    std::vector<uint8_t> seen(n, 0);
+    for (uint64_t s = 0; s < L.ncols; ++s) {
+        const uint32_t g = L.perm[s];
+        if (g < col0 || g >= n || seen[g]) return E.fail("perm[%llu] = %u is out of range or repeated", (unsigned long long)s, g);
+        seen[g] = 1;
+    }
+    if (want_sorted) {
+        uint64_t s = 0;
+        for (size_t q = 0; q + 1 < L.parts.size(); ++q)
+            for (uint64_t r = L.parts[q]; r < L.parts[q + 1]; ++r, ++s)
+                if (L.perm[s] < L.parts[q] || L.perm[s] >= L.parts[q + 1])
+                    return E.fail("column %llu holds sketch %u, not a row of part %zu", (unsigned long long)s, L.perm[s], q);
+        for (; s < L.ncols; ++s)
+            if (L.perm[s] < lre) return E.fail("column %llu (after the wanted rows) holds wanted row %u", (unsigned long long)s, L.perm[s]);
+        if (L.whole)
+            for (uint64_t i = 0; i < n; ++i)
+                if (L.perm[n + L.perm[i]] != i) return E.fail("inverse permutation wrong at %llu", (unsigned long long)i);
+    }
+    Tuning tu;
+    const uint64_t m = 1ull << p;
+    tu.W = (uint32_t)std::max<uint64_t>(1, m / 32);
+    tu.kc = tu.W >= 32 ? 32 : 16;
+    tu.cum_bytes = p <= 15 ? 2 : 4;
+    tu.cum_budget = cum_budget;
+    tu.nsplit = nsplit;
+    tu.lockstep = lockstep && tu.W >= (uint32_t)tu.kc;
+    tu.ls_item_chunks = ls_item_chunks;
+    PairQuery q;
+    q.rect = mode == 1;
+    q.sorted_rows = mode == 2;
+    q.want_parts = want_parts && mode == 0 && want_sorted;
+    q.row_begin = rb;
+    q.row_end = re;
+    q.col_begin = cb;
+    q.col_end = ce;
+    PairPlan pp;
+    const bool any = build_pairs(L, q, tu, pp);
+    for (int i = 0; i < 7; ++i) stats[i] = 0;
+    stats[5] = L.Npad;
+    stats[6] = L.P;
+    // ---- every wanted pair is owned by exactly one (tile, lane) -- the `active` predicate of k_finalize
+    std::vector<uint8_t> hit;
+    uint64_t wanted = 0;
+    auto orig = [&](uint64_t s) -> uint64_t { return L.perm[s]; };
+    if (mode == 1) {
+        const uint64_t nr = re > rb ? re - rb : 0, nc = ce > cb ? ce - cb : 0;
+        wanted = nr * nc;
+        hit.assign(wanted, 0);
+    } else {
+        hit.assign(n * n, 0);
+        for (uint64_t i = rb; i < re; ++i) wanted += n - 1 - i;
+        if (mode == 2) {
+            wanted = 0;
+            for (uint64_t si = rb; si < re; ++si) wanted += n - 1 - si;
+        }
+    }
+    if (!any) {
+        if (wanted) return E.fail("nothing planned although %llu pairs are wanted", (unsigned long long)wanted);
+        return 0;
+    }
+    const std::vector<U4> &T = pp.T;
+    uint64_t got = 0, planes_sum = 0;
+    for (const U4 &t : T) {
+        if (t.z > t.w || t.w > L.P) return E.fail("tile (%u,%u) has the plane range [%u,%u) of %u", t.x, t.y, t.z, t.w, L.P);
+        planes_sum += t.w - t.z;
+        for (uint32_t a = 0; a < kTile; ++a)
+            for (uint32_t b = 0; b < kTile; ++b) {
+                const uint64_t si = (uint64_t)t.x * kTile + a, sj = (uint64_t)t.y * kTile + b;
+                if (si >= L.ncols || sj >= L.ncols) continue;
+                const uint64_t i = orig(si), j = orig(sj);
+                bool active;
+                uint64_t slot;
+                if (mode == 1) {
+                    active = i >= rb && i < re && j >= cb && j < ce;
+                    slot = active ? (i - rb) * (ce - cb) + (j - cb) : 0;
+                } else if (mode == 2) {
+                    active = si < sj && si >= rb && si < re;
+                    slot = si * n + sj;
+                } else {
+                    const uint64_t oi = std::min(i, j), oj = std::max(i, j);
+                    active = si < sj && oi >= rb && oi < re;
+                    slot = oi * n + oj;
+                }
+                if (!active) continue;
+                if (hit[slot]++) return E.fail("pair slot %llu computed twice (tile %u,%u)", (unsigned long long)slot, t.x, t.y);
+                ++got;
+                // exactness of the tile's dense range for this pair: everything above T is listed by
+                // one of the two sketches, everything below Lp is below both low thresholds or below both minima
+                const uint32_t ka = keys[i], kb = keys[j];
+                const int Tp = L.pbase + (int)t.w, Lp = L.pbase + (int)t.z;
+                if (Tp < std::max(key_T(ka), key_T(kb))) return E.fail("tile (%u,%u): T %d below a sketch's threshold", t.x, t.y, Tp);
+                if (Lp > std::max(std::max(key_lo(ka), key_lo(kb)), std::min(key_L(ka), key_L(kb))))
+                    return E.fail("tile (%u,%u): Lp %d above what the low lists cover", t.x, t.y, Lp);
+            }
+    }
+    if (got != wanted) return E.fail("%llu of %llu wanted pairs are covered", (unsigned long long)got, (unsigned long long)wanted);
+    // ---- bands cover the tiles in order and respect the scratch budget (a single tile may exceed it)
+    size_t at = 0;
+    if (pp.bands.size() != pp.segs.size() || pp.bands.size() != pp.band_items.size()) return E.fail("band bookkeeping sizes differ");
+    std::vector<int> part_done(pp.nparts, 0);
+    int last_part = -1;
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi) {
+        const auto &bd = pp.bands[bi];
+        if (bd.first != at || bd.second <= bd.first || bd.second > T.size()) return E.fail("band %zu = [%zu,%zu) does not follow %zu", bi, bd.first, bd.second, at);
+        at = bd.second;
+        if (bd.second - bd.first > 1 && (bd.second - bd.first) * pp.per_tile_bytes > cum_budget)
+            return E.fail("band %zu needs %llu bytes of C(v), budget %llu", bi, (unsigned long long)((bd.second - bd.first) * pp.per_tile_bytes), (unsigned long long)cum_budget);
+        size_t sa = bd.first;
+        for (const Seg &sg : pp.segs[bi]) {
+            if (sg.b != sa || sg.e <= sg.b || sg.e > bd.second) return E.fail("segment [%zu,%zu) of band %zu does not follow %zu", sg.b, sg.e, bi, sa);
+            sa = sg.e;
+            if (sg.part >= 0) {
+                if ((uint32_t)sg.part >= pp.nparts || part_done[sg.part]++ || sg.part != last_part + 1)
+                    return E.fail("part %d completed out of order or twice", sg.part);
+                last_part = sg.part;
+            }
+            // every tile of the segment belongs to the part that is current
+            if (q.want_parts)
+                for (size_t t = sg.b; t < sg.e; ++t) {
+                    const uint64_t row0 = (uint64_t)T[t].x * kTile + L.rb;
+                    const int cur = last_part + (sg.part >= 0 ? 0 : 1);
+                    if (cur < 0 || (size_t)cur + 1 >= L.parts.size() || row0 < L.parts[cur] || row0 >= L.parts[cur + 1])
+                        return E.fail("tile row %u is not in part %d", T[t].x, cur);
+                }
+        }
+        if (sa != bd.second) return E.fail("segments of band %zu end at %zu, not %zu", bi, sa, bd.second);
+        // items of the band cover every tile's chunk range exactly once
+        const auto &bi_ = pp.band_items[bi];
+        std::vector<uint32_t> next(bd.second - bd.first);
+        for (size_t t = bd.first; t < bd.second; ++t) next[t - bd.first] = pp.chunks[t].x;
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per(bd.second - bd.first);
+        for (size_t it = bi_.first; it < bi_.second; ++it) {
+            const U4 &I = pp.items[it];
+            if (I.x >= per.size() || I.y >= I.z) return E.fail("item %zu is malformed", it);
+            per[I.x].emplace_back(I.y, I.z);
+        }
+        const uint32_t cpp_ = tu.W >= (uint32_t)tu.kc ? tu.W / tu.kc : 1;
+        for (size_t t = 0; t < per.size(); ++t) {
+            std::sort(per[t].begin(), per[t].end());
+            uint32_t x = pp.chunks[bd.first + t].x;
+            for (auto &pr : per[t]) {
+                if (pr.first != x) return E.fail("items of tile %zu leave a gap or overlap at chunk %u", t, x);
+                if (tu.W >= (uint32_t)tu.kc && ((pr.first % cpp_) || (pr.second % cpp_))) return E.fail("an item of tile %zu is not whole planes", t);
+                x = pr.second;
+            }
+            if (x != pp.chunks[bd.first + t].y) return E.fail("items of tile %zu end at chunk %u, not %u", t, x, pp.chunks[bd.first + t].y);
+        }
+    }
+    if (at != T.size()) return E.fail("bands end at %zu of %zu tiles", at, T.size());
+    for (uint32_t qd = 0; qd < pp.nparts; ++qd)
+        if (part_done[qd] != 1) return E.fail("part %u never completes", qd);
+    if (q.want_parts && pp.nparts + 1 != L.parts.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.parts.size() - 1);
+    // ---- the two device lists describe the same tiles
+    std::vector<U4> dt(T.size()), df(T.size());
+    emit_tile_lists(L, pp, dt.data(), df.data());
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi)
+        for (const Seg &sg : pp.segs[bi]) {
+            std::vector<uint8_t> used(pp.bands[bi].second - pp.bands[bi].first, 0);
+            for (size_t t = sg.b; t < sg.e; ++t) {
+                const U4 &f = df[t];
+                const size_t src = pp.bands[bi].first + f.w;
+                if (f.w >= used.size() || src < sg.b || src >= sg.e || used[f.w]++) return E.fail("finalize list names a C(v) block twice or outside its segment");
+                if (f.x != T[src].x || f.y != T[src].y || (f.z & 0xFFu) != T[src].z || ((f.z >> 8) & 0xFFu) != T[src].w)
+                    return E.fail("finalize list entry %zu does not match tile %zu", t, src);
+                if (dt[src].x != T[src].x || dt[src].y != T[src].y || dt[src].z != (T[src].z | (T[src].w << 8)))
+                    return E.fail("tile list entry %zu is wrong", src);
+                const int lo = (int)((f.z >> 16) & 0xFFu), hi = (int)(f.z >> 24);
+                if (hi - lo + 1 > sg.hist_bins) return E.fail("segment hist_bins %d too small for tile %zu", sg.hist_bins, src);
+            }
+            if (pp.finalize_rowmajor)  // row-major inside the segment
+                for (size_t t = sg.b + 1; t < sg.e; ++t)
+                    if (df[t - 1].x > df[t].x || (df[t - 1].x == df[t].x && df[t - 1].y >= df[t].y))
+                        return E.fail("finalize list of a segment is not row-major at %zu", t);
+        }
+    stats[0] = T.size();
+    stats[1] = pp.bands.size();
+    stats[2] = pp.items.size();
+    stats[3] = pp.nparts;
+    stats[4] = T.empty() ? 0 : planes_sum * 100 / T.size();
+    return 0;
+}
+
+}  // extern "C"

@@ -3,12 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace dsh {
+#include "consts.h"
 
-constexpr uint32_t kTile = 128;   // sketches per tile side in k_pair_counts
-constexpr uint32_t kListCap = 512;  // capacity of a sketch's register list (entries): upper tail (emax <= 255) + lower tail (elow <= 255)
-constexpr uint32_t kMaxListSide = 255;  // cap of either tail (their per-value counts are bytes)
-constexpr uint32_t kMaxBuckets = 1u << 15;  // buckets of a column block's index: (position group, tail)
+namespace dsh {
 
 hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t first, uint64_t n, int p, int estim,
                                 int emax, int elow, uint32_t *hist, void *exc, uint8_t *excv, uint32_t *exc_n,
@@ -92,10 +89,6 @@ struct SketchWork {
     uint32_t nsub;   // number of 8192-base sub-chunks this workgroup walks
     uint32_t slot;   // row of the resident sketch matrix
 };
-constexpr int kMaxPLds = 17;   // largest p whose registers fit a workgroup's LDS (k_sketch)
-constexpr int kMaxPCompare = 24;  // the compare path takes every p the sketches can have 
-constexpr int kMaxP = 24;      // largest p for sketching / cardinalities / up- and download (positions are 24-bit)
-constexpr uint32_t kSketchSub = 8192;  // bases per sub-chunk (256 threads x 32 start positions)
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs);
 

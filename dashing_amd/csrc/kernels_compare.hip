@@ -685,6 +685,8 @@ __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restri
 // (nibble -> 4 bytes by one multiply + one mask).  A and B are expanded the same way, so byte e of an A lane and
 // byte e of the B lane with the same h stand for the same register position: whatever k-order the hardware assigns
 // to the 16 bytes of a lane, the dot product pairs equal positions.
+// Built only with `make WHATIF=1` (-DDSH_WHATIF_MFMA): the default library refuses the option.
+#ifdef DSH_WHATIF_MFMA
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 
@@ -842,10 +844,18 @@ static hipError_t launch_pcm(hipStream_t st, const uint32_t *planes, uint32_t Np
     return hipGetLastError();
 }
 
+#endif  // DSH_WHATIF_MFMA
+
 hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes, uint32_t Npad,
                                    uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
                                    uint32_t nitems, void *cum, uint64_t nslots)
 {
+#ifndef DSH_WHATIF_MFMA
+    // the product library is built without the what-if (csrc/Makefile: `make WHATIF=1` adds it)
+    (void)st, (void)kc, (void)cum_bytes, (void)planes, (void)Npad, (void)Kpad, (void)W, (void)P, (void)tiles, (void)items;
+    (void)nitems, (void)cum, (void)nslots;
+    return hipErrorNotSupported;
+#else
     if (nitems == 0 || Kpad == 0) return hipSuccess;
     if (cum_bytes == 2) {
         switch (kc) {
@@ -861,6 +871,7 @@ hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const 
     case 64: return launch_pcm<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     default: return hipErrorInvalidValue;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,451 @@
+// plan.cpp -- see plan.h.  Pure host code: compiled into libdashing_hip.so (the product) and into
+// libdashing_host.so (CPU unit tests of the planner, tests/test_plan.py).
+#include "plan.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace dsh {
+namespace plan {
+
+uint64_t tri_index(uint64_t n, uint64_t i, uint64_t j) { return i * (2 * n - i - 1) / 2 + j - (i + 1); }
+
+uint64_t tri_span(uint64_t n, uint64_t rb, uint64_t re)
+{
+    if (re > n) re = n;
+    if (rb >= re) return 0;
+    // sum_{i=rb}^{re-1} (n-1-i)
+    const uint64_t cnt = re - rb;
+    return cnt * (n - 1) - (rb + re - 1) * cnt / 2;
+}
+
+void partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds)
+{
+    if (align == 0) align = 1;
+    const uint64_t total = n ? n * (n - 1) / 2 : 0;
+    bounds[0] = 0;
+    uint64_t row = 0;
+    for (uint32_t r = 1; r < nparts; ++r) {
+        const long double target = (long double)total * r / nparts;
+        // advance in `align` steps to the boundary whose cumulative pair count is nearest target
+        uint64_t best = row;
+        long double bestd = -1;
+        for (uint64_t cand = row; cand <= n; cand += align) {
+            const long double cum = (long double)tri_span(n, 0, cand);
+            const long double d = cum > target ? cum - target : target - cum;
+            if (bestd < 0 || d < bestd) {
+                bestd = d;
+                best = cand;
+            }
+            if (cum > target) break;
+        }
+        row = std::min<uint64_t>(best, n);
+        bounds[r] = row;
+    }
+    bounds[nparts] = n;
+}
+
+void balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds)
+{
+    // Contiguous row ranges on 128-row (tile) boundaries that minimise the largest cost of any part.  A part with
+    // the tile rows [a,b) of NT computes sum_{t=a}^{b-1} (NT - t) tiles (its triangle + the rectangle to its right)
+    // and first prepares its own plane matrix over the columns a*128 .. n (per-sketch pass, key order, transform):
+    // kPrepPerTileRow tile-equivalents per 128 columns (0.42 ms per 10 000 columns vs 6.0 us per tile on the C3
+    // workload, profiles/r2d) -- the first ranks hold every column, the last only a third, so they get fewer tiles.
+    // Unaligned bounds would leave part of a tile row empty on every rank (at n = 10 000 / 8 ranks the first rank has
+    // ~5 tile rows: up to 16 % waste).
+    constexpr double kPrepPerTileRow = 0.9;
+    const uint64_t NT = (n + kTile - 1) / kTile;
+    auto cost = [NT](uint64_t t) { return (double)(NT - t); };
+    auto fill = [&](double limit, uint64_t *out) -> bool {
+        uint64_t t = 0;
+        for (uint32_t r = 0; r < nparts; ++r) {
+            double acc = kPrepPerTileRow * (double)(NT - t);  // the part's prepare, paid once it holds any row
+            if (out) out[r] = std::min<uint64_t>(n, t * kTile);
+            while (t < NT && acc + cost(t) <= limit) acc += cost(t++);
+        }
+        if (out) out[nparts] = n;
+        return t == NT;
+    };
+    double lo = 0, hi = (double)NT * (double)(NT + 1) / 2.0 + kPrepPerTileRow * (double)NT + 1.0;
+    if (NT == 0) lo = hi = 0;
+    for (int it = 0; it < 100 && hi - lo > 1e-3; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, nullptr)) hi = mid;
+        else lo = mid;
+    }
+    fill(hi, bounds);
+}
+
+void range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &out)
+{
+    out.assign(1, rb);
+    if (re > n) re = n;
+    if (rb > re) rb = re, out[0] = rb;
+    const uint64_t total = tri_span(n, rb, re);
+    for (uint32_t q = 1; q < nparts && out.back() < re; ++q) {
+        const long double target = (long double)total * q / nparts;
+        uint64_t best = out.back() + kTile;
+        for (uint64_t cand = out.back() + kTile; cand < re; cand += kTile) {
+            best = cand;
+            if ((long double)tri_span(n, rb, cand) >= target) break;
+        }
+        if (best >= re) break;
+        out.push_back(best);
+    }
+    if (out.back() != re) out.push_back(re);
+}
+
+// A pair shares cap^2 / 2^p listed positions per side, each one an LDS atomic in k_finalize; every halving of the
+// upper tail (a plane saved) costs twice the entries, while the lower tail of the register law falls off
+// double-exponentially: listing ~200 registers removes the one or two nearly empty planes at the bottom.  2^p / 32
+// entries per side = one shared position per pair and side on average: 32/32 at p = 10, 128/128 at p = 12, the caps
+// 255/200 from p = 13.
+int auto_list_cap(int p, bool upper)
+{
+    const uint64_t m = 1ull << p;
+    return (int)std::min<uint64_t>(upper ? kMaxListSide : 200, m >> 5);
+}
+
+void tile_planes(const Layout &L, uint32_t ti, uint32_t tj, int &pb, int &pe)
+{
+    const int lo_t = std::max<int>(std::max<int>(L.blk_lo[ti], L.blk_lo[tj]), std::min<int>(L.blk_L[ti], L.blk_L[tj]));
+    const int T_t = std::max<int>(L.blk_T[ti], L.blk_T[tj]);
+    pb = std::max(0, lo_t - L.pbase);
+    pe = std::max(pb, T_t - L.pbase);
+}
+
+void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
+                  const std::vector<uint64_t> &parts, Layout &L)
+{
+    if (re > n) re = n;
+    if (!want_sorted) rb = 0, re = n;
+    if (rb > re) rb = re;
+    // the plane matrix holds the sketches col0 .. n-1 (a row range [rb,re) of the triangle never looks at
+    // sketches before rb); value range and thresholds are taken over those only
+    const uint64_t col0 = want_sorted ? rb : 0;
+    const uint64_t ncols = n - col0;
+    int vr[3] = {63, 0, 0};  // min register value anywhere, max value, max threshold
+    for (uint64_t i = col0; i < n; ++i) {
+        const uint32_t key = k32[i];
+        vr[0] = std::min<int>(vr[0], key_lo(key));
+        vr[1] = std::max<int>(vr[1], key_hi(key));
+        vr[2] = std::max<int>(vr[2], key_T(key));
+    }
+    if (ncols == 0) vr[0] = vr[1] = vr[2] = 0;
+    L.sorted = want_sorted;
+    L.rb = rb;
+    L.re = re;
+    L.parts = want_sorted ? parts : std::vector<uint64_t>();
+    L.n = n;
+    L.vlo = vr[0];
+    L.vhi = vr[1];
+    L.ncols = ncols;
+    L.Npad = (uint32_t)((ncols + kTile - 1) / kTile * kTile);
+    L.whole = want_sorted && rb == 0 && re == n;
+    // column order: identity, or a counting sort by (threshold, min value, max value): the first
+    // two make the 128-column blocks need few planes, the third keeps the 64 pairs of a finalize
+    // wave alike in their largest register, i.e. in the trip count of the estimator's loops.
+    // With a row range the wanted rows [rb,re) come first (their tile rows are the only ones computed),
+    // then the later rows; each part is key-ordered on its own.
+    L.perm.resize(ncols);
+    if (want_sorted) {
+        auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each: high threshold, low threshold, max value
+            const uint32_t key = k32[i];
+            return ((uint32_t)key_T(key) << 12) | ((uint32_t)key_L(key) << 6) | (uint32_t)key_hi(key);
+        };
+        // stable LSD radix sort, two 9-bit digits (a single 2^18-bucket counting sort spends ~0.1 ms clearing
+        // and scanning its counters); the host sits between the per-sketch pass and the transform, so this is
+        // on the critical path of every layout: scratch is kept with the layout
+        std::vector<uint32_t> &a = L.sort_a, &keys = L.sort_keys;
+        keys.resize(n);
+        for (uint64_t i = col0; i < n; ++i) keys[i] = skey(i);
+        auto sort_part = [&](uint64_t lo, uint64_t hi, uint32_t *dst) {
+            const uint64_t cnt_ = hi - lo;
+            if (a.size() < cnt_) a.resize(cnt_);
+            uint32_t cnt[513];
+            std::memset(cnt, 0, sizeof cnt);
+            for (uint64_t i = 0; i < cnt_; ++i) cnt[(keys[lo + i] & 511u) + 1u]++;
+            for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+            for (uint64_t i = 0; i < cnt_; ++i) a[cnt[keys[lo + i] & 511u]++] = (uint32_t)(lo + i);
+            std::memset(cnt, 0, sizeof cnt);
+            for (uint64_t i = 0; i < cnt_; ++i) cnt[((keys[a[i]] >> 9) & 511u) + 1u]++;
+            for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+            for (uint64_t i = 0; i < cnt_; ++i) dst[cnt[(keys[a[i]] >> 9) & 511u]++] = a[i];
+        };
+        for (size_t q = 0; q + 1 < L.parts.size(); ++q) sort_part(L.parts[q], L.parts[q + 1], L.perm.data() + (L.parts[q] - rb));
+        sort_part(re, n, L.perm.data() + (re - rb));
+        // (whole collection only) the inverse for the un-permute of the shard path
+        if (L.whole) {
+            L.perm.resize(2 * n);
+            for (uint64_t s = 0; s < n; ++s) L.perm[n + L.perm[s]] = (uint32_t)s;
+        }
+    } else {
+        for (uint64_t i = 0; i < n; ++i) L.perm[i] = (uint32_t)i;
+    }
+    const uint32_t NT = L.Npad / kTile;
+    L.blk_T.assign(NT, 0);
+    L.blk_lo.assign(NT, 255);
+    L.blk_L.assign(NT, 255);
+    L.blk_hi.assign(NT, 0);
+    int pbase = vr[2];
+    for (uint64_t s = 0; s < ncols; ++s) {
+        const uint32_t key = k32[L.perm[s]];
+        const uint32_t b = (uint32_t)(s / kTile);
+        L.blk_T[b] = std::max<uint8_t>(L.blk_T[b], (uint8_t)key_T(key));
+        L.blk_lo[b] = std::min<uint8_t>(L.blk_lo[b], (uint8_t)key_lo(key));
+        L.blk_L[b] = std::min<uint8_t>(L.blk_L[b], (uint8_t)key_L(key));
+        L.blk_hi[b] = std::max<uint8_t>(L.blk_hi[b], (uint8_t)key_hi(key));
+        pbase = std::min<int>(pbase, key_L(key));
+    }
+    // dense planes cover v in (pbase, Tmax]: below the smallest low threshold every C(v) comes from the list join
+    L.pbase = pbase;
+    L.P = (uint32_t)(vr[2] - pbase);
+}
+
+// Order the tiles of a segment so that workgroups that run on the same XCD (block b -> XCD b % 8,
+// observed dispatch behaviour; speed only, never correctness) walk one tile row together and
+// share its A panel in that XCD's L2.
+static void xcd_order(std::vector<U4> &t, std::vector<uint32_t> &rank, size_t b, size_t e, size_t group)
+{
+    const size_t cnt = e - b;
+    if (cnt < 16) return;
+    std::vector<U4> tmp(cnt);
+    std::vector<uint32_t> rtmp(cnt);
+    const size_t nx = 8, per = (cnt + nx - 1) / nx;
+    // `group` consecutive positions of the launch order share a workgroup (2 with the lockstep kernel); workgroup w
+    // runs on XCD w % 8; give XCD x the contiguous range [x*per, (x+1)*per) of the row-major list
+    size_t q = 0;
+    for (size_t r = 0; r < per; r += group)
+        for (size_t x = 0; x < nx; ++x)
+            for (size_t u = 0; u < group && r + u < per; ++u) {
+                const size_t src = x * per + r + u;
+                if (src < cnt) {
+                    rtmp[q] = rank[b + src];
+                    tmp[q++] = t[b + src];
+                }
+            }
+    std::copy(tmp.begin(), tmp.begin() + q, t.begin() + b);
+    std::copy(rtmp.begin(), rtmp.begin() + q, rank.begin() + b);
+}
+
+static void tile_vrange(const Layout &L, const U4 &t, int &lo, int &hi)
+{
+    lo = std::min<int>(L.blk_lo[t.x], L.blk_lo[t.y]);
+    hi = std::max<int>(L.blk_hi[t.x], L.blk_hi[t.y]);
+    if (hi < lo) hi = lo;  // (blocks of padding only)
+}
+
+bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPlan &pp)
+{
+    std::vector<U4> &T = pp.T;
+    T.clear();
+    pp.bands.clear();
+    pp.band_items.clear();
+    pp.segs.clear();
+    pp.items.clear();
+    pp.nparts = 0;
+    pp.max_band = 0;
+    pp.finalize_rowmajor = tu.finalize_rowmajor;
+    const uint32_t NT = L.Npad / kTile;
+    // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes
+    // v in (max(min lo of its two blocks), max threshold of its two blocks]
+    auto tile_of = [&](uint32_t ti, uint32_t tj) {
+        int pb, pe;
+        tile_planes(L, ti, tj, pb, pe);
+        return U4{ti, tj, (uint32_t)pb, (uint32_t)pe};
+    };
+    if (job.rect) {
+        if (job.row_begin >= job.row_end || job.col_begin >= job.col_end) return false;
+        const uint32_t r0 = (uint32_t)(job.row_begin / kTile), r1 = (uint32_t)((job.row_end + kTile - 1) / kTile);
+        const uint32_t c0 = (uint32_t)(job.col_begin / kTile), c1 = (uint32_t)((job.col_end + kTile - 1) / kTile);
+        for (uint32_t ti = r0; ti < r1; ++ti)
+            for (uint32_t tj = c0; tj < c1; ++tj) T.push_back(tile_of(ti, tj));
+    } else {
+        if (job.row_begin >= job.row_end) return false;
+        uint32_t r0 = 0, r1 = NT;
+        if (!L.sorted || job.sorted_rows) {  // rows index plane columns: only their tile rows
+            r0 = (uint32_t)(job.row_begin / kTile);
+            r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
+        } else {  // the wanted rows are the first re - rb columns
+            r1 = std::min<uint32_t>(NT, (uint32_t)((L.re - L.rb + kTile - 1) / kTile));
+        }
+        for (uint32_t ti = r0; ti < r1; ++ti)
+            for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(tile_of(ti, tj));
+    }
+    if (T.empty()) return false;
+    // bands bounded by the cum scratch budget
+    pp.per_tile_bytes = (uint64_t)kTile * kTile * tu.cum_bytes * std::max<uint32_t>(L.P, 1);
+    const uint64_t max_tiles = std::max<uint64_t>(1, tu.cum_budget / pp.per_tile_bytes);
+    // Parts (dsh_dist_rows_parts_device_async): k_finalize runs once per SEGMENT -- the tiles of one part inside one
+    // band -- and an event marks the end of a part's last segment: the part's span of the matrix is final and can travel
+    // while the other parts are computed.  The tile kernel runs once per band; a band is also cut at a part boundary
+    // when the part is large (>= kPartBandTiles tiles: a cut costs 0.2-0.3 ms -- two tails and a pipeline bubble,
+    // profiles/r3g -- nothing against the ~1 ms per 1 000 tiles the part takes, and the first part can leave after 1/nparts of
+    // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
+    // A layout with ONE part (a short range) still gets its event: the exchange of every rank looks the same.
+    constexpr size_t kPartBandTiles = 2048;
+    const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.parts.size() >= 2;
+    // first tile of every part: T is row-major and a part is a run of whole tile rows, so the part of a tile is monotone
+    std::vector<size_t> pstart{0};
+    if (parts_on) {
+        size_t q = 0;
+        for (size_t t = 0; t < T.size(); ++t) {
+            const uint64_t pos = (uint64_t)T[t].x * kTile;
+            while (q + 2 < L.parts.size() && pos >= L.parts[q + 1] - L.rb) {
+                ++q;
+                pstart.push_back(t);
+            }
+        }
+        pp.nparts = (uint32_t)pstart.size();
+    }
+    pstart.push_back(T.size());
+    auto part_of_tile = [&](size_t t) -> size_t {
+        return (size_t)(std::upper_bound(pstart.begin(), pstart.end() - 1, t) - pstart.begin()) - 1;
+    };
+    for (size_t b = 0; b < T.size();) {
+        size_t e = std::min<size_t>(T.size(), b + max_tiles);
+        if (parts_on) {  // a large part also ends the band
+            const size_t q = part_of_tile(b);
+            if (pstart[q + 1] - pstart[q] >= kPartBandTiles) e = std::min(e, pstart[q + 1]);
+        }
+        pp.bands.emplace_back(b, e);
+        b = e;
+    }
+    pp.segs.resize(pp.bands.size());
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi) {
+        size_t b = pp.bands[bi].first;
+        while (b < pp.bands[bi].second) {
+            const size_t q = part_of_tile(b);  // part of a tile = part of its tile row (parts are runs of whole tile rows)
+            const size_t e = std::min(pp.bands[bi].second, pstart[q + 1]);
+            const bool last_of_part = e == pstart[q + 1];
+            Seg sg{b, e, parts_on && last_of_part ? (int)q : -1, 1};
+            for (size_t t = b; t < e; ++t) {
+                int lo, hi;
+                tile_vrange(L, T[t], lo, hi);
+                sg.hist_bins = std::max(sg.hist_bins, hi - lo + 1);
+            }
+            pp.segs[bi].push_back(sg);
+            b = e;
+        }
+    }
+    // rank[t] = position of tile t in the row-major order of its segment (the order k_finalize walks)
+    std::vector<uint32_t> &rank = pp.rank;
+    rank.resize(T.size());
+    for (auto &sv : pp.segs)
+        for (auto &sg : sv)
+            for (size_t t = sg.b; t < sg.e; ++t) rank[t] = (uint32_t)(t - sg.b);
+    if (tu.xcd_swizzle)
+        for (auto &sv : pp.segs)
+            for (auto &sg : sv) xcd_order(T, rank, sg.b, sg.e, tu.lockstep ? 2 : 1);
+    // work items per band: {tile index in band, chunk begin, chunk end}
+    const uint32_t KC = (uint32_t)tu.kc;
+    std::vector<U4> &I = pp.items;
+    const uint32_t cpp = tu.W >= KC ? tu.W / KC : 1;  // chunks per plane when a plane spans chunks
+    std::vector<U2> &CR = pp.chunks;  // chunk range of every tile, computed once
+    CR.resize(T.size());
+    for (size_t t = 0; t < T.size(); ++t)
+        CR[t] = U2{(uint32_t)(((uint64_t)T[t].z * tu.W) / KC), (uint32_t)(((uint64_t)T[t].w * tu.W + KC - 1) / KC)};
+    for (auto &bd : pp.bands) {
+        const size_t nt = bd.second - bd.first;
+        pp.max_band = std::max(pp.max_band, nt);
+        uint64_t tot = 0;
+        for (size_t t = bd.first; t < bd.second; ++t) tot += CR[t].y - CR[t].x;
+        // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
+        uint64_t piece = tu.nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + tu.nsplit - 1) / tu.nsplit)
+                                       : std::max<uint64_t>(1, tot / (16 * 512));
+        if (tu.nsplit == 0 && tu.lockstep)  // equal, short items: the two items of a workgroup run in lockstep
+            piece = std::min<uint64_t>(piece, std::max<uint64_t>(cpp, (uint64_t)tu.ls_item_chunks));
+        piece = (piece + cpp - 1) / cpp * cpp;
+        const size_t i0 = I.size();
+        uint32_t maxpieces = 0;
+        for (size_t t = bd.first; t < bd.second; ++t)
+            maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((CR[t].y - CR[t].x + piece - 1) / piece));
+        for (uint32_t s = 0; s < maxpieces; ++s) {  // piece-major so neighbours in launch order share planes
+            const size_t g0 = I.size();
+            uint32_t lmin = ~0u, lmax = 0;
+            for (size_t t = bd.first; t < bd.second; ++t) {
+                const uint64_t b0 = CR[t].x + (uint64_t)s * piece;
+                if (b0 >= CR[t].y) continue;
+                const uint32_t e0 = (uint32_t)std::min<uint64_t>(CR[t].y, b0 + piece);
+                I.push_back(U4{(uint32_t)(t - bd.first), (uint32_t)b0, e0, 0});
+                lmin = std::min<uint32_t>(lmin, e0 - (uint32_t)b0);
+                lmax = std::max<uint32_t>(lmax, e0 - (uint32_t)b0);
+            }
+            // the lockstep kernel pairs consecutive items: keep equal lengths together (only a tile's last piece can be
+            // shorter; with whole-plane pieces every item of the group is the same length and there is nothing to do)
+            if (tu.lockstep && tu.ls_sort_items && lmin != lmax)
+                std::stable_sort(I.begin() + g0, I.end(), [](const U4 &x, const U4 &y) { return x.z - x.y > y.z - y.y; });
+        }
+        pp.band_items.emplace_back(i0, I.size());
+    }
+    return true;
+}
+
+void emit_tile_lists(const Layout &L, const PairPlan &pp, U4 *pinT, U4 *pinF)
+{
+    // The tile kernel's list (launch order: XCD-interleaved, see xcd_order) holds {row block, column block, ..}.
+    // k_finalize has its own list, every segment in ROW-MAJOR order: {row block, column block, plane begin | plane end
+    // << 8 | smallest << 16 | largest << 24 register value of the two blocks' sketches (its histogram columns only span
+    // the values the tile's sketches can hold), index of the tile's C(v) block in the band}.  A block of k_finalize
+    // writes one row of a tile into row perm[si] of the packed matrix, scattered over the row (the columns are
+    // key-ordered); block b runs on XCD b % 8 = tile row % 8, so a given output row is always written through the same
+    // L2.  Walking a tile row's tiles one after the other keeps that row's lines in L2 until they are complete (the 128
+    // rows of a tile row are 5 MB at C3, spread over the 8 L2s); in the tile kernel's interleaved order 8 tile rows were
+    // in flight at once, lines left the L2 partly written and WRITE_SIZE was 6x the output (profiles/r3a, r3i).
+    const std::vector<U4> &T = pp.T;
+    for (size_t t = 0; t < T.size(); ++t) {
+        int lo, hi;
+        tile_vrange(L, T[t], lo, hi);
+        pinT[t] = U4{T[t].x, T[t].y, T[t].z | (T[t].w << 8), (uint32_t)lo | ((uint32_t)hi << 8)};
+    }
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi)
+        for (const Seg &sg : pp.segs[bi])
+            for (size_t t = sg.b; t < sg.e; ++t) {
+                int lo, hi;
+                tile_vrange(L, T[t], lo, hi);
+                const size_t at = pp.finalize_rowmajor ? sg.b + pp.rank[t] : t;
+                pinF[at] = U4{T[t].x, T[t].y, T[t].z | (T[t].w << 8) | ((uint32_t)lo << 16) | ((uint32_t)hi << 24),
+                              (uint32_t)(t - pp.bands[bi].first)};
+            }
+}
+
+}  // namespace plan
+}  // namespace dsh
+
+// ---- C-ABI (include/dashing_hip.h): the pure entry points ------------------------------------------------------------
+#include "../../include/dashing_hip.h"
+
+extern "C" {
+
+uint64_t dsh_tri_index(uint64_t n, uint64_t i, uint64_t j) { return dsh::plan::tri_index(n, i, j); }
+
+uint64_t dsh_tri_span(uint64_t n, uint64_t rb, uint64_t re) { return dsh::plan::tri_span(n, rb, re); }
+
+int dsh_partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds)
+{
+    if (!bounds || nparts == 0) return DSH_EINVAL;
+    dsh::plan::partition_rows(n, nparts, align, bounds);
+    return DSH_OK;
+}
+
+int dsh_balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds)
+{
+    if (!bounds || nparts == 0) return DSH_EINVAL;
+    dsh::plan::balance_rows(n, nparts, bounds);
+    return DSH_OK;
+}
+
+int dsh_range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, uint64_t *part_rows, uint32_t *nparts_out)
+{
+    if (!part_rows || !nparts_out || nparts == 0) return DSH_EINVAL;
+    if (re > n) re = n;
+    if (rb > re) rb = re;
+    std::vector<uint64_t> parts;
+    dsh::plan::range_parts(n, rb, re, nparts, parts);
+    for (size_t q = 0; q < parts.size(); ++q) part_rows[q] = parts[q];
+    *nparts_out = (uint32_t)parts.size() - 1;
+    return DSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// plan.h -- the host-side planner of the compare path: pure C++ (no HIP), so that it is unit-tested on a CPU-only box
+// (host/host_capi.cpp exports dshh_plan_check for tests/test_plan.py).
+//
+// What is planned here replaces the SCHEDULE of the reference's dist_loop (src/sketch_and_cmp.h:785-880:
+// perform_core_op row by row, :699-710, with OpenMP dynamic over j) and of dm::parallel_fill
+// (distmat/distmat.h:459-512): which pairs run where and in which order, and where each result lands in
+// dashing's packed triangle (distmat/distmat.h:260-264).  Three layers:
+//   * triangle arithmetic and row partitions (dsh_tri_*, dsh_partition_rows, dsh_balance_rows, dsh_range_parts);
+//   * Layout: the column order of the bit-plane matrix for a row range -- the wanted rows first (in parts), then the
+//     later rows, each part ordered by the per-sketch key (T, L, hi) -- and the per-128-column-block statistics the
+//     per-tile plane ranges come from;
+//   * PairPlan: tiles, bands (bounded by the C(v) scratch), segments (tiles of one part inside one band: one k_finalize
+//     launch each), work items of the tile kernel, and the two device tile lists.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <utility>
+#include <vector>
+
+#include "consts.h"
+
+namespace dsh {
+namespace plan {
+
+struct U4 { uint32_t x, y, z, w; };  // same layout as HIP's uint4: the device lists are arrays of it
+struct U2 { uint32_t x, y; };
+
+// fields of a per-sketch key (k_selfhist_card): bad << 31 | hi << 18 | T << 12 | L << 6 | lo
+inline int key_lo(uint32_t k) { return (int)(k & 63u); }
+inline int key_L(uint32_t k) { return (int)((k >> 6) & 63u); }
+inline int key_T(uint32_t k) { return (int)((k >> 12) & 63u); }
+inline int key_hi(uint32_t k) { return (int)((k >> 18) & 63u); }
+inline bool key_bad(uint32_t k) { return (k & 0x80000000u) != 0; }
+
+// ---- triangle arithmetic (distmat/distmat.h:260-264) and row partitions -------------------------------------------
+uint64_t tri_index(uint64_t n, uint64_t i, uint64_t j);
+uint64_t tri_span(uint64_t n, uint64_t rb, uint64_t re);
+void partition_rows(uint64_t n, uint32_t nparts, uint32_t align, uint64_t *bounds);
+void balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds);
+// rows [rb, re) cut into nparts consecutive parts of about equal pair counts, every cut a whole number of 128-row
+// tile rows after rb (fewer parts if the range has fewer tile rows); out gets the boundaries
+void range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &out);
+
+// default caps of the two listed tails (profiles/r3f/list_cap_sweep.jsonl)
+int auto_list_cap(int p, bool upper);
+
+// ---- column layout of the plane matrix ------------------------------------------------------------------------------
+struct Layout {
+    int sorted = 0;               // 0: identity over all n sketches.  1: the sub-collection {rb .. n-1}, key-ordered
+    uint64_t rb = 0, re = 0;      // wanted rows of a sorted layout (rb = 0, re = n: the whole collection)
+    std::vector<uint64_t> parts;  // row boundaries of the parts of the wanted rows, front() = rb, back() = re
+    uint64_t n = 0, ncols = 0;    // sketches in the collection; real columns of the plane matrix
+    uint32_t Npad = 0;            // ncols padded to whole 128-column blocks
+    bool whole = false;           // sorted over the whole collection: perm also holds its inverse at [n, 2n)
+    std::vector<uint32_t> perm;   // plane-matrix column -> sketch
+    std::vector<uint8_t> blk_T, blk_lo, blk_L, blk_hi;  // per block: max high threshold, min value, min low threshold, max value
+    int vlo = 0, vhi = 0;         // register value range of the columns
+    int pbase = 0;                // plane pl is the threshold pbase + 1 + pl
+    uint32_t P = 0;               // dense planes
+    std::vector<uint32_t> sort_a, sort_keys;  // scratch of the column sort
+};
+
+// keys: the n per-sketch keys (only [rb, n) is read for a sorted layout).  `parts` as range_parts() gives them
+// (ignored for the identity layout).
+void build_layout(const uint32_t *keys, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
+                  const std::vector<uint64_t> &parts, Layout &L);
+
+// dense plane range of the tile (ti, tj): C(v) is needed for v in (max(larger of the two minima, smaller of the two
+// low thresholds), larger of the two high thresholds] -- below that every C(v) is 0 or comes from the low-list join
+void tile_planes(const Layout &L, uint32_t ti, uint32_t tj, int &pb, int &pe);
+
+// ---- the pair plan ------------------------------------------------------------------------------------------------------
+struct PairQuery {
+    int rect = 0;          // rows x columns rectangle (identity layout) instead of triangle rows
+    int sorted_rows = 0;   // rows index plane columns of the whole sorted layout (shards, band-wise kNN)
+    int want_parts = 0;    // an event per part of the layout (dsh_dist_rows_parts_device_async)
+    uint64_t row_begin = 0, row_end = 0, col_begin = 0, col_end = 0;
+};
+
+struct Tuning {
+    uint32_t W = 0;        // 32-bit words per plane
+    int kc = 32;           // k-rows per LDS stage
+    int cum_bytes = 2;     // bytes of a C(v) count
+    uint64_t cum_budget = 8ull << 30;
+    int nsplit = 0;
+    bool lockstep = true;
+    int ls_item_chunks = 64;
+    int ls_sort_items = 1;
+    int xcd_swizzle = 1;
+    int finalize_rowmajor = 1;
+};
+
+struct Seg {
+    size_t b, e;     // tiles [b, e) of the plan
+    int part;        // part completed by this segment, or -1
+    int hist_bins;   // largest value span of its tiles (LDS histogram columns of the k_finalize launch)
+};
+
+struct PairPlan {
+    std::vector<U4> T;                                   // {row block, col block, plane begin, plane end}, launch order
+    std::vector<std::pair<size_t, size_t>> bands;        // tile ranges, one tile-kernel launch each
+    std::vector<std::pair<size_t, size_t>> band_items;   // item ranges of the bands
+    std::vector<std::vector<Seg>> segs;                  // per band
+    std::vector<U4> items;                               // {tile index in band, chunk begin, chunk end, 0}
+    std::vector<uint32_t> rank;                          // position of tile t in the row-major order of its segment
+    std::vector<U2> chunks;                              // chunk range of every tile
+    uint64_t per_tile_bytes = 0;                         // C(v) scratch per tile
+    size_t max_band = 0;                                 // tiles of the largest band
+    uint32_t nparts = 0;                                 // parts that get an event (0 without want_parts)
+    int finalize_rowmajor = 1;
+};
+
+// returns false when there is nothing to compute
+bool build_pairs(const Layout &L, const PairQuery &q, const Tuning &t, PairPlan &pp);
+// the two device lists: the tile kernel's {row block, col block, pb | pe << 8, lo | hi << 8} in launch order and
+// k_finalize's {row block, col block, pb | pe << 8 | lo << 16 | hi << 24, index of the tile's C(v) block in its band},
+// every segment row-major
+void emit_tile_lists(const Layout &L, const PairPlan &pp, U4 *tiles_out, U4 *ftiles_out);
+
+}  // namespace plan
+}  // namespace dsh

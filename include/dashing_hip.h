@@ -144,7 +144,9 @@ int dsh_wait(dsh_ctx *ctx);
 /* Per-call completion.  dsh_event_record: *ticket marks everything enqueued on the ctx so far (kernels, sketch
  * batches, and the host copies of dsh_dist_rows_async).  dsh_event_wait blocks the calling host thread until that
  * point has completed; work enqueued after the record keeps running.  dsh_event_query: *done = 1/0 without blocking.
- * Tickets are cheap (a ring of 64 event pairs; a ticket more than 64 records old counts as complete). */
+ * Tickets are cheap (a ring of 64 event pairs; a ticket more than 64 records old counts as complete).  A ticket is one
+ * event on each of the context's two streams and orders NOTHING between them: taken between a compute call and
+ * dsh_collect_parts_async it does not hold the per-part transfers back behind the kernels. */
 int dsh_event_record(dsh_ctx *ctx, uint64_t *ticket);
 int dsh_event_wait(dsh_ctx *ctx, uint64_t ticket);
 int dsh_event_query(dsh_ctx *ctx, uint64_t ticket, int *done);
@@ -230,7 +232,17 @@ int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_
  * matrix keeps every part key-ordered on its own) and marks the completion of each part on the ctx stream;
  * dsh_collect_parts_async then enqueues, on the copy stream, one round of grouped ncclSend/ncclRecv per part, each
  * round waiting only for its own part -- part q travels over xGMI while part q+1 is computed.  Every rank calls both
- * with the same bounds / nparts; dsh_wait (or a ticket) completes them. */
+ * with the same bounds / nparts; dsh_comm_wait (or dsh_wait / a ticket) completes them.  A range of any length works: a
+ * call with parts always lays its range out in exactly the parts dsh_range_parts reports (a short range: one part),
+ * and a rank without rows simply takes no part in the rounds.
+ * Failure behaviour (a multi-rank job must end with an error, not hang):
+ *   dsh_comm_available   DSH_OK if librccl can be loaded here (DSH_ENODEV otherwise) -- local, no communication: let
+ *                        every rank check it and agree BEFORE the collective dsh_comm_init
+ *   dsh_comm_library     the resolved path of the loaded librccl and its ncclGetVersion code (for logs)
+ *   dsh_comm_init        gives up after DSH_COMM_INIT_TIMEOUT_S (default 90 s) when not every rank joins
+ *   dsh_comm_wait        like dsh_wait, but with a deadline (DSH_COMM_TIMEOUT_S, default 120 s): when a peer never posts
+ *                        its side of an exchange the communicator is aborted and DSH_EIO returned; the blocking
+ *                        exchange calls (dsh_collect_spans, dsh_allgather_device, dsh_dist_collect) wait the same way */
 #define DSH_UNIQUE_ID_BYTES 128
 int dsh_range_parts(uint64_t n, uint64_t row_begin, uint64_t row_end, uint32_t nparts, uint64_t *part_rows, /* [nparts + 1] */
                     uint32_t *nparts_out);
@@ -238,10 +250,13 @@ int dsh_dist_rows_parts_device_async(dsh_ctx *ctx, int estim, int result_type, i
                                      void *d_out, uint32_t nparts);
 int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
                             void *d_final, int dst);
+int dsh_comm_available(void);
+int dsh_comm_library(char *path_out, size_t cap, int *version_out);
 int dsh_comm_unique_id(void *id_out);
 int dsh_comm_init(dsh_ctx *ctx, const void *unique_id, int rank, int world);
 int dsh_comm_destroy(dsh_ctx *ctx);
 int dsh_comm_rank(const dsh_ctx *ctx, int *rank, int *world);
+int dsh_comm_wait(dsh_ctx *ctx);
 int dsh_collect_spans(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst);
 int dsh_collect_spans_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, const void *d_local, void *d_final, int dst);
 int dsh_allgather_device(dsh_ctx *ctx, const void *d_send, uint64_t bytes_per_rank, void *d_recv);

@@ -47,7 +47,9 @@ def source_hash():
     """sha256 over the device sources the timed kernels are built from (same function in bench.py)."""
     h = hashlib.sha256()
     for rel in ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
-                "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/dsh_api.hip"):
+                "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
+                "dashing_amd/csrc/plan.h", "dashing_amd/csrc/plan.cpp", "dashing_amd/csrc/engine.hip", "dashing_amd/csrc/abi.hip",
+                "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
