@@ -13,13 +13,18 @@ sends its span straight into its place on rank 0 (RCCL over xGMI) -- no collecti
 compare, no un-permute.  The exchange runs through the library's own C-ABI (dsh_comm_init + the pipelined
 dsh_dist_rows_parts_device_async / dsh_collect_parts_async: part q of a rank's rows travels on the copy stream
 while the later parts are still being finalized); `python bench.py --gpus N` launches its N ranks itself.
+Outputs beyond 2 GB (configs[3]-sized: DSH_BENCH_N=100000 DSH_BENCH_P=10) are NOT gathered by default: every rank keeps
+its span (what `dashing-amd dist --ngpus -b` writes per device); the gathered variant is reported beside it.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_pair_counts_ls / k_pair_counts), timed
-with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a restatement of the
-reference algorithm and row schedule with an AVX-512BW / AVX2 histogram-of-max -- the reference
-itself is not buildable: its bonsai/sketch submodules are absent) timed on this host on a bounded
-sample of the same rows; `secondary` is the same pass on a configs[3]-shaped matrix (100 000 x p=10),
-where the per-pair estimator, not the popcounts, is the hot kernel.
+Prints ONE JSON line on rank 0 -- also when the run fails (then with "error").  `roofline` describes the dominant kernel
+(k_pair_counts_ls), timed with HIP events on the library's own stream; `roofline.binding` names the resource that
+actually bounds it (integer VALU issue -- the streaming-model HBM figure above 1 only says the kernel is not HBM-bound).
+`cpu_baseline` is the CPU oracle (a restatement of the reference algorithm and row schedule with an AVX-512BW / AVX2
+histogram-of-max -- the reference itself is not buildable: its bonsai/sketch submodules are absent) timed on this host on
+a bounded sample of the same rows.  `configs` carries, per BASELINE config measurable on one GPU, throughput, the binding
+resource, physical HBM, the CPU sample and parity: configs[1] (k_sketch on 200 x 5 Mbp resident in HBM), configs[2] (the
+headline), configs[3] shape (100 000 x p=10, where k_finalize is the hot kernel) and a configs[4]-shaped band (one row
+range of 300 000 x p=14, extrapolated and labelled so).
 """
 import argparse
 import hashlib
@@ -27,6 +32,7 @@ import json
 import os
 import sys
 import time
+import traceback
 
 import numpy as np
 
@@ -39,16 +45,19 @@ K = 31
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 CLOCK_HZ = 2.4e9       # max shader clock (same guide); cycle figures below are "wall time x 2.4 GHz"
 N_SIMD = 256 * 4
+GATHER_LIMIT_BYTES = 2 << 30  # larger outputs stay on the ranks that computed them (default; --exchange overrides)
+
+DEVICE_SOURCES = ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
+                  "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
+                  "dashing_amd/csrc/plan.h", "dashing_amd/csrc/plan.cpp", "dashing_amd/csrc/engine.hip", "dashing_amd/csrc/abi.hip",
+                  "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip")
 
 
 def source_hash():
     """sha256 over the device sources (same function as tools/pmc_collect.py): PMC files measured on other
     sources are refused."""
     h = hashlib.sha256()
-    for rel in ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
-                "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
-                "dashing_amd/csrc/plan.h", "dashing_amd/csrc/plan.cpp", "dashing_amd/csrc/engine.hip", "dashing_amd/csrc/abi.hip",
-                "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip"):
+    for rel in DEVICE_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -62,6 +71,15 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cached_sketches(synth, n, p, tag):
+    """the SURVEY 8d register arrays; the parent keeps them as .npy under /tmp for the PMC child passes of the same run
+    (generation takes seconds, the children only need the bytes)"""
+    path = os.environ.get("DSH_BENCH_CACHE_" + tag)
+    if path and os.path.exists(path):
+        return np.load(path)
+    return synth.survey_sketches(n, p, seed=0x5EED0000)[0]
 
 
 def measure_kernels(ctx, regs_d, n, p, calls, reps=3):
@@ -82,11 +100,92 @@ def measure_kernels(ctx, regs_d, n, p, calls, reps=3):
     return acc
 
 
-def live_pmc_traffic(n, p):
-    """roofline.traffic measured by THIS run: two child processes of bench.py under `rocprofv3 --pmc` (FETCH_SIZE, then
-    WRITE_SIZE -- separate passes, never combined with a trace, as MI355X_MICROARCH.md prescribes), each running the same
-    workload for one warm-up and two timed steps; per launch of the tile kernel, bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB
-    (gfx950 counts wide coalesced reads at half their bytes).  Returns (bytes or None, note)."""
+# ---- synthetic genomes in HBM (configs[1] shape) -----------------------------------------------------------------------------
+def device_genomes(torch, dev, G, L, seed=0xDA5410):
+    """G related genomes of L bases as ASCII in ONE device buffer (genome g at [g*L, (g+1)*L), L a multiple of 32): a random
+    root, clusters of 10 at 5 % from it, members at 0.1 % .. 5 % from their cluster ancestor, every 10th
+    genome with a run of 50 N and a lowercase kilobase.  Generated on the GPU: the bench times the kernel, not numpy."""
+    assert L % 32 == 0
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+
+    def mutate(codes, rate):
+        hit = torch.rand(codes.shape, generator=g, device=dev) < rate
+        shift = torch.randint(1, 4, codes.shape, generator=g, device=dev, dtype=torch.uint8)
+        return torch.where(hit, (codes + shift) & 3, codes)
+
+    root = torch.randint(0, 4, (L,), generator=g, device=dev, dtype=torch.uint8)
+    seq = torch.empty(G * L + 256, dtype=torch.uint8, device=dev)
+    seq[G * L:] = ord("N")
+    rates = (0.001, 0.005, 0.01, 0.02, 0.05)
+    anc = None
+    for i in range(G):
+        if i % 10 == 0:
+            anc = mutate(root, 0.05)
+        seq[i * L:(i + 1) * L] = lut[mutate(anc, rates[i % 5]).long()]
+        if i % 10 == 0:
+            seq[i * L + L // 3: i * L + L // 3 + 50] = ord("N")
+            seq[i * L + L // 2: i * L + L // 2 + 1000] |= 0x20
+    return seq
+
+
+def sketch_workload(ctx, torch, dev, G, L, p, steps):
+    """k_sketch over G x L bases resident in HBM; returns (seq, seconds per call wall, kernel ms by HIP events, registers)"""
+    seq = device_genomes(torch, dev, G, L)
+    offs = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+    ctx.alloc(G, p)
+    ctx.clear()
+    ctx.sketch_batch_device(seq.data_ptr(), offs, 0, K, True)  # warm-up (and the registers for the parity check)
+    regs = ctx.download(0, G)
+    ctx.set_profiling(True)
+    kms, ts = [], []
+    for _ in range(steps):
+        ctx.clear()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.sketch_batch_device(seq.data_ptr(), offs, 0, K, True)  # returns when the kernel is done
+        ts.append(time.perf_counter() - t0)
+        kms.append(ctx.info("sketch_kernel_us") / 1e3)
+    ctx.set_profiling(False)
+    return seq, min(ts), sum(kms) / len(kms), regs
+
+
+# ---- PMC child passes ------------------------------------------------------------------------------------------------------------
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"))
+PMC_SKETCH_GENOMES = 40
+
+
+def pmc_child():
+    """(internal, run under rocprofv3 --pmc by live_pmc): the three workloads in short form, nothing printed"""
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    dev = torch.device("cuda", 0)
+    ctx = dashing_amd.Context(0)
+    for tag, n, p in (("C3", N_SKETCH, P), ("C4", 100_000, 10)):
+        if tag == "C4" and not os.environ.get("DSH_BENCH_CACHE_C4"):
+            continue
+        regs_d = torch.from_numpy(cached_sketches(synth, n, p, tag)).to(dev)
+        out = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device=dev)
+        for _ in range(3 if tag == "C3" else 2):  # the LAST pass of each workload is the one read
+            ctx.attach_device(regs_d.data_ptr(), n, p)
+            ctx.dist_rows_device(out.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+        del regs_d, out
+        torch.cuda.empty_cache()
+    sketch_workload(ctx, torch, dev, PMC_SKETCH_GENOMES, 5_000_000, 10, 1)
+    ctx.close()
+
+
+def live_pmc(n, p, cache_env):
+    """PMC counters measured by THIS run: child processes of bench.py under `rocprofv3 --pmc` -- separate passes per counter
+    group, never combined with a trace, as MI355X_MICROARCH.md prescribes -- each running the headline workload, the
+    configs[3]-shaped matrix and the sketch kernel in short form.  Returns ({workload_kernel: {counter: sum over the
+    dispatches of the LAST pass of that workload, launches_<counter>: their number}}, note).  Keys: C3_pair, C3_finalize,
+    C4_pair, C4_finalize (k_pair_counts* / k_finalize) and sketch (the last k_sketch dispatch)."""
     import csv
     import glob
     import shutil
@@ -99,39 +198,98 @@ def live_pmc_traffic(n, p):
     # ROCPROF* / ROCP_TOOL* variables) a second profiler in a child would inherit that environment
     if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself being profiled"
-    vals = {}
+    res = {}
     work = tempfile.mkdtemp(prefix="dsh_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(work, counter)
+        for counters in PMC_PASSES:
+            d = os.path.join(work, counters[0])
             os.makedirs(d)
-            argv = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
-                    os.path.abspath(__file__), "--no-cpu-baseline", "--no-secondary", "--no-pmc", "--steps", "2", "--warmup", "1"]
-            env = dict(os.environ, TMPDIR="/tmp", DSH_BENCH_N=str(n), DSH_BENCH_P=str(p))
+            argv = ["rocprofv3", "--pmc"] + list(counters) + ["-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                                                            os.path.abspath(__file__), "--pmc-child"]
+            env = dict(os.environ, TMPDIR="/tmp", DSH_BENCH_N=str(n), DSH_BENCH_P=str(p), **cache_env)
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
                 env.pop(k, None)
             try:
-                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             except (OSError, subprocess.TimeoutExpired) as e:
-                return None, "rocprofv3 --pmc %s pass did not finish (%s)" % (counter, type(e).__name__)
-            got = []
+                return None, "rocprofv3 --pmc %s pass did not finish (%s)" % (counters[0], type(e).__name__)
+            rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if "k_pair_counts" in row["Kernel_Name"] and "mfma" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        got.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or not got:
-                return None, "rocprofv3 --pmc %s pass: rc %d, %d tile-kernel rows" % (counter, r.returncode, len(got))
-            vals[counter] = sum(got) / len(got)
+                rows += list(csv.DictReader(open(f)))
+            if r.returncode != 0 or not rows:
+                return None, "rocprofv3 --pmc %s pass: rc %d, %d rows" % (counters[0], r.returncode, len(rows))
+            rows.sort(key=lambda x: int(x.get("Dispatch_Id", 0) or 0))
+            # the child runs C3 (3 passes), then C4 (2 passes), then the sketch kernel; every compare pass starts with one
+            # k_selfhist_card dispatch: split the dispatch stream there, keep the last pass of each compare workload
+            passes, cur = [], None
+            for row in rows:
+                if "k_selfhist_card" in row["Kernel_Name"] and row["Counter_Name"] == counters[0]:
+                    cur = []
+                    passes.append(cur)
+                if cur is not None:
+                    cur.append(row)
+            last = {}
+            if len(passes) >= 3:
+                last["C3"] = passes[2]
+            if len(passes) >= 5:
+                last["C4"] = passes[4]
+            for wl, prow in last.items():
+                for row in prow:
+                    kn = row["Kernel_Name"]
+                    fam = "pair" if ("k_pair_counts" in kn and "mfma" not in kn) else "finalize" if "k_finalize" in kn else None
+                    if fam:
+                        d_ = res.setdefault("%s_%s" % (wl, fam), {})
+                        c_ = row["Counter_Name"]
+                        d_[c_] = d_.get(c_, 0.0) + float(row["Counter_Value"])
+                        d_["launches_" + c_] = d_.get("launches_" + c_, 0) + 1
+            for c_ in counters:
+                v = [float(row["Counter_Value"]) for row in rows if "k_sketch" in row["Kernel_Name"] and row["Counter_Name"] == c_]
+                if v:
+                    res.setdefault("sketch", {})[c_] = v[-1]
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
-        "bytes/launch measured in this run: two child runs of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; separate "
-        "passes, no trace), mean over the tile-kernel launches; (2*FETCH_SIZE + WRITE_SIZE) KiB as MI355X_MICROARCH.md prescribes for gfx950")
+    return res, ("measured in this run: three child runs of this script under rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU, "
+                 "SQ_INSTS_SALU, SQ_WAVES; separate passes, no trace); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB as MI355X_MICROARCH.md prescribes for gfx950")
+
+
+def hbm_bytes(pm):
+    if not pm or "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:
+        return None
+    return (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
 
 
 def pair_slots(ctx):
     """wave-level (AND, BCNT) slots of the last pair-kernel schedule: per tile, planes x words x 128x128 pairs / 64 lanes"""
     return ctx.info("avg_tile_planes_x100") / 100.0 * ctx.info("words_per_plane") * ctx.info("tiles") * 128 * 128 / 64.0
+
+
+def pair_binding(ctx, pair_ms_per_pass):
+    """What bounds the tile kernel: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
+    Cycles are wall time x 2.4 GHz on 1024 SIMDs, the same convention as profiles/ubench/pair_sched.txt:
+      nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                                  = 6.0
+      each op on its own   2.06 + 4.07..4.42  (and_only / bcnt_only rows of pair_sched.txt)       = 6.13 (..6.49)
+      the mix with the waves of a SIMD phase-locked, with the LDS operand reads                   = 6.9
+      the mix free-running (waves of a SIMD in different instruction classes), any order/banks    = 8.18"""
+    slots = pair_slots(ctx)
+    cyc = pair_ms_per_pass * 1e-3 * CLOCK_HZ * N_SIMD / slots if pair_ms_per_pass > 0 and slots > 0 else 0.0
+    return cyc, {"resource": "int VALU issue (v_and_b32 + v_bcnt_u32_b32)", "frac": round(6.0 / cyc, 4) if cyc else None,
+                 "cycles_per_pair": round(cyc, 3), "ceiling": 6.0,
+                 "note": "cycles per wave64 (AND,BCNT) pair = wall x 2.4 GHz x 1024 SIMDs / (tiles x planes x words x 16384 / 64); ceiling = 2 + 4 issue cycles"}
+
+
+def finalize_binding(fin_ms, pairs, pm):
+    """k_finalize is VALU-issue bound too, most of it fp64 (4 issue cycles per wave64 instruction at the DP rate, 2 for the
+    integer ones): with SQ_INSTS_VALU from the PMC pass the fraction is (instructions x 4) / SIMD-cycles spent -- an upper
+    bound of the true issue utilisation by the share of 2-cycle integer instructions in the mix."""
+    cyc_wave = fin_ms * 1e-3 * CLOCK_HZ * N_SIMD / (pairs / 64.0) if fin_ms > 0 and pairs else 0.0
+    b = {"resource": "VALU issue, mostly fp64 (the bit-exact Ertl-MLE recurrence)", "cycles_per_wave64_of_pairs": round(cyc_wave, 1), "ceiling_cycles_per_valu_inst": 4.0,
+         "frac": None, "valu_insts_per_wave": None, "cycles_per_valu_inst": None}
+    if pm and pm.get("SQ_INSTS_VALU") and pm.get("SQ_WAVES"):
+        ipw = pm["SQ_INSTS_VALU"] / pm["SQ_WAVES"]
+        cpi = fin_ms * 1e-3 * CLOCK_HZ * N_SIMD / pm["SQ_INSTS_VALU"]
+        b.update({"valu_insts_per_wave": round(ipw, 1), "cycles_per_valu_inst": round(cpi, 3), "frac": round(4.0 / cpi, 4) if cpi else None,
+                  "salu_insts_per_wave": round(pm.get("SQ_INSTS_SALU", 0.0) / pm["SQ_WAVES"], 1)})
+    return b
 
 
 def self_launch(n_gpus, backend):
@@ -158,16 +316,32 @@ def self_launch(n_gpus, backend):
     return subprocess.call(argv, env=env)
 
 
+def flush_c_stdio():
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary p=10 workload line")
-    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the per-config entries (configs[1], [3], [4]) and the data-dependence line")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline.traffic, VALU counts)")
+    ap.add_argument("--what-if", action="store_true", help="also time the matrix-core what-if of the tile kernel (needs a library built with make WHATIF=1)")
+    ap.add_argument("--exchange", choices=("auto", "gather", "keep"), default="auto",
+                    help="N>1: gather the spans on rank 0 (the BASELINE formulation) or keep every span on its rank; auto = gather up to 2 GB of output")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child()
+        return
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     backend = os.environ.get("DSH_BENCH_BACKEND", "nccl")
@@ -176,15 +350,48 @@ def main():
             sys.exit(self_launch(args.gpus, backend))  # one rank per GPU under torch.distributed.run; never a silent 1-GPU run
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit("bench.py: launched with WORLD_SIZE=%s but --gpus %d: refusing to report a mislabelled run" % (os.environ["WORLD_SIZE"], args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    line = {"metric": "genome-pairs/sec, all-pairs HLL Jaccard (Ertl-MLE), N=%d p=%d" % (N_SKETCH, P), "value": None, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8/u32 popcount + f64 estimator", "data": "synthetic"}
+    dist_on = [False]
+    try:
+        run(args, backend, world, rank, line, dist_on)
+    except BaseException as e:  # noqa: BLE001 -- the contract is ONE JSON line, whatever happened
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        line["error"] = "%s: %s" % (type(e).__name__, e)
+        line["traceback_tail"] = traceback.format_exc().strip().splitlines()[-6:]
+        sys.stderr.write(traceback.format_exc())
+    finally:
+        if dist_on[0]:
+            import torch.distributed as dist
 
+            flush_c_stdio()
+            try:
+                if "error" not in line:
+                    dist.barrier()
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        # The JSON line must be the LAST thing on stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes) prints its
+        # banner through C stdio, which is block-buffered when stdout is a pipe: flush it before the line goes out.
+        flush_c_stdio()
+        if rank == 0:
+            sys.stdout.flush()
+            print(json.dumps(line), flush=True)
+    if "error" in line:
+        sys.exit(1)
+
+
+def run(args, backend, world, rank, line, dist_on):
     import torch
     import torch.distributed as dist
 
     import dashing_amd
     from dashing_amd import multigpu, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DSH_BENCH_BACKEND=gloo is a dry-run of the N>1 code path on a box with ONE GPU: all ranks share
     # cuda:0 and the spans travel through host memory.  Never used for reported numbers.
@@ -203,17 +410,19 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             if torch.cuda.device_count() < world:
-                sys.exit("bench.py: %d ranks but only %d visible GPUs" % (world, torch.cuda.device_count()))
+                raise RuntimeError("%d ranks but only %d visible GPUs" % (world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+        dist_on[0] = True
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cpu_or_dev = dev if backend == "nccl" else "cpu"
 
     n, p, m = N_SKETCH, P, 1 << P
-    regs_h = synth.survey_sketches(n, p, seed=0x5EED0000)[0]  # SURVEY 8d; identical bytes on every rank
-    regs_d = torch.from_numpy(regs_h).to(dev)                 # resident in HBM before timing
+    regs_h = cached_sketches(synth, n, p, "C3")  # SURVEY 8d; identical bytes on every rank
+    regs_d = torch.from_numpy(regs_h).to(dev)    # resident in HBM before timing
     total_pairs = n * (n - 1) // 2
     ctx = dashing_amd.Context(local_rank)
     for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # tuning sweeps, e.g. "kc=64,emax=32"
@@ -221,54 +430,75 @@ def main():
         ctx.set_option(k_, int(v_))
     ctx.attach_device(regs_d.data_ptr(), n, p)
 
-    # The exchange of the spans: through the C-ABI (dsh_comm_init / dsh_collect_spans: RCCL inside libdashing_hip.so, on
-    # the library's stream -- what a C++ host calls) unless DSH_BENCH_EXCHANGE=torch; if the library's communicator
-    # cannot be brought up, torch.distributed's RCCL does the same point-to-point transfers (recorded in the line).
+    # The exchange of the spans: through the C-ABI (dsh_comm_init / dsh_collect_parts_async: RCCL inside libdashing_hip.so, on
+    # the library's streams -- what a C++ host calls) unless DSH_BENCH_EXCHANGE=torch; if the library's communicator
+    # cannot be brought up ON EVERY RANK, torch.distributed's RCCL does the same point-to-point transfers (recorded in the
+    # line).  Availability is agreed on BEFORE the collective dsh_comm_init: a rank that cannot load librccl must not leave
+    # the others waiting inside ncclCommInitRank.
     exchange = "none"
+    rccl_info = None
     if multi:
         exchange = "torch.distributed" if backend == "nccl" else "gloo (host staged)"
+        path, ver = dashing_amd.comm_library()
+        rccl_info = {"library": path, "nccl_version_code": ver, "available_on_rank0": dashing_amd.comm_available(),
+                     "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
+                     "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None}
         if backend == "nccl" and os.environ.get("DSH_BENCH_EXCHANGE", "cabi") == "cabi":
-            try:
-                multigpu.cabi_comm_init(ctx, rank, world)
-                exchange = "c-abi rccl (dsh_collect_spans)"
-            except Exception as e:  # noqa: BLE001
-                sys.stderr.write("bench.py: rank %d: C-ABI communicator unavailable (%s): torch.distributed exchange\n" % (rank, e))
-            flag = torch.tensor([1 if exchange.startswith("c-abi") else 0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
-            if int(flag.item()) == 0:
-                exchange = "torch.distributed"
+            flag = torch.tensor([1 if dashing_amd.comm_available() else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) == 1
+            why = None if ok else "librccl not loadable by libdashing_hip.so on at least one rank (%s)" % path
+            if ok:
+                try:
+                    multigpu.cabi_comm_init(ctx, rank, world)
+                except Exception as e:  # noqa: BLE001
+                    ok, why = False, "dsh_comm_init failed on rank %d: %s" % (rank, e)
+                mine_ok = ok
+                flag = torch.tensor([1 if ok else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
+                if int(flag.item()) == 0:
+                    if mine_ok:
+                        ctx.comm_destroy()
+                    ok, why = False, why or "dsh_comm_init failed on another rank"
+            if ok:
+                exchange = "c-abi rccl"
+            else:
+                sys.stderr.write("bench.py: rank %d: C-ABI communicator not used (%s): torch.distributed exchange\n" % (rank, why))
+                rccl_info["cabi_fallback_reason"] = why
     use_cabi = exchange.startswith("c-abi")
     NPARTS = int(os.environ.get("DSH_BENCH_PARTS", "8"))
     if use_cabi:
         exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_dist_rows_parts_device_async + dsh_collect_parts_async)" % NPARTS
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
-    offs = [0]
-    for s_ in sizes:
-        offs.append(offs[-1] + s_)
     my_pairs = sizes[rank] if multi else total_pairs
     host_stage = backend == "gloo" and multi
-    final = None
-    if rank == 0:
-        final = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev)
-    # rank 0 computes in place (its rows are the head of the matrix); the others into a span-sized buffer
-    local = final if rank == 0 else torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
-    final_h = torch.empty(max(total_pairs, 1), dtype=torch.float32) if host_stage and rank == 0 else None
+    gather = not multi or args.exchange == "gather" or (args.exchange == "auto" and 4 * total_pairs <= GATHER_LIMIT_BYTES)
+    buf = {"final": None, "local": None, "final_h": None}
+
+    def alloc_buffers(with_final):
+        buf["final"] = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev) if (rank == 0 and with_final) else None
+        # rank 0 computes in place (its rows are the head of the matrix); the others into a span-sized buffer
+        buf["local"] = buf["final"] if buf["final"] is not None else torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
+        buf["final_h"] = torch.empty(max(total_pairs, 1), dtype=torch.float32) if host_stage and rank == 0 and with_final else None
+
+    alloc_buffers(gather)
     phase = {"compute": 0.0, "exchange": 0.0}
 
-    def step(timed=False):
+    def step(timed=False, do_gather=True):
+        local, final, final_h = buf["local"], buf["final"], buf["final_h"]
         # re-attach: invalidates cached planes/cardinalities, so every step is a full pass
         t0 = time.perf_counter()
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        if use_cabi:
+        if use_cabi and do_gather:
             # pipelined: the rank's rows in NPARTS parts; part q travels to rank 0 (copy stream, grouped ncclSend/ncclRecv
             # behind the part's event) while the later parts are still being finalized on the ctx stream
             ctx.dist_rows_parts_device_async(local.data_ptr(), bounds[rank], bounds[rank + 1], NPARTS, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-            computed = ctx.event_record()
+            computed = ctx.event_record()  # (a ticket orders nothing between the streams: the transfers are not held back)
             ctx.collect_parts_async(n, bounds, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
             ctx.event_wait(computed)
             t1 = time.perf_counter()
-            ctx.wait()
+            ctx.comm_wait()  # (with a deadline: a missing peer is an error, not a hang)
             t2 = time.perf_counter()
             if timed:
                 phase["compute"] += t1 - t0
@@ -277,7 +507,7 @@ def main():
         ctx.dist_rows_device(local.data_ptr(), bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
         t1 = time.perf_counter()
-        if multi:
+        if multi and do_gather:
             if host_stage:
                 lh = local[: max(my_pairs, 1)].cpu()
                 if rank == 0:
@@ -292,87 +522,116 @@ def main():
         if timed:
             phase["compute"] += t1 - t0
             phase["exchange"] += t2 - t1
-        return final
+        return final if do_gather else local
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full = step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    phases = [phase["compute"] / max(args.steps, 1) * 1e3, phase["exchange"] / max(args.steps, 1) * 1e3]
-    if multi:
-        t = torch.tensor([dt] + phases, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0].item())
-        phases = [float(t[1].item()), float(t[2].item())]
+    def timed_loop(do_gather):
+        phase["compute"] = phase["exchange"] = 0.0
+        for _ in range(args.warmup):
+            step(False, do_gather)
+        fence()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(args.steps):
+            res = step(True, do_gather)
+        fence()
+        dt_ = time.perf_counter() - t0
+        ph = [phase["compute"] / max(args.steps, 1) * 1e3, phase["exchange"] / max(args.steps, 1) * 1e3]
+        if multi:
+            t = torch.tensor([dt_] + ph, dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_, ph = float(t[0].item()), [float(t[1].item()), float(t[2].item())]
+        return dt_, ph, res
+
+    dt, phases, full = timed_loop(gather)
     ms_per_step = dt / args.steps * 1e3
     value = total_pairs * args.steps / dt
+    line.update({"value": value, "ms_per_step": ms_per_step})
+    gathered_variant = None
+    if multi and not gather and args.exchange == "auto":
+        # the second figure: the same step with every span collected on rank 0 (what bounds a configs[3]-sized job on 8 GPUs)
+        try:
+            alloc_buffers(True)
+            dt_g, ph_g, _ = timed_loop(True)
+            gathered_variant = {"ms_per_step": dt_g / args.steps * 1e3, "pairs_per_s": total_pairs * args.steps / dt_g,
+                                "phase_ms_max_over_ranks": {"compute_incl_prepare": round(ph_g[0], 4), "exchange": round(ph_g[1], 4)}}
+        except Exception as e:  # noqa: BLE001
+            gathered_variant = {"error": "%s: %s" % (type(e).__name__, e)}
+    local = buf["local"]
 
     # ---- kernel phases: HIP events on the library stream, outside the timed region
     reps = 3
     km = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), bounds[rank], bounds[rank + 1])], reps)
     pair_ms, fin_ms, prep_ms, launches = km["pair_ms"], km["finalize_ms"], km["prepare_ms"], km["pair_launches"]
     kphase = [pair_ms / reps, fin_ms / reps, prep_ms / reps]
+    cyc, pbind = pair_binding(ctx, pair_ms / reps)
+    lockstep = bool(ctx.info("lockstep"))
+    rinfo = {"dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
+             "listed_tail_caps": {"upper": ctx.info("emax"), "lower": ctx.info("elow")}, "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
+             "key_ordered_columns": bool(ctx.info("sorted"))}
     if multi:
-        t = torch.tensor(kphase, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor(kphase, dtype=torch.float64, device=cpu_or_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kphase = [float(x) for x in t.tolist()]
 
     src = source_hash()
-    traffic, traffic_note = None, "no PMC file for this workload (tools/pmc_collect.py writes profiles/pmc_pair_kernel.json)"
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pair_kernel.json")))
-        if pm.get("source_sha256") != src:
-            traffic_note = "profiles/pmc_pair_kernel.json was measured on other kernel sources (sha256 differs): refused as stale"
-        elif pm["workload"]["n_sketches"] == n and pm["workload"]["p"] == p and world == 1:
-            traffic = pm["hbm_bytes_per_launch"]
-            traffic_note = "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) collected by tools/pmc_collect.py in separate --pmc passes on these kernel sources (sha256 checked); not measured in this run"
-    except (OSError, KeyError, ValueError):
-        pass
-    if rank == 0 and not multi and not args.no_pmc and not os.environ.get("DSH_BENCH_NO_PMC"):
-        live, live_note = live_pmc_traffic(n, p)
-        if live is not None:
-            if traffic is not None:
-                live_note += "; the committed profiles/pmc_pair_kernel.json (same sources, sha256 checked) says %.0f" % traffic
-            traffic, traffic_note = live, live_note
-        else:
-            traffic_note += " [live PMC passes unavailable: %s]" % live_note
+    single = rank == 0 and not multi
+    # ---- PMC: the child passes of this run (single GPU only), else the committed file of the same sources
+    pmc, pmc_note, cache_env, cache_files = None, "no PMC passes in this run", {}, []
+    want_cfg = single and not args.no_secondary and (n, p) == (10000, 14)
+    regs4_h = synth.survey_sketches(100_000, 10, seed=0x5EED0000)[0] if want_cfg else None
+    if single and not args.no_pmc and not os.environ.get("DSH_BENCH_NO_PMC"):
+        for tag, arr in (("C3", regs_h), ("C4", regs4_h)):
+            if arr is not None:
+                path = "/tmp/dsh_bench_%s_%d.npy" % (tag, os.getpid())
+                np.save(path, arr)
+                cache_env["DSH_BENCH_CACHE_" + tag] = path
+                cache_files.append(path)
+        try:
+            pmc, pmc_note = live_pmc(n, p, cache_env)
+        finally:
+            for f_ in cache_files:
+                try:
+                    os.unlink(f_)
+                except OSError:
+                    pass
+    pmc = pmc or {}
+    traffic, traffic_note = hbm_bytes(pmc.get("C3_pair")), pmc_note
+    if traffic is not None:
+        traffic /= max(pmc["C3_pair"].get("launches_FETCH_SIZE", 1), 1)
+    else:
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_pair_kernel.json")))
+            if pm.get("source_sha256") != src:
+                traffic_note += "; profiles/pmc_pair_kernel.json was measured on other kernel sources (sha256 differs): refused as stale"
+            elif pm["workload"]["n_sketches"] == n and pm["workload"]["p"] == p and world == 1:
+                traffic = pm["hbm_bytes_per_launch"]
+                traffic_note = "bytes/launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) collected by tools/pmc_collect.py in separate --pmc passes on these kernel sources (sha256 checked); not measured in this run [" + pmc_note + "]"
+        except (OSError, KeyError, ValueError):
+            pass
     b_pair = 2 * m + 4                                   # algorithmic bytes per pair
     achieved = my_pairs * reps * b_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
     avg_launch_ms = pair_ms / max(launches, 1)
+    fbind = finalize_binding(kphase[1], my_pairs, pmc.get("C3_finalize"))
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-        "kernel": "k_pair_counts", "launches_per_step": launches // reps,
+        # the resource that actually bounds the kernel: `frac` above is the SURVEY 8d streaming model and exceeds 1 for an
+        # LDS-tiled kernel -- read `binding.frac` for how close the kernel is to its ceiling
+        "binding": pbind,
+        "kernel": "k_pair_counts_ls" if lockstep else "k_pair_counts", "launches_per_step": launches // reps,
         "avg_launch_ms": round(avg_launch_ms, 4),
         "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
-        "dense_planes": ctx.info("planes"), "reg_value_range": [ctx.info("vlo"), ctx.info("vhi")],
-        "listed_tail_caps": {"upper": ctx.info("emax"), "lower": ctx.info("elow")}, "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
-        "key_ordered_columns": bool(ctx.info("sorted")),
-        "note": "SURVEY 8d streaming-model bytes (2*2^p+4 per pair, the reference's own traffic): frac > 1 only says the LDS-tiled kernel is not HBM-bound (each staged sketch is reused 128x); the binding resource is integer VALU issue, see valu_int; physical HBM is physical_hbm_gbs",
+        **rinfo,
+        "note": "SURVEY 8d streaming-model bytes (2*2^p+4 per pair, the reference's own traffic): frac > 1 only says the LDS-tiled kernel is not HBM-bound (each staged sketch is reused 128x); the binding resource is integer VALU issue, see binding / valu_int; physical HBM is physical_hbm_gbs",
         "physical_hbm_gbs": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
         "physical_hbm_frac_of_peak": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pair_ms > 0 else None,
         "compulsory_bytes_per_step": n * m + 4 * total_pairs,
     }
-    # What actually bounds the tile kernel: integer VALU issue of one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits.
-    # Cycles are wall time x 2.4 GHz on 1024 SIMDs, the same convention as profiles/ubench/pair_sched.txt:
-    #   nominal issue model  2 (v_and, SIMD-32 rate) + 4 (v_bcnt)                                  = 6.0
-    #   each op on its own   2.06 + 4.07..4.42  (and_only / bcnt_only rows of pair_sched.txt)       = 6.13 (..6.49)
-    #   the mix with the waves of a SIMD phase-locked (all ANDs, barrier, all BCNTs, barrier),
-    #     registers only 6.4-6.8, with the LDS operand reads 6.9                                     = 6.9
-    #   the mix free-running (waves of a SIMD in different instruction classes), any order/banks    = 8.18
-    slots = pair_slots(ctx)
-    cyc = pair_ms / reps * 1e-3 * CLOCK_HZ * N_SIMD / slots if pair_ms > 0 and slots > 0 else 0.0
-    lockstep = bool(ctx.info("lockstep"))
-    roofline["kernel"] = "k_pair_counts_ls" if lockstep else "k_pair_counts"
     roofline["valu_int"] = {
         "cycles_per_and_bcnt_pair": round(cyc, 3),
         "frac_of_free_running_mix_ceiling": round(8.18 / cyc, 4) if cyc else 0.0,
@@ -384,10 +643,10 @@ def main():
         "note": "wave64 (AND,BCNT) slots = tiles x planes x words x 16384 / 64; cycles = wall x 2.4 GHz x 1024 SIMDs / slots. A SIMD issues ANDs from two waves at one per 2.06 cycles and BCNTs at one per 4.07-4.42 (run to run), but an AND stream next to a BCNT stream costs 8.18 per pair in any order or VGPR-bank placement (profiles/ubench/pair_sched.txt); k_pair_counts_ls keeps the 8 waves of a CU in one instruction class with ONE s_barrier per k-row (after the BCNT batch; round 2 had two: profiles/r3f), the k loop fully unrolled: a k-row is 64 v_and_b32 + 64 v_bcnt_u32_b32 + 4 ds_read_b128 + 1 s_barrier. The chip holds 2.30-2.39 GHz under this mix, so 6.9 shader cycles of the micro-benchmark twin are ~7.1 of the wall cycles quoted here",
     }
     roofline["finalize"] = {
-        "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue",
+        "kernel": "k_finalize", "ms_per_step": round(kphase[1], 4), "bound": "fp64 VALU issue", "binding": fbind,
         "pairs_per_s": round(my_pairs / (kphase[1] * 1e-3), 1) if kphase[1] > 0 else 0.0,
-        "cycles_per_wave64_of_pairs": round(kphase[1] * 1e-3 * CLOCK_HZ * N_SIMD / (my_pairs / 64.0), 1) if kphase[1] > 0 and my_pairs else 0.0,
-        "note": "VALU-issue bound; most of its VALU instructions are the Ertl-MLE estimator (~3 secant iterations x ~17 bins = ~51 steps x 19 instructions, 15 of them dependent fp64 operations, plus fp64 divisions per iteration) that must be reproduced bit for bit; the sparse tails of the histogram come from a position-index join (k_build_colindex) instead of round 2's per-pair list walk -- profiles/r3a (before), r3b, r3f, DESIGN.md 3.5",
+        "physical_hbm_bytes_per_step": hbm_bytes(pmc.get("C3_finalize")),
+        "note": "VALU-issue bound; about half of its VALU instructions are the Ertl-MLE estimator (secant iterations x live bins x ~20 instructions, 15 of them dependent fp64 operations) that must be reproduced bit for bit; the sparse tails of the histogram come from a position-index join (k_build_colindex) -- profiles/r4*, DESIGN.md 3.5",
     }
     roofline["step"] = {
         "ms": {"prepare": round(kphase[2], 4), "pair_counts": round(kphase[0], 4), "finalize": round(kphase[1], 4)},
@@ -397,96 +656,253 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and multi:
-        # assembled multi-rank matrix vs one single-GPU call on rank 0 (outside the timed region)
-        ref = torch.empty(total_pairs, dtype=torch.float32, device=dev)
-        ctx.attach_device(regs_d.data_ptr(), n, p)
-        ctx.dist_rows_device(ref.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        ctx.synchronize()
-        parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full[:total_pairs])), "pairs_checked": total_pairs}
-        del ref
-    if rank == 0 and not multi and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(regs_h, full, n, p, args.cpu_seconds)
-
-    what_if = None
-    if rank == 0 and not multi and not args.no_secondary:
-        # WHAT-IF, never the product path (the north star excludes the matrix cores; `value` above is the integer-VALU
-        # kernel): the same tile kernel with the AND+popcount done as a 0/1 i8 MFMA (option pair_mfma), same inputs
-        ref = full[:total_pairs].clone()
-        ctx.set_option("pair_mfma", 1)
-        ctx.set_option("kc", 16)  # (the what-if kernel was tuned at 16 rows per stage: two workgroups per CU)
-        ts = []
-        for _ in range(3):
+        if gather:
+            # assembled multi-rank matrix vs one single-GPU call on rank 0 (outside the timed region)
+            ref = torch.empty(total_pairs, dtype=torch.float32, device=dev)
             ctx.attach_device(regs_d.data_ptr(), n, p)
-            t0 = time.perf_counter()
-            ctx.dist_rows_device(local.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.dist_rows_device(ref.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             ctx.synchronize()
-            ts.append(time.perf_counter() - t0)
-        same = bool(torch.equal(ref, local[:total_pairs]))
-        kw = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), 0, n)], 1)
-        ctx.set_option("pair_mfma", 0)
-        ctx.set_option("kc", 0)
-        what_if = {"label": "WHAT-IF ONLY, not the shipped path and not `value`: v_mfma_i32_32x32x32_i8 on 0/1 bytes expanded from the bit-planes in registers (option pair_mfma=1, default 0)",
-                   "ms_per_step": round(min(ts) * 1e3, 3), "pairs_per_s": total_pairs / min(ts),
-                   "k_pair_counts_mfma_ms": round(kw["pair_ms"], 3), "output_identical_to_valu_path": same}
-        del ref
-    secondary = None
-    if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
-        secondary = secondary_p10(ctx, torch, dev, synth, dashing_amd)
+            parity = {"assembled_equals_single_gpu": bool(torch.equal(ref, full[:total_pairs])), "pairs_checked": total_pairs}
+            del ref
+        else:
+            parity = {"assembled_equals_single_gpu": None, "note": "spans kept on their ranks (not gathered): rank 0's own span is checked against the CPU oracle"}
+    if rank == 0 and not args.no_cpu_baseline and (not multi or not gather):
+        cpu, par2 = cpu_baseline(regs_h, full, n, p, args.cpu_seconds if not multi else min(args.cpu_seconds, 4.0), max_rows=bounds[1])
+        parity = par2 if parity is None else {**parity, "rank0_span_vs_cpu": par2}
 
-    dependence = None
-    if rank == 0 and not multi and not args.no_secondary and (n, p) == (10000, 14):
-        dependence = data_dependence(ctx, torch, dev, dashing_amd, n, p)
-
-    line = None
-    if rank == 0:
-        line = {
-            "metric": "genome-pairs/sec, all-pairs HLL Jaccard (Ertl-MLE), N=%d p=%d" % (n, p),
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u8/u32 popcount + f64 estimator",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
-                       "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                       "sharding": "tile-count-balanced row ranges of the final triangle, one per rank (plane matrix laid out per range); point-to-point send of each span into place on rank 0, no un-permute" if multi else "single GPU"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "parity_vs_cpu": parity,
-            "kernel_source_sha256": src,
-        }
-        if multi:
-            line["multi_gpu"] = {
-                "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend, "exchange": exchange,
-                "row_bounds": bounds, "pairs_per_rank": sizes,
-                "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange" if not use_cabi else "exchange_exposed_after_last_kernel": round(phases[1], 4),
-                                            "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},
-                "exchange_bytes_into_rank0": 4 * (total_pairs - sizes[0]),
-            }
-        if secondary:
-            line["secondary"] = secondary
-        if dependence:
-            line["data_dependence"] = dependence
-        if what_if:
-            line["what_if_mfma"] = what_if
-    ctx.close()
-    # The JSON line must be the LAST thing on stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes)
-    # prints its banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise
-    # come out at process exit, after the line.  Flush C stdio on every rank, tear the group down, then print.
-    import ctypes
-
-    def flush_c_stdio():
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-
+    line.update({
+        "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
+                   "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
+                   "sharding": "tile-count-balanced row ranges of the final triangle, one per rank (plane matrix laid out per range); point-to-point send of each span into place on rank 0, no un-permute" if multi else "single GPU"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "parity_vs_cpu": parity,
+        "kernel_source_sha256": src,
+    })
     if multi:
-        flush_c_stdio()
-        dist.barrier()
-        dist.destroy_process_group()
-    flush_c_stdio()
-    if line is not None:
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        line["multi_gpu"] = {
+            "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
+            "exchange": exchange if gather else "none: every rank keeps its span (output %.1f GB > %.1f GB; --exchange gather collects it)" % (4 * total_pairs / 1e9, GATHER_LIMIT_BYTES / 1e9),
+            "exchange_library": rccl_info, "row_bounds": bounds, "pairs_per_rank": sizes,
+            "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange" if not use_cabi else "exchange_exposed_after_last_kernel": round(phases[1], 4),
+                                        "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},
+            "exchange_bytes_into_rank0": 4 * (total_pairs - sizes[0]) if gather else 0,
+            "gathered_variant": gathered_variant,
+        }
+
+    if want_cfg:
+        # ---- per-config entries: each guarded so that a failure costs its entry, not the line
+        cfgs = []
+
+        def guarded(name, fn):
+            try:
+                cfgs.append(fn())
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(traceback.format_exc())
+                cfgs.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
+
+        guarded("BASELINE configs[1] shape", lambda: config_sketch(ctx, torch, dev, dashing_amd, pmc.get("sketch")))
+        cfgs.append({"workload": line["config"]["workload"], "pairs_per_s": value, "ms_per_step": ms_per_step,
+                     "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": roofline["frac"], "physical_hbm_gbs": roofline["physical_hbm_gbs"]},
+                     "cpu_baseline": None if cpu is None else {"value": cpu["value"], "cores": cpu["cores"], "sample": cpu["sample"]},
+                     "parity": parity, "note": "the headline: full detail at top level"})
+        guarded("BASELINE configs[3] shape", lambda: config_c4(ctx, torch, dev, dashing_amd, regs4_h, pmc, args))
+        regs4_h = None
+        guarded("BASELINE configs[4] shape, one band", lambda: config_c5_band(ctx, torch, dev, dashing_amd, synth))
+        line["configs"] = cfgs
+        line["secondary"] = next((c for c in cfgs if c.get("workload", "").startswith("BASELINE configs[3]") and "error" not in c), None)
+        try:
+            line["data_dependence"] = data_dependence(ctx, torch, dev, dashing_amd, n, p)
+        except Exception as e:  # noqa: BLE001
+            line["data_dependence"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if single and args.what_if:
+        line["what_if_mfma"] = what_if_mfma(ctx, torch, dashing_amd, regs_d, full, local, n, p, total_pairs)
+    ctx.close()
+
+
+def what_if_mfma(ctx, torch, dashing_amd, regs_d, full, local, n, p, total_pairs):
+    """WHAT-IF, never the product path (the north star excludes the matrix cores; `value` is the integer-VALU kernel): the
+    same tile kernel with the AND+popcount done as a 0/1 i8 MFMA (option pair_mfma; only in a library built with
+    `make WHATIF=1`), same inputs.  Run only with --what-if."""
+    if not ctx.info("whatif_mfma"):
+        return {"skipped": "libdashing_hip.so was built without the what-if kernel (make -C dashing_amd/csrc WHATIF=1)"}
+    ref = full[:total_pairs].clone()
+    ctx.set_option("pair_mfma", 1)
+    ctx.set_option("kc", 16)  # (the what-if kernel was tuned at 16 rows per stage: two workgroups per CU)
+    ts = []
+    for _ in range(3):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        t0 = time.perf_counter()
+        ctx.dist_rows_device(local.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        ts.append(time.perf_counter() - t0)
+    same = bool(torch.equal(ref, local[:total_pairs]))
+    kw = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), 0, n)], 1)
+    ctx.set_option("pair_mfma", 0)
+    ctx.set_option("kc", 0)
+    return {"label": "WHAT-IF ONLY, not the shipped path and not `value`: v_mfma_i32_32x32x32_i8 on 0/1 bytes expanded from the bit-planes in registers (option pair_mfma=1, default 0, library built with WHATIF=1)",
+            "ms_per_step": round(min(ts) * 1e3, 3), "pairs_per_s": total_pairs / min(ts),
+            "k_pair_counts_mfma_ms": round(kw["pair_ms"], 3), "output_identical_to_valu_path": same}
+
+
+def config_sketch(ctx, torch, dev, dashing_amd, pm, G=200, L=5_000_000, p=10):
+    """BASELINE configs[1] shape: the sketch kernel (hot loop 1, src/sketch_and_cmp.h:314-360's replacement) on G x 5 Mbp
+    genomes resident in HBM, k=31, p=10: bases/s, fraction of HBM at 1 B/base, VALU-issue fraction, CPU oracle, parity."""
+    from oracle import oracle_c
+
+    seq, wall_s, kernel_ms, regs = sketch_workload(ctx, torch, dev, G, L, p, 3)
+    bases = G * L
+    # registers bit-exact on a sample of genomes (two decorated ones among them)
+    sample = [0, 1, 10, 57, G - 1]
+    exact = True
+    for g_ in sample:
+        host = seq[g_ * L:(g_ + 1) * L].cpu().numpy()
+        want = oracle_c.sketch_batch(host, np.array([0, L], np.uint64), K, p, True)
+        exact = exact and bool((regs[g_] == want[0]).all())
+    cores = oracle_c.effective_cpus()
+    oracle_c.load(threads=cores)
+    nc = min(G, 2 * cores)
+    hs = seq[: nc * L].cpu().numpy()
+    t0 = time.perf_counter()
+    oracle_c.sketch_batch(hs, np.arange(nc + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
+    tc = time.perf_counter() - t0
+    ksec = kernel_ms * 1e-3
+    binding = {"resource": "int VALU issue (Wang hash: 25 of ~47 VALU instructions per k-mer are 64-bit shifts/adds fixed by the bit-exactness contract)",
+               "frac": None, "valu_insts_per_kmer": None, "ceiling_cycles_per_valu_inst": 2.0}
+    if pm and pm.get("SQ_INSTS_VALU"):
+        # the PMC child sketches PMC_SKETCH_GENOMES genomes of the same length: instructions per base carry over
+        per_base = pm["SQ_INSTS_VALU"] * 64.0 / (PMC_SKETCH_GENOMES * L)
+        cpi = ksec * CLOCK_HZ * N_SIMD / (per_base * bases / 64.0)
+        binding.update({"valu_insts_per_kmer": round(per_base, 2), "cycles_per_valu_inst": round(cpi, 3), "frac": round(2.0 / cpi, 4)})
+    traffic = hbm_bytes(pm)
+    del seq
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE configs[1] shape: k_sketch on %d synthetic %d bp genomes resident in HBM, k=%d, p=%d (canonical k-mers)" % (G, L, K, p),
+            "bases_per_s": bases / ksec, "ms_per_step": kernel_ms, "wall_ms_per_call": wall_s * 1e3, "steps": 3,
+            "roofline": {"bound": "hbm", "achieved": round(bases / ksec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bases / ksec / 1e9 / HBM_PEAK_GBS, 4),
+                         "bytes_per_base": 1, "binding": binding,
+                         "physical_hbm_bytes_per_base": round(traffic / (PMC_SKETCH_GENOMES * L), 3) if traffic else None,
+                         "note": "HBM is the nominal roof at 1 B/base (SURVEY 8d); the kernel is bound by integer VALU issue"},
+            "cpu_baseline": {"value": nc * L / tc, "unit": "bases/s", "cores": cores, "kind": "port",
+                             "sample": "%d of the same genomes (%d bases) in %.2f s; oracle/dsh_oracle.c dsho_sketch_batch, one genome per thread as src/sketch_and_cmp.h:314-360" % (nc, nc * L, tc)},
+            "parity": {"registers_bit_exact": exact, "genomes_checked": len(sample)}}
+
+
+def config_c4(ctx, torch, dev, dashing_amd, regs, pmc, args, n=100_000, p=10):
+    """configs[3]-shaped matrix on ONE GPU (the 8-GPU run is the driver's): at 1 KiB per sketch the popcounts are
+    cheap and the per-pair estimator (k_finalize) is the hot kernel, which the p=14 headline hides."""
+    from oracle import oracle_c
+
+    regs_d = torch.from_numpy(regs).to(dev)
+    total = n * (n - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        ctx.attach_device(regs_d.data_ptr(), n, p)
+        t0 = time.perf_counter()
+        ctx.dist_rows_device(out.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        times.append(time.perf_counter() - t0)
+    km = measure_kernels(ctx, regs_d, n, p, [(out.data_ptr(), 0, n)], 1)
+    t = min(times[1:])
+    _, pbind = pair_binding(ctx, km["pair_ms"])
+    planes = ctx.info("avg_tile_planes_x100") / 100.0
+    # CPU oracle on a sample of >= 1e7 pairs of the same matrix + parity on them
+    cpu = parity = None
+    if not args.no_cpu_baseline:
+        cores = oracle_c.effective_cpus()
+        lib = oracle_c.load(threads=cores)
+        level = oracle_c.simd_level(lib)
+        oracle_c.set_simd(level, lib)
+        rows = 128
+        t0 = time.perf_counter()
+        ref = oracle_c.dist_rows(regs, 0, rows, lib=lib)
+        tc = time.perf_counter() - t0
+        oracle_c.set_simd(0, lib)
+        got = out[: ref.size].cpu().numpy()
+        rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
+        cpu = {"value": ref.size / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
+               "sample": "rows [0,%d) = %d pairs in %.2f s (oracle/dsh_oracle.c, %s histogram-of-max, OpenMP dynamic over j per row)" % (rows, ref.size, tc, {0: "scalar", 1: "avx2", 2: "avx512bw"}[level])}
+        parity = {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6, "exact_float32_matches": int((got == ref).sum())}
+    fb = finalize_binding(km["finalize_ms"], total, pmc.get("C4_finalize"))
+    phys_f, phys_p = hbm_bytes(pmc.get("C4_finalize")), hbm_bytes(pmc.get("C4_pair"))
+    b_pair = 2 * (1 << p) + 4
+    res = {"workload": "BASELINE configs[3] shape on one GPU: %d synthetic sketches, p=%d, full triangle (%.1f GB of float32 left in HBM)" % (n, p, total * 4 / 1e9),
+           "value": total / t, "pairs_per_s": total / t, "unit": "pairs/s", "ms_per_step": t * 1e3, "steps": 2,
+           "kernel_ms": {"k_pair_counts": round(km["pair_ms"], 3), "k_finalize": round(km["finalize_ms"], 3), "prepare": round(km["prepare_ms"], 3),
+                         "pair_launches": km["pair_launches"]},
+           "avg_planes_per_tile": planes,
+           "finalize_cycles_per_wave64_of_pairs": round(km["finalize_ms"] * 1e-3 * CLOCK_HZ * N_SIMD / (total / 64.0), 1),
+           "roofline": {"dominant_kernel": "k_finalize", "binding": fb, "tile_kernel_binding": pbind,
+                        "streaming_model_gbs": round(total * b_pair / t / 1e9, 1), "streaming_model_frac_of_hbm": round(total * b_pair / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "physical_hbm_bytes_per_step": {"k_finalize": phys_f, "k_pair_counts": phys_p},
+                        "physical_hbm_gbs": round((phys_f + phys_p) / t / 1e9, 1) if phys_f and phys_p else None,
+                        "compulsory_bytes_per_step": n * (1 << p) + 4 * total},
+           "cpu_baseline": cpu, "parity": parity}
+    del out, regs_d
+    torch.cuda.empty_cache()
+    return res
+
+
+def config_c5_band(ctx, torch, dev, dashing_amd, synth, n=300_000, p=14, rows=2048, nbase=4000):
+    """configs[4] shape (300 000 x p=14): ONE row range of the triangle on one GPU, extrapolated to the full matrix by pair
+    count and labelled so.  Sketch g >= nbase = max(base[a_g], base[b_g]): unions of two base sketches, built on the device
+    (as tests/test_gpu_configs.py); parity on sampled pairs of the band against the CPU oracle."""
+    from oracle import oracle_c
+
+    base = synth.survey_sketches(nbase, p, seed=0x5EED0000)[0]
+    bd = torch.from_numpy(base).to(dev)
+    regs = torch.empty((n, 1 << p), dtype=torch.uint8, device=dev)
+    regs[:nbase] = bd
+    g = torch.arange(nbase, n, device=dev, dtype=torch.int64)
+    a, b2 = g % nbase, (g * 2654435761 + 12345) % nbase
+    for s0 in range(0, n - nbase, 1 << 14):
+        e0 = min(n - nbase, s0 + (1 << 14))
+        regs[nbase + s0: nbase + e0] = torch.maximum(bd[a[s0:e0]], bd[b2[s0:e0]])
+    del bd
+    span = dashing_amd.tri_span(n, 0, rows)
+    out = torch.empty(span, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(2):
+        ctx.attach_device(regs.data_ptr(), n, p)
+        t0 = time.perf_counter()
+        ctx.dist_rows_device(out.data_ptr(), 0, rows, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ctx.set_profiling(True)
+    ctx.attach_device(regs.data_ptr(), n, p)
+    ctx.dist_rows_device(out.data_ptr(), 0, rows, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+    ctx.synchronize()
+    k = ctx.last_kernel_ms()
+    ctx.set_profiling(False)
+    _, pbind = pair_binding(ctx, k["pair_ms"])
+    t = min(ts)
+    total = n * (n - 1) // 2
+    # parity: 2 rows x 3 000 sampled columns
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.choice(np.arange(rows, n), 3000, replace=False))
+    qi = [1, rows - 1]
+    q_h = regs[qi].cpu().numpy()
+    c_h = regs[torch.from_numpy(cols).to(dev)].cpu().numpy()
+    ref = oracle_c.dist_rect(q_h, c_h)
+    got = np.stack([out[torch.from_numpy(np.array([dashing_amd.tri_index(n, i, int(j)) for j in cols], np.int64)).to(dev)].cpu().numpy() for i in qi])
+    rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
+    res = {"workload": "BASELINE configs[4] shape, ONE BAND: rows [0,%d) of %d synthetic sketches, p=%d (%.2e of the matrix's %.2e pairs) on one GPU" % (rows, n, p, span, total),
+           "pairs_per_s": span / t, "ms_band": t * 1e3, "pairs_in_band": span,
+           "extrapolated_full_matrix_s": round(total / (span / t), 2),
+           "extrapolation": "full matrix = pairs / (band pairs per second); the band pays the per-sketch pass and the bit-plane transform of ALL %d columns (%.1f ms of %.1f), which a full pass pays once per row range of its own columns: pessimistic" % (n, k["prepare_ms"], t * 1e3),
+           "kernel_ms": {"k_pair_counts": round(k["pair_ms"], 3), "k_finalize": round(k["finalize_ms"], 3), "prepare": round(k["prepare_ms"], 3)},
+           "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
+           "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": round(span * (2 * (1 << p) + 4) / t / 1e9 / HBM_PEAK_GBS, 4), "physical_hbm_gbs": None},
+           "cpu_baseline": None,
+           "parity": {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6, "exact_float32_matches": int((got == ref).sum())},
+           "note": "the full 300 000 x p=14 matrix (45e9 pairs, 180 GB) is computed twice on one GPU by tests/test_gpu_configs.py::test_config4_full_300k_p14_eight_ranges; CPU rate per pair at p=14: see the headline's cpu_baseline"}
+    del out, regs
+    torch.cuda.empty_cache()
+    return res
 
 
 def data_dependence(ctx, torch, dev, dashing_amd, n, p):
@@ -523,35 +939,7 @@ def data_dependence(ctx, torch, dev, dashing_amd, n, p):
     return res
 
 
-def secondary_p10(ctx, torch, dev, synth, dashing_amd, n=100_000, p=10):
-    """configs[3]-shaped matrix on ONE GPU (the 8-GPU run is the driver's): at 1 KiB per sketch the popcounts are
-    cheap and the per-pair estimator (k_finalize) is the hot kernel, which the p=14 headline hides."""
-    regs = synth.survey_sketches(n, p, seed=0x5EED0000)[0]
-    regs_d = torch.from_numpy(regs).to(dev)
-    total = n * (n - 1) // 2
-    out = torch.empty(total, dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-    times = []
-    for _ in range(3):
-        ctx.attach_device(regs_d.data_ptr(), n, p)
-        t0 = time.perf_counter()
-        ctx.dist_rows_device(out.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
-        ctx.synchronize()
-        times.append(time.perf_counter() - t0)
-    km = measure_kernels(ctx, regs_d, n, p, [(out.data_ptr(), 0, n)], 1)
-    t = min(times[1:])
-    res = {"workload": "BASELINE configs[3] shape on one GPU: %d synthetic sketches, p=%d, full triangle (%.1f GB of float32 left in HBM)" % (n, p, total * 4 / 1e9),
-           "value": total / t, "unit": "pairs/s", "ms_per_step": t * 1e3, "steps": 2,
-           "kernel_ms": {"k_pair_counts": round(km["pair_ms"], 3), "k_finalize": round(km["finalize_ms"], 3), "prepare": round(km["prepare_ms"], 3),
-                         "pair_launches": km["pair_launches"]},
-           "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
-           "finalize_cycles_per_wave64_of_pairs": round(km["finalize_ms"] * 1e-3 * CLOCK_HZ * N_SIMD / (total / 64.0), 1)}
-    del out, regs_d
-    torch.cuda.empty_cache()
-    return res
-
-
-def cpu_baseline(regs_h, gpu_full, n, p, seconds):
+def cpu_baseline(regs_h, gpu_full, n, p, seconds, max_rows=None):
     """Time the CPU oracle (reference algorithm + row schedule) on a bounded sample of rows.
     The oracle is only the checker/baseline here -- never the thing measured as `value`."""
     import subprocess
@@ -582,9 +970,11 @@ def cpu_baseline(regs_h, gpu_full, n, p, seconds):
     r0, t_cal = timed_rows(8, level)
     rate = r0.size / max(t_cal, 1e-6)
     rows = int(min(n - 1, max(16, seconds * rate / n)))
+    if max_rows:
+        rows = max(1, min(rows, int(max_rows)))  # (the rows `gpu_full` holds)
     ref, t = timed_rows(rows, level)
-    # the scalar histogram on a quarter of the sample, for the record (and as a cross-check of the SIMD one)
-    rows_s = max(8, rows // 4)
+    # the scalar histogram on a small part of the sample, for the record (and as a cross-check of the SIMD one)
+    rows_s = max(8, rows // 8)
     ref_s, t_s = timed_rows(rows_s, 0)
     oracle_c.set_simd(0, kind_lib)
     assert (ref[: ref_s.size] == ref_s).all(), "SIMD and scalar CPU histograms disagree"

@@ -28,7 +28,7 @@ SYMBOLS = [
     "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
-    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_set_option", "dsh_get_info", "dsh_stream",
+    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
     lib.dsh_comm_available.argtypes = []
     lib.dsh_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i32)]
     lib.dsh_comm_wait.argtypes = [vp]
+    lib.dsh_finalize_phase_cycles.argtypes = [vp, vp]
     lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.dsh_comm_destroy.argtypes = [vp]
     lib.dsh_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
@@ -411,6 +412,12 @@ class Context:
 
     def comm_destroy(self):
         self._ck(self._lib.dsh_comm_destroy(self._h))
+
+    def finalize_phase_cycles(self):
+        """per-phase cycle sums of the last call with the option finalize_timing (dsh_finalize_phase_cycles)"""
+        out = np.zeros(16, np.uint64)
+        self._ck(self._lib.dsh_finalize_phase_cycles(self._h, out.ctypes.data))
+        return [int(x) for x in out]
 
     def comm_wait(self):
         """dsh_wait with a deadline on the RCCL traffic (DSH_COMM_TIMEOUT_S): an error instead of a hang"""

@@ -44,7 +44,7 @@ static void release_ctx(dsh_ctx *c)
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
                       &c->keys, &c->tailhist, &c->hist, &c->cidx_off, &c->cidx_ent, &c->perm, &c->items, &c->cum, &c->tiles,
-                      &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf})
+                      &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc})
         b->release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
     c->pin_perm = nullptr;
@@ -242,8 +242,22 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
     if (!c->ev_work) HIPCHK(c, hipEventCreateWithFlags(&c->ev_work, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_work, c->stream));
     c->work_in_flight = true;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {  // k_sketch alone, on the stream it runs on
+        c->ev_used = 0;
+        e0 = next_event(c);
+        e1 = next_event(c);
+        if (e0) (void)hipEventRecord(e0, c->stream);
+    }
     HIPCHK(c, launch_sketch(c->stream, d_seq, (const SketchWork *)c->workbuf.ptr,
                             (uint32_t)work.size(), k, c->p, canon, (uint8_t *)c->regs_own.ptr));
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        c->sketch_ms = ms;
+    }
     return DSH_OK;
 }
 
@@ -694,7 +708,7 @@ int dsh_set_profiling(dsh_ctx *c, int enable)
 {
     if (!c) return DSH_EINVAL;
     c->profiling = enable != 0;
-    if (!c->profiling) c->finalize_stop = 0;  // the stop points exist for profiling runs only
+    if (!c->profiling) c->finalize_stop = c->finalize_timing = 0;  // the stop points and stamps exist for profiling runs only
     return DSH_OK;
 }
 
@@ -705,6 +719,17 @@ int dsh_last_kernel_ms(dsh_ctx *c, double *pair_ms, double *fin_ms, double *prep
     if (fin_ms) *fin_ms = c->fin_ms;
     if (prep_ms) *prep_ms = c->prep_ms;
     if (launches) *launches = c->pair_launches;
+    return DSH_OK;
+}
+
+int dsh_finalize_phase_cycles(dsh_ctx *c, uint64_t *out16)
+{
+    if (!c || !out16) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->phase_cyc.ptr) return fail(c, DSH_ESTATE, "no call with the option finalize_timing yet");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out16, c->phase_cyc.ptr, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return DSH_OK;
 }
 
@@ -723,6 +748,8 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "elow")) *out = c->elow;
     else if (!std::strcmp(name, "kc")) *out = c->kc;
     else if (!std::strcmp(name, "tile")) *out = kTile;
+    else if (!std::strcmp(name, "parts_done")) *out = c->parts_done;
+    else if (!std::strcmp(name, "sketch_kernel_us")) *out = (int64_t)(c->sketch_ms * 1000.0);
     else if (!std::strcmp(name, "whatif_mfma")) {
 #ifdef DSH_WHATIF_MFMA
         *out = 1;
@@ -818,6 +845,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         if (v < 0 || v > 4) return fail(c, DSH_EINVAL, "finalize_stop must be in [0,4]");
         if (v && !c->profiling) return fail(c, DSH_ESTATE, "finalize_stop needs dsh_set_profiling(ctx, 1)");
         c->finalize_stop = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_timing")) {  // profiling only: same results, the stamped instance of k_finalize
+        if (v && !c->profiling) return fail(c, DSH_ESTATE, "finalize_timing needs dsh_set_profiling(ctx, 1)");
+        c->finalize_timing = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "nsplit")) {

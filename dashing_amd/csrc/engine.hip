@@ -247,6 +247,10 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     HIPCHK(c, c->cum.ensure(std::max<uint64_t>(pp.per_tile_bytes * pp.max_band, 256)));
 
     const float ksinv_f = (float)(1. / (double)job.k);
+    if (c->finalize_timing) {
+        HIPCHK(c, c->phase_cyc.ensure(16 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->phase_cyc.ptr, 0, 16 * sizeof(unsigned long long), c->stream));
+    }
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evp, evf;
     for (size_t bi = 0; bi < pp.bands.size(); ++bi) {
         const auto &bd = pp.bands[bi];
@@ -299,6 +303,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.n = c->n;
             f.ncols = L.ncols;
             f.stop = c->finalize_stop;
+            f.phase_cyc = c->finalize_timing ? (unsigned long long *)c->phase_cyc.ptr : nullptr;
             f.rect = job.rect;
             f.sorted_out = job.sorted_rows;
             f.square = job.square;

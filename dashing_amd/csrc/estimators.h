@@ -128,7 +128,7 @@ __device__ __forceinline__ double twice(double x)
 // count reads all fall in that range).  The next count is fetched one step ahead so the LDS
 // read overlaps the dependent fp64 divide chain.
 template <class Hist, class Raw>
-__device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint)
+__device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint, int *iters = nullptr)
 {
     const int q = 64 - p;
     const uint64_t m = 1ull << p;
@@ -154,7 +154,9 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     // sqrt(2^p) without the sqrt sequence: 2^(p/2), times the correctly rounded sqrt(2) for odd p (a power-of-two
     // scaling keeps it the correctly rounded root, i.e. what sqrt() returns)
     const double relerr = 1e-2 / ldexp((p & 1) ? 0x1.6a09e667f3bcdp+0 : 1.0, p >> 1);
+    if (iters) *iters = (kMaxPrime - kMinPrime + 1) << 8;  // live bins of the inner recurrence, iterations below
     while (deltaX > x * relerr) {
+        if (iters) ++*iters;  // (profiling instances only)
         int kappaMinus1;
         (void)frexp(x, &kappaMinus1);
         const int sh = kMaxPrime + 1 > kappaMinus1 + 2 ? kMaxPrime + 1 : kappaMinus1 + 2;
@@ -189,12 +191,12 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
 
 template <class Hist, class Raw>
 __device__ inline double estimate(const Hist &c, const Raw &raw, int p, int estim, int lo_hint,
-                                  int hi_hint)
+                                  int hi_hint, int *iters = nullptr)
 {
     switch (estim) {
     case 0: return estimate_original(c, raw, p, lo_hint, hi_hint);
     case 1: return estimate_improved(c, p);
-    default: return estimate_mle(c, raw, p, lo_hint, hi_hint);
+    default: return estimate_mle(c, raw, p, lo_hint, hi_hint, iters);
     }
 }
 

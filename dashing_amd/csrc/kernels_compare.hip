@@ -916,6 +916,7 @@ struct FinalizeArgs {
     float *out2;
     uint64_t knn_ld, knn_rows;
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
+    unsigned long long *phase_cyc;  // profiling only (TIMED instances): shader-clock cycles per phase, summed over waves
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
@@ -932,10 +933,16 @@ struct FinalizeArgs {
 // sketch's e-th listed register and visits the bucket of its position -- |list_i| lookups per tile row instead of
 // 128 list walks -- and applies what it finds to the owning lane's histogram column with LDS atomics.  Exact and
 // order-independent.  C(Lp) = number of low joins, so c[Lp] = C(Lp+1) - C(Lp) and c[T] = m - |union above T| - C(T).
-template <typename CT>
+// TIMED (option "finalize_timing", profiling only): s_memtime stamps between the phases of the FULL kernel, summed per
+// phase over all waves that finish (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per lane
+// and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
+// accounting VERDICT r3 asked for instead of early-exit stops, whose occupancy and overlap differ from the real kernel.
+template <typename CT, bool TIMED>
 // 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_finalize(FinalizeArgs a)
 {
+    unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0};
+    if constexpr (TIMED) tph[0] = __builtin_readcyclecounter();
     // histogram columns hold counts <= 2^p: CT (uint16 when p <= 15) halves the LDS footprint and
     // doubles the resident waves of this latency-sensitive kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];
@@ -1032,6 +1039,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         keyj = a.keys[j];
         keyi = a.keys[i];
     }
+    if constexpr (TIMED) tph[1] = __builtin_readcyclecounter();
     __syncthreads();  // histA, corr, actm are set
     if (active) {
         // bins below the dense range start empty (the lower-tail join fills them); dense part: c[x] = C(x+1) - C(x),
@@ -1073,6 +1081,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     __syncthreads();
+    if constexpr (TIMED) tph[2] = __builtin_readcyclecounter();
     if (a.stop == 2) {
         if (active) a.out[oidx] = (float)(nb + prev + keyj);
         return;
@@ -1147,6 +1156,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     __syncthreads();
+    if constexpr (TIMED) tph[3] = __builtin_readcyclecounter();
     if (!active) return;
     const uint32_t ucnt = actm[4] + nb - corr[tid];  // |list_i above T| + |list_j above T| - shared positions
     uint32_t clow = 0;                                // C(Lp) = the lower-tail joins = the bins below the dense range
@@ -1168,7 +1178,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
-    const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv);
+    if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
+    int mle_it = 0;
+    const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
+    if constexpr (TIMED) tph[5] = __builtin_readcyclecounter();
     if (a.stop == 4) {
         a.out[oidx] = (float)us;
         return;
@@ -1187,6 +1200,38 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return;
     }
     a.out[oidx] = res;
+    if constexpr (TIMED) {
+        tph[6] = __builtin_readcyclecounter();
+        const unsigned long long live = __ballot(1);
+        if ((unsigned)(tid & 63) == (unsigned)(__ffsll((long long)live) - 1)) {  // the wave's first finishing lane
+            for (int k = 0; k < 6; ++k) atomicAdd(&a.phase_cyc[k], tph[k + 1] - tph[k]);
+            atomicAdd(&a.phase_cyc[6], 1ull);
+        }
+        // divergence of the estimator inside a wave: per lane its MLE iterations and live bins (the trip counts of the
+        // outer and the inner loop); a wave pays the maxima
+        corr[tid] = (uint32_t)mle_it;  // (corr is dead by now; the wave's lanes read back only their own wave's half)
+        if ((unsigned)(tid & 63) == (unsigned)(__ffsll((long long)live) - 1)) {
+            unsigned mx_it = 0, mx_bins = 0, sum_it = 0, sum_bins = 0, sum_work = 0, lanes = 0;
+            for (int l = 0; l < 64; ++l) {
+                if (!((live >> l) & 1ull)) continue;
+                const uint32_t v = corr[(tid & 64) + l];
+                const unsigned it = v & 255u, bins = v >> 8;
+                mx_it = it > mx_it ? it : mx_it;
+                mx_bins = bins > mx_bins ? bins : mx_bins;
+                sum_it += it;
+                sum_bins += bins;
+                sum_work += it * bins;
+                ++lanes;
+            }
+            atomicAdd(&a.phase_cyc[7], (unsigned long long)lanes);
+            atomicAdd(&a.phase_cyc[8], (unsigned long long)sum_it);
+            atomicAdd(&a.phase_cyc[9], (unsigned long long)sum_bins);
+            atomicAdd(&a.phase_cyc[10], (unsigned long long)sum_work);
+            atomicAdd(&a.phase_cyc[11], (unsigned long long)mx_it);
+            atomicAdd(&a.phase_cyc[12], (unsigned long long)mx_bins);
+            atomicAdd(&a.phase_cyc[13], (unsigned long long)(mx_it * mx_bins));
+        }
+    }
 }
 
 // sorted packed triangle -> packed triangle in original sketch order (one block per sorted row)
@@ -1639,10 +1684,14 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;
+    a.phase_cyc = f.phase_cyc;
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
-    if (f.cum_bytes == 2) hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(blocks), dim3(128), lds, st, a);
-    else hipLaunchKernelGGL(k_finalize<uint32_t>, dim3(blocks), dim3(128), lds, st, a);
+    if (f.phase_cyc) {  // profiling only
+        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true>), dim3(blocks), dim3(128), lds, st, a);
+        else hipLaunchKernelGGL((k_finalize<uint32_t, true>), dim3(blocks), dim3(128), lds, st, a);
+    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false>), dim3(blocks), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL((k_finalize<uint32_t, false>), dim3(blocks), dim3(128), lds, st, a);
     return hipGetLastError();
 }
 

@@ -292,6 +292,12 @@ void dsh_free_host(void *p);
 int dsh_set_profiling(dsh_ctx *ctx, int enable);
 int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
                        double *prepare_ms, uint32_t *pair_kernel_launches);
+/* Profiling aid: after a compare call with dsh_set_profiling(ctx, 1) and the option "finalize_timing" = 1 (the
+ * s_memtime-stamped instance of k_finalize; results unchanged), out16 = shader-clock cycles summed over the waves that
+ * finished, per phase [0..5] {prologue + loads issued, histogram columns, list joins, fix-ups, estimator, result + store};
+ * [6] such waves; [7] their lanes; sums over lanes of [8] MLE iterations, [9] live bins, [10] iterations x bins; sums over
+ * waves of the per-wave maxima [11] iterations, [12] bins, [13] their product (what a wave pays); [14..15] zero. */
+int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
 /* Tunables; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
  * byte-identical output over their ranges): "kc" (0 auto | 16 | 32 | 64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),

@@ -155,3 +155,70 @@ def test_bench_measures_hbm_traffic_itself():
     r = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-pmc"], {"DSH_BENCH_N": "4000"})
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert "measured in this run" not in line["roofline"]["traffic_note"]
+
+
+def test_bench_falls_back_when_the_library_cannot_load_rccl():
+    """with the C-ABI communicator unavailable (DSH_RCCL_LIB points nowhere) the N-rank code path of
+    bench.py (forced with one rank) still prints ONE valid JSON line: the exchange that actually ran (torch.distributed),
+    the reason, the library the loader tried; and with RCCL loadable the same command uses the C-ABI exchange and names
+    the resolved librccl and its version."""
+    import json
+
+    common = {"DSH_BENCH_FORCE_DIST": "1", "DSH_BENCH_N": "3000", "MASTER_PORT": "29533"}
+    common["MASTER_PORT"] = str(_free_port())
+    r = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-pmc"], dict(common, DSH_RCCL_LIB="/nonexistent/librccl.so"))
+    out = r.stdout.decode()
+    assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    mg = json.loads(lines[0])["multi_gpu"]
+    assert mg["exchange"] == "torch.distributed" and mg["rccl_ranks"] == 1
+    assert mg["exchange_library"]["available_on_rank0"] is False and "cabi_fallback_reason" in mg["exchange_library"]
+    assert json.loads(lines[0])["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+    r = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-pmc"], dict(common, MASTER_PORT=str(_free_port())))
+    out = r.stdout.decode()
+    assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    mg = line["multi_gpu"]
+    assert mg["exchange"].startswith("c-abi rccl") and mg["exchange_library"]["nccl_version_code"] > 0
+    assert "librccl" in mg["exchange_library"]["library"]
+    assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+
+
+def test_parts_of_short_ranges_get_their_events(ctx):
+    import dashing_amd
+    from dashing_amd import synth
+
+    _parts_of_short_ranges(ctx, dashing_amd, synth)
+
+
+def _parts_of_short_ranges(ctx, dashing_amd, synth):
+    """the ranks of an 8-way run at n = 10 000 hold 640-896 rows -- below range_sort_min_rows -- and a
+    rank may hold a single part.  A call with parts must still lay its range out in exactly dsh_range_parts' parts and
+    mark every one, or dsh_collect_parts_async refuses (and the peers hang).  Same values as the plain call."""
+    import torch
+
+    n, p = 2600, 12
+    regs = torch.from_numpy(synth.survey_sketches(n, p, seed=11)[0]).cuda()
+    ctx.attach_device(regs.data_ptr(), n, p)
+    want = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device="cuda")
+    ctx.dist_rows_device(want.data_ptr(), 0, n)
+    ctx.synchronize()
+    bounds = [0, 640, 1280, 1290, 1290, 2048, 2599, n]
+    for nparts in (1, 3, 8):
+        for r in range(len(bounds) - 1):
+            rb, re = bounds[r], bounds[r + 1]
+            span = dashing_amd.tri_span(n, rb, re)
+            got = torch.full((max(span, 1),), -1.0, dtype=torch.float32, device="cuda")
+            ctx.dist_rows_parts_device_async(got.data_ptr(), rb, re, nparts)
+            ctx.synchronize()
+            parts = dashing_amd.range_parts(n, rb, re, nparts)
+            assert ctx.info("parts_done") == (len(parts) - 1 if rb < re else 0), (rb, re, nparts, parts)
+            off = dashing_amd.tri_span(n, 0, rb)
+            assert torch.equal(got[:span], want[off:off + span]), (rb, re, nparts)
+    # one rank, full range: the collect call accepts what the compute call left
+    out = torch.empty_like(want)
+    ctx.dist_rows_parts_device_async(out.data_ptr(), 0, n, 4)
+    ctx.collect_parts_async(n, [0, n], 4, 0, out.data_ptr(), 0)
+    ctx.comm_wait()
+    assert torch.equal(out, want)
