@@ -142,6 +142,7 @@ struct dsh_ctx {
     int pair_lockstep = -1;
     int pair_mfma = 0;  // WHAT-IF only (built with `make WHATIF=1`): 1 = the AND+popcount tile kernel on the matrix cores
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
+    int mle_variant = 0;      // profiling only: experimental evaluations of the MLE's inner step (results differ in the last bits)
     int finalize_timing = 0;  // profiling only: the s_memtime-stamped instance of k_finalize (same results, per-phase cycles)
     DevBuf phase_cyc;       // 8 x u64 of the last call with finalize_timing
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)

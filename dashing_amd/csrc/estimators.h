@@ -104,6 +104,19 @@ __device__ __forceinline__ double div_normal(double num, double den)
     return __builtin_fma(rem, r, q);
 }
 
+// EXPERIMENT (mle_variant, profiling only): ONE Newton step.  v_rcp_f64 delivers ~2^-27 (tools/ubench/div_accuracy.hip),
+// one step ~2^-54, the residual correction then rounds correctly except when the exact quotient lies within ~2^-100 of a
+// rounding boundary -- not proven never to happen, which is why it does not ship.
+__device__ __forceinline__ double div_normal_n1(double num, double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    const double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = num * r;
+    const double rem = __builtin_fma(-den, q, num);
+    return __builtin_fma(rem, r, q);
+}
+
 // The same for operands that are only KNOWN to be finite: the fast sequence when both magnitudes lie in [2^-500, 2^500]
 // (or the numerator is zero) -- then the reciprocal, the quotient (in [2^-1000, 2^1000]) and the residual (>= 2^-553)
 // are all normal and the result is the correctly rounded quotient, signs included -- and the plain `/` otherwise.
@@ -127,7 +140,10 @@ __device__ __forceinline__ double twice(double x)
 // v in [lo_hint, hi_hint] and skips the bounds test that `c(v)` performs (the iteration's
 // count reads all fall in that range).  The next count is fetched one step ahead so the LDS
 // read overlaps the dependent fp64 divide chain.
-template <class Hist, class Raw>
+// V (profiling experiments only, option mle_variant; 0 ships): bit 0 = one Newton step in the inner division, bit 1 = the
+// two products feeding an addition in the inner step contracted to fma (what g++ -O3 -march=native does to the reference
+// by default; NOT what the oracle evaluates).
+template <int V = 0, class Hist, class Raw>
 __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint, int *iters = nullptr)
 {
     const int q = 64 - p;
@@ -176,9 +192,10 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
             const double ck = (double)cnext;
             cnext = raw(k - 1);
             const double hPrime = 1. - h;
-            h = div_normal(xPrime + h * hPrime, xPrime + hPrime);
+            const double num = (V & 2) ? __builtin_fma(h, hPrime, xPrime) : xPrime + h * hPrime;
+            h = (V & 1) ? div_normal_n1(num, xPrime + hPrime) : div_normal(num, xPrime + hPrime);
             xPrime = twice(xPrime);
-            g += ck * h;
+            g = (V & 2) ? __builtin_fma(ck, h, g) : g + ck * h;
         }
         g += x * a;
         if (gprev < g && g <= mPrime) deltaX *= div_guarded(g - mPrime, gprev - g);
@@ -189,14 +206,14 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     return x * (double)m;
 }
 
-template <class Hist, class Raw>
+template <int V = 0, class Hist, class Raw>
 __device__ inline double estimate(const Hist &c, const Raw &raw, int p, int estim, int lo_hint,
                                   int hi_hint, int *iters = nullptr)
 {
     switch (estim) {
     case 0: return estimate_original(c, raw, p, lo_hint, hi_hint);
     case 1: return estimate_improved(c, p);
-    default: return estimate_mle(c, raw, p, lo_hint, hi_hint, iters);
+    default: return estimate_mle<V>(c, raw, p, lo_hint, hi_hint, iters);
     }
 }
 

@@ -937,7 +937,7 @@ struct FinalizeArgs {
 // phase over all waves that finish (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per lane
 // and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
 // accounting VERDICT r3 asked for instead of early-exit stops, whose occupancy and overlap differ from the real kernel.
-template <typename CT, bool TIMED>
+template <typename CT, bool TIMED, int MLEV>
 // 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_finalize(FinalizeArgs a)
 {
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
     if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
     int mle_it = 0;
-    const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
+    const double us = estimate<MLEV>(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
     if constexpr (TIMED) tph[5] = __builtin_readcyclecounter();
     if (a.stop == 4) {
         a.out[oidx] = (float)us;
@@ -1688,10 +1688,16 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
     if (f.phase_cyc) {  // profiling only
-        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true>), dim3(blocks), dim3(128), lds, st, a);
-        else hipLaunchKernelGGL((k_finalize<uint32_t, true>), dim3(blocks), dim3(128), lds, st, a);
-    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false>), dim3(blocks), dim3(128), lds, st, a);
-    else hipLaunchKernelGGL((k_finalize<uint32_t, false>), dim3(blocks), dim3(128), lds, st, a);
+        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true, 0>), dim3(blocks), dim3(128), lds, st, a);
+        else hipLaunchKernelGGL((k_finalize<uint32_t, true, 0>), dim3(blocks), dim3(128), lds, st, a);
+    } else if (f.mle_variant && f.cum_bytes == 2) {  // profiling experiments only (p <= 15)
+        switch (f.mle_variant) {
+        case 1: hipLaunchKernelGGL((k_finalize<uint16_t, false, 1>), dim3(blocks), dim3(128), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_finalize<uint16_t, false, 2>), dim3(blocks), dim3(128), lds, st, a); break;
+        default: hipLaunchKernelGGL((k_finalize<uint16_t, false, 3>), dim3(blocks), dim3(128), lds, st, a); break;
+        }
+    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false, 0>), dim3(blocks), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL((k_finalize<uint32_t, false, 0>), dim3(blocks), dim3(128), lds, st, a);
     return hipGetLastError();
 }
 
