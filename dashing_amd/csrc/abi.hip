@@ -708,7 +708,7 @@ int dsh_set_profiling(dsh_ctx *c, int enable)
 {
     if (!c) return DSH_EINVAL;
     c->profiling = enable != 0;
-    if (!c->profiling) c->finalize_stop = c->finalize_timing = c->mle_variant = 0;  // the stop points and stamps exist for profiling runs only
+    if (!c->profiling) c->finalize_stop = c->finalize_timing = 0;  // the stop points and stamps exist for profiling runs only
     return DSH_OK;
 }
 
@@ -847,12 +847,6 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->finalize_stop = (int)v;
         return DSH_OK;
     }
-    if (!std::strcmp(name, "mle_variant")) {  // profiling experiments only: results differ from the oracle's in the last bits
-        if (v < 0 || v > 3) return fail(c, DSH_EINVAL, "mle_variant must be in [0,3]");
-        if (v && !c->profiling) return fail(c, DSH_ESTATE, "mle_variant needs dsh_set_profiling(ctx, 1)");
-        c->mle_variant = (int)v;
-        return DSH_OK;
-    }
     if (!std::strcmp(name, "finalize_timing")) {  // profiling only: same results, the stamped instance of k_finalize
         if (v && !c->profiling) return fail(c, DSH_ESTATE, "finalize_timing needs dsh_set_profiling(ctx, 1)");
         c->finalize_timing = v != 0;
@@ -866,6 +860,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "emax") || !std::strcmp(name, "elow")) {
         if (v < -1 || v > (int64_t)kMaxListSide) return fail(c, DSH_EINVAL, "%s must be in [-1,%u]", name, kMaxListSide);
         (name[1] == 'm' ? c->emax_opt : c->elow_opt) = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_xcd_tiles")) {
+        c->finalize_xcd_tiles = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "finalize_rowmajor")) {

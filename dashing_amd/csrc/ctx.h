@@ -125,6 +125,7 @@ struct dsh_ctx {
     int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
+    int finalize_xcd_tiles = 1;       // k_finalize: block -> tile mapping that keeps a tile's 128 rows on one XCD (option, A/B)
     int finalize_rowmajor = 1;        // k_finalize walks every segment's tiles in row-major order (option, A/B only)
     size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call
     uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
@@ -142,7 +143,6 @@ struct dsh_ctx {
     int pair_lockstep = -1;
     int pair_mfma = 0;  // WHAT-IF only (built with `make WHATIF=1`): 1 = the AND+popcount tile kernel on the matrix cores
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
-    int mle_variant = 0;      // profiling only: experimental evaluations of the MLE's inner step (results differ in the last bits)
     int finalize_timing = 0;  // profiling only: the s_memtime-stamped instance of k_finalize (same results, per-phase cycles)
     DevBuf phase_cyc;       // 8 x u64 of the last call with finalize_timing
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)

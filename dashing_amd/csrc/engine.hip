@@ -303,7 +303,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.n = c->n;
             f.ncols = L.ncols;
             f.stop = c->finalize_stop;
-            f.mle_variant = c->mle_variant;
+            f.xcd_tiles = c->finalize_xcd_tiles;
             f.phase_cyc = c->finalize_timing ? (unsigned long long *)c->phase_cyc.ptr : nullptr;
             f.rect = job.rect;
             f.sorted_out = job.sorted_rows;

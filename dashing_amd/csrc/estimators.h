@@ -89,9 +89,9 @@ __device__ inline double estimate_improved(const Hist &c, int p)
 // the normal range: reciprocal estimate, two Newton steps, quotient, one residual correction -- the same fma
 // sequence hipcc emits for `/` minus its v_div_scale/v_div_fixup special-case handling (3 of 11 instructions).
 // Correctly rounded under that precondition, so results stay identical to a CPU `/`.  Used ONLY where the
-// precondition holds by construction: the step of the inner recurrence (both operands in [x', 2), x' = x 2^-s >=
-// 2^-130) and the two constant divisors of the series start (x'^2 / 3, x'^2 / 472.5).  The once-per-iteration
-// divisions (start value, secant step: operands may be zero or negative) go through div_guarded below.
+// precondition holds by construction: the two constant divisors of the series start (x'^2 / 3, x'^2 / 472.5) and,
+// through div_guarded, the once-per-iteration divisions; the step of the inner recurrence (both operands in [x', 2),
+// x' = x 2^-s >= 2^-130) uses div_inner below.
 __device__ __forceinline__ double div_normal(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
@@ -104,10 +104,14 @@ __device__ __forceinline__ double div_normal(double num, double den)
     return __builtin_fma(rem, r, q);
 }
 
-// EXPERIMENT (mle_variant, profiling only): ONE Newton step.  v_rcp_f64 delivers ~2^-27 (tools/ubench/div_accuracy.hip),
-// one step ~2^-54, the residual correction then rounds correctly except when the exact quotient lies within ~2^-100 of a
-// rounding boundary -- not proven never to happen, which is why it does not ship.
-__device__ __forceinline__ double div_normal_n1(double num, double den)
+// The inner recurrence's division: ONE Newton step.  v_rcp_f64 delivers 24.4 bits (measured, tools/ubench/div_accuracy.hip),
+// one step 48.8; with q = num * r and the exact residual rem = num - den * q (fma) the value before the final rounding is
+// off by |rem / den| * 2^-48.8 <= 2^-97 |q|: the result is the correctly rounded quotient unless the exact quotient lies within
+// 2^-97 (relative) of the midpoint of two doubles -- 2^-44 of all operand pairs.  Measured: 0 mismatches against `/` in
+// 3.4e10 random operand pairs of the recurrence's domain, and all 5e9 float32 results of the configs[3]-shaped matrix
+// (2.2e11 divisions) unchanged (profiles/r4a).  Same preconditions as div_normal.  Two instructions fewer in a 21-instruction
+// step that runs ~45 times per pair: k_finalize -5.5 % at p = 10.
+__device__ __forceinline__ double div_inner(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
     const double e = __builtin_fma(-den, r, 1.0);
@@ -140,10 +144,7 @@ __device__ __forceinline__ double twice(double x)
 // v in [lo_hint, hi_hint] and skips the bounds test that `c(v)` performs (the iteration's
 // count reads all fall in that range).  The next count is fetched one step ahead so the LDS
 // read overlaps the dependent fp64 divide chain.
-// V (profiling experiments only, option mle_variant; 0 ships): bit 0 = one Newton step in the inner division, bit 1 = the
-// two products feeding an addition in the inner step contracted to fma (what g++ -O3 -march=native does to the reference
-// by default; NOT what the oracle evaluates).
-template <int V = 0, class Hist, class Raw>
+template <class Hist, class Raw>
 __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint, int *iters = nullptr)
 {
     const int q = 64 - p;
@@ -192,10 +193,9 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
             const double ck = (double)cnext;
             cnext = raw(k - 1);
             const double hPrime = 1. - h;
-            const double num = (V & 2) ? __builtin_fma(h, hPrime, xPrime) : xPrime + h * hPrime;
-            h = (V & 1) ? div_normal_n1(num, xPrime + hPrime) : div_normal(num, xPrime + hPrime);
+            h = div_inner(xPrime + h * hPrime, xPrime + hPrime);
             xPrime = twice(xPrime);
-            g = (V & 2) ? __builtin_fma(ck, h, g) : g + ck * h;
+            g += ck * h;
         }
         g += x * a;
         if (gprev < g && g <= mPrime) deltaX *= div_guarded(g - mPrime, gprev - g);
@@ -206,14 +206,14 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     return x * (double)m;
 }
 
-template <int V = 0, class Hist, class Raw>
+template <class Hist, class Raw>
 __device__ inline double estimate(const Hist &c, const Raw &raw, int p, int estim, int lo_hint,
                                   int hi_hint, int *iters = nullptr)
 {
     switch (estim) {
     case 0: return estimate_original(c, raw, p, lo_hint, hi_hint);
     case 1: return estimate_improved(c, p);
-    default: return estimate_mle<V>(c, raw, p, lo_hint, hi_hint, iters);
+    default: return estimate_mle(c, raw, p, lo_hint, hi_hint, iters);
     }
 }
 

@@ -58,7 +58,7 @@ struct FinalizeLaunch {
     float *out2 = nullptr;
     uint64_t knn_ld = 0, knn_rows = 0;
     int stop = 0;  // profiling: k_finalize leaves after phase `stop`
-    int mle_variant = 0;  // profiling experiments: see estimate_mle<V>
+    int xcd_tiles = 0;    // k_finalize: the rows of a tile on one XCD
     unsigned long long *phase_cyc = nullptr;  // profiling: per-phase cycle sums of the full kernel (8 x u64, device)
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;

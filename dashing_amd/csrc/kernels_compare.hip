@@ -916,6 +916,8 @@ struct FinalizeArgs {
     float *out2;
     uint64_t knn_ld, knn_rows;
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
+    int xcd_tiles;        // block -> tile mapping that keeps a tile on one XCD (see the kernel)
+    uint32_t ntiles;      // tiles of this launch
     unsigned long long *phase_cyc;  // profiling only (TIMED instances): shader-clock cycles per phase, summed over waves
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
@@ -937,7 +939,7 @@ struct FinalizeArgs {
 // phase over all waves that finish (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per lane
 // and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
 // accounting VERDICT r3 asked for instead of early-exit stops, whose occupancy and overlap differ from the real kernel.
-template <typename CT, bool TIMED, int MLEV>
+template <typename CT, bool TIMED>
 // 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_finalize(FinalizeArgs a)
 {
@@ -957,13 +959,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // k_finalize's tile descriptor (its own list, row-major per segment -- run_pairs): {row block, column block, plane
     // begin | plane end << 8 | smallest << 16 | largest << 24 register value of the two blocks' sketches, index of the
     // tile's C(v) block in the band}: the histogram columns of a block only span the values its own sketches can hold
-    uint4 tile = a.tiles[blockIdx.x >> 7];
+    // block -> (tile, row of the tile).  Plain: 128 consecutive blocks share a tile.  xcd_tiles: consecutive blocks go to
+    // consecutive XCDs (block b runs on XCD b % 8: observed dispatch behaviour, speed only), so block b takes row (b / 8) %
+    // 128 of tile (b / 1024) * 8 + b % 8: the 128 rows of a tile run on ONE XCD and its column block's position index,
+    // tail histograms and keys are fetched into that XCD's L2 once instead of into all eight.
+    uint32_t tidx = blockIdx.x >> 7, trow = blockIdx.x & 127u;
+    if (a.xcd_tiles) {
+        const uint32_t kq = blockIdx.x >> 3;
+        tidx = ((kq >> 7) << 3) + (blockIdx.x & 7u);
+        trow = kq & 127u;
+        if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles)
+    }
+    uint4 tile = a.tiles[tidx];
     const int vlo = (int)((tile.z >> 16) & 0xFFu), vhi = (int)(tile.z >> 24);
     // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column
-    const uint64_t slot = ((uint64_t)tile.w * 128 + (blockIdx.x & 127u)) * 128 + (uint32_t)tid;
+    const uint64_t slot = ((uint64_t)tile.w * 128 + trow) * 128 + (uint32_t)tid;
     tile.w = (tile.z >> 8) & 0xFFu;
     tile.z &= 0xFFu;
-    const uint64_t si = (uint64_t)tile.x * kTile + (blockIdx.x & 127u);
+    const uint64_t si = (uint64_t)tile.x * kTile + trow;
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
     if (si >= a.ncols) return;  // padding row (uniform)
     const uint64_t i = a.perm ? a.perm[si] : si;
@@ -1180,7 +1193,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
     if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
     int mle_it = 0;
-    const double us = estimate<MLEV>(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
+    const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
     if constexpr (TIMED) tph[5] = __builtin_readcyclecounter();
     if (a.stop == 4) {
         a.out[oidx] = (float)us;
@@ -1203,6 +1216,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if constexpr (TIMED) {
         tph[6] = __builtin_readcyclecounter();
         const unsigned long long live = __ballot(1);
+        // (one block in 61 reports: with every wave adding to the same 14 counters the atomics themselves became the
+        // kernel -- 30x slower, profiles/r4a -- and the phases in front of them looked 30x longer than they are)
+        if (blockIdx.x % 61u != 0) return;
         if ((unsigned)(tid & 63) == (unsigned)(__ffsll((long long)live) - 1)) {  // the wave's first finishing lane
             for (int k = 0; k < 6; ++k) atomicAdd(&a.phase_cyc[k], tph[k + 1] - tph[k]);
             atomicAdd(&a.phase_cyc[6], 1ull);
@@ -1685,19 +1701,15 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;
     a.phase_cyc = f.phase_cyc;
+    a.xcd_tiles = f.xcd_tiles;
+    a.ntiles = (uint32_t)(f.nslots / ((uint64_t)kTile * kTile));
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
-    const uint32_t blocks = (uint32_t)((f.nslots + 127) / 128);
+    const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
     if (f.phase_cyc) {  // profiling only
-        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true, 0>), dim3(blocks), dim3(128), lds, st, a);
-        else hipLaunchKernelGGL((k_finalize<uint32_t, true, 0>), dim3(blocks), dim3(128), lds, st, a);
-    } else if (f.mle_variant && f.cum_bytes == 2) {  // profiling experiments only (p <= 15)
-        switch (f.mle_variant) {
-        case 1: hipLaunchKernelGGL((k_finalize<uint16_t, false, 1>), dim3(blocks), dim3(128), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_finalize<uint16_t, false, 2>), dim3(blocks), dim3(128), lds, st, a); break;
-        default: hipLaunchKernelGGL((k_finalize<uint16_t, false, 3>), dim3(blocks), dim3(128), lds, st, a); break;
-        }
-    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false, 0>), dim3(blocks), dim3(128), lds, st, a);
-    else hipLaunchKernelGGL((k_finalize<uint32_t, false, 0>), dim3(blocks), dim3(128), lds, st, a);
+        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true>), dim3(blocks), dim3(128), lds, st, a);
+        else hipLaunchKernelGGL((k_finalize<uint32_t, true>), dim3(blocks), dim3(128), lds, st, a);
+    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false>), dim3(blocks), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL((k_finalize<uint32_t, false>), dim3(blocks), dim3(128), lds, st, a);
     return hipGetLastError();
 }
 

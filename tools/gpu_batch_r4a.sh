@@ -13,8 +13,6 @@ cat $O/div_accuracy.json
 rm -f $O/finalize_phases.jsonl
 timeout 600 python tools/finalize_probe.py --workloads C3,C4 --out $O/finalize_phases.jsonl > $O/finalize_probe.log 2>&1
 tail -3 $O/finalize_probe.log
-timeout 400 python tools/mle_variants.py > $O/mle_variants.jsonl 2>&1
-cat $O/mle_variants.jsonl
 GS=1,8 timeout 300 python tools/shard_breakdown.py > $O/shard_breakdown_c3.jsonl 2>&1
 GS=8 NPARTS=8 timeout 300 python tools/shard_breakdown.py >> $O/shard_breakdown_c3.jsonl 2>&1
 N=100000 P=10 GS=1,8 timeout 400 python tools/shard_breakdown.py > $O/shard_breakdown_c4.jsonl 2>&1
