@@ -97,8 +97,10 @@ struct dsh_ctx {
     DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
     DevBuf hist;                        // [n][64] per-sketch register histograms (k_selfhist_card -> k_card_from_hist)
     hipEvent_t ev_keys = nullptr;       // the keys have reached the host
-    DevBuf cidx_off, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
+    DevBuf cidx_rec, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
     uint32_t nbuckets = 0, ent_stride = 0;
+    DevBuf colS_n, colS_key, colS_card, colS_th, colS_rl;  // per column of the layout, in layout order (k_finalize's inputs)
+    uint32_t rl_stride = 0;             // entries of a compact list row (emax + elow)
     // column layout of the cached plane matrix (plan.h) and the plan of the last compare call
     dsh::plan::Layout lay;
     dsh::plan::PairPlan pp;

@@ -136,14 +136,42 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         // per-sketch pass and the permutation, the tile kernels wait for both
         c->nbuckets = (uint32_t)std::min<uint64_t>(2 * m, kMaxBuckets);  // (position group, upper | lower tail)
         c->ent_stride = std::max<uint32_t>(1, kTile * (uint32_t)(c->emax + c->elow));
-        HIPCHK(c, c->cidx_off.ensure(std::max<size_t>(NT, 1) * (c->nbuckets + 2) * sizeof(uint16_t)));
-        HIPCHK(c, c->cidx_ent.ensure(std::max<size_t>(NT, 1) * c->ent_stride * sizeof(uint32_t)));
+        c->rl_stride = std::max<uint32_t>(1, (uint32_t)(c->emax + c->elow));
+        const size_t nbk = std::max<size_t>(NT, 1);
+        HIPCHK(c, c->cidx_rec.ensure(nbk * c->nbuckets * (size_t)(colindex_inline(c->p, c->rl_stride) + 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->cidx_ent.ensure(nbk * c->ent_stride * sizeof(uint32_t)));
+        HIPCHK(c, c->colS_n.ensure(nbk * kTile * sizeof(uint32_t)));
+        HIPCHK(c, c->colS_key.ensure(nbk * kTile * sizeof(uint32_t)));
+        HIPCHK(c, c->colS_card.ensure(nbk * kTile * sizeof(double)));
+        HIPCHK(c, c->colS_th.ensure(nbk * kTile * 64));
+        HIPCHK(c, c->colS_rl.ensure(nbk * kTile * (size_t)c->rl_stride * sizeof(uint32_t)));
         c->host_layout_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h1).count();
         HIPCHK(c, hipEventRecord(c->ev_aux_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_aux_fork, 0));
-        HIPCHK(c, launch_build_colindex(c->aux_stream, c->exc.ptr, (const uint8_t *)c->excv.ptr, (const uint32_t *)c->exc_n.ptr,
-                                        (const uint32_t *)c->keys.ptr, want_sorted ? (const uint32_t *)c->perm.ptr : nullptr, L.ncols,
-                                        c->p, NT, c->nbuckets, c->ent_stride, (uint16_t *)c->cidx_off.ptr, (uint32_t *)c->cidx_ent.ptr));
+        {
+            ColIndexLaunch ci;
+            ci.exc = c->exc.ptr;
+            ci.excv = (const uint8_t *)c->excv.ptr;
+            ci.exc_n = (const uint32_t *)c->exc_n.ptr;
+            ci.keys = (const uint32_t *)c->keys.ptr;
+            ci.card = (const double *)c->card.ptr;
+            ci.tailhist = (const uint8_t *)c->tailhist.ptr;
+            ci.perm = want_sorted ? (const uint32_t *)c->perm.ptr : nullptr;
+            ci.ncols = L.ncols;
+            ci.p = c->p;
+            ci.nblocks = NT;
+            ci.nbuckets = c->nbuckets;
+            ci.ent_stride = c->ent_stride;
+            ci.E = c->rl_stride;
+            ci.rec = (uint32_t *)c->cidx_rec.ptr;
+            ci.ent = (uint32_t *)c->cidx_ent.ptr;
+            ci.nS = (uint32_t *)c->colS_n.ptr;
+            ci.keyS = (uint32_t *)c->colS_key.ptr;
+            ci.cardS = (double *)c->colS_card.ptr;
+            ci.thS = (uint8_t *)c->colS_th.ptr;
+            ci.rl = (uint32_t *)c->colS_rl.ptr;
+            HIPCHK(c, launch_build_colindex(c->aux_stream, ci));
+        }
         HIPCHK(c, hipEventRecord(c->ev_aux_join, c->aux_stream));
         const uint64_t K = (uint64_t)L.P * c->W;
         c->Kpad = (uint32_t)((K + c->kc - 1) / c->kc * c->kc);
@@ -282,16 +310,17 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.cum_bytes = c->cum_bytes;
             f.cum_stride = nslots;
             f.hist_bins = sg.hist_bins;
-            f.exc = c->exc.ptr;
-            f.exc_n = (const uint32_t *)c->exc_n.ptr;
-            f.excv = (const uint8_t *)c->excv.ptr;
-            f.keys = (const uint32_t *)c->keys.ptr;
-            f.tailhist = (const uint8_t *)c->tailhist.ptr;
+            f.nS = (const uint32_t *)c->colS_n.ptr;
+            f.keyS = (const uint32_t *)c->colS_key.ptr;
+            f.cardS = (const double *)c->colS_card.ptr;
+            f.thS = (const uint8_t *)c->colS_th.ptr;
+            f.rl = (const uint32_t *)c->colS_rl.ptr;
+            f.E = c->rl_stride;
             f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
             f.tiles = (const uint4 *)c->tiles.ptr + T.size() + sg.b;
             f.perm = L.sorted ? (const uint32_t *)c->perm.ptr : nullptr;
             f.pbase = L.pbase;
-            f.cidx_off = (const uint16_t *)c->cidx_off.ptr;
+            f.cidx_rec = (const uint32_t *)c->cidx_rec.ptr;
             f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;
             f.nbuckets = c->nbuckets;
             f.ent_stride = c->ent_stride;
@@ -299,7 +328,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.estim = job.estim;
             f.result_type = job.result_type;
             f.ksinv = job.ksinv_double ? 1. / (double)job.k : (double)ksinv_f;
-            f.card = (const double *)c->card.ptr;
             f.n = c->n;
             f.ncols = L.ncols;
             f.stop = c->finalize_stop;

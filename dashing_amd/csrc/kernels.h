@@ -12,11 +12,28 @@ hipError_t launch_selfhist_card(hipStream_t st, const uint8_t *regs, uint64_t fi
                                 uint32_t *keys, uint8_t *tailhist);
 hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uint32_t *keys, uint64_t first, uint64_t n, int p,
                                  int estim, double *card);
-// position index of every 128-column block of the plane layout (perm == nullptr: identity): off[nblocks][nbuckets + 2]
-// (uint16), ent[nblocks][ent_stride]
-hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
-                                 const uint32_t *keys, const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks,
-                                 uint32_t nbuckets, uint32_t ent_stride, uint16_t *off, uint32_t *ent);
+// position index of every 128-column block of the plane layout (perm == nullptr: identity) and the per-column side
+// data of k_finalize in layout order (kernels_compare.hip, k_build_colindex)
+// entries held inside a bucket's record: 7 (32-byte records) where a bucket holds ~4 entries and a list at most 256
+inline int colindex_inline(int p, uint32_t E) { return p <= 12 && E <= 256 ? 7 : 3; }
+struct ColIndexLaunch {
+    const void *exc;          // per sketch (original index): listed positions, values, counts, keys, cardinalities, tail histograms
+    const uint8_t *excv;
+    const uint32_t *exc_n, *keys;
+    const double *card;
+    const uint8_t *tailhist;
+    const uint32_t *perm;
+    uint64_t ncols;
+    int p;
+    uint32_t nblocks, nbuckets, ent_stride, E;  // E = entries of a compact list row (emax + elow)
+    uint32_t *rec;            // [nblocks][nbuckets][colindex_inline(p, E) + 1]
+    uint32_t *ent;            // [nblocks][ent_stride]
+    uint32_t *nS, *keyS;      // [Npad]
+    double *cardS;            // [Npad]
+    uint8_t *thS;             // [Npad][64]
+    uint32_t *rl;             // [Npad][E]
+};
+hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
                             uint32_t P, uint32_t W, uint32_t Npad, uint32_t *planes,
                             const uint32_t *perm);
@@ -44,12 +61,14 @@ struct FinalizeLaunch {
     const uint32_t *perm;
     int hist_bins, pbase, p, estim, result_type;  // hist_bins: max over the launch's tiles of (largest - smallest value + 1)
     double ksinv;
-    const double *card;
-    const void *exc;
-    const uint32_t *exc_n, *keys;
-    const uint8_t *excv;
-    const uint8_t *tailhist;
-    const uint16_t *cidx_off;
+    // per column of the layout, in layout order (k_build_colindex): listed registers, key, cardinality, tail histogram,
+    // compact list (position << 8 | value, E entries per column); the position index of the column blocks
+    const uint32_t *nS, *keyS;
+    const double *cardS;
+    const uint8_t *thS;
+    const uint32_t *rl;
+    uint32_t E;
+    const uint32_t *cidx_rec;
     const uint32_t *cidx_ent;
     uint32_t nbuckets, ent_stride;
     uint64_t n, ncols;  // collection size (output dimension); real columns of the plane matrix

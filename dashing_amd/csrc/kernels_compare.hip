@@ -225,23 +225,36 @@ __global__ __launch_bounds__(64) void k_card_from_hist(const uint32_t *__restric
 
 // ------------------------------------------------------------------------------------------
 // Position index of one 128-column block of the plane matrix: every listed (position, value) of its sketches,
-// bucketed by (position, tail).  bucket = (pos >> sh) * 2 + (1 for the lower tail), at most 2^14 position groups;
-// off[b] .. off[b+1] (uint16: a block holds at most 128 x 510 entries) delimit bucket b in ent[]; an entry is
-// (pos & (2^sh - 1)) << 13 | column within the block << 6 | value.  k_finalize looks the row sketch's listed positions
-// up here: the two sketches of a pair list the same position |list_i| x |list_j| / 2^p times per tail -- a sparse join
-// instead of every pair walking a whole list.  One 1024-thread workgroup per column block; counting sort through LDS
-// counters (the order inside a bucket is whatever the atomics give: every consumer treats a bucket as a set).  A wave
-// takes 8 sketches; the (up to 510) entries of a sketch are loaded together, 8 per lane, before any is used.
-template <typename PT>
+// bucketed by (position, tail).  bucket = (pos >> sh) * 2 + (1 for the lower tail), at most 2^14 position groups.
+// k_finalize looks the row sketch's listed positions up here: the two sketches of a pair list the same position
+// |list_i| x |list_j| / 2^p times per tail -- a sparse join instead of every pair walking a whole list.
+//   rec[b]  one RECORD per bucket, RK + 1 words (16 bytes with RK = 3 for p >= 13, 32 bytes with RK = 7 below, where a
+//           bucket holds ~4 entries): word 0 = entries in the bucket | first slot in ent[] << 16, then its first RK
+//           entries (0xFFFFFFFF = none).  A look-up is ONE gather; only a bucket with more than RK entries (14 % at C3,
+//           5 % at p = 10) sends the reader on to ent[] (round 3 read two bounds and then the entries: three dependent
+//           levels, 6x read amplification -- VERDICT r3 item 1b).
+//   ent[]   all entries in bucket order (uint16 slots: a block holds at most 128 x 510 entries); an entry is
+//           (pos & (2^sh - 1)) << 13 | column within the block << 6 | value.
+// The kernel also leaves everything k_finalize needs per COLUMN in layout order, so that nothing there waits for the
+// permutation: n_s (listed registers), key_s, card_s, the 64-byte tail histogram th_s and the compact list rl_s[E]
+// (position << 8 | value).  One 1024-thread workgroup per column block; counting sort through LDS counters (the order
+// inside a bucket is whatever the atomics give: every consumer treats a bucket as a set).  A wave takes 8 sketches; the
+// (up to 510) entries of a sketch are loaded together, 8 per lane, before any is used.
+template <typename PT, int RK>
 __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ exc, const uint8_t *__restrict__ excv,
                                                           const uint32_t *__restrict__ exc_n,
-                                                          const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ keys, const double *__restrict__ card,
+                                                          const uint8_t *__restrict__ tailhist,
                                                           const uint32_t *__restrict__ perm, uint64_t ncols, int p,
-                                                          uint32_t nbuckets, uint32_t ent_stride,
-                                                          uint16_t *__restrict__ off, uint32_t *__restrict__ ent)
+                                                          uint32_t nbuckets, uint32_t ent_stride, uint32_t E,
+                                                          uint32_t *__restrict__ rec, uint32_t *__restrict__ ent,
+                                                          uint32_t *__restrict__ nS, uint32_t *__restrict__ keyS,
+                                                          double *__restrict__ cardS, uint8_t *__restrict__ thS,
+                                                          uint32_t *__restrict__ rl)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nbuckets] counters, then cursors
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nbuckets] counters, then first slot << 16 | cursor
     __shared__ uint32_t part[1024];
+    constexpr uint32_t RW = (uint32_t)RK + 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t sh = p > 14 ? (uint32_t)(p - 14) : 0u;
     const uint64_t c0 = (uint64_t)blockIdx.x * kTile;
@@ -264,6 +277,14 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
         Ts[q] = (keys[s] >> 12) & 63u;
         ps[q] = exc + s * kListCap;
         vs[q] = excv + s * kListCap;
+        // the column's side data in layout order (padding columns: zeros)
+        const uint64_t col = c0 + sl;
+        if (lane == 0) {
+            nS[col] = ne[q];
+            keyS[col] = ok ? keys[s] : 0u;
+            cardS[col] = ok ? card[s] : 0.;
+        }
+        if (lane < 16) reinterpret_cast<uint32_t *>(thS + col * 64)[lane] = ok ? reinterpret_cast<const uint32_t *>(tailhist + s * 64)[lane] : 0u;
     }
     uint32_t bk[kSk][kPer], pv[kSk][kPer];
 #pragma unroll
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
             const uint32_t val = e < ne[q] ? (uint32_t)vs[q][e] : 0u;
             bk[q][u] = e < ne[q] ? (((pos >> sh) << 1) | (val > Ts[q] ? 0u : 1u)) : 0xFFFFFFFFu;
             pv[q][u] = ((pos & ((1u << sh) - 1u)) << 13) | ((wave + 16u * (uint32_t)q) << 6) | val;
+            if (e < ne[q]) rl[(c0 + wave + 16u * (uint32_t)q) * E + e] = (pos << 8) | val;
         }
 #pragma unroll
     for (int q = 0; q < kSk; ++q)
@@ -298,21 +320,27 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < wave; ++w) wbase += part[w];
     uint32_t run = wbase + incl - sum;
-    uint16_t *myoff = off + (uint64_t)blockIdx.x * (nbuckets + 2);
+    uint32_t *myrec = rec + (uint64_t)blockIdx.x * nbuckets * RW;
     for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) {
         const uint32_t x = cnt[b];
-        myoff[b] = (uint16_t)run;
-        cnt[b] = run;  // becomes the bucket's cursor
+        uint4 *r4 = reinterpret_cast<uint4 *>(myrec + (uint64_t)b * RW);
+        r4[0] = make_uint4(x | (run << 16), 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if constexpr (RK > 3) r4[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        cnt[b] = (run << 16) | run;  // first slot | cursor (at most 128 x 510 < 2^16 entries: the cursor never carries)
         run += x;
     }
-    if (tid * per < nbuckets && (tid + 1) * per >= nbuckets) myoff[nbuckets] = (uint16_t)run;  // owner of the last bucket: end mark
-    __syncthreads();
+    __syncthreads();  // (also orders the record headers before the inline entries below: same workgroup, same L2 lines)
     uint32_t *myent = ent + (uint64_t)blockIdx.x * ent_stride;
 #pragma unroll
     for (int q = 0; q < kSk; ++q)
 #pragma unroll
         for (int u = 0; u < kPer; ++u)
-            if (bk[q][u] != 0xFFFFFFFFu) myent[atomicAdd(&cnt[bk[q][u]], 1u)] = pv[q][u];
+            if (bk[q][u] != 0xFFFFFFFFu) {
+                const uint32_t w = atomicAdd(&cnt[bk[q][u]], 1u);
+                const uint32_t slot = w & 0xFFFFu, rel = slot - (w >> 16);
+                myent[slot] = pv[q][u];
+                if (rel < (uint32_t)RK) myrec[(uint64_t)bk[q][u] * RW + 1u + rel] = pv[q][u];
+            }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -888,14 +916,15 @@ struct FinalizeArgs {
     int estim;
     int result_type;
     double ksinv;
-    const double *card;
-    const void *exc;          // [n][kListCap] listed POSITIONS as PT (uint16 for p <= 15, else uint32)
-    const uint8_t *excv;      // [n][kListCap]: the listed values, same order
-    const uint32_t *exc_n;    // [n] entries listed
-    const uint8_t *tailhist;  // [n][64]: per sketch, how many listed registers have each value above its T
-    const uint32_t *keys;     // [n]: hi << 18 | T << 12 | L << 6 | lo
-    const uint16_t *cidx_off; // position index of the column blocks: [blocks][nbuckets + 2]
-    const uint32_t *cidx_ent; // [blocks][ent_stride]
+    // per COLUMN of the layout, in layout order (k_build_colindex): nothing below waits for the permutation
+    const uint32_t *nS;       // [Npad] listed registers of the column's sketch
+    const uint32_t *keyS;     // [Npad] hi << 18 | T << 12 | L << 6 | lo
+    const double *cardS;      // [Npad]
+    const uint8_t *thS;       // [Npad][64]: how many listed registers have each value above the sketch's T
+    const uint32_t *rl;       // [Npad][E]: the listed registers, position << 8 | value
+    uint32_t E;
+    const uint32_t *cidx_rec; // position index of the column blocks: [blocks][nbuckets][RK + 1] records
+    const uint32_t *cidx_ent; // [blocks][ent_stride] all entries in bucket order (buckets with more than RK entries)
     uint32_t nbuckets, ent_stride;
     uint64_t n;      // sketches in the collection = dimension of the output matrix
     uint64_t ncols;  // real columns of the plane matrix (a sub-collection when only a row range is wanted)
@@ -932,14 +961,19 @@ struct FinalizeArgs {
 //     both low lists: the bins below Lp are exactly the positions both sketches list, at the larger of the two values
 //     (if Lp comes from the value minima instead, no register pair lies below it and the join finds nothing).
 // The shared positions are found through the column block's position index (k_build_colindex): lane e takes the row
-// sketch's e-th listed register and visits the bucket of its position -- |list_i| lookups per tile row instead of
-// 128 list walks -- and applies what it finds to the owning lane's histogram column with LDS atomics.  Exact and
-// order-independent.  C(Lp) = number of low joins, so c[Lp] = C(Lp+1) - C(Lp) and c[T] = m - |union above T| - C(T).
+// sketch's e-th listed register and reads the RECORD of its position's bucket (one gather: count + the first RK
+// entries) -- |list_i| lookups per tile row instead of 128 list walks -- and applies what it finds to the owning lane's
+// histogram column with LDS atomics.  Exact and order-independent.  C(Lp) = number of low joins, so c[Lp] = C(Lp+1) -
+// C(Lp) and c[T] = m - |union above T| - C(T).
+// Loads (round 4, profiles/r4b: the join and the prologue were 54 % of a wave's life at p = 10, all of it dependent
+// global loads): every input of a block is addressed by the TILE alone -- the per-column side arrays are in layout
+// order -- so the row list, C(v), tail histograms, keys and cardinalities are requested together at the top, the bucket
+// records as soon as the row list is there, and they travel while the histogram columns are built.
 // TIMED (option "finalize_timing", profiling only): s_memtime stamps between the phases of the FULL kernel, summed per
-// phase over all waves that finish (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per lane
-// and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
+// phase over the waves of every 61st block (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per
+// lane and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
 // accounting VERDICT r3 asked for instead of early-exit stops, whose occupancy and overlap differ from the real kernel.
-template <typename CT, bool TIMED>
+template <typename CT, int RK, bool TIMED>
 // 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_finalize(FinalizeArgs a)
 {
@@ -952,7 +986,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t *corr = histA + 64;                              // [128] per column: upper-tail positions shared with the row sketch
     uint32_t *actm = corr + 128;                              // [4] lanes whose column is live (bit per lane) + naLive
     CT *hs = reinterpret_cast<CT *>(hs_raw + (64 + 128 + 8) * 4);
-    using PT = CT;  // positions are stored as uint16 exactly when the counts are (p <= 15)
+    constexpr uint32_t RW = (uint32_t)RK + 1u;  // words of a bucket record
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     const int tid = threadIdx.x;
     // one block = one row of a 128 x 128 tile: everything derived from the tile is block-uniform and is
     // written so that the compiler sees it (scalar loads, SGPR compares, scalar branches)
@@ -979,22 +1014,62 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint64_t si = (uint64_t)tile.x * kTile + trow;
     const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
     if (si >= a.ncols) return;  // padding row (uniform)
-    const uint64_t i = a.perm ? a.perm[si] : si;
     // this tile's own plane range: dense C(v) for v in (Lp, T]
     const int Lp = a.pbase + (int)tile.z, T = a.pbase + (int)tile.w;
+    // ---- requests that only need the tile, oldest first.  (1) the row sketch's listed registers: lane e takes entry e
+    // (+128 per round); the bucket records below depend on them
+    constexpr int kR = RK > 3 ? 2 : (int)(kListCap / 128);  // (the wide records are only used with lists of <= 256 entries)
+    const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.nS[si]);
+    const int nr = (int)((ni + 127u) >> 7);  // rounds that hold an entry (uniform): 1 at p <= 11, up to 4 at p = 14
+    uint32_t le[kR];
+    {
+        const uint32_t *rli = a.rl + si * a.E;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            le[r] = kNone;
+            if (r >= nr) continue;
+            const uint32_t e = (uint32_t)tid + 128u * (uint32_t)r;
+            if (e < ni) le[r] = rli[e];
+        }
+    }
+    // (2) the sketch indices: only the output index and the row/column filters need them
+    const uint64_t i = a.perm ? a.perm[si] : si;
+    const bool col_ok = sj < a.ncols;
+    const uint64_t j = col_ok ? (a.perm ? a.perm[sj] : sj) : 0;
+    // (3) this lane's inputs: the C(v) of up to 16 planes, 48 bins of column j's tail histogram, the keys, the
+    // cardinalities -- one round trip for all of them
+    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
+    constexpr int kBatch = 16;
+    uint32_t cvv[kBatch];
+    const int w0 = (T + 1) >> 4;  // first 16-byte word of the tail histogram that holds a bin > T (uniform)
+    uint4 tq[3];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+        const uint32_t pl = tile.z + (uint32_t)t;
+        cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
+    }
+    {
+        const uint4 *tb = reinterpret_cast<const uint4 *>(a.thS + sj * 64);  // (padding columns hold zeros)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t keyj = a.keyS[sj];
+    const uint32_t keyi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.keyS[si]);
+    const uint32_t hrow = tid < 64 ? (uint32_t)a.thS[si * 64 + tid] : 0u;
+    const uint32_t sh = a.p > 14 ? (uint32_t)(a.p - 14) : 0u;
+    const uint32_t *brec = a.cidx_rec + (uint64_t)tile.y * a.nbuckets * RW;
+    const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
     // block-level skip (uniform) when the row sketch cannot be wanted
     if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
     corr[tid] = 0;
     if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = its live upper entries
-        const uint32_t h = tid > T ? a.tailhist[i * 64 + tid] : 0u;
+        const uint32_t h = tid > T ? hrow : 0u;
         histA[tid] = h;
         uint32_t tot = h;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
         if (tid == 0) actm[4] = tot;
     }
-    const bool col_ok = sj < a.ncols;
-    const uint64_t j = col_ok ? (a.perm ? a.perm[sj] : sj) : 0;
     uint64_t oi = i, oj = j;
     bool active;
     if (a.rect) {
@@ -1031,27 +1106,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     const uint32_t m = 1u << a.p;
     CT *col = hs + tid;
-    uint32_t prev = 0, nb = 0, keyj = 0, keyi = 0;
-    // All global loads of this lane's inputs are issued together, before anything waits on them: the
-    // C(v) of up to 16 planes, 48 bins of sketch j's tail histogram, the two keys (one round trip
-    // instead of one per plane / per bin -- with dependent loads this part was half of the kernel).
-    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
-    constexpr int kBatch = 16;
-    uint32_t cvv[kBatch];
-    const int w0 = (T + 1) >> 4;  // first 16-byte word of the tail histogram that holds a bin > T (uniform)
-    uint4 tq[3];
-    if (active) {
-#pragma unroll
-        for (int t = 0; t < kBatch; ++t) {
-            const uint32_t pl = tile.z + (uint32_t)t;
-            cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
-        }
-        const uint4 *tb = reinterpret_cast<const uint4 *>(a.tailhist + j * 64);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
-        keyj = a.keys[j];
-        keyi = a.keys[i];
-    }
+    uint32_t prev = 0, nb = 0;
     if constexpr (TIMED) tph[1] = __builtin_readcyclecounter();
     __syncthreads();  // histA, corr, actm are set
     if (active) {
@@ -1072,6 +1127,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             dcol[pl * 128] = (CT)(cv - prev);
             prev = cv;
         }
+    }
+    // (4) the bucket records of the row entries (the list arrived long ago): one gather each, in flight while the tail
+    // bins are written and the block meets at the barrier.  Issued here, not at the top, for the registers: the C(v)
+    // batch is dead by now (64 VGPRs = 8 waves per SIMD).
+    uint4 rc[kR], rc2[RK > 3 ? kR : 1];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        rc[r] = make_uint4(0u, kNone, kNone, kNone);
+        if constexpr (RK > 3) rc2[r] = make_uint4(kNone, kNone, kNone, kNone);
+        if (r >= nr) continue;
+        const int va = (int)(le[r] & 0xFFu);
+        const bool up = va > T;
+        if (le[r] == kNone || !(up || va < Lp)) continue;  // (T itself and the dense range are never joined)
+        const uint32_t bk = (((le[r] >> 8) >> sh) << 1) | (up ? 0u : 1u);
+        const uint4 *rp = reinterpret_cast<const uint4 *>(brec + (uint64_t)bk * RW);
+        rc[r] = rp[0];
+        if constexpr (RK > 3) rc2[r] = rp[1];
+    }
+    if (active) {
         // tail bins: histogram of i's listed values + histogram of j's listed values (both > T)
         const uint32_t qw[12] = {tq[0].x, tq[0].y, tq[0].z, tq[0].w, tq[1].x, tq[1].y, tq[1].z, tq[1].w,
                                  tq[2].x, tq[2].y, tq[2].z, tq[2].w};
@@ -1088,7 +1162,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             dst[s_ * 128] = (CT)(hA[s_] + qj);
         }
         for (int x = x0 + 48; x <= vhi; ++x) {  // more than 48 bins above T: only with a very small emax
-            const uint32_t qj = a.tailhist[j * 64 + x];
+            const uint32_t qj = a.thS[sj * 64 + x];
             nb += qj;
             col[(x - vlo) * 128] = (CT)(histA[x] + qj);
         }
@@ -1099,47 +1173,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (active) a.out[oidx] = (float)(nb + prev + keyj);
         return;
     }
-    // ---- the join: lane e takes the row sketch's e-th listed register
+    // ---- the join: what the records hold is applied to the owning lanes' histogram columns
     {
-        const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.exc_n[i]);
-        const int nr = (int)((ni + 127u) >> 7);  // rounds that hold an entry (uniform): 1 at p <= 11, up to 4 at p = 14
-        const PT *ap = reinterpret_cast<const PT *>(a.exc) + i * kListCap;
-        const uint8_t *av = a.excv + i * kListCap;
-        const uint32_t sh = a.p > 14 ? (uint32_t)(a.p - 14) : 0u;
-        const uint16_t *boff = a.cidx_off + (uint64_t)tile.y * (a.nbuckets + 2);
-        const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
         uint32_t *hw = reinterpret_cast<uint32_t *>(hs);
-        // The look-ups are three levels of dependent global loads (list entry -> bucket bounds -> bucket entries): the
-        // up to 4 entries a lane takes (|list| <= 510 over 128 lanes) go through each level TOGETHER, and the first two
-        // entries of every bucket (1.8 on average at C3) are fetched unconditionally -- three round trips per block
-        // instead of a dozen one after the other.
-        constexpr int kR = (int)(kListCap / 128);
-        constexpr uint32_t kNone = 0xFFFFFFFFu;
-        int va[kR];
-        uint32_t pos[kR], q0[kR], q1[kR], x0[kR], x1[kR];
-        bool up[kR];
-#pragma unroll
-        for (int r = 0; r < kR; ++r) {
-            if (r >= nr) break;
-            const uint32_t e = (uint32_t)tid + 128u * (uint32_t)r;
-            va[r] = e < ni ? (int)av[e] : T;  // (T itself is never listed: neither tail)
-            pos[r] = e < ni ? (uint32_t)ap[e] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < kR; ++r) {
-            if (r >= nr) break;
-            up[r] = va[r] > T;
-            const bool use = up[r] || va[r] < Lp;
-            const uint32_t bk = ((pos[r] >> sh) << 1) | (up[r] ? 0u : 1u);
-            q0[r] = use ? (uint32_t)boff[bk] : 0u;
-            q1[r] = use ? (uint32_t)boff[bk + 1] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < kR; ++r) {
-            if (r >= nr) break;
-            x0[r] = q0[r] < q1[r] ? bent[q0[r]] : kNone;
-            x1[r] = q0[r] + 1 < q1[r] ? bent[q0[r] + 1] : kNone;
-        }
         auto apply = [&](uint32_t x, int var, bool upr, uint32_t plow) {
             const uint32_t jl = (x >> 6) & 127u;
             const int vb = (int)(x & 63u);
@@ -1162,10 +1198,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             if (r >= nr) break;
-            const uint32_t plow = pos[r] & ((1u << sh) - 1u);
-            apply(x0[r], va[r], up[r], plow);
-            apply(x1[r], va[r], up[r], plow);
-            for (uint32_t q = q0[r] + 2; q < q1[r]; ++q) apply(bent[q], va[r], up[r], plow);
+            const int va = (int)(le[r] & 0xFFu);
+            const bool up = va > T;
+            const uint32_t plow = (le[r] >> 8) & ((1u << sh) - 1u);
+            apply(rc[r].y, va, up, plow);
+            apply(rc[r].z, va, up, plow);
+            apply(rc[r].w, va, up, plow);
+            if constexpr (RK > 3) {
+                apply(rc2[r].x, va, up, plow);
+                apply(rc2[r].y, va, up, plow);
+                apply(rc2[r].z, va, up, plow);
+                apply(rc2[r].w, va, up, plow);
+            }
+            const uint32_t cnt = rc[r].x & 0xFFFFu, q0 = rc[r].x >> 16;
+            for (uint32_t q = (uint32_t)RK; q < cnt; ++q) apply(bent[q0 + q], va, up, plow);  // a crowded bucket (rare)
         }
     }
     __syncthreads();
@@ -1191,6 +1237,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
     auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
+    const double cardj = a.cardS[sj], cardi = a.cardS[si];  // (requested here, used after the estimator)
     if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
     int mle_it = 0;
     const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
@@ -1199,10 +1246,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         a.out[oidx] = (float)us;
         return;
     }
-    const float res = result_cmp_from(a.card[j], a.card[i], us, a.result_type, a.ksinv);  // lhs = j, rhs = i
+    const float res = result_cmp_from(cardj, cardi, us, a.result_type, a.ksinv);  // lhs = j, rhs = i
     if (a.square || a.knn) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
         const bool asym = a.result_type == 4 || a.result_type == 5 || a.result_type == 6;
-        const float rev = asym ? result_cmp_from(a.card[i], a.card[j], us, a.result_type, a.ksinv) : res;
+        const float rev = asym ? result_cmp_from(cardi, cardj, us, a.result_type, a.ksinv) : res;
         if (a.square) {
             a.out[i * a.n + j] = res;
             a.out[j * a.n + i] = rev;
@@ -1565,25 +1612,23 @@ hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_build_colindex(hipStream_t st, const void *exc, const uint8_t *excv, const uint32_t *exc_n,
-                                 const uint32_t *keys, const uint32_t *perm, uint64_t ncols, int p, uint32_t nblocks,
-                                 uint32_t nbuckets, uint32_t ent_stride, uint16_t *off, uint32_t *ent)
+hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c)
 {
-    if (nblocks == 0) return hipSuccess;
-    const size_t lds = (size_t)nbuckets * sizeof(uint32_t);
-    if (p <= 15) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint16_t>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_build_colindex<uint16_t>, dim3(nblocks), dim3(1024), lds, st, (const uint16_t *)exc, excv,
-                           exc_n, keys, perm, ncols, p, nbuckets, ent_stride, off, ent);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<uint32_t>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_build_colindex<uint32_t>, dim3(nblocks), dim3(1024), lds, st, (const uint32_t *)exc, excv,
-                           exc_n, keys, perm, ncols, p, nbuckets, ent_stride, off, ent);
-    }
+    if (c.nblocks == 0) return hipSuccess;
+    const size_t lds = (size_t)c.nbuckets * sizeof(uint32_t);
+#define DSH_COLINDEX(PT, RK)                                                                                                  \
+    do {                                                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<PT, RK>),                          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        if (e != hipSuccess) return e;                                                                                        \
+        hipLaunchKernelGGL((k_build_colindex<PT, RK>), dim3(c.nblocks), dim3(1024), lds, st, (const PT *)c.exc, c.excv,       \
+                           c.exc_n, c.keys, c.card, c.tailhist, c.perm, c.ncols, c.p, c.nbuckets, c.ent_stride, c.E, c.rec,    \
+                           c.ent, c.nS, c.keyS, c.cardS, c.thS, c.rl);                                                         \
+    } while (0)
+    if (c.p > 15) DSH_COLINDEX(uint32_t, 3);
+    else if (colindex_inline(c.p, c.E) == 3) DSH_COLINDEX(uint16_t, 3);
+    else DSH_COLINDEX(uint16_t, 7);
+#undef DSH_COLINDEX
     return hipGetLastError();
 }
 
@@ -1693,8 +1738,8 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     FinalizeArgs a;
     a.cum = f.cum; a.nslots = f.cum_stride; a.tiles = f.tiles; a.perm = f.perm; a.hist_bins = f.hist_bins; a.pbase = f.pbase;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
-    a.card = f.card; a.exc = f.exc; a.excv = f.excv; a.exc_n = f.exc_n; a.keys = f.keys; a.tailhist = f.tailhist;
-    a.cidx_off = f.cidx_off; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;
+    a.nS = f.nS; a.keyS = f.keyS; a.cardS = f.cardS; a.thS = f.thS; a.rl = f.rl; a.E = f.E;
+    a.cidx_rec = f.cidx_rec; a.cidx_ent = f.cidx_ent; a.nbuckets = f.nbuckets; a.ent_stride = f.ent_stride;
     a.n = f.n; a.ncols = f.ncols; a.rect = f.rect; a.sorted_out = f.sorted_out; a.square = f.square;
     a.knn = f.knn; a.out2 = f.out2; a.knn_ld = f.knn_ld; a.knn_rows = f.knn_rows;
     a.row_begin = f.row_begin; a.row_end = f.row_end; a.col_begin = f.col_begin;
@@ -1705,11 +1750,17 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.ntiles = (uint32_t)(f.nslots / ((uint64_t)kTile * kTile));
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
-    if (f.phase_cyc) {  // profiling only
-        if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, true>), dim3(blocks), dim3(128), lds, st, a);
-        else hipLaunchKernelGGL((k_finalize<uint32_t, true>), dim3(blocks), dim3(128), lds, st, a);
-    } else if (f.cum_bytes == 2) hipLaunchKernelGGL((k_finalize<uint16_t, false>), dim3(blocks), dim3(128), lds, st, a);
-    else hipLaunchKernelGGL((k_finalize<uint32_t, false>), dim3(blocks), dim3(128), lds, st, a);
+    const bool timed = f.phase_cyc != nullptr;  // profiling only
+#define DSH_FIN(CT, RK)                                                                                            \
+    do {                                                                                                           \
+        if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true>), dim3(blocks), dim3(128), lds, st, a);            \
+        else hipLaunchKernelGGL((k_finalize<CT, RK, false>), dim3(blocks), dim3(128), lds, st, a);                 \
+    } while (0)
+    // (the record width follows the precision like k_build_colindex: colindex_inline)
+    if (f.cum_bytes != 2) DSH_FIN(uint32_t, 3);
+    else if (colindex_inline(f.p, f.E) == 3) DSH_FIN(uint16_t, 3);
+    else DSH_FIN(uint16_t, 7);
+#undef DSH_FIN
     return hipGetLastError();
 }
 
