@@ -127,6 +127,7 @@ def device_genomes(torch, dev, G, L, seed=0xDA5410):
         if i % 10 == 0:
             seq[i * L + L // 3: i * L + L // 3 + 50] = ord("N")
             seq[i * L + L // 2: i * L + L // 2 + 1000] |= 0x20
+    torch.cuda.synchronize(dev)  # torch's stream wrote the bases; the library reads them on its own stream
     return seq
 
 

@@ -39,6 +39,9 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
     const uint64_t need_from = (card_only || !want_sorted) ? 0 : want_rb;
     const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
     if (have_pass && (card_only || same_layout)) return DSH_OK;
+    // (a new per-sketch pass -- another estimator, other list caps -- also invalidates what the layout keeps of it per
+    // column: cardinalities, keys, lists in layout order and the position index are rebuilt with the layout)
+    const bool keep_layout = same_layout && have_pass;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
@@ -83,7 +86,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         }
         return DSH_OK;
     }
-    if (!same_layout) {
+    if (!keep_layout) {
         if (c->p > kMaxPCompare)
             return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPCompare, c->p);
         // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no

@@ -142,7 +142,7 @@ __device__ __forceinline__ double twice(double x)
 
 // lo_hint/hi_hint: a range known to contain every non-empty bin; `raw(v)` may be called only for
 // v in [lo_hint, hi_hint] and skips the bounds test that `c(v)` performs (the iteration's
-// count reads all fall in that range).  The next count is fetched one step ahead so the LDS
+// count reads all fall in that range).  `Raw` also gives the address of a bin: raw.at(v), bins Raw::stride elements apart.  The next count is fetched one step ahead so the LDS
 // read overlaps the dependent fp64 divide chain.
 template <class Hist, class Raw>
 __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int lo_hint, int hi_hint, int *iters = nullptr)
@@ -187,11 +187,16 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
         }
         double g = (double)cPrime * h;
         // the count of the NEXT step is read one step ahead, unconditionally: below kMinPrime that is one bin
-        // under the range (never used; `raw` must tolerate the read -- an LDS column / array slot below its start)
-        uint32_t cnext = kMaxPrime - 1 >= kMinPrime ? raw(kMaxPrime - 1) : 0u;
-        for (int k = kMaxPrime - 1; k >= kMinPrime; --k) {
+        // under the range (never used; `raw` must tolerate the read -- an LDS column / array slot below its start).
+        // The loop runs on the ADDRESS of the bin (raw.at(k), raw.stride elements apart): one integer add serves as
+        // counter and address -- 18 instead of 19 VALU instructions per step (profiles/r4c).
+        const auto *pk = raw.at(kMaxPrime - 1);
+        const auto *const pmin = raw.at(kMinPrime);
+        uint32_t cnext = pk >= pmin ? (uint32_t)*pk : 0u;
+        while (pk >= pmin) {
             const double ck = (double)cnext;
-            cnext = raw(k - 1);
+            pk -= Raw::stride;
+            cnext = (uint32_t)*pk;
             const double hPrime = 1. - h;
             h = div_inner(xPrime + h * hPrime, xPrime + hPrime);
             xPrime = twice(xPrime);

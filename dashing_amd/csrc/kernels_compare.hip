@@ -218,7 +218,13 @@ __global__ __launch_bounds__(64) void k_card_from_hist(const uint32_t *__restric
     const uint64_t s = first + (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     const uint32_t *h = hist + s * 64;
-    auto c = [h](int v) -> uint32_t { return h[v & 63]; };
+    struct Bins {  // bin v of the sketch's own histogram
+        const uint32_t *h;
+        enum { stride = 1 };
+        __device__ uint32_t operator()(int v) const { return h[v & 63]; }
+        __device__ const uint32_t *at(int v) const { return h + v; }  // (v - 1 >= 0 wherever the estimator reads ahead: kMinPrime >= 1)
+    };
+    const Bins c{h};
     const uint32_t key = keys[s];
     card[s] = estimate(c, c, p, estim, (int)(key & 63u), (int)((key >> 18) & 63u));
 }
@@ -1236,7 +1242,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     auto c = [col, vlo, vhi](int v) -> uint32_t {
         return (v < vlo || v > vhi) ? 0u : col[(v - vlo) * 128];
     };
-    auto raw = [col, vlo](int v) -> uint32_t { return col[(v - vlo) * 128]; };
+    struct RawCol {  // bin v of this lane's histogram column (no bounds test), and its address
+        const CT *col;
+        int vlo;
+        enum { stride = 128 };
+        __device__ uint32_t operator()(int v) const { return col[(v - vlo) * 128]; }
+        __device__ const CT *at(int v) const { return col + (v - vlo) * 128; }
+    };
+    const RawCol raw{col, vlo};
     const double cardj = a.cardS[sj], cardi = a.cardS[si];  // (requested here, used after the estimator)
     if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
     int mle_it = 0;

@@ -40,6 +40,7 @@ def main():
         b = g * gstride
         seq[b + L // 3 : b + L // 3 + 50] = ord("N")
         seq[b + L // 2 : b + L // 2 + 1000] |= 0x20
+    torch.cuda.synchronize()  # torch's stream wrote the bases; the library reads them on its own stream
     off = np.array([g * gstride for g in range(G)] + [0], np.uint64)
     off_end = off[:-1] + np.uint64(L)
     # genome g occupies [g*gstride, g*gstride+L): pass explicit per-genome spans by calling per run

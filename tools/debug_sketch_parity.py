@@ -24,6 +24,7 @@ for G, L in (((200, 5_000_000),) if os.environ.get("G200") else ((12, 1_000_000)
     print(json.dumps({"G": G, "L": L, "genomes_that_differ": bad[:20], "n_bad": len(bad)}), flush=True)
     # one genome at a time through the host-buffer entry point
     g = bad[0][0] if bad else 0
+    ctx.clear()
     one = ctx.sketch_batch(host[g * L:(g + 1) * L], np.array([0, L], np.uint64), 0, 31, True)
     print(json.dumps({"single_genome_call_equals_oracle": bool((one[0] == want[g]).all()), "genome": g}), flush=True)
     # the same genomes with the decorations removed
