@@ -77,6 +77,7 @@ struct dsh_ctx {
     bool planes_valid = false;
     int card_estim = -1;
     uint64_t card_from = 0;             // the per-sketch pass (cardinalities, lists, keys) covers the sketches [card_from, n)
+    uint64_t pass_gen = 0, lay_gen = 0; // per-sketch passes so far; the one the layout's per-column data was built from
     DevBuf card, planes, cum, tiles, items, outbuf, seqbuf, workbuf, exc, excv, exc_n, keys, perm, tailhist;
     // copy-out pipeline of dsh_dist_rows_async: results alternate between two device buffers; the copy of call b to the
     // host runs on its own stream while the kernels of call b+1 fill the other buffer

@@ -33,15 +33,15 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
     }
     c->emax = emax_new;
     c->elow = elow_new;
-    const bool same_layout = c->planes_valid && c->lay.sorted == want_sorted &&
+    // (the layout keeps cardinalities, keys and lists per column: it is only "the same" while it was built from the
+    // per-sketch pass that is current -- another estimator or other list caps start a new pass)
+    const bool same_layout = c->planes_valid && c->lay_gen == c->pass_gen && c->lay.sorted == want_sorted &&
                              (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.parts == parts));
     // sketches the per-sketch pass has to cover: a row range of the triangle never looks at the sketches before it
     const uint64_t need_from = (card_only || !want_sorted) ? 0 : want_rb;
     const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
     if (have_pass && (card_only || same_layout)) return DSH_OK;
-    // (a new per-sketch pass -- another estimator, other list caps -- also invalidates what the layout keeps of it per
-    // column: cardinalities, keys, lists in layout order and the position index are rebuilt with the layout)
-    const bool keep_layout = same_layout && have_pass;
+    const bool keep_layout = same_layout && have_pass;  // (a new pass below also outdates the layout's per-column data)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = next_event(c);
@@ -75,6 +75,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         c->card_estim = estim;
         c->card_from = need_from;
         c->hk32_valid = false;
+        ++c->pass_gen;
     }
     if (card_only) {  // a cardinality query never builds planes (and leaves stale ones marked so)
         if (e0 && e1) {
@@ -190,6 +191,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
                                        want_sorted ? (const uint32_t *)c->perm.ptr : nullptr));
         }
         c->aux_join_pending = true;  // only k_finalize reads the index: the tile kernel starts without waiting for it
+        c->lay_gen = c->pass_gen;
         c->planes_valid = true;
     }
     if (e0 && e1) {

@@ -1013,12 +1013,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     uint4 tile = a.tiles[tidx];
     const int vlo = (int)((tile.z >> 16) & 0xFFu), vhi = (int)(tile.z >> 24);
-    // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column
-    const uint64_t slot = ((uint64_t)tile.w * 128 + trow) * 128 + (uint32_t)tid;
+    // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column.  (32-bit: a
+    // band holds at most 2^16 tiles, plan.cpp.)
+    const uint32_t slot = (tile.w * 128u + trow) * 128u + (uint32_t)tid;
     tile.w = (tile.z >> 8) & 0xFFu;
     tile.z &= 0xFFu;
-    const uint64_t si = (uint64_t)tile.x * kTile + trow;
-    const uint64_t sj = (uint64_t)tile.y * kTile + (uint32_t)tid;
+    // (sketch indices and layout positions are 32-bit -- the permutation is -- only the output index is wider)
+    const uint32_t si = tile.x * kTile + trow;
+    const uint32_t sj = tile.y * kTile + (uint32_t)tid;
     if (si >= a.ncols) return;  // padding row (uniform)
     // this tile's own plane range: dense C(v) for v in (Lp, T]
     const int Lp = a.pbase + (int)tile.z, T = a.pbase + (int)tile.w;
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int nr = (int)((ni + 127u) >> 7);  // rounds that hold an entry (uniform): 1 at p <= 11, up to 4 at p = 14
     uint32_t le[kR];
     {
-        const uint32_t *rli = a.rl + si * a.E;
+        const uint32_t *rli = a.rl + (uint64_t)si * a.E;
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             le[r] = kNone;
@@ -1039,12 +1041,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     // (2) the sketch indices: only the output index and the row/column filters need them
-    const uint64_t i = a.perm ? a.perm[si] : si;
+    const uint32_t i = a.perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.perm[si]) : si;
     const bool col_ok = sj < a.ncols;
-    const uint64_t j = col_ok ? (a.perm ? a.perm[sj] : sj) : 0;
-    // (3) this lane's inputs: the C(v) of up to 16 planes, 48 bins of column j's tail histogram, the keys, the
-    // cardinalities -- one round trip for all of them
-    const CT *cum = reinterpret_cast<const CT *>(a.cum) + slot;
+    const uint32_t j = col_ok ? (a.perm ? a.perm[sj] : sj) : 0u;
+    // (3) this lane's inputs: the C(v) of up to 16 planes, 48 bins of column j's tail histogram, the keys -- one round
+    // trip for all of them.  (Uniform base + 32-bit lane offset: the plane stride is added on the scalar side.)
+    const CT *cum0 = reinterpret_cast<const CT *>(a.cum);
     constexpr int kBatch = 16;
     uint32_t cvv[kBatch];
     const int w0 = (T + 1) >> 4;  // first 16-byte word of the tail histogram that holds a bin > T (uniform)
@@ -1052,60 +1054,61 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int t = 0; t < kBatch; ++t) {
         const uint32_t pl = tile.z + (uint32_t)t;
-        cvv[t] = pl < tile.w ? (uint32_t)cum[(uint64_t)pl * a.nslots] : 0u;
+        cvv[t] = pl < tile.w ? (uint32_t)(cum0 + (uint64_t)pl * a.nslots)[slot] : 0u;
     }
     {
-        const uint4 *tb = reinterpret_cast<const uint4 *>(a.thS + sj * 64);  // (padding columns hold zeros)
+        const uint4 *tb = reinterpret_cast<const uint4 *>(a.thS) + (sj << 2);  // (padding columns hold zeros)
 #pragma unroll
         for (int k = 0; k < 3; ++k) tq[k] = w0 + k < 4 ? tb[w0 + k] : make_uint4(0, 0, 0, 0);
     }
     const uint32_t keyj = a.keyS[sj];
     const uint32_t keyi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.keyS[si]);
-    const uint32_t hrow = tid < 64 ? (uint32_t)a.thS[si * 64 + tid] : 0u;
+    const uint32_t hrow = tid < 64 ? (uint32_t)(a.thS + (uint64_t)si * 64)[tid] : 0u;
     const uint32_t sh = a.p > 14 ? (uint32_t)(a.p - 14) : 0u;
     const uint32_t *brec = a.cidx_rec + (uint64_t)tile.y * a.nbuckets * RW;
     const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
     // block-level skip (uniform) when the row sketch cannot be wanted
-    if (a.rect && !(i >= a.row_begin && i < a.row_end)) return;
+    const uint32_t rb32 = (uint32_t)a.row_begin, re32 = (uint32_t)a.row_end;  // (<= n < 2^32)
+    if (a.rect && !(i >= rb32 && i < re32)) return;
     corr[tid] = 0;
-    if (tid < 64) {  // the row sketch's tail histogram above this tile's threshold; its sum = its live upper entries
-        const uint32_t h = tid > T ? hrow : 0u;
-        histA[tid] = h;
-        uint32_t tot = h;
+    if (tid < 64) histA[tid] = tid > T ? hrow : 0u;  // the row sketch's tail histogram above this tile's threshold
+    {
+        // its sum = the row sketch's listed registers above T: counted from the list itself, a ballot per round (the
+        // shuffle reduction over the 64 bins cost wave 0 ~30 instructions); the block's two waves leave their shares in
+        // actm[4] and actm[5]
+        uint32_t nup = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
-        if (tid == 0) actm[4] = tot;
+        for (int r = 0; r < kR; ++r) {
+            if (r >= nr) break;
+            nup += (uint32_t)__popcll(__ballot(le[r] != kNone && (int)(le[r] & 0xFFu) > T));
+        }
+        if ((tid & 63) == 0) actm[4 + (tid >> 6)] = nup;
     }
-    uint64_t oi = i, oj = j;
+    uint32_t oi = i, oj = j;
     bool active;
     if (a.rect) {
-        active = j >= a.col_begin && j < a.col_end;
+        active = j >= (uint32_t)a.col_begin && j < (uint32_t)a.col_end;
     } else if (a.square) {
         active = si < sj;
     } else if (a.sorted_out || a.knn) {
         oi = si;
         oj = sj;
-        active = si < sj && si >= a.row_begin && si < a.row_end;
+        active = si < sj && si >= rb32 && si < re32;
     } else {
-        if (oi > oj) {
-            const uint64_t t = oi;
-            oi = oj;
-            oj = t;
-        }
-        active = si < sj && oi >= a.row_begin && oi < a.row_end;
+        oi = i < j ? i : j;
+        oj = i < j ? j : i;
+        active = si < sj && oi >= rb32 && oi < re32;
     }
     active = active && col_ok;
-    {
-        const unsigned long long bal = __ballot(active);
-        if ((tid & 63) == 0) {
-            actm[(tid >> 6) * 2] = (uint32_t)bal;
-            actm[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32);
-        }
+    const unsigned long long bal = __ballot(active);
+    if ((tid & 63) == 0) {
+        actm[(tid >> 6) * 2] = (uint32_t)bal;
+        actm[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32);
     }
     uint64_t oidx = 0;
-    if (active) oidx = a.rect  ? (i - a.row_begin) * (a.col_end - a.col_begin) + (j - a.col_begin)
-                       : a.knn ? (si - a.row_begin) * a.knn_ld + sj
-                               : oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
+    if (active) oidx = a.rect  ? (uint64_t)(i - rb32) * (a.col_end - a.col_begin) + (j - (uint32_t)a.col_begin)
+                       : a.knn ? (uint64_t)(si - rb32) * a.knn_ld + sj
+                               : (uint64_t)oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     if (a.stop == 1) {
         if (active) a.out[oidx] = (float)T;
         return;
@@ -1129,7 +1132,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
         }
         for (uint32_t pl = tile.z + kBatch; pl < tile.w; ++pl) {  // wide plane ranges (heterogeneous tiles)
-            const uint32_t cv = cum[(uint64_t)pl * a.nslots];
+            const uint32_t cv = (cum0 + (uint64_t)pl * a.nslots)[slot];
             dcol[pl * 128] = (CT)(cv - prev);
             prev = cv;
         }
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             dst[s_ * 128] = (CT)(hA[s_] + qj);
         }
         for (int x = x0 + 48; x <= vhi; ++x) {  // more than 48 bins above T: only with a very small emax
-            const uint32_t qj = a.thS[sj * 64 + x];
+            const uint32_t qj = a.thS[(uint64_t)sj * 64 + x];
             nb += qj;
             col[(x - vlo) * 128] = (CT)(histA[x] + qj);
         }
@@ -1182,12 +1185,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // ---- the join: what the records hold is applied to the owning lanes' histogram columns
     {
         uint32_t *hw = reinterpret_cast<uint32_t *>(hs);
+        // every lane of the block owns a pair (any tile off the diagonal of a full range): no per-entry ownership test
+        const bool all_own = (actm[0] & actm[1] & actm[2] & actm[3]) == 0xFFFFFFFFu;
         auto apply = [&](uint32_t x, int var, bool upr, uint32_t plow) {
             const uint32_t jl = (x >> 6) & 127u;
             const int vb = (int)(x & 63u);
-            // same position, a live value on the column's side too, and a lane that owns a pair (diagonal tile, row
-            // range, padding)
-            if (x == kNone || (x >> 13) != plow || !(upr ? vb > T : vb < Lp) || !((actm[jl >> 5] >> (jl & 31u)) & 1u)) return;
+            // same position (groups of positions share a bucket only for p > 14), a live value on the column's side too,
+            // and a lane that owns a pair (diagonal tile, row range, padding)
+            if (x == kNone || (sh && (x >> 13) != plow) || !(upr ? vb > T : vb < Lp)) return;
+            if (!all_own && !((actm[jl >> 5] >> (jl & 31u)) & 1u)) return;
             // upper tail: the position was counted in both tail histograms, take the smaller value out again;
             // lower tail: both registers are below the dense range, max(a_t, b_t) is the larger one
             const int bin = upr ? (var < vb ? var : vb) : (var > vb ? var : vb);
@@ -1223,7 +1229,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     if constexpr (TIMED) tph[3] = __builtin_readcyclecounter();
     if (!active) return;
-    const uint32_t ucnt = actm[4] + nb - corr[tid];  // |list_i above T| + |list_j above T| - shared positions
+    const uint32_t ucnt = actm[4] + actm[5] + nb - corr[tid];  // |list_i above T| + |list_j above T| - shared positions
     uint32_t clow = 0;                                // C(Lp) = the lower-tail joins = the bins below the dense range
     for (int x = vlo; x < Lp; ++x) clow += col[(x - vlo) * 128];
     if (tile.w > tile.z) col[(Lp - vlo) * 128] -= (CT)clow;  // c[Lp] = C(Lp+1) - C(Lp)
@@ -1264,11 +1270,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const bool asym = a.result_type == 4 || a.result_type == 5 || a.result_type == 6;
         const float rev = asym ? result_cmp_from(cardi, cardj, us, a.result_type, a.ksinv) : res;
         if (a.square) {
-            a.out[i * a.n + j] = res;
-            a.out[j * a.n + i] = rev;
+            a.out[(uint64_t)i * a.n + j] = res;
+            a.out[(uint64_t)j * a.n + i] = rev;
         } else {
             a.out[oidx] = res;
-            a.out2[sj * a.knn_rows + (si - a.row_begin)] = rev;
+            a.out2[(uint64_t)sj * a.knn_rows + (si - rb32)] = rev;
         }
         return;
     }

@@ -276,7 +276,8 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     if (T.empty()) return false;
     // bands bounded by the cum scratch budget
     pp.per_tile_bytes = (uint64_t)kTile * kTile * tu.cum_bytes * std::max<uint32_t>(L.P, 1);
-    const uint64_t max_tiles = std::max<uint64_t>(1, tu.cum_budget / pp.per_tile_bytes);
+    // (at most 2^16 tiles per band: k_finalize addresses a pair slot of the band with 32 bits)
+    const uint64_t max_tiles = std::min<uint64_t>(65536, std::max<uint64_t>(1, tu.cum_budget / pp.per_tile_bytes));
     // Parts (dsh_dist_rows_parts_device_async): k_finalize runs once per SEGMENT -- the tiles of one part inside one
     // band -- and an event marks the end of a part's last segment: the part's span of the matrix is final and can travel
     // while the other parts are computed.  The tile kernel runs once per band; a band is also cut at a part boundary

@@ -63,37 +63,33 @@ def main():
     rc = subprocess.call(argv, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if "k_finalize" in r["Kernel_Name"]]
+        rows += list(csv.DictReader(open(f)))
     shutil.rmtree(d, ignore_errors=True)
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    # group the dispatches of one pass (bands): consecutive k_finalize dispatches between two k_selfhist_card are one pass --
-    # here simply: per workload the passes come in RUNS order and every pass has the same number of dispatches
-    per_disp = {}
+    # every compare pass starts with ONE k_selfhist_card dispatch: split the dispatch stream there; the passes come in
+    # the order workloads x RUNS; a pass may hold several k_finalize dispatches (bands): summed
+    passes, cur, seen = [], None, set()
     for r in rows:
-        per_disp.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
-    disp = [per_disp[k] for k in sorted(per_disp)]
-    res = []
+        if "k_selfhist_card" in r["Kernel_Name"] and r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            cur = {}
+            passes.append(cur)
+        if cur is not None and "k_finalize" in r["Kernel_Name"]:
+            cur[r["Counter_Name"]] = cur.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            cur["_n"] = cur.get("_n", 0) + (1 if r["Counter_Name"] == "SQ_WAVES" else 0)
     with open(args.out, "a") as fo:
-        if rc != 0 or not disp:
-            fo.write(json.dumps({"error": "rocprofv3 rc %d, %d k_finalize dispatches" % (rc, len(disp))}) + "\n")
-            print("rocprofv3 rc", rc, len(disp))
+        if rc != 0 or len(passes) != len(wls) * len(RUNS):
+            fo.write(json.dumps({"error": "rocprofv3 rc %d, %d passes (expected %d)" % (rc, len(passes), len(wls) * len(RUNS))}) + "\n")
+            print("rocprofv3 rc", rc, len(passes))
             return
-        per_wl = len(disp) // len(wls)
         for wi, wl in enumerate(wls):
-            chunk = disp[wi * per_wl:(wi + 1) * per_wl]
-            per_run = max(1, len(chunk) // len(RUNS))
             for ri, (estim, stop) in enumerate(RUNS):
-                acc = {}
-                for dd in chunk[ri * per_run:(ri + 1) * per_run]:
-                    for k, v in dd.items():
-                        acc[k] = acc.get(k, 0.0) + v
+                acc = passes[wi * len(RUNS) + ri]
                 w = acc.get("SQ_WAVES", 0.0) or 1.0
-                row = {"workload": wl, "estim": estim, "finalize_stop": stop, "dispatches": per_run, "waves": acc.get("SQ_WAVES"),
-                       "per_wave": {k.replace("SQ_INSTS_", "").lower(): round(v / w, 1) for k, v in acc.items() if k != "SQ_WAVES"}}
-                res.append(row)
+                row = {"workload": wl, "estim": estim, "finalize_stop": stop, "dispatches": acc.get("_n"), "waves": acc.get("SQ_WAVES"),
+                       "per_wave": {k.replace("SQ_INSTS_", "").lower(): round(v / w, 1) for k, v in acc.items() if k not in ("SQ_WAVES", "_n")}}
                 fo.write(json.dumps(row) + "\n")
                 print(json.dumps(row), flush=True)
-
 
 if __name__ == "__main__":
     main()
