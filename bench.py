@@ -11,8 +11,9 @@ N>1 (strong scaling, the matrix is fixed): rank r computes the rows [b_r, b_{r+1
 contiguous span of the final packed matrix) and the only exchange is point-to-point: every rank
 sends its span straight into its place on rank 0 (RCCL over xGMI) -- no collective inside the
 compare, no un-permute.  The exchange runs through the library's own C-ABI (dsh_comm_init + the pipelined
-dsh_dist_rows_parts_device_async / dsh_collect_parts_async: part q of a rank's rows travels on the copy stream
-while the later parts are still being finalized); `python bench.py --gpus N` launches its N ranks itself.
+dsh_exchange_rows_device_async / dsh_exchange_collect_async: part q of a rank's rows travels on the copy stream
+while the later parts are still being finalized; short ranges keep their rows key-ordered as one run and rank 0 puts
+the rows of a received part into place); `python bench.py --gpus N` launches its N ranks itself.
 Outputs beyond 2 GB (configs[3]-sized: DSH_BENCH_N=100000 DSH_BENCH_P=10) are NOT gathered by default: every rank keeps
 its span (what `dashing-amd dist --ngpus -b` writes per device); the gathered variant is reported beside it.
 
@@ -469,7 +470,7 @@ def run(args, backend, world, rank, line, dist_on):
     use_cabi = exchange.startswith("c-abi")
     NPARTS = int(os.environ.get("DSH_BENCH_PARTS", "8"))
     if use_cabi:
-        exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_dist_rows_parts_device_async + dsh_collect_parts_async)" % NPARTS
+        exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_exchange_rows_device_async + dsh_exchange_collect_async)" % NPARTS
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
     my_pairs = sizes[rank] if multi else total_pairs
@@ -492,11 +493,12 @@ def run(args, backend, world, rank, line, dist_on):
         t0 = time.perf_counter()
         ctx.attach_device(regs_d.data_ptr(), n, p)
         if use_cabi and do_gather:
-            # pipelined: the rank's rows in NPARTS parts; part q travels to rank 0 (copy stream, grouped ncclSend/ncclRecv
-            # behind the part's event) while the later parts are still being finalized on the ctx stream
-            ctx.dist_rows_parts_device_async(local.data_ptr(), bounds[rank], bounds[rank + 1], NPARTS, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            # pipelined: the rank's rows in <= NPARTS parts (short ranges: row-sorted parts, placed row by row on rank 0);
+            # part q travels to rank 0 (copy stream, grouped ncclSend/ncclRecv behind the part's event) while the later
+            # parts are still being finalized on the ctx stream
+            ctx.exchange_rows_device_async(local.data_ptr(), bounds, rank, NPARTS, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             computed = ctx.event_record()  # (a ticket orders nothing between the streams: the transfers are not held back)
-            ctx.collect_parts_async(n, bounds, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
+            ctx.exchange_collect_async(n, bounds, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
             ctx.event_wait(computed)
             t1 = time.perf_counter()
             ctx.comm_wait()  # (with a deadline: a missing peer is an error, not a hang)

@@ -25,7 +25,8 @@ SYMBOLS = [
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
-    "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
+    "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_exchange_mode", "dsh_exchange_rows_device_async",
+    "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
@@ -111,6 +112,10 @@ def load_library():
     lib.dsh_comm_available.argtypes = []
     lib.dsh_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i32)]
     lib.dsh_comm_wait.argtypes = [vp]
+    lib.dsh_exchange_mode.argtypes = [u64, vp, i32, i32, C.c_uint32, i32, C.POINTER(i32), C.POINTER(C.c_uint32)]
+    lib.dsh_exchange_rows_device_async.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_uint32, i32, vp]
+    lib.dsh_exchange_collect_async.argtypes = [vp, u64, vp, C.c_uint32, vp, vp, i32]
+    lib.dsh_exchange_place_device.argtypes = [vp, vp, i32, i32, C.c_uint32, i32, vp, vp]
     lib.dsh_finalize_phase_cycles.argtypes = [vp, vp]
     lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.dsh_comm_destroy.argtypes = [vp]
@@ -178,6 +183,16 @@ def comm_library():
     v = C.c_int(0)
     load_library().dsh_comm_library(buf, len(buf), C.byref(v))
     return buf.value.decode(errors="replace"), int(v.value)
+
+
+def exchange_mode(n, bounds, rank, nparts, dst=0):
+    """(rowsorted, parts) of rank `rank`'s buffer under dsh_exchange_* (dsh_exchange_mode)"""
+    b = np.ascontiguousarray(bounds, np.uint64)
+    rs, k = C.c_int(), C.c_uint32()
+    rc = load_library().dsh_exchange_mode(n, b.ctypes.data, len(b) - 1, rank, nparts, dst, C.byref(rs), C.byref(k))
+    if rc:
+        raise DshError(rc, "dsh_exchange_mode")
+    return bool(rs.value), int(k.value)
 
 
 def range_parts(n, rb, re, nparts):
@@ -418,6 +433,18 @@ class Context:
         out = np.zeros(16, np.uint64)
         self._ck(self._lib.dsh_finalize_phase_cycles(self._h, out.ctypes.data))
         return [int(x) for x in out]
+
+    def exchange_rows_device_async(self, out_ptr, bounds, rank, nparts, dst=0, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        self._ck(self._lib.dsh_exchange_rows_device_async(self._h, estim, result_type, k, b.ctypes.data, len(b) - 1, rank, nparts, dst, C.c_void_p(out_ptr)))
+
+    def exchange_collect_async(self, n, bounds, nparts, local_ptr, final_ptr, dst=0):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        self._ck(self._lib.dsh_exchange_collect_async(self._h, n, b.ctypes.data, nparts, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
+
+    def exchange_place_device(self, bounds, src, nparts, src_local_ptr, final_ptr, dst=0):
+        b = np.ascontiguousarray(bounds, np.uint64)
+        self._ck(self._lib.dsh_exchange_place_device(self._h, b.ctypes.data, len(b) - 1, src, nparts, dst, C.c_void_p(src_local_ptr), C.c_void_p(final_ptr)))
 
     def comm_wait(self):
         """dsh_wait with a deadline on the RCCL traffic (DSH_COMM_TIMEOUT_S): an error instead of a hang"""

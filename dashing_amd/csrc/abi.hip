@@ -43,7 +43,7 @@ static void release_ctx(dsh_ctx *c)
         if (s) (void)hipStreamSynchronize(s);
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
-                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->perm, &c->items, &c->cum, &c->tiles,
+                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->perm, &c->items, &c->cum, &c->tiles,
                       &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc})
         b->release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
@@ -51,8 +51,10 @@ static void release_ctx(dsh_ctx *c)
     c->pin_lists.release();
     c->pin_work.release();
     c->pin_keys.release();
+    c->pin_rowoff.release();
+    c->pin_xch.release();
     for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join}) {
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
     }

@@ -96,6 +96,12 @@ struct dsh_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
+    // dsh_exchange_*: on the destination, the row-sorted spans as they arrive and the sources' key order + row offsets
+    DevBuf xch_stage, xch_tab;
+    PinBuf pin_xch;
+    hipEvent_t ev_xch_tab = nullptr;
+    bool xch_tab_in_flight = false;
+    bool pass_from_zero = false;        // the next per-sketch pass covers every sketch (the destination of an exchange)
     DevBuf hist;                        // [n][64] per-sketch register histograms (k_selfhist_card -> k_card_from_hist)
     hipEvent_t ev_keys = nullptr;       // the keys have reached the host
     DevBuf cidx_rec, cidx_ent;          // position index of the column blocks of the current layout (k_build_colindex)
@@ -115,6 +121,8 @@ struct dsh_ctx {
     double host_layout_us = 0, host_lists_us = 0, host_keys_wait_us = 0;  // host time of the last call (dsh_get_info)
     uint32_t *pin_perm = nullptr;       // page-locked copy of lay.perm: its upload is then truly asynchronous
     size_t pin_perm_cap = 0;
+    DevBuf rowoff;                      // (row-sorted parts) offset of the row at layout position s in the rank's buffer
+    PinBuf pin_rowoff;
     PinBuf pin_work;                    // sketch work list of the call in flight
     hipEvent_t ev_work = nullptr;
     bool work_in_flight = false;
@@ -229,6 +237,7 @@ struct PairJob {
     int sorted_rows = 0;  // rows (and the output) are in sorted plane-column order (shards)
     int square = 0;       // full triangle, each value written at (i,j) and (j,i) of an n x n matrix
     uint32_t nparts = 0;  // > 0: triangle rows in (at most) this many parts of a key-ordered layout, an event per part
+    int rowsorted = 0;    // with nparts: row-sorted parts -- d_out holds the rows in key order (plan.h), not the final span
     int knn = 0;          // band of the key-ordered triangle for the nearest-neighbour selection: d_out = V, d_out2 = Vt
     float *d_out2 = nullptr;
     uint64_t knn_ld = 0, knn_rows = 0;
@@ -241,7 +250,7 @@ struct PairJob {
 // cardinalities + thresholds/lists + planes + position index for the current sketch matrix.  want_sorted < 0: whatever
 // is cached.  card_only: the per-sketch pass alone.
 int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint64_t want_rb = 0,
-            uint64_t want_re = ~0ull, uint32_t nparts = 1);
+            uint64_t want_re = ~0ull, uint32_t nparts = 1, int rowsorted = 0);
 int run_pairs(dsh_ctx *c, const PairJob &job);
 
 // exchange.hip: waits for both streams of the communicator's traffic and destroys it (no-op without one)

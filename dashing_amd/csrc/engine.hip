@@ -10,7 +10,8 @@
 
 namespace dsh {
 
-int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t want_rb, uint64_t want_re, uint32_t nparts)
+int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t want_rb, uint64_t want_re, uint32_t nparts,
+            int rowsorted)
 {
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
@@ -18,13 +19,16 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         want_sorted = c->lay.sorted;
         want_rb = c->lay.rb;
         want_re = c->lay.re;
+        rowsorted = 0;
     }
+    if (!want_sorted) rowsorted = 0;
     if (want_re > c->n) want_re = c->n;
     if (!want_sorted) want_rb = 0, want_re = c->n;
     if (want_rb > want_re) want_rb = want_re;
     const uint64_t n = c->n;
-    std::vector<uint64_t> parts;
-    if (want_sorted) plan::range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
+    std::vector<uint64_t> parts, rs_pos;
+    if (want_sorted && !rowsorted) plan::range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
+    if (rowsorted) plan::rowsorted_part_positions(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), rs_pos);
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, true);
     const int elow_new = c->elow_opt >= 0 ? std::min<int>(c->elow_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, false);
     if (emax_new != c->emax || elow_new != c->elow) {  // thresholds and lists (hence planes) depend on them
@@ -36,9 +40,10 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
     // (the layout keeps cardinalities, keys and lists per column: it is only "the same" while it was built from the
     // per-sketch pass that is current -- another estimator or other list caps start a new pass)
     const bool same_layout = c->planes_valid && c->lay_gen == c->pass_gen && c->lay.sorted == want_sorted &&
-                             (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.parts == parts));
+                             (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.rowsorted == rowsorted &&
+                                               (rowsorted ? c->lay.part_pos == rs_pos : c->lay.parts == parts)));
     // sketches the per-sketch pass has to cover: a row range of the triangle never looks at the sketches before it
-    const uint64_t need_from = (card_only || !want_sorted) ? 0 : want_rb;
+    const uint64_t need_from = (card_only || !want_sorted || c->pass_from_zero) ? 0 : want_rb;
     const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
     if (have_pass && (card_only || same_layout)) return DSH_OK;
     const bool keep_layout = same_layout && have_pass;  // (a new pass below also outdates the layout's per-column data)
@@ -106,7 +111,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
                             (unsigned long long)i, 64 - c->p + 1, c->p);
         c->planes_valid = false;  // (the cached layout is overwritten from here on)
         plan::Layout &L = c->lay;
-        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L);
+        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0);
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
@@ -129,6 +134,13 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
                 }
                 std::memcpy(c->pin_perm, L.perm.data(), nperm * sizeof(uint32_t));
                 HIPCHK(c, launch_upload(c->stream, c->perm.ptr, c->pin_perm, nperm * sizeof(uint32_t)));
+                if (L.rowsorted) {  // where the rows of the rank's buffer start
+                    const size_t rb_ = L.rowoff.size() * sizeof(uint64_t);
+                    HIPCHK(c, c->pin_rowoff.ensure(rb_));
+                    HIPCHK(c, c->rowoff.ensure(rb_));
+                    std::memcpy(c->pin_rowoff.ptr, L.rowoff.data(), rb_);
+                    HIPCHK(c, launch_upload(c->stream, c->rowoff.ptr, c->pin_rowoff.ptr, rb_));
+                }
                 if (!c->ev_perm) HIPCHK(c, hipEventCreateWithFlags(&c->ev_perm, hipEventDisableTiming));
                 HIPCHK(c, hipEventRecord(c->ev_perm, c->stream));
                 c->perm_in_flight = true;
@@ -225,7 +237,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         lre = jre;
     }
     c->parts_done = 0;
-    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, with_parts ? job.nparts : 1);
+    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, with_parts ? job.nparts : 1, with_parts && job.rowsorted);
     if (rc) return rc;
     if (job.result_type < 0 || job.result_type > 8)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
@@ -324,6 +336,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.nslots = (uint64_t)(sg.e - sg.b) * kTile * kTile;
             f.tiles = (const uint4 *)c->tiles.ptr + T.size() + sg.b;
             f.perm = L.sorted ? (const uint32_t *)c->perm.ptr : nullptr;
+            f.rowoff = L.rowsorted ? (const uint64_t *)c->rowoff.ptr : nullptr;
             f.pbase = L.pbase;
             f.cidx_rec = (const uint32_t *)c->cidx_rec.ptr;
             f.cidx_ent = (const uint32_t *)c->cidx_ent.ptr;

@@ -89,9 +89,9 @@ __device__ inline double estimate_improved(const Hist &c, int p)
 // the normal range: reciprocal estimate, two Newton steps, quotient, one residual correction -- the same fma
 // sequence hipcc emits for `/` minus its v_div_scale/v_div_fixup special-case handling (3 of 11 instructions).
 // Correctly rounded under that precondition, so results stay identical to a CPU `/`.  Used ONLY where the
-// precondition holds by construction: the two constant divisors of the series start (x'^2 / 3, x'^2 / 472.5) and,
-// through div_guarded, the once-per-iteration divisions; the step of the inner recurrence (both operands in [x', 2),
-// x' = x 2^-s >= 2^-130) uses div_inner below.
+// precondition holds by construction: through div_guarded, the once-per-iteration divisions; the step of the inner
+// recurrence (both operands in [x', 2), x' = x 2^-s >= 2^-130) and the two constant divisors of the series start
+// (x'^2 / 3, x'^2 / 472.5; x'^2 >= 2^-260) use div_inner below.
 __device__ __forceinline__ double div_normal(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
@@ -157,7 +157,10 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     const int kMinPrime = kMin > 1 ? kMin : 1;
     const int kMaxPrime = kMax < q ? kMax : q;
     double z = 0.;
-    for (int k = kMaxPrime; k >= kMinPrime; --k) z = 0.5 * z + (double)raw(k);
+    {  // (address-driven like the recurrence below: the bin address is the loop counter)
+        const auto *const pz0 = raw.at(kMinPrime);
+        for (const auto *pz = raw.at(kMaxPrime); pz >= pz0; pz -= Raw::stride) z = 0.5 * z + (double)(uint32_t)*pz;
+    }
     z = ldexp(z, -kMinPrime);
     uint32_t cPrime = cq1;
     if (q >= 1) cPrime += c(kMaxPrime);
@@ -168,9 +171,11 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
     double x = gprev <= 1.5 * a ? div_guarded(mPrime, 0.5 * gprev + a) : (mPrime / gprev) * log1p(gprev / a);
     gprev = 0.;
     double deltaX = x;
-    // sqrt(2^p) without the sqrt sequence: 2^(p/2), times the correctly rounded sqrt(2) for odd p (a power-of-two
-    // scaling keeps it the correctly rounded root, i.e. what sqrt() returns)
-    const double relerr = 1e-2 / ldexp((p & 1) ? 0x1.6a09e667f3bcdp+0 : 1.0, p >> 1);
+    // 1e-2 / sqrt(2^p): sqrt(2^p) = 2^(p/2), times the correctly rounded sqrt(2) for odd p (what sqrt() returns: a
+    // power-of-two scaling keeps a correctly rounded root correctly rounded); the quotient likewise is the correctly
+    // rounded 1e-2 / 1 or 1e-2 / sqrt(2) scaled by a power of two -- one v_ldexp_f64 instead of a division per pair
+    constexpr double kRelEven = 1e-2, kRelOdd = 1e-2 / 0x1.6a09e667f3bcdp+0;
+    const double relerr = ldexp((p & 1) ? kRelOdd : kRelEven, -(p >> 1));
     if (iters) *iters = (kMaxPrime - kMinPrime + 1) << 8;  // live bins of the inner recurrence, iterations below
     while (deltaX > x * relerr) {
         if (iters) ++*iters;  // (profiling instances only)
@@ -179,7 +184,7 @@ __device__ inline double estimate_mle(const Hist &c, const Raw &raw, int p, int 
         const int sh = kMaxPrime + 1 > kappaMinus1 + 2 ? kMaxPrime + 1 : kappaMinus1 + 2;
         double xPrime = ldexp(x, -sh);
         const double xPrime2 = xPrime * xPrime;
-        double h = xPrime - div_normal(xPrime2, 3.) + (xPrime2 * xPrime2) * (1. / 45. - div_normal(xPrime2, 472.5));
+        double h = xPrime - div_inner(xPrime2, 3.) + (xPrime2 * xPrime2) * (1. / 45. - div_inner(xPrime2, 472.5));
         for (int k = kappaMinus1; k >= kMaxPrime; --k) {
             const double hPrime = 1. - h;
             h = (xPrime + h * hPrime) / (xPrime + hPrime);

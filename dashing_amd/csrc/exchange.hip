@@ -372,6 +372,253 @@ int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint
     return DSH_OK;
 }
 
+}  // extern "C"
+
+/* ---- the exchange-aware pair: every rank's buffer laid out for the exchange (plan.h: row-sorted parts) ---------------- */
+namespace {
+
+// what rank r does under dsh_exchange_*: the destination keeps its rows in place as ONE part; a short range goes in
+// row-sorted parts (key-ordered as one run, homogeneous tiles); a long one in parts of consecutive rows
+struct XMode {
+    bool rowsorted = false;
+    std::vector<uint64_t> cut;  // rowsorted: positions of the key order; else row boundaries (range_parts)
+    size_t nparts() const { return cut.empty() ? 0 : cut.size() - 1; }
+};
+
+XMode xmode(uint64_t n, const uint64_t *bounds, int r, uint32_t nparts, int dst)
+{
+    XMode m;
+    const uint64_t rb = bounds[r], re = bounds[r + 1];
+    if (rb >= re) return m;
+    if (r == dst) {
+        m.cut = {rb, re};
+    } else if (plan::rowsorted_rule(n, rb, re, nparts)) {
+        m.rowsorted = true;
+        plan::rowsorted_part_positions(n, rb, re, nparts, m.cut);
+    } else {
+        plan::range_parts(n, rb, re, nparts, m.cut);
+    }
+    return m;
+}
+
+// the key order and the row offsets of rank r's row-sorted buffer, from THIS context's host copy of the keys (every rank
+// holds every sketch, the per-sketch pass is deterministic: the destination derives what the source used)
+int rowsorted_tables(dsh_ctx *c, uint64_t n, uint64_t rb, uint64_t re, std::vector<uint32_t> &order, std::vector<uint64_t> &rowoff,
+                     std::vector<uint32_t> &scratch)
+{
+    if (!c->hk32_valid || c->card_from > rb)
+        return fail(c, DSH_ESTATE, "the per-sketch pass of this context does not cover the rows from %llu on (compute this rank's rows first)",
+                    (unsigned long long)rb);
+    order.resize(re - rb);
+    plan::sort_rows_by_key(c->hk32, rb, re, order.data(), scratch);
+    plan::rowsorted_offsets(n, order.data(), re - rb, rowoff);
+    return DSH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsh_exchange_mode(uint64_t n, const uint64_t *bounds, int world, int rank, uint32_t nparts, int dst, int *rowsorted,
+                      uint32_t *nparts_out)
+{
+    if (!bounds || world < 1 || rank < 0 || rank >= world || nparts == 0) return DSH_EINVAL;
+    const XMode m = xmode(n, bounds, rank, nparts, dst);
+    if (rowsorted) *rowsorted = m.rowsorted ? 1 : 0;
+    if (nparts_out) *nparts_out = (uint32_t)m.nparts();
+    return DSH_OK;
+}
+
+int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *bounds, int world, int rank,
+                                   uint32_t nparts, int dst, void *d_local)
+{
+    if (!c || !bounds || nparts == 0 || world < 1 || rank < 0 || rank >= world) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    if ((rc = validate_bounds(c, c->n, bounds, world, dst))) return rc;
+    reset_prof(c);
+    c->parts_done = 0;
+    const uint64_t rb = bounds[rank], re = bounds[rank + 1];
+    if (rb >= re || c->n < 2) return DSH_OK;
+    if (!d_local) return DSH_EINVAL;
+    const XMode m = xmode(c->n, bounds, rank, nparts, dst);
+    // the destination places the row-sorted spans of the others: its per-sketch pass must cover their rows too
+    c->pass_from_zero = false;
+    if (rank == dst)
+        for (int r = 0; r < rank; ++r) c->pass_from_zero = c->pass_from_zero || xmode(c->n, bounds, r, nparts, dst).rowsorted;
+    PairJob j;
+    j.estim = estim;
+    j.result_type = result_type;
+    j.k = k;
+    j.rect = 0;
+    j.nparts = rank == dst ? 1 : nparts;
+    j.rowsorted = m.rowsorted ? 1 : 0;
+    j.row_begin = rb;
+    j.row_end = re;
+    j.col_begin = j.col_end = 0;
+    j.base_index = dsh_tri_span(c->n, 0, rb);
+    j.d_out = (float *)d_local;
+    rc = run_pairs(c, j);
+    c->pass_from_zero = false;
+    return rc;
+}
+
+// rank `src`'s parts, as they lie in its buffer: offset and length of part q (floats), and where a part of consecutive
+// rows lands in the final matrix
+static void part_span(uint64_t n, const XMode &m, const std::vector<uint64_t> &rowoff, uint64_t rb, size_t q, uint64_t &off, uint64_t &cnt,
+                      uint64_t &final_off)
+{
+    if (m.rowsorted) {
+        off = rowoff[m.cut[q]];
+        cnt = rowoff[m.cut[q + 1]] - off;
+        final_off = 0;
+    } else {
+        off = dsh_tri_span(n, rb, m.cut[q]);
+        cnt = dsh_tri_span(n, m.cut[q], m.cut[q + 1]);
+        final_off = dsh_tri_span(n, 0, m.cut[q]);
+    }
+}
+
+int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local, void *d_final,
+                               int dst)
+{
+    if (!c || !bounds || nparts == 0) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+    if (!c->comm && !(bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;
+    if (rank == dst && !d_final) return DSH_EINVAL;
+    std::vector<XMode> modes((size_t)world);
+    size_t maxparts = 0;
+    for (int r = 0; r < world; ++r) {
+        modes[r] = xmode(n, bounds, r, nparts, dst);
+        maxparts = std::max(maxparts, modes[r].nparts());
+    }
+    const XMode &mine = modes[rank];
+    if (c->parts_done != mine.nparts())
+        return fail(c, DSH_ESTATE, "dsh_exchange_rows_device_async of this rank's rows must come first (%u parts computed, %zu expected)",
+                    c->parts_done, mine.nparts());
+    Rccl *rc_ = world > 1 ? rccl() : nullptr;
+    // row-sorted sources: their key order and row offsets.  A source knows its own (the layout); the destination derives
+    // them from its keys, stages what it receives and puts the rows into place behind every round.
+    std::vector<std::vector<uint64_t>> rowoff((size_t)world);
+    std::vector<std::vector<uint32_t>> order((size_t)world);
+    std::vector<uint64_t> stage_off((size_t)world, 0), tab_off((size_t)world, 0);
+    uint64_t stage_total = 0, tab_bytes = 0;
+    if (rank != dst) {
+        if (mine.rowsorted) rowoff[rank] = c->lay.rowoff;
+    } else {
+        for (int r = 0; r < world; ++r) {
+            if (r == dst || !modes[r].rowsorted) continue;
+            if ((rc = rowsorted_tables(c, n, bounds[r], bounds[r + 1], order[r], rowoff[r], c->lay.sort_a))) return rc;
+            stage_off[r] = stage_total;
+            stage_total += rowoff[r].back();
+            tab_off[r] = tab_bytes;
+            tab_bytes += (rowoff[r].size() * sizeof(uint64_t) + order[r].size() * sizeof(uint32_t) + 15) & ~(uint64_t)15;
+        }
+        if (stage_total) {
+            HIPCHK(c, c->xch_stage.ensure(stage_total * sizeof(float)));
+            if (c->xch_tab_in_flight) {  // the previous call's upload from the pinned tables
+                HIPCHK(c, hipEventSynchronize(c->ev_xch_tab));
+                c->xch_tab_in_flight = false;
+            }
+            HIPCHK(c, c->pin_xch.ensure(tab_bytes));
+            HIPCHK(c, c->xch_tab.ensure(tab_bytes));
+            for (int r = 0; r < world; ++r) {
+                if (r == dst || !modes[r].rowsorted) continue;
+                uint8_t *h = (uint8_t *)c->pin_xch.ptr + tab_off[r];
+                std::memcpy(h, rowoff[r].data(), rowoff[r].size() * sizeof(uint64_t));
+                std::memcpy(h + rowoff[r].size() * sizeof(uint64_t), order[r].data(), order[r].size() * sizeof(uint32_t));
+            }
+            HIPCHK(c, hipMemcpyAsync(c->xch_tab.ptr, c->pin_xch.ptr, tab_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            if (!c->ev_xch_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xch_tab, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_xch_tab, c->copy_stream));
+            c->xch_tab_in_flight = true;
+        }
+    }
+    for (size_t q = 0; q < maxparts; ++q) {
+        // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
+        // there while the ctx stream computes part q+1
+        if (q < mine.nparts()) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+        if (rank == dst && q < mine.nparts() && d_local) {  // (the destination's own rows: one part, normally in place)
+            float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[rank]);
+            const uint64_t cnt = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
+            if (cnt && (const float *)d_local != own)
+                HIPCHK(c, hipMemcpyAsync(own, d_local, cnt * sizeof(float), hipMemcpyDeviceToDevice, c->copy_stream));
+        }
+        if (world == 1) continue;
+        NCCLCHK(c, rc_->GroupStart());
+        ncclResult_t e = ncclSuccess;
+        if (rank == dst) {
+            for (int src = 0; src < world && e == ncclSuccess; ++src) {
+                if (src == dst || q >= modes[src].nparts()) continue;
+                uint64_t off, cnt, foff;
+                part_span(n, modes[src], rowoff[src], bounds[src], q, off, cnt, foff);
+                float *to = modes[src].rowsorted ? (float *)c->xch_stage.ptr + stage_off[src] + off : (float *)d_final + foff;
+                if (cnt) e = rc_->Recv(to, cnt, ncclFloat32, src, c->comm, c->copy_stream);
+            }
+        } else if (q < mine.nparts()) {
+            uint64_t off, cnt, foff;
+            part_span(n, mine, rowoff[rank], bounds[rank], q, off, cnt, foff);
+            if (cnt) {
+                if (!d_local) e = ncclInvalidArgument;
+                else e = rc_->Send((const float *)d_local + off, cnt, ncclFloat32, dst, c->comm, c->copy_stream);
+            }
+        }
+        if (e != ncclSuccess) {
+            (void)rc_->GroupEnd();
+            return fail(c, DSH_EIO, "ncclSend/ncclRecv: %s", rc_->GetErrorString(e));
+        }
+        NCCLCHK(c, rc_->GroupEnd());
+        if (rank == dst)  // the rows of the row-sorted parts that just arrived go to their places
+            for (int src = 0; src < world; ++src) {
+                if (src == dst || !modes[src].rowsorted || q >= modes[src].nparts()) continue;
+                const uint8_t *t = (const uint8_t *)c->xch_tab.ptr + tab_off[src];
+                HIPCHK(c, launch_row_place(c->copy_stream, (const float *)c->xch_stage.ptr + stage_off[src], (float *)d_final,
+                                           (const uint32_t *)(t + rowoff[src].size() * sizeof(uint64_t)), (const uint64_t *)t,
+                                           modes[src].cut[q], modes[src].cut[q + 1], n));
+            }
+    }
+    return DSH_OK;
+}
+
+int dsh_exchange_place_device(dsh_ctx *c, const uint64_t *bounds, int world, int src, uint32_t nparts, int dst, const void *d_src_local,
+                              void *d_final)
+{
+    if (!c || !bounds || nparts == 0 || world < 1 || src < 0 || src >= world || !d_final) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
+    const uint64_t n = c->n;
+    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;
+    const XMode m = xmode(n, bounds, src, nparts, dst);
+    const uint64_t span = dsh_tri_span(n, bounds[src], bounds[src + 1]);
+    if (!span) return DSH_OK;
+    if (!d_src_local) return DSH_EINVAL;
+    if (!m.rowsorted) {  // final order already: the span goes to its place
+        float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[src]);
+        if ((const float *)d_src_local != own)
+            HIPCHK(c, hipMemcpyAsync(own, d_src_local, span * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return DSH_OK;
+    }
+    std::vector<uint32_t> order;
+    std::vector<uint64_t> rowoff;
+    if ((rc = rowsorted_tables(c, n, bounds[src], bounds[src + 1], order, rowoff, c->lay.sort_a))) return rc;
+    const size_t ro_bytes = rowoff.size() * sizeof(uint64_t), bytes = ro_bytes + order.size() * sizeof(uint32_t);
+    HIPCHK(c, c->xch_tab.ensure(bytes));
+    HIPCHK(c, hipMemcpyAsync(c->xch_tab.ptr, rowoff.data(), ro_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->xch_tab.ptr + ro_bytes, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    for (size_t q = 0; q + 1 < m.cut.size(); ++q)
+        HIPCHK(c, launch_row_place(c->stream, (const float *)d_src_local, (float *)d_final,
+                                   (const uint32_t *)((const uint8_t *)c->xch_tab.ptr + ro_bytes), (const uint64_t *)c->xch_tab.ptr,
+                                   m.cut[q], m.cut[q + 1], n));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the pageable tables must outlive their copies)
+    return DSH_OK;
+}
+
 int dsh_allgather_device(dsh_ctx *c, const void *d_send, uint64_t bytes_per_rank, void *d_recv)
 {
     if (!c || (bytes_per_rank && (!d_send || !d_recv))) return DSH_EINVAL;

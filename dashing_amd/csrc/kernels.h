@@ -59,6 +59,7 @@ struct FinalizeLaunch {
     uint64_t nslots;      // pair slots to finalize (a band, or a segment of it: cum/tiles point at its first tile)
     const uint4 *tiles;
     const uint32_t *perm;
+    const uint64_t *rowoff = nullptr;  // row-sorted parts: out index = rowoff[layout position of the pair's row] + column offset
     int hist_bins, pbase, p, estim, result_type;  // hist_bins: max over the launch's tiles of (largest - smallest value + 1)
     double ksinv;
     // per column of the layout, in layout order (k_build_colindex): listed registers, key, cardinality, tail histogram,
@@ -83,6 +84,9 @@ struct FinalizeLaunch {
     float *out;
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
+// rows [pos0, pos1) of a row-sorted buffer (order[s] = original row, rowoff[s] = its offset) into the packed triangle
+hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,
+                            uint64_t pos0, uint64_t pos1, uint64_t n);
 hipError_t launch_unpermute_staged(hipStream_t st, const float *in, const uint32_t *inv,
                                    const int64_t *rowdelta, uint64_t n, float *out);
 // inv != nullptr: destination-driven variant (coalesced writes, gathered reads); else scatter via perm

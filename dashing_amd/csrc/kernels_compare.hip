@@ -916,6 +916,9 @@ struct FinalizeArgs {
     uint64_t nslots;       // distance between two planes of cum (pair slots of the band)
     const uint4 *tiles;    // {row block, col block, plane begin, plane end} per tile
     const uint32_t *perm;  // plane-matrix column -> sketch index (nullptr: identity)
+    // row-sorted parts (plan.h): the output buffer holds the wanted rows in KEY order, the row at layout position s
+    // starting at rowoff[s]; nullptr: the rows' span of the packed triangle in final order
+    const uint64_t *rowoff;
     int hist_bins;  // histogram columns allocated per lane (>= the value span of any tile of the launch)
     int pbase;  // plane pl is the threshold v = pbase + 1 + pl
     int p;
@@ -1108,6 +1111,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint64_t oidx = 0;
     if (active) oidx = a.rect  ? (uint64_t)(i - rb32) * (a.col_end - a.col_begin) + (j - (uint32_t)a.col_begin)
                        : a.knn ? (uint64_t)(si - rb32) * a.knn_ld + sj
+                       : a.rowoff ? a.rowoff[i < j ? si : sj] + (oj - oi - 1)  // (the pair's row is the smaller sketch index)
                                : (uint64_t)oi * (2 * a.n - oi - 1) / 2 + oj - (oi + 1) - a.base_index;
     if (a.stop == 1) {
         if (active) a.out[oidx] = (float)T;
@@ -1210,6 +1214,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             if (r >= nr) break;
+            if (__ballot(rc[r].y != kNone) == 0) continue;  // no lane of this wave found anything (a short list: wave 1)
             const int va = (int)(le[r] & 0xFFu);
             const bool up = va > T;
             const uint32_t plow = (le[r] >> 8) & ((1u << sh) - 1u);
@@ -1314,6 +1319,28 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             atomicAdd(&a.phase_cyc[13], (unsigned long long)(mx_it * mx_bins));
         }
     }
+}
+
+// row-sorted parts (plan.h): the rows at the positions [pos0, pos1) of a source rank's key order, lying at rowoff[s] of its
+// buffer, go to their places in dashing's packed triangle (row r starts at r (2n - r - 1) / 2 and holds n - 1 - r values).
+// One block per row; a row is contiguous on both sides.
+__global__ __launch_bounds__(256) void k_row_place(const float *__restrict__ src, float *__restrict__ out,
+                                                    const uint32_t *__restrict__ order, const uint64_t *__restrict__ rowoff,
+                                                    uint64_t pos0, uint64_t n)
+{
+    const uint64_t s = pos0 + blockIdx.x;
+    const uint64_t r = order[s], len = n - 1 - r;
+    const float *from = src + rowoff[s];
+    float *to = out + r * (2 * n - r - 1) / 2;
+    for (uint64_t x = threadIdx.x; x < len; x += 256) to[x] = from[x];
+}
+
+hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,
+                            uint64_t pos0, uint64_t pos1, uint64_t n)
+{
+    if (pos1 <= pos0) return hipSuccess;
+    hipLaunchKernelGGL(k_row_place, dim3((uint32_t)(pos1 - pos0)), dim3(256), 0, st, src, out, order, rowoff, pos0, n);
+    return hipGetLastError();
 }
 
 // sorted packed triangle -> packed triangle in original sketch order (one block per sorted row)
@@ -1755,6 +1782,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
 {
     if (f.nslots == 0) return hipSuccess;
     FinalizeArgs a;
+    a.rowoff = f.rowoff;
     a.cum = f.cum; a.nslots = f.cum_stride; a.tiles = f.tiles; a.perm = f.perm; a.hist_bins = f.hist_bins; a.pbase = f.pbase;
     a.p = f.p; a.estim = f.estim; a.result_type = f.result_type; a.ksinv = f.ksinv;
     a.nS = f.nS; a.keyS = f.keyS; a.cardS = f.cardS; a.thS = f.thS; a.rl = f.rl; a.E = f.E;

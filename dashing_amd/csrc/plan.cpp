@@ -107,6 +107,67 @@ int auto_list_cap(int p, bool upper)
     return (int)std::min<uint64_t>(upper ? kMaxListSide : 200, m >> 5);
 }
 
+bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts)
+{
+    if (re > n) re = n;
+    if (nparts < 2 || rb >= re) return false;
+    return re - rb < (uint64_t)1024 * nparts && tri_span(n, rb, re) * sizeof(float) <= ((uint64_t)1 << 30);
+}
+
+void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos)
+{
+    pos.assign(1, 0);
+    if (re > n) re = n;
+    if (rb >= re) return;
+    const uint64_t R = re - rb, TR = (R + kTile - 1) / kTile, NTc = (n - rb + kTile - 1) / kTile;
+    // tile row t of the layout holds NTc - t tiles; cut after the tile row that reaches q / nparts of them
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < TR; ++t) total += NTc - t;
+    uint64_t acc = 0, t = 0;
+    for (uint32_t q = 1; q < nparts && t < TR; ++q) {
+        const uint64_t t0 = t;
+        while (t < TR && (acc * nparts < total * q || t == t0)) acc += NTc - t++;
+        if (t >= TR) break;
+        pos.push_back(t * kTile);
+    }
+    pos.push_back(R);
+}
+
+void sort_rows_by_key(const uint32_t *k32, uint64_t lo, uint64_t hi, uint32_t *dst, std::vector<uint32_t> &a)
+{
+    // stable LSD radix sort, two 9-bit digits of the 18-bit key (T, L, max value) (a single 2^18-bucket counting sort
+    // spends ~0.1 ms clearing and scanning its counters); the host sits between the per-sketch pass and the transform,
+    // so this is on the critical path of every layout
+    auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each: high threshold, low threshold, max value
+        const uint32_t key = k32[i];
+        return ((uint32_t)key_T(key) << 12) | ((uint32_t)key_L(key) << 6) | (uint32_t)key_hi(key);
+    };
+    const uint64_t cnt_ = hi - lo;
+    if (a.size() < 2 * cnt_) a.resize(2 * cnt_);  // [indices after the first digit | sort keys]
+    uint32_t *const ks = a.data() + cnt_;
+    for (uint64_t i = 0; i < cnt_; ++i) ks[i] = skey(lo + i);
+    uint32_t cnt[513];
+    std::memset(cnt, 0, sizeof cnt);
+    for (uint64_t i = 0; i < cnt_; ++i) cnt[(ks[i] & 511u) + 1u]++;
+    for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+    for (uint64_t i = 0; i < cnt_; ++i) a[cnt[ks[i] & 511u]++] = (uint32_t)i;
+    std::memset(cnt, 0, sizeof cnt);
+    for (uint64_t i = 0; i < cnt_; ++i) cnt[((ks[a[i]] >> 9) & 511u) + 1u]++;
+    for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
+    for (uint64_t i = 0; i < cnt_; ++i) dst[cnt[(ks[a[i]] >> 9) & 511u]++] = (uint32_t)(lo + a[i]);
+}
+
+void rowsorted_offsets(uint64_t n, const uint32_t *order, uint64_t cnt, std::vector<uint64_t> &rowoff)
+{
+    rowoff.resize(cnt + 1);
+    uint64_t acc = 0;
+    for (uint64_t s = 0; s < cnt; ++s) {
+        rowoff[s] = acc;
+        acc += n - 1 - order[s];
+    }
+    rowoff[cnt] = acc;
+}
+
 void tile_planes(const Layout &L, uint32_t ti, uint32_t tj, int &pb, int &pe)
 {
     const int lo_t = std::max<int>(std::max<int>(L.blk_lo[ti], L.blk_lo[tj]), std::min<int>(L.blk_L[ti], L.blk_L[tj]));
@@ -116,7 +177,7 @@ void tile_planes(const Layout &L, uint32_t ti, uint32_t tj, int &pb, int &pe)
 }
 
 void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
-                  const std::vector<uint64_t> &parts, Layout &L)
+                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts)
 {
     if (re > n) re = n;
     if (!want_sorted) rb = 0, re = n;
@@ -136,7 +197,9 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     L.sorted = want_sorted;
     L.rb = rb;
     L.re = re;
-    L.parts = want_sorted ? parts : std::vector<uint64_t>();
+    L.rowsorted = want_sorted && rowsorted_nparts > 0;
+    if (L.rowsorted) L.parts = {rb, re};  // ONE key-ordered run
+    else L.parts = want_sorted ? parts : std::vector<uint64_t>();
     L.n = n;
     L.vlo = vr[0];
     L.vhi = vr[1];
@@ -149,32 +212,18 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     // With a row range the wanted rows [rb,re) come first (their tile rows are the only ones computed),
     // then the later rows; each part is key-ordered on its own.
     L.perm.resize(ncols);
+    L.part_pos.clear();
+    L.rowoff.clear();
     if (want_sorted) {
-        auto skey = [&](uint64_t i) -> uint32_t {  // 6 bits each: high threshold, low threshold, max value
-            const uint32_t key = k32[i];
-            return ((uint32_t)key_T(key) << 12) | ((uint32_t)key_L(key) << 6) | (uint32_t)key_hi(key);
-        };
-        // stable LSD radix sort, two 9-bit digits (a single 2^18-bucket counting sort spends ~0.1 ms clearing
-        // and scanning its counters); the host sits between the per-sketch pass and the transform, so this is
-        // on the critical path of every layout: scratch is kept with the layout
-        std::vector<uint32_t> &a = L.sort_a, &keys = L.sort_keys;
-        keys.resize(n);
-        for (uint64_t i = col0; i < n; ++i) keys[i] = skey(i);
-        auto sort_part = [&](uint64_t lo, uint64_t hi, uint32_t *dst) {
-            const uint64_t cnt_ = hi - lo;
-            if (a.size() < cnt_) a.resize(cnt_);
-            uint32_t cnt[513];
-            std::memset(cnt, 0, sizeof cnt);
-            for (uint64_t i = 0; i < cnt_; ++i) cnt[(keys[lo + i] & 511u) + 1u]++;
-            for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
-            for (uint64_t i = 0; i < cnt_; ++i) a[cnt[keys[lo + i] & 511u]++] = (uint32_t)(lo + i);
-            std::memset(cnt, 0, sizeof cnt);
-            for (uint64_t i = 0; i < cnt_; ++i) cnt[((keys[a[i]] >> 9) & 511u) + 1u]++;
-            for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
-            for (uint64_t i = 0; i < cnt_; ++i) dst[cnt[(keys[a[i]] >> 9) & 511u]++] = a[i];
-        };
-        for (size_t q = 0; q + 1 < L.parts.size(); ++q) sort_part(L.parts[q], L.parts[q + 1], L.perm.data() + (L.parts[q] - rb));
-        sort_part(re, n, L.perm.data() + (re - rb));
+        for (size_t q = 0; q + 1 < L.parts.size(); ++q)
+            sort_rows_by_key(k32, L.parts[q], L.parts[q + 1], L.perm.data() + (L.parts[q] - rb), L.sort_a);
+        sort_rows_by_key(k32, re, n, L.perm.data() + (re - rb), L.sort_a);
+        if (L.rowsorted) {
+            rowsorted_part_positions(n, rb, re, rowsorted_nparts, L.part_pos);
+            rowsorted_offsets(n, L.perm.data(), re - rb, L.rowoff);
+        } else {
+            for (uint64_t r : L.parts) L.part_pos.push_back(r - rb);
+        }
         // (whole collection only) the inverse for the un-permute of the shard path
         if (L.whole) {
             L.perm.resize(2 * n);
@@ -286,14 +335,14 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
     // A layout with ONE part (a short range) still gets its event: the exchange of every rank looks the same.
     constexpr size_t kPartBandTiles = 2048;
-    const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.parts.size() >= 2;
+    const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.part_pos.size() >= 2;
     // first tile of every part: T is row-major and a part is a run of whole tile rows, so the part of a tile is monotone
     std::vector<size_t> pstart{0};
     if (parts_on) {
         size_t q = 0;
         for (size_t t = 0; t < T.size(); ++t) {
             const uint64_t pos = (uint64_t)T[t].x * kTile;
-            while (q + 2 < L.parts.size() && pos >= L.parts[q + 1] - L.rb) {
+            while (q + 2 < L.part_pos.size() && pos >= L.part_pos[q + 1]) {
                 ++q;
                 pstart.push_back(t);
             }

@@ -45,11 +45,29 @@ void range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vec
 // default caps of the two listed tails (profiles/r3f/list_cap_sweep.jsonl)
 int auto_list_cap(int p, bool upper);
 
+// ---- row-sorted parts (the exchange of SHORT row ranges) -------------------------------------------------------------
+// Parts that are runs of original rows (range_parts) are key-ordered each on its own: a range of a few tile rows cut
+// into 8 parts has one 128-row block per part, i.e. no ordering at all, and its tiles need 10 planes instead of 8.7
+// (profiles/r4b: C3 over 8 ranks).  For such ranges the wanted rows are key-ordered as ONE run and a part is a run of
+// whole tile rows of THAT order; the rank's buffer then holds its rows in key order (row s at rowoff[s]) and the
+// destination puts the rows of a received part into place (k_row_place).
+// rowsorted_rule: a range of fewer than 1024 rows per part whose span is at most 1 GiB (the destination stages it).
+bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts);
+// cut positions (multiples of 128 rows of the key order, front() = 0, back() = re - rb) of about equal tile counts
+void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos);
+// the key order of the rows [lo, hi): dst[0 .. hi - lo) = their indices, stable by (T, L, hi) of the per-sketch keys
+void sort_rows_by_key(const uint32_t *keys, uint64_t lo, uint64_t hi, uint32_t *dst, std::vector<uint32_t> &scratch);
+// offsets of the rows of a row-sorted buffer: rowoff[s] = sum over s' < s of (n - 1 - order[s']), rowoff[cnt] = span
+void rowsorted_offsets(uint64_t n, const uint32_t *order, uint64_t cnt, std::vector<uint64_t> &rowoff);
+
 // ---- column layout of the plane matrix ------------------------------------------------------------------------------
 struct Layout {
     int sorted = 0;               // 0: identity over all n sketches.  1: the sub-collection {rb .. n-1}, key-ordered
     uint64_t rb = 0, re = 0;      // wanted rows of a sorted layout (rb = 0, re = n: the whole collection)
     std::vector<uint64_t> parts;  // row boundaries of the parts of the wanted rows, front() = rb, back() = re
+    int rowsorted = 0;            // the wanted rows are ONE key-ordered run; the parts are runs of whole tile rows of that order
+    std::vector<uint64_t> part_pos;  // the parts as positions of the layout, front() = 0, back() = re - rb
+    std::vector<uint64_t> rowoff;    // (rowsorted) offset of the row at position s in the rank's buffer, [re - rb + 1]
     uint64_t n = 0, ncols = 0;    // sketches in the collection; real columns of the plane matrix
     uint32_t Npad = 0;            // ncols padded to whole 128-column blocks
     bool whole = false;           // sorted over the whole collection: perm also holds its inverse at [n, 2n)
@@ -58,13 +76,14 @@ struct Layout {
     int vlo = 0, vhi = 0;         // register value range of the columns
     int pbase = 0;                // plane pl is the threshold pbase + 1 + pl
     uint32_t P = 0;               // dense planes
-    std::vector<uint32_t> sort_a, sort_keys;  // scratch of the column sort
+    std::vector<uint32_t> sort_a;  // scratch of the column sort
 };
 
 // keys: the n per-sketch keys (only [rb, n) is read for a sorted layout).  `parts` as range_parts() gives them
 // (ignored for the identity layout).
+// rowsorted_nparts > 0 (sorted layouts only): row-sorted parts, `parts` is ignored.
 void build_layout(const uint32_t *keys, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
-                  const std::vector<uint64_t> &parts, Layout &L);
+                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts = 0);
 
 // dense plane range of the tile (ti, tj): C(v) is needed for v in (max(larger of the two minima, smaller of the two
 // low thresholds), larger of the two high thresholds] -- below that every C(v) is 0 or comes from the low-list join

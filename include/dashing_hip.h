@@ -250,6 +250,27 @@ int dsh_dist_rows_parts_device_async(dsh_ctx *ctx, int estim, int result_type, i
                                      void *d_out, uint32_t nparts);
 int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
                             void *d_final, int dst);
+/* The exchange-aware pair (round 4).  Parts of consecutive rows are key-ordered each on its own, so a SHORT range cut into
+ * many parts loses the ordering its tiles live on (one 128-row block per part: 10 planes per tile instead of 8.7 at
+ * BASELINE configs[2] over 8 ranks).  Here the layout of every rank's buffer follows from (bounds, nparts, dst) alone:
+ *   - the destination computes its own rows in place (d_local = d_final + its offset) as ONE part;
+ *   - a range of fewer than 1024 rows per part (span <= 1 GiB) is key-ordered as ONE run, its parts are runs of whole tile
+ *     rows of that order, d_local holds the rows in key order; the destination stages what it receives and puts the rows
+ *     of every part into place (one contiguous copy per row) behind the part's transfer;
+ *   - longer ranges go in parts of consecutive rows, received in place, as with dsh_collect_parts_async.
+ * dsh_exchange_rows_device_async computes rank `rank`'s rows (enqueued; an event per part), dsh_exchange_collect_async
+ * enqueues the rounds of grouped ncclSend/ncclRecv on the copy stream; every rank calls both with the same arguments;
+ * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts).
+ * dsh_exchange_place_device does, for ONE source rank and without a communicator, what the destination does with that
+ * rank's buffer (tests and single-GPU timing of an N-rank plan). */
+int dsh_exchange_mode(uint64_t n, const uint64_t *bounds, int world, int rank, uint32_t nparts, int dst, int *rowsorted,
+                      uint32_t *nparts_out);
+int dsh_exchange_rows_device_async(dsh_ctx *ctx, int estim, int result_type, int k, const uint64_t *bounds, int world, int rank,
+                                   uint32_t nparts, int dst, void *d_local);
+int dsh_exchange_collect_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
+                               void *d_final, int dst);
+int dsh_exchange_place_device(dsh_ctx *ctx, const uint64_t *bounds, int world, int src, uint32_t nparts, int dst,
+                              const void *d_src_local, void *d_final);
 int dsh_comm_available(void);
 int dsh_comm_library(char *path_out, size_t cap, int *version_out);
 int dsh_comm_unique_id(void *id_out);

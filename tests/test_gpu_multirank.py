@@ -222,3 +222,59 @@ def _parts_of_short_ranges(ctx, dashing_amd, synth):
     ctx.collect_parts_async(n, [0, n], 4, 0, out.data_ptr(), 0)
     ctx.comm_wait()
     assert torch.equal(out, want)
+
+
+def test_exchange_pair_virtual_ranks_row_sorted_parts(ctx):
+    """dsh_exchange_*: every rank's buffer laid out for the exchange.  Virtual ranks on one GPU: each rank's rows computed
+    with dsh_exchange_rows_device_async (short ranges in row-sorted parts: the buffer holds the rows in key order), then
+    handed to dsh_exchange_place_device, which does what the destination does with a received buffer.  The assembled
+    matrix must equal the single-GPU one byte for byte; worlds 1..8, destinations first / middle / last, parts 1..8."""
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    n, p = 2600, 12
+    regs = torch.from_numpy(synth.survey_sketches(n, p, seed=13)[0]).cuda()
+    ctx.attach_device(regs.data_ptr(), n, p)
+    total = n * (n - 1) // 2
+    want = torch.empty(total, dtype=torch.float32, device="cuda")
+    ctx.dist_rows_device(want.data_ptr(), 0, n)
+    ctx.synchronize()
+    seen_rowsorted = seen_plain = False
+    for world, dst, nparts in ((1, 0, 4), (2, 0, 8), (3, 1, 2), (8, 0, 8), (8, 7, 3), (5, 2, 1)):
+        bounds = dashing_amd.balance_rows(n, world)
+        final = torch.full((total,), -7.0, dtype=torch.float32, device="cuda")
+        order = [dst] + [r for r in range(world) if r != dst]  # (the destination's per-sketch pass comes first, as in a real run)
+        for r in order:
+            rs, k = dashing_amd.exchange_mode(n, bounds, r, nparts, dst)
+            span = dashing_amd.tri_span(n, bounds[r], bounds[r + 1])
+            if r == dst:
+                assert not rs and k == (1 if bounds[r] < bounds[r + 1] else 0)
+                local = final[dashing_amd.tri_span(n, 0, bounds[r]):]
+            else:
+                local = torch.full((max(span, 1),), -3.0, dtype=torch.float32, device="cuda")
+            seen_rowsorted |= rs
+            seen_plain |= (not rs and r != dst and span > 0)
+            ctx.attach_device(regs.data_ptr(), n, p)  # a rank starts from the registers alone
+            ctx.exchange_rows_device_async(local.data_ptr(), bounds, r, nparts, dst)
+            ctx.synchronize()
+            assert ctx.info("parts_done") == k, (world, dst, nparts, r)
+            if rs and span:  # key order, not the final span
+                off = dashing_amd.tri_span(n, 0, bounds[r])
+                assert not torch.equal(local[:span], want[off:off + span])
+                assert torch.equal(torch.sort(local[:span])[0], torch.sort(want[off:off + span])[0])
+            if r != dst:
+                ctx.exchange_place_device(bounds, r, nparts, local.data_ptr(), final.data_ptr(), dst)
+        assert torch.equal(final, want), (world, dst, nparts)
+    assert seen_rowsorted
+    # one rank, no communicator: the collect call accepts what the compute call left
+    out = torch.empty_like(want)
+    ctx.attach_device(regs.data_ptr(), n, p)
+    ctx.exchange_rows_device_async(out.data_ptr(), [0, n], 0, 4, 0)
+    ctx.exchange_collect_async(n, [0, n], 4, 0, out.data_ptr(), 0)
+    ctx.comm_wait()
+    assert torch.equal(out, want)
+    # a long range keeps parts of consecutive rows (received in place): n large enough that 1024 rows per part are exceeded
+    rs, k = dashing_amd.exchange_mode(100000, dashing_amd.balance_rows(100000, 2), 1, 2, 0)
+    assert not rs and k == 2
