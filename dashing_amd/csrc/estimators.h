@@ -253,7 +253,7 @@ __device__ __forceinline__ float result_from_ji(double ji, int result_type, doub
 // src/dashing.h:550-552; the formulas ON the triple are in-tree: tests/test_reference_anchors.py).  EmissionType values: SIZES 2, FULL_CONTAINMENT_DIST 4,
 // CONTAINMENT_INDEX 5, CONTAINMENT_DIST 6, SYMMETRIC_CONTAINMENT_INDEX 7, _DIST 8.
 __device__ __forceinline__ double max0(double x) { return x < 0. ? 0. : x; }
-__device__ inline float result_from_triple(double mys, double os, double us, int result_type, double ksinv)
+__device__ __forceinline__ float result_from_triple(double mys, double os, double us, int result_type, double ksinv)
 {
     const double is = max0(mys + os - us);
     const double t0 = max0(mys - is), t1 = max0(os - is), t2 = is;
@@ -270,7 +270,7 @@ __device__ inline float result_from_triple(double mys, double os, double us, int
 }
 
 // result_cmp(lhs, rhs): mys/os = cardinalities of lhs/rhs, us = union size
-__device__ inline float result_cmp_from(double mys, double os, double us, int result_type, double ksinv)
+__device__ __forceinline__ float result_cmp_from(double mys, double os, double us, int result_type, double ksinv)
 {
     if (result_type == 0 || result_type == 1 || result_type == 3)
         return result_from_ji(jaccard_from(mys, os, us), result_type, ksinv);

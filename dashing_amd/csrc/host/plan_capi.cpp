@@ -35,7 +35,8 @@ struct Err {
 extern "C" {
 
 // mode: 0 triangle rows [rb, re) (want_sorted decides the layout), 1 rectangle rows [rb,re) x cols [cb,ce) (identity
-// layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN).
+// layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN), 3 triangle
+// rows in ROW-SORTED parts (the wanted rows one key-ordered run, parts = runs of whole tile rows of that order).
 // stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P.
 int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
                     uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
@@ -43,14 +44,32 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
 {
     Err E{err, cap};
     if (re > n) re = n;
+    const bool rowsorted = mode == 3;
+    if (rowsorted) mode = 0, want_sorted = 1, want_parts = 1;
     if (mode == 1 || !want_sorted) want_sorted = mode == 2 ? 1 : 0;
     if (mode == 2) want_sorted = 1;
     std::vector<uint64_t> parts;
     uint64_t lrb = 0, lre = n;
     if (want_sorted && mode == 0) lrb = rb, lre = re;
-    if (want_sorted) range_parts(n, lrb, lre, std::max<uint32_t>(want_parts ? nparts : 1, 1), parts);
+    if (want_sorted && !rowsorted) range_parts(n, lrb, lre, std::max<uint32_t>(want_parts ? nparts : 1, 1), parts);
     Layout L;
-    build_layout(keys, n, want_sorted, lrb, lre, parts, L);
+    build_layout(keys, n, want_sorted, lrb, lre, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0);
+    if (rowsorted) {  // one key-ordered run, cuts on whole tile rows of it, row offsets of the rank's buffer
+        auto skey = [&](uint32_t g) { return ((uint32_t)key_T(keys[g]) << 12) | ((uint32_t)key_L(keys[g]) << 6) | (uint32_t)key_hi(keys[g]); };
+        for (uint64_t s = 1; s < lre - lrb; ++s)
+            if (skey(L.perm[s - 1]) > skey(L.perm[s])) return E.fail("row-sorted: the wanted rows are not one key-ordered run at %llu", (unsigned long long)s);
+        if (L.part_pos.empty() || L.part_pos.front() != 0 || L.part_pos.back() != lre - lrb) return E.fail("row-sorted: part positions do not span the rows");
+        for (size_t q = 1; q + 1 < L.part_pos.size(); ++q)
+            if (L.part_pos[q] % kTile || L.part_pos[q] <= L.part_pos[q - 1]) return E.fail("row-sorted: cut %zu at %llu", q, (unsigned long long)L.part_pos[q]);
+        if (L.part_pos.size() - 1 > std::max<uint32_t>(nparts, 1)) return E.fail("row-sorted: more parts than asked for");
+        uint64_t acc = 0;
+        if (L.rowoff.size() != lre - lrb + 1) return E.fail("row-sorted: rowoff size");
+        for (uint64_t s = 0; s < lre - lrb; ++s) {
+            if (L.rowoff[s] != acc) return E.fail("row-sorted: rowoff[%llu]", (unsigned long long)s);
+            acc += n - 1 - L.perm[s];
+        }
+        if (L.rowoff.back() != acc || acc != tri_span(n, lrb, lre)) return E.fail("row-sorted: the rows do not add up to the span");
+    }
     // ---- layout: perm is a permutation of the columns; the parts hold exactly their rows; block stats are right
     const uint64_t col0 = want_sorted ? lrb : 0;
     if (L.ncols != n - col0) return E.fail("ncols %llu != %llu", (unsigned long long)L.ncols, (unsigned long long)(n - col0));
@@ -67,6 +86,10 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
             for (uint64_t r = L.parts[q]; r < L.parts[q + 1]; ++r, ++s)
                 if (L.perm[s] < L.parts[q] || L.perm[s] >= L.parts[q + 1])
                     return E.fail("column %llu holds sketch %u, not a row of part %zu", (unsigned long long)s, L.perm[s], q);
+        if (L.part_pos.size() != (rowsorted ? L.part_pos.size() : L.parts.size())) return E.fail("part positions and parts differ in number");
+        if (!rowsorted)
+            for (size_t q = 0; q < L.parts.size(); ++q)
+                if (L.part_pos[q] != L.parts[q] - lrb) return E.fail("part position %zu", q);
         for (; s < L.ncols; ++s)
             if (L.perm[s] < lre) return E.fail("column %llu (after the wanted rows) holds wanted row %u", (unsigned long long)s, L.perm[s]);
         if (L.whole)
@@ -174,9 +197,9 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
             // every tile of the segment belongs to the part that is current
             if (q.want_parts)
                 for (size_t t = sg.b; t < sg.e; ++t) {
-                    const uint64_t row0 = (uint64_t)T[t].x * kTile + L.rb;
+                    const uint64_t pos0 = (uint64_t)T[t].x * kTile;
                     const int cur = last_part + (sg.part >= 0 ? 0 : 1);
-                    if (cur < 0 || (size_t)cur + 1 >= L.parts.size() || row0 < L.parts[cur] || row0 >= L.parts[cur + 1])
+                    if (cur < 0 || (size_t)cur + 1 >= L.part_pos.size() || pos0 < L.part_pos[cur] || pos0 >= L.part_pos[cur + 1])
                         return E.fail("tile row %u is not in part %d", T[t].x, cur);
                 }
         }
@@ -206,7 +229,7 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
     if (at != T.size()) return E.fail("bands end at %zu of %zu tiles", at, T.size());
     for (uint32_t qd = 0; qd < pp.nparts; ++qd)
         if (part_done[qd] != 1) return E.fail("part %u never completes", qd);
-    if (q.want_parts && pp.nparts + 1 != L.parts.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.parts.size() - 1);
+    if (q.want_parts && pp.nparts + 1 != L.part_pos.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.part_pos.size() - 1);
     // ---- the two device lists describe the same tiles
     std::vector<U4> dt(T.size()), df(T.size());
     emit_tile_lists(L, pp, dt.data(), df.data());

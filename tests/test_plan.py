@@ -99,6 +99,23 @@ def test_parts_any_range_length(host):
         assert st["parts"] >= 1
 
 
+def test_row_sorted_parts(host):
+    """short ranges under dsh_exchange_*: the wanted rows ONE key-ordered run (homogeneous 128-row blocks), parts = runs of
+    whole tile rows of that order, the rank's buffer in key order (rowoff) -- same pairs, each exactly once"""
+    rng = np.random.default_rng(8)
+    n = 2600
+    keys = make_keys(rng, n, 12, spread=10)
+    for (rb, re) in ((0, 640), (640, 1280), (1280, 1290), (2048, 2599), (2599, 2600), (0, n)):
+        for nparts in (1, 2, 8):
+            st = check(host, keys, mode=3, rb=rb, re=re, nparts=nparts, want_parts=1)
+            assert 1 <= st["parts"] <= nparts
+    # the point of it: a short range in 8 parts of consecutive rows has one 128-row block per part (no ordering at all)
+    keys = make_keys(rng, 10000, 14, spread=12)
+    plain = check(host, keys, rb=0, re=640, nparts=8, want_parts=1, p=14)
+    rs = check(host, keys, mode=3, rb=0, re=640, nparts=8, want_parts=1, p=14)
+    assert rs["tiles"] == plain["tiles"] and rs["planes_x100"] < plain["planes_x100"], (rs, plain)
+
+
 def test_bands_follow_the_scratch_budget_and_large_parts_cut_them(host):
     rng = np.random.default_rng(4)
     n = 1500
