@@ -302,7 +302,8 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
             const uint32_t val = e < ne[q] ? (uint32_t)vs[q][e] : 0u;
             bk[q][u] = e < ne[q] ? (((pos >> sh) << 1) | (val > Ts[q] ? 0u : 1u)) : 0xFFFFFFFFu;
             pv[q][u] = ((pos & ((1u << sh) - 1u)) << 13) | ((wave + 16u * (uint32_t)q) << 6) | val;
-            if (e < ne[q]) rl[(c0 + wave + 16u * (uint32_t)q) * E + e] = (pos << 8) | val;
+            // the compact list row, unused slots filled: k_finalize reads a row without asking for its length first
+            if (e < E) rl[(c0 + wave + 16u * (uint32_t)q) * E + e] = e < ne[q] ? ((pos << 8) | val) : 0xFFFFFFFFu;
         }
 #pragma unroll
     for (int q = 0; q < kSk; ++q)
@@ -1042,8 +1043,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     // ---- requests that only need the tile, oldest first.  (1) the row sketch's listed registers: lane e takes entry e
     // (+128 per round); the bucket records below depend on them
     constexpr int kR = RK > 3 ? 2 : (int)(kListCap / 128);  // (the wide records are only used with lists of <= 256 entries)
-    const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.nS[si]);
-    const int nr = (int)((ni + 127u) >> 7);  // rounds that hold an entry (uniform): 1 at p <= 11, up to 4 at p = 14
+    // (every row of rl holds E slots, the unused ones 0xFFFFFFFF: no look at the list's length first -- one dependent
+    // scalar load less in front of the records)
+    const int nr = (int)((a.E + 127u) >> 7);  // rounds (uniform): 1 at p <= 11, 4 at p = 14
     uint32_t le[kR];
     {
         const uint32_t *rli = a.rl + (uint64_t)si * a.E;
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
             le[r] = kNone;
             if (r >= nr) continue;
             const uint32_t e = (uint32_t)tid + 128u * (uint32_t)r;
-            if (e < ni) le[r] = rli[e];
+            if (e < a.E) le[r] = rli[e];
         }
     }
     // (2) the sketch indices: only the output index and the row/column filters need them
@@ -1288,20 +1290,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         __device__ const CT *at(int v) const { return col + (v - vlo) * 128; }
     };
     const RawCol raw{col, vlo};
+    // ---- the epilogue's arguments come from the kernarg segment only now (late_args): requested BEFORE the estimator --
+    // the scalar registers are free by then and the loads (the two cardinalities among them) travel under its ~1 000
+    // fp64 instructions -- and used after it
+    const FinalizeArgs *L = late_args();
+    const double cardj = L->cardS[sj], cardi = L->cardS[si];
+    const int rtype = L->result_type;
+    const double ksinv = L->ksinv;
+    const uint64_t oidx = out_index(L);
+    float *const outp = L->out;
     if constexpr (TIMED) tph[4] = __builtin_readcyclecounter();
     int mle_it = 0;
     const double us = estimate(c, raw, a.p, a.estim, minv < T ? minv : T, maxv, TIMED ? &mle_it : nullptr);
     if constexpr (TIMED) tph[5] = __builtin_readcyclecounter();
-    // ---- epilogue: its arguments come from the kernarg segment only now (late_args)
-    const FinalizeArgs *L = late_args();
-    const uint64_t oidx = out_index(L);
     if (a.stop == 4) {
-        L->out[oidx] = (float)us;
+        outp[oidx] = (float)us;
         return;
     }
-    const double cardj = L->cardS[sj], cardi = L->cardS[si];
-    const int rtype = L->result_type;
-    const double ksinv = L->ksinv;
     const float res = result_cmp_from(cardj, cardi, us, rtype, ksinv);  // lhs = j, rhs = i
     if (L->square || L->knn) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
         const bool asym = rtype == 4 || rtype == 5 || rtype == 6;
@@ -1310,12 +1315,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
             L->out[(uint64_t)i * L->n + j] = res;
             L->out[(uint64_t)j * L->n + i] = rev;
         } else {
-            L->out[oidx] = res;
+            outp[oidx] = res;
             L->out2[(uint64_t)sj * L->knn_rows + (si - (uint32_t)L->row_begin)] = rev;
         }
         return;
     }
-    L->out[oidx] = res;
+    outp[oidx] = res;
     if constexpr (TIMED) {
         tph[6] = __builtin_readcyclecounter();
         const unsigned long long live = __ballot(1);
