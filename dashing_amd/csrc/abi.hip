@@ -864,6 +864,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         (name[1] == 'm' ? c->emax_opt : c->elow_opt) = (int)v;
         return DSH_OK;
     }
+    if (!std::strcmp(name, "part_band_tiles")) {
+        if (v < 1 || v > (1 << 30)) return fail(c, DSH_EINVAL, "part_band_tiles out of range");
+        c->part_band_tiles = (int)v;
+        return DSH_OK;
+    }
     if (!std::strcmp(name, "finalize_xcd_tiles")) {
         c->finalize_xcd_tiles = v != 0;
         return DSH_OK;

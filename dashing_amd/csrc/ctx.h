@@ -136,6 +136,7 @@ struct dsh_ctx {
     int kc_opt = 0;   // 0 auto: 32 where a plane is at least that long (p >= 10), else 16 (profiles/r3f/lockstep_ab.jsonl)
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
+    int part_band_tiles = 2048;       // a part of at least this many tiles gets its own launch of the tile kernel (plan.cpp)
     int finalize_xcd_tiles = 1;       // k_finalize: block -> tile mapping that keeps a tile's 128 rows on one XCD (option, A/B)
     int finalize_rowmajor = 1;        // k_finalize walks every segment's tiles in row-major order (option, A/B only)
     size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call

@@ -264,6 +264,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     tu.ls_sort_items = c->ls_sort_items;
     tu.xcd_swizzle = c->xcd_swizzle;
     tu.finalize_rowmajor = c->finalize_rowmajor;
+    tu.part_band_tiles = (uint32_t)c->part_band_tiles;
     if (!plan::build_pairs(L, q, tu, pp)) {
         pp.T.clear();
         return DSH_OK;

@@ -983,19 +983,11 @@ struct FinalizeArgs {
 // phase over the waves of every 61st block (a.phase_cyc[0..5] cycles, [6] waves, [7..13] the estimator's trip counts per
 // lane and per wave: what divergence costs; layout in include/dashing_hip.h at dsh_finalize_phase_cycles) -- the
 // accounting VERDICT r3 asked for instead of early-exit stops, whose occupancy and overlap differ from the real kernel.
-// The kernel arguments the EPILOGUE alone needs (output pointers and index bases, cardinalities, the result type): read
-// from the kernarg segment where they are used.  Taken from the by-value argument they are loaded at the top like
-// everything else and, with ~70 dwords of arguments and the uniform state of the histogram phases on top, overflow the
-// scalar registers: the compiler parked them in VGPR lanes -- 67 v_writelane + 105 v_readlane VALU instructions in the
-// p <= 12 instance (profiles/r4f).  The empty asm keeps the loads behind it.
-__device__ __forceinline__ const FinalizeArgs *late_args()
-{
-    const FinalizeArgs *p = (const FinalizeArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-template <typename CT, int RK, bool TIMED>
+// GENERAL = false is the instance of the plain triangle (rows in original order: full matrix, row ranges, row-sorted
+// parts): it never reads the arguments of the rectangle / square / sorted-output / nearest-neighbour forms, which
+// relieves the scalar registers (~70 dwords of arguments: the compiler parked the overflow in VGPR lanes -- 67
+// v_writelane + 105 v_readlane VALU instructions in the p <= 12 instance, profiles/r4f).
+template <typename CT, int RK, bool TIMED, bool GENERAL>
 // 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(96))) void k_finalize(FinalizeArgs a)
 {
@@ -1096,7 +1088,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     const uint32_t *bent = a.cidx_ent + (uint64_t)tile.y * a.ent_stride;
     // block-level skip (uniform) when the row sketch cannot be wanted
     const uint32_t rb32 = (uint32_t)a.row_begin, re32 = (uint32_t)a.row_end;  // (<= n < 2^32)
-    if (a.rect && !(i >= rb32 && i < re32)) return;
+    const bool m_rect = GENERAL && a.rect, m_square = GENERAL && a.square, m_sorted = GENERAL && a.sorted_out, m_knn = GENERAL && a.knn;
+    if (m_rect && !(i >= rb32 && i < re32)) return;
     corr[tid] = 0;
     if (tid < 64) histA[tid] = tid > T ? hrow : 0u;  // the row sketch's tail histogram above this tile's threshold
     {
@@ -1113,11 +1106,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     }
     uint32_t oi = i, oj = j;
     bool active;
-    if (a.rect) {
+    if (m_rect) {
         active = j >= (uint32_t)a.col_begin && j < (uint32_t)a.col_end;
-    } else if (a.square) {
+    } else if (m_square) {
         active = si < sj;
-    } else if (a.sorted_out || a.knn) {
+    } else if (m_sorted || m_knn) {
         oi = si;
         oj = sj;
         active = si < sj && si >= rb32 && si < re32;
@@ -1132,15 +1125,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         actm[(tid >> 6) * 2] = (uint32_t)bal;
         actm[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32);
     }
-    // where the pair's value goes: computed by whoever stores (the epilogue; the profiling stops), from late_args()
+    // where the pair's value goes: computed by whoever stores (right before the estimator; the profiling stops) -- not
+    // here, where it would hold two VGPRs through the histogram phases
     auto out_index = [&](const FinalizeArgs *L) -> uint64_t {
-        return L->rect  ? (uint64_t)(i - (uint32_t)L->row_begin) * (L->col_end - L->col_begin) + (j - (uint32_t)L->col_begin)
-               : L->knn ? (uint64_t)(si - (uint32_t)L->row_begin) * L->knn_ld + sj
+        return m_rect  ? (uint64_t)(i - (uint32_t)L->row_begin) * (L->col_end - L->col_begin) + (j - (uint32_t)L->col_begin)
+               : m_knn ? (uint64_t)(si - (uint32_t)L->row_begin) * L->knn_ld + sj
                : L->rowoff ? L->rowoff[i < j ? si : sj] + (oj - oi - 1)  // (the pair's row is the smaller sketch index)
                            : (uint64_t)oi * (2 * L->n - oi - 1) / 2 + oj - (oi + 1) - L->base_index;
     };
     if (a.stop == 1) {
-        const FinalizeArgs *L = late_args();
+        const FinalizeArgs *L = &a;
         if (active) L->out[out_index(L)] = (float)T;
         return;
     }
@@ -1210,7 +1204,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     __syncthreads();
     if constexpr (TIMED) tph[2] = __builtin_readcyclecounter();
     if (a.stop == 2) {
-        const FinalizeArgs *L = late_args();
+        const FinalizeArgs *L = &a;
         if (active) L->out[out_index(L)] = (float)(nb + prev + keyj);
         return;
     }
@@ -1269,7 +1263,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     else prev = clow;                                         // no dense plane: C(T) = C(Lp)
     col[(T - vlo) * 128] = (CT)(m - ucnt - prev);  // c[T] = C(T+1) - C(T), C(T+1) = m - |union above T|
     if (a.stop == 3) {
-        const FinalizeArgs *L = late_args();
+        const FinalizeArgs *L = &a;
         L->out[out_index(L)] = (float)(ucnt + clow);
         return;
     }
@@ -1290,10 +1284,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         __device__ const CT *at(int v) const { return col + (v - vlo) * 128; }
     };
     const RawCol raw{col, vlo};
-    // ---- the epilogue's arguments come from the kernarg segment only now (late_args): requested BEFORE the estimator --
-    // the scalar registers are free by then and the loads (the two cardinalities among them) travel under its ~1 000
-    // fp64 instructions -- and used after it
-    const FinalizeArgs *L = late_args();
+    // ---- what the epilogue needs is requested BEFORE the estimator (the two cardinalities travel under its ~1 000 fp64
+    // instructions) and used after it.  (Reading these arguments late from the kernarg segment instead -- to spare the
+    // scalar registers they occupy from the top -- was tried: fewer VALU instructions, but the scalar loads share the
+    // LDS counter and every wave waited for them at the estimator's first LDS read: ORIGINAL +10 %, profiles/r4g, r4h.)
+    const FinalizeArgs *L = &a;
     const double cardj = L->cardS[sj], cardi = L->cardS[si];
     const int rtype = L->result_type;
     const double ksinv = L->ksinv;
@@ -1308,10 +1303,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         return;
     }
     const float res = result_cmp_from(cardj, cardi, us, rtype, ksinv);  // lhs = j, rhs = i
-    if (L->square || L->knn) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
+    if (m_square || m_knn) {  // row i sees j as lhs, row j sees i as lhs (only the containment measures differ)
         const bool asym = rtype == 4 || rtype == 5 || rtype == 6;
         const float rev = asym ? result_cmp_from(cardi, cardj, us, rtype, ksinv) : res;
-        if (L->square) {
+        if (m_square) {
             L->out[(uint64_t)i * L->n + j] = res;
             L->out[(uint64_t)j * L->n + i] = rev;
         } else {
@@ -1835,10 +1830,12 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
     const bool timed = f.phase_cyc != nullptr;  // profiling only
-#define DSH_FIN(CT, RK)                                                                                            \
-    do {                                                                                                           \
-        if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true>), dim3(blocks), dim3(128), lds, st, a);            \
-        else hipLaunchKernelGGL((k_finalize<CT, RK, false>), dim3(blocks), dim3(128), lds, st, a);                 \
+    const bool general = f.rect || f.square || f.sorted_out || f.knn;
+#define DSH_FIN(CT, RK)                                                                                                  \
+    do {                                                                                                                 \
+        if (general) hipLaunchKernelGGL((k_finalize<CT, RK, false, true>), dim3(blocks), dim3(128), lds, st, a);        \
+        else if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true, false>), dim3(blocks), dim3(128), lds, st, a);      \
+        else hipLaunchKernelGGL((k_finalize<CT, RK, false, false>), dim3(blocks), dim3(128), lds, st, a);                \
     } while (0)
     // (the record width follows the precision like k_build_colindex: colindex_inline)
     if (f.cum_bytes != 2) DSH_FIN(uint32_t, 3);

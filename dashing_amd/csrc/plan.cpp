@@ -334,7 +334,7 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     // profiles/r3g -- nothing against the ~1 ms per 1 000 tiles the part takes, and the first part can leave after 1/nparts of
     // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
     // A layout with ONE part (a short range) still gets its event: the exchange of every rank looks the same.
-    constexpr size_t kPartBandTiles = 2048;
+    const size_t kPartBandTiles = tu.part_band_tiles;
     const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.part_pos.size() >= 2;
     // first tile of every part: T is row-major and a part is a run of whole tile rows, so the part of a tile is monotone
     std::vector<size_t> pstart{0};

@@ -108,6 +108,7 @@ struct Tuning {
     int ls_sort_items = 1;
     int xcd_swizzle = 1;
     int finalize_rowmajor = 1;
+    uint32_t part_band_tiles = 2048;  // a part of at least this many tiles also ends the band of the tile kernel
 };
 
 struct Seg {

@@ -72,7 +72,7 @@ for r in range(G):
     step()
     km = ctx.last_kernel_ms()
     ctx.set_profiling(False)
-    rows.append({"rank": r, "rows": [b[r], b[r + 1]], "rowsorted": rs, "parts": k, "span_bytes": 4 * span, "tiles": ctx.info("tiles"),
+    rows.append({"rank": r, "rows": [b[r], b[r + 1]], "rowsorted": rs, "parts": k, "span_bytes": 4 * span, "tiles": ctx.info("tiles"), "bands": ctx.info("bands"),
                  "wall_ms": round(best * 1e3, 3), "prepare_ms": round(km["prepare_ms"], 3), "pair_ms": round(km["pair_ms"], 3),
                  "finalize_ms": round(km["finalize_ms"], 3), "planes_per_tile": ctx.info("avg_tile_planes_x100") / 100})
 # rank 0 places what it received: all sources, timed together (its per-sketch pass covers every sketch: redo rank 0's step)
@@ -95,7 +95,10 @@ for x in rows[1:]:
     done = 0.0
     for q in range(k):
         by = x["span_bytes"] / k
-        ready = x["prepare_ms"] + x["pair_ms"] + x["finalize_ms"] * (q + 1) / k
+        if x["bands"] >= k > 1:  # the tile kernel is cut per part: part q is ready after (q+1)/k of tile kernel + finalize
+            ready = x["prepare_ms"] + (x["pair_ms"] + x["finalize_ms"]) * (q + 1) / k
+        else:
+            ready = x["prepare_ms"] + x["pair_ms"] + x["finalize_ms"] * (q + 1) / k
         if q == k - 1:
             ready = max(ready, x["wall_ms"])
         done = max(ready, done) + by / LINK * 1e3 + 0.02
