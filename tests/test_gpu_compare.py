@@ -566,6 +566,37 @@ def test_set_triple_measures(ctx, oracle, rt):
     assert np.allclose(rect[f2], wr[f2], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("p", [9, 10, 12, 13])
+def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
+    """round 4: the position index keeps a bucket's first 7 (p <= 12, lists of <= 256 entries) or 3 entries inside its
+    record; list caps beyond 256 entries switch a small-p collection to the narrow records and four look-up rounds; the
+    blocks of k_finalize map to tiles XCD-wise or plainly.  Same exact histograms whatever the combination -- and equal
+    to the oracle's."""
+    n = 300
+    regs = synth.synthetic_sketches(n, p, seed=70 + p)
+    ctx.set_sketches(regs)
+    base = ctx.dist_rows()
+    want = oracle.dist_tri(regs)
+    assert np.allclose(base, want, rtol=1e-6, atol=1e-15)
+    try:
+        for emax, elow in ((255, 255), (200, 17), (128, 128), (0, 0), (64, 255), (3, 250), (-1, -1)):
+            ctx.set_option("emax", emax)
+            ctx.set_option("elow", elow)
+            for xcd in (1, 0):
+                ctx.set_option("finalize_xcd_tiles", xcd)
+                assert ctx.dist_rows().tobytes() == base.tobytes(), (p, emax, elow, xcd)
+            assert ctx.dist_rows(estim=dashing_amd.ESTIM_ORIGINAL).tobytes() != b""  # (runs; checked against the oracle below)
+        ctx.set_option("emax", 255)
+        ctx.set_option("elow", 255)
+        for estim in (0, 1, 2):  # every estimator on the narrow-record path of a small p
+            got = ctx.dist_rows(estim=estim)
+            assert np.allclose(got, oracle.dist_tri(regs, estim), rtol=1e-6, atol=1e-15), (p, estim)
+    finally:
+        ctx.set_option("emax", -1)
+        ctx.set_option("elow", -1)
+        ctx.set_option("finalize_xcd_tiles", 1)
+
+
 @pytest.mark.parametrize("p", [8, 11, 15])
 def test_adversarial_registers(ctx, oracle, p):
     """Register arrays that do NOT follow the HLL law: uniform random over the whole value range
