@@ -106,7 +106,7 @@ for x in rows[1:]:
         done += x["span_bytes"] / k / place_rate * 1e3  # the last part's rows put into place
     if done > step_ms:
         step_ms, worst = done, x["rank"]
-print(json.dumps({"n": n, "p": p, "G": G, "nparts": NPARTS, "single_gpu_ms": round(t1 * 1e3, 3), "ranks": rows,
+print(json.dumps({"n": n, "p": p, "G": G, "nparts": NPARTS, "opts": os.environ.get("OPTS", ""), "single_gpu_ms": round(t1 * 1e3, 3), "ranks": rows,
                   "max_rank_wall_ms": max(x["wall_ms"] for x in rows), "mean_rank_wall_ms": round(sum(x["wall_ms"] for x in rows) / G, 3),
                   "dst_place_all_sources_ms": round(place * 1e3, 3), "assembled_equals_single_gpu": same,
                   "exchange_model": {"assumed_link_GBs": LINK / 1e9, "step_model_ms": round(step_ms, 3),
