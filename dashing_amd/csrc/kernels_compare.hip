@@ -352,14 +352,21 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // registers -> thermometer bit-planes.  Thread (i, w) reads 32 registers of sketch i and emits
-// one 32-bit word per plane: bit r of planes[(pl*W + w)*Npad + i] = (reg[i][32w + r] < vlo+1+pl).
+// one 32-bit word per plane: the 32 bits of planes[(pl*W + w)*Npad + i] are (reg[i][32w + r] < vlo+1+pl), r = 0..31,
+// in the order of lt_word below.
 // Padding sketches (i >= N) get zeros (they never count).
-__device__ __forceinline__ uint32_t lt_nibble(uint32_t x, uint32_t vrep)
+// The 32 flags (register < v) of 8 words of 4 register bytes each, y = x | 0x80808080 (bytes of x are < 128, or the
+// 0xFF of a padding sketch): bit 7 of every byte of y - v says "byte >= v" (no borrow crosses a byte).  Word k's four
+// flags go to bits k, 8+k, 16+k, 24+k -- register 4k + b sits at bit 8b + k of the plane word.  That order is the
+// same for every sketch and nothing looks at it: the tile kernel only counts the bits two words share.  (Round 4:
+// collecting every word's flags into a nibble in register order first took a 32-bit multiply per word -- 63 M VALU
+// instructions at C3, the kernel was bound by them; 3 instructions per word now.)
+__device__ __forceinline__ uint32_t lt_word(const uint32_t (&y)[8], uint32_t vrep)
 {
-    // bytes of x are < 128 (or 0xFF fillers); bit7 of (x|0x80)-v is set iff byte >= v
-    const uint32_t ge = ((x | 0x80808080u) - vrep) & 0x80808080u;
-    const uint32_t lt = (ge ^ 0x80808080u) >> 7;  // 0/1 per byte
-    return (lt * 0x01020408u) >> 24;              // bit k = byte k (partial products never collide)
+    uint32_t ge = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ge |= ((y[k] - vrep) >> (7 - k)) & (0x01010101u << k);
+    return ~ge;
 }
 
 __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ regs, uint64_t n,
@@ -385,12 +392,11 @@ __global__ __launch_bounds__(256) void k_transform(const uint8_t *__restrict__ r
             x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] |= 0x80808080u;
     for (uint32_t pl = 0; pl < P; ++pl) {
         const uint32_t vrep = (uint32_t)(vlo + 1 + (int)pl) * 0x01010101u;
-        uint32_t word = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) word |= (lt_nibble(x[k], vrep) & 0xFu) << (4 * k);
-        planes[((uint64_t)pl * W + w) * Npad + i] = word;
+        planes[((uint64_t)pl * W + w) * Npad + i] = lt_word(x, vrep);
     }
 }
 
@@ -425,15 +431,13 @@ __global__ __launch_bounds__(256) void k_transform_t(const uint8_t *__restrict__
         const uint32_t wl = g * 2 + h;  // word (32 registers) within the 256-byte run
         const uint4 a = *reinterpret_cast<const uint4 *>(stage + il * kRow + wl * 32u);
         const uint4 b = *reinterpret_cast<const uint4 *>(stage + il * kRow + wl * 32u + 16u);
-        const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const uint32_t y[8] = {a.x | 0x80808080u, a.y | 0x80808080u, a.z | 0x80808080u, a.w | 0x80808080u,
+                               b.x | 0x80808080u, b.y | 0x80808080u, b.z | 0x80808080u, b.w | 0x80808080u};
         const uint64_t w = (uint64_t)blockIdx.y * 8 + wl;
-        for (uint32_t pl = 0; pl < P; ++pl) {
-            const uint32_t vrep = (uint32_t)(vlo + 1 + (int)pl) * 0x01010101u;
-            uint32_t word = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) word |= (lt_nibble(x[k], vrep) & 0xFu) << (4 * k);
-            planes[((uint64_t)pl * W + w) * Npad + i0 + il] = word;
-        }
+        uint32_t *dst = planes + w * Npad + i0 + il;  // plane 0; the next plane is W rows further on
+        const uint64_t step = (uint64_t)W * Npad;
+        uint32_t vrep = (uint32_t)(vlo + 1) * 0x01010101u;
+        for (uint32_t pl = 0; pl < P; ++pl, dst += step, vrep += 0x01010101u) *dst = lt_word(y, vrep);
     }
 }
 
