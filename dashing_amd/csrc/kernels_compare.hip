@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
                                                         uint8_t *__restrict__ tailhist)
 {
     __shared__ uint32_t hist[4][64];
-    __shared__ uint32_t sub[4][8][65];  // 8 privatised copies per wave: the register values pile up in ~8 bins, so
-                                        // one copy would serialise its LDS atomics; rows padded to 65 words so that
-                                        // the same bin of different copies falls into different banks (with a stride
-                                        // of 64 every copy's bin b shared bank b and the copies bought nothing)
+    __shared__ uint32_t sub[4][8][72];  // 8 privatised copies per wave: the register values pile up in ~8 bins, so
+                                        // one copy would serialise its LDS atomics; rows padded to 72 words: copy c's
+                                        // bin b is in bank (8c + b) mod 64, so the 8 copies of a window of 8 adjacent
+                                        // values -- where nearly all registers are -- use 64 different banks (a stride
+                                        // of 64 put every copy's bin b into bank b, 65 a window into 15 banks)
     __shared__ int thr[4], thrL[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t s = first + (uint64_t)blockIdx.x * 4 + wave;  // sketches [first, n)
