@@ -824,6 +824,12 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->ls_sort_items = v != 0;
         return DSH_OK;
     }
+    if (!std::strcmp(name, "colindex_split")) {
+        if (v != 0 && v != 1 && v != 2 && v != 4) return fail(c, DSH_EINVAL, "colindex_split must be 0 (automatic), 1, 2 or 4");
+        c->colindex_split = (int)v;
+        c->planes_valid = false;
+        return DSH_OK;
+    }
     if (!std::strcmp(name, "ls_item_chunks")) {
         if (v < 1 || v > (1 << 20)) return fail(c, DSH_EINVAL, "ls_item_chunks out of range");
         c->ls_item_chunks = (int)v;

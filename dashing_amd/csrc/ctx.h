@@ -149,6 +149,7 @@ struct dsh_ctx {
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int ls_sort_items = 1;
+    int colindex_split = 0;  // workgroups per column block of k_build_colindex (0: automatic)
     int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
     // = 1 = wherever a plane is at least one chunk (W >= kc), 0 never (the free-running k_pair_counts)

@@ -186,6 +186,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
             ci.cardS = (double *)c->colS_card.ptr;
             ci.thS = (uint8_t *)c->colS_th.ptr;
             ci.rl = (uint32_t *)c->colS_rl.ptr;
+            ci.split = c->colindex_split;
             HIPCHK(c, launch_build_colindex(c->aux_stream, ci));
         }
         HIPCHK(c, hipEventRecord(c->ev_aux_join, c->aux_stream));

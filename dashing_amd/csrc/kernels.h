@@ -32,6 +32,7 @@ struct ColIndexLaunch {
     double *cardS;            // [Npad]
     uint8_t *thS;             // [Npad][64]
     uint32_t *rl;             // [Npad][E]
+    int split = 0;            // workgroups per column block (1, 2, 4); 0: chosen from the number of blocks
 };
 hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,

@@ -79,11 +79,16 @@ __global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict
     // flight together, and reused by the second pass; larger sketches re-read the remainder
     constexpr int kRegCache = 16;
     uint4 cache[kRegCache];
+    // (every load is issued -- at a clamped chunk where the sketch is shorter -- and masked afterwards: a load under a
+    // condition is a branch region of its own, and the 16 loads went two at a time with a full wait in between)
 #pragma unroll
     for (int k = 0; k < kRegCache; ++k) {
         const uint64_t c = (uint64_t)k * 64 + lane;
-        cache[k] = (s < n && c < nch) ? src[c] : make_uint4(0, 0, 0, 0);
+        cache[k] = src[c < nch ? c : nch - 1];
     }
+#pragma unroll
+    for (int k = 0; k < kRegCache; ++k)
+        if (!(s < n && (uint64_t)k * 64 + lane < nch)) cache[k] = make_uint4(0, 0, 0, 0);
     // registers above q+1 = 64-p+1 cannot come from the register rule (a corrupt or foreign .hll): they would alias
     // into wrong histogram bins (& 63) and break the bit-planes (bytes >= 128); flagged in bit 31 of the key
     uint32_t bad = 0;
@@ -259,63 +264,102 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
                                                           double *__restrict__ cardS, uint8_t *__restrict__ thS,
                                                           uint32_t *__restrict__ rl)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nbuckets] counters, then first slot << 16 | cursor
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nown] counters, then first slot << 16 | cursor
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t below_s;
     constexpr uint32_t RW = (uint32_t)RK + 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t sh = p > 14 ? (uint32_t)(p - 14) : 0u;
     const uint64_t c0 = (uint64_t)blockIdx.x * kTile;
-    for (uint32_t b = tid; b < nbuckets; b += 1024) cnt[b] = 0;
+    // gridDim.y workgroups share a column block, each owning a range of the buckets (a collection of few column blocks
+    // -- C3: 79 -- is otherwise 79 workgroups' worth of latency sticking out under the first round of the tile kernel):
+    // every one reads all entries, counts and places the ones in its range [blo, blo + nown); its entries start in ent[]
+    // behind those of the ranges below (counted on the way).  gridDim.y divides nbuckets (both powers of two).
+    const uint32_t G = gridDim.y, g = blockIdx.y;
+    const uint32_t nown = nbuckets / G, blo = g * nown;
+    for (uint32_t b = tid; b < nown; b += 1024) cnt[b] = 0;
+    if (tid == 0) below_s = 0;
     __syncthreads();
     // a wave's 8 sketches x 8 entries per lane are loaded ONCE, all loads in flight together (bucket << 13 | column
     // << 6 | value; 0xFFFFFFFF = none): both passes run from registers -- the kernel is one workgroup per column
     // block, i.e. latency, not throughput
     constexpr int kPer = (int)(kListCap / 64);  // entries per lane and sketch
     constexpr int kSk = (int)(kTile / 16);      // sketches per wave
-    uint32_t ne[kSk], Ts[kSk];
-    const PT *ps[kSk];
-    const uint8_t *vs[kSk];
+    // one register per entry: position << 8 | value (what the compact list row holds; 0xFFFFFFFF = none) -- bucket and
+    // index entry are re-derived from it in both passes -- and one sketch's loads at a time.  (Round 4: with bucket AND
+    // entry kept per entry and all 8 sketches' loads issued together the kernel spilled ~190 registers to scratch, 400
+    // bytes per thread, and ran 272 us at C3.)
+    uint32_t Ts[kSk], pk[kSk][kPer];
+    uint32_t sk[kSk], nes[kSk];  // the 8 sketches of this wave, their list lengths and keys: all 24 loads in flight together
+#pragma unroll
+    for (int q = 0; q < kSk; ++q) {
+        const uint64_t col = c0 + wave + 16u * (uint32_t)q;
+        sk[q] = col < ncols ? (perm ? perm[col] : (uint32_t)col) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int q = 0; q < kSk; ++q) {
+        nes[q] = sk[q] != 0xFFFFFFFFu ? exc_n[sk[q]] : 0u;
+        Ts[q] = keys[sk[q] != 0xFFFFFFFFu ? sk[q] : 0u];  // (the whole key for now)
+    }
 #pragma unroll
     for (int q = 0; q < kSk; ++q) {
         const uint32_t sl = wave + 16u * (uint32_t)q;
-        const bool ok = c0 + sl < ncols;
-        const uint64_t s = ok ? (perm ? perm[c0 + sl] : c0 + sl) : 0;
-        ne[q] = ok ? exc_n[s] : 0u;
-        Ts[q] = (keys[s] >> 12) & 63u;
-        ps[q] = exc + s * kListCap;
-        vs[q] = excv + s * kListCap;
-        // the column's side data in layout order (padding columns: zeros)
+        const bool ok = sk[q] != 0xFFFFFFFFu;
+        const uint64_t s = ok ? sk[q] : 0;
+        const uint32_t ne = nes[q];
+        const uint32_t key = Ts[q];
+        Ts[q] = (key >> 12) & 63u;
+        const PT *ps = exc + s * kListCap;
+        const uint8_t *vs = excv + s * kListCap;
         const uint64_t col = c0 + sl;
-        if (lane == 0) {
-            nS[col] = ne[q];
-            keyS[col] = ok ? keys[s] : 0u;
+        const bool mine = (uint32_t)q % G == g;  // the workgroups of a block share the columns' side data
+        // the column's side data in layout order (padding columns: zeros)
+        if (mine && lane == 0) {
+            nS[col] = ne;
+            keyS[col] = ok ? key : 0u;
             cardS[col] = ok ? card[s] : 0.;
         }
-        if (lane < 16) reinterpret_cast<uint32_t *>(thS + col * 64)[lane] = ok ? reinterpret_cast<const uint32_t *>(tailhist + s * 64)[lane] : 0u;
+        if (mine && lane < 16) reinterpret_cast<uint32_t *>(thS + col * 64)[lane] = ok ? reinterpret_cast<const uint32_t *>(tailhist + s * 64)[lane] : 0u;
+        // the sketch's 16 loads first, whether listed or not (a list has room for kListCap entries; selected afterwards):
+        // a load or store under a condition is a branch region of its own, and the loads went one by one
+        uint32_t pos[kPer], val[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            pos[u] = (uint32_t)ps[lane + 64u * (uint32_t)u];
+            val[u] = (uint32_t)vs[lane + 64u * (uint32_t)u];
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const uint32_t e = lane + 64u * (uint32_t)u;
+            pk[q][u] = e < ne ? ((pos[u] << 8) | val[u]) : 0xFFFFFFFFu;
+            // the compact list row, unused slots filled: k_finalize reads a row without asking for its length first
+            if (e < E && mine) rl[col * E + e] = pk[q][u];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the next sketch's loads stay behind this one's: 16 values in flight, not 128)
     }
-    uint32_t bk[kSk][kPer], pv[kSk][kPer];
+    auto bucket_of = [sh](uint32_t x, uint32_t T) -> uint32_t {  // (position group, upper | lower tail); none stays none
+        return x == 0xFFFFFFFFu ? x : ((((x >> 8) >> sh) << 1) | ((x & 0xFFu) > T ? 0u : 1u));
+    };
+    uint32_t below = 0;  // entries of the ranges below this workgroup's
 #pragma unroll
     for (int q = 0; q < kSk; ++q)
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
-            const uint32_t e = lane + 64u * (uint32_t)u;
-            const uint32_t pos = e < ne[q] ? (uint32_t)ps[q][e] : 0u;
-            const uint32_t val = e < ne[q] ? (uint32_t)vs[q][e] : 0u;
-            bk[q][u] = e < ne[q] ? (((pos >> sh) << 1) | (val > Ts[q] ? 0u : 1u)) : 0xFFFFFFFFu;
-            pv[q][u] = ((pos & ((1u << sh) - 1u)) << 13) | ((wave + 16u * (uint32_t)q) << 6) | val;
-            // the compact list row, unused slots filled: k_finalize reads a row without asking for its length first
-            if (e < E) rl[(c0 + wave + 16u * (uint32_t)q) * E + e] = e < ne[q] ? ((pos << 8) | val) : 0xFFFFFFFFu;
+            const uint32_t b = bucket_of(pk[q][u], Ts[q]);
+            const uint32_t rel = b - blo;  // (0xFFFFFFFF - blo >= nown: "none" is in no range)
+            if (rel < nown) atomicAdd(&cnt[rel], 1u);
+            else if (b < blo) ++below;
         }
+    if (G > 1) {
 #pragma unroll
-    for (int q = 0; q < kSk; ++q)
-#pragma unroll
-        for (int u = 0; u < kPer; ++u)
-            if (bk[q][u] != 0xFFFFFFFFu) atomicAdd(&cnt[bk[q][u]], 1u);
+        for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, 64);
+        if (lane == 0 && below) atomicAdd(&below_s, below);
+    }
     __syncthreads();
-    // exclusive scan: thread t owns the buckets [t*per, (t+1)*per)
-    const uint32_t per = (nbuckets + 1023) / 1024;
+    // exclusive scan: thread t owns the buckets [t*per, (t+1)*per) of the range
+    const uint32_t per = (nown + 1023) / 1024;
     uint32_t sum = 0;
-    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) sum += cnt[b];
+    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nown; ++b) sum += cnt[b];
     // block scan of the 1024 partial sums: within a wave by shuffles, across the 16 waves through part[]
     uint32_t incl = sum;
 #pragma unroll
@@ -327,9 +371,9 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
     __syncthreads();
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < wave; ++w) wbase += part[w];
-    uint32_t run = wbase + incl - sum;
-    uint32_t *myrec = rec + (uint64_t)blockIdx.x * nbuckets * RW;
-    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nbuckets; ++b) {
+    uint32_t run = below_s + wbase + incl - sum;
+    uint32_t *myrec = rec + ((uint64_t)blockIdx.x * nbuckets + blo) * RW;
+    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nown; ++b) {
         const uint32_t x = cnt[b];
         uint4 *r4 = reinterpret_cast<uint4 *>(myrec + (uint64_t)b * RW);
         r4[0] = make_uint4(x | (run << 16), 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -343,12 +387,18 @@ __global__ __launch_bounds__(1024) void k_build_colindex(const PT *__restrict__ 
     for (int q = 0; q < kSk; ++q)
 #pragma unroll
         for (int u = 0; u < kPer; ++u)
-            if (bk[q][u] != 0xFFFFFFFFu) {
-                const uint32_t w = atomicAdd(&cnt[bk[q][u]], 1u);
+        {
+            uint32_t x = pk[q][u];
+            asm volatile("" : "+v"(x));  // (re-derive the bucket: kept from the first pass, 64 of them went to scratch)
+            const uint32_t b = bucket_of(x, Ts[q]) - blo;
+            if (b < nown) {
+                const uint32_t pv = ((((x >> 8) & ((1u << sh) - 1u)) << 13) | ((wave + 16u * (uint32_t)q) << 6) | (x & 0xFFu));
+                const uint32_t w = atomicAdd(&cnt[b], 1u);
                 const uint32_t slot = w & 0xFFFFu, rel = slot - (w >> 16);
-                myent[slot] = pv[q][u];
-                if (rel < (uint32_t)RK) myrec[(uint64_t)bk[q][u] * RW + 1u + rel] = pv[q][u];
+                myent[slot] = pv;
+                if (rel < (uint32_t)RK) myrec[(uint64_t)b * RW + 1u + rel] = pv;
             }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,14 +466,31 @@ __global__ __launch_bounds__(256) void k_transform_t(const uint8_t *__restrict__
     const uint32_t i0 = blockIdx.x * 64;
     const uint64_t b0 = (uint64_t)blockIdx.y * 256;
     const uint64_t m = 1ull << p;
+    // the four 16-byte pieces of this thread: column indices first, then all four loads (from a clamped column where the
+    // block sticks out of the collection, masked afterwards), then the stores -- written as one loop the loads went one
+    // by one, each behind the previous piece's permutation look-up
+    uint32_t src_col[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = i0 + ((tid + 256u * r) >> 4);
+        src_col[r] = i < n ? i : (uint32_t)(n - 1);
+    }
+    if (perm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) src_col[r] = perm[src_col[r]];
+    }
+    uint4 piece[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t c = (tid + 256u * r) & 15u;
+        piece[r] = *reinterpret_cast<const uint4 *>(regs + (uint64_t)src_col[r] * m + b0 + c * 16u);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t q = tid + 256u * r;
         const uint32_t sl = q >> 4, c = q & 15u;
-        const uint32_t i = i0 + sl;
-        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // padding sketches: no bit ever set
-        if (i < n) v = *reinterpret_cast<const uint4 *>(regs + (uint64_t)(perm ? perm[i] : i) * m + b0 + c * 16u);
-        *reinterpret_cast<uint4 *>(stage + sl * kRow + c * 16u) = v;
+        if (i0 + sl >= n) piece[r] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // padding sketches: no bit ever set
+        *reinterpret_cast<uint4 *>(stage + sl * kRow + c * 16u) = piece[r];
     }
     __syncthreads();
     const uint32_t il = tid & 63u, g = tid >> 6;
@@ -1698,13 +1765,17 @@ hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uin
 hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c)
 {
     if (c.nblocks == 0) return hipSuccess;
-    const size_t lds = (size_t)c.nbuckets * sizeof(uint32_t);
+    // few column blocks (C3: 79; a rank of 8: 28-79): up to 4 workgroups per block, each a quarter of the buckets
+    uint32_t G = 1;
+    while (G < 4 && c.nblocks * G < 256 && c.nbuckets / (2 * G) >= 4096) G *= 2;
+    if (c.split == 1 || c.split == 2 || c.split == 4) G = std::min<uint32_t>((uint32_t)c.split, std::max<uint32_t>(1, c.nbuckets / 1024));
+    const size_t lds = (size_t)(c.nbuckets / G) * sizeof(uint32_t);
 #define DSH_COLINDEX(PT, RK)                                                                                                  \
     do {                                                                                                                      \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<PT, RK>),                          \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
         if (e != hipSuccess) return e;                                                                                        \
-        hipLaunchKernelGGL((k_build_colindex<PT, RK>), dim3(c.nblocks), dim3(1024), lds, st, (const PT *)c.exc, c.excv,       \
+        hipLaunchKernelGGL((k_build_colindex<PT, RK>), dim3(c.nblocks, G), dim3(1024), lds, st, (const PT *)c.exc, c.excv,    \
                            c.exc_n, c.keys, c.card, c.tailhist, c.perm, c.ncols, c.p, c.nbuckets, c.ent_stride, c.E, c.rec,    \
                            c.ent, c.nS, c.keyS, c.cardS, c.thS, c.rl);                                                         \
     } while (0)

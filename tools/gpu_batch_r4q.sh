@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU batch q: prepare kernels without scratch spills / with their loads in flight together
+# (k_build_colindex: one register per entry, split over bucket ranges; k_selfhist_card, k_transform_t: unconditional loads)
+set -x
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r4q
+mkdir -p "$O"
+timeout 900 python -m pytest tests/test_gpu_compare.py tests/test_gpu_fuzz.py tests/test_gpu_multirank.py -x -q > $O/pytest_part.log 2>&1; echo "rc $?" >> $O/pytest_part.log; tail -3 $O/pytest_part.log
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p --output-format csv -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-secondary --no-pmc --steps 10 > "$GRAFT_REPO_ROOT/$O/bench_under_rocprof.json" 2> "$GRAFT_REPO_ROOT/$O/bench_under_rocprof.err")
+f=$(find /tmp/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv
+python - <<'PY'
+import csv
+for r in csv.reader(open("gpurun_out/r4q/kernel_stats.csv")):
+    print(r[0][:45], r[1:4])
+PY
+: > $O/step_options.jsonl
+SETS=';colindex_split=1;colindex_split=2;colindex_split=4;' REPS=20 timeout 300 python tools/step_options.py >> $O/step_options.jsonl 2>> $O/step_options.err
+N=4000 SETS=';colindex_split=1;colindex_split=4' REPS=20 timeout 300 python tools/step_options.py >> $O/step_options.jsonl 2>> $O/step_options.err
+N=30000 P=10 SETS=';' REPS=5 timeout 300 python tools/step_options.py >> $O/step_options.jsonl 2>> $O/step_options.err
+cat $O/step_options.jsonl
