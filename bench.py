@@ -771,13 +771,22 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, G=200, L=5_000_000, p=10):
     oracle_c.sketch_batch(hs, np.arange(nc + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
     tc = time.perf_counter() - t0
     ksec = kernel_ms * 1e-3
-    binding = {"resource": "int VALU issue (Wang hash: 25 of ~47 VALU instructions per k-mer are 64-bit shifts/adds fixed by the bit-exactness contract)",
-               "frac": None, "valu_insts_per_kmer": None, "ceiling_cycles_per_valu_inst": 2.0}
+    # the kernel's static mix (tools/isa_mix.py kernels_sketch.hip _ZN3dsh8k_sketchILb0ELb1EEE: 1299 of its 2302 VALU
+    # instructions are full-rate VOP1/VOP2 moves, logic, adds and compares, 1003 are shifts, VOP3 forms, multiplies and the 64-bit
+    # ops of the Wang hash): nominal issue 2 / 4 cycles per wave64 instruction, measured alone 2.5 / 4.4 (profiles/ubench)
+    full_share = 0.5643
+    ceil_nominal = 2.0 * full_share + 4.0 * (1 - full_share)
+    ceil_measured = 2.5 * full_share + 4.4 * (1 - full_share)
+    binding = {"resource": "int VALU issue (the 64-bit Wang hash: v_mad_u64_u32 / v_lshrrev_b64 / v_lshlrev_b64, fixed by the bit-exactness contract, are 44 % half-rate instructions)",
+               "frac": None, "valu_insts_per_kmer": None, "ceiling_cycles_per_valu_inst": round(ceil_nominal, 3),
+               "ceiling_note": "mix-aware: %.1f %% full-rate (2 cycles per wave64 instruction) + %.1f %% half-rate (4); measured alone 2.5 / 4.4 -> %.2f" % (
+                   100 * full_share, 100 * (1 - full_share), ceil_measured)}
     if pm and pm.get("SQ_INSTS_VALU"):
         # the PMC child sketches PMC_SKETCH_GENOMES genomes of the same length: instructions per base carry over
         per_base = pm["SQ_INSTS_VALU"] * 64.0 / (PMC_SKETCH_GENOMES * L)
         cpi = ksec * CLOCK_HZ * N_SIMD / (per_base * bases / 64.0)
-        binding.update({"valu_insts_per_kmer": round(per_base, 2), "cycles_per_valu_inst": round(cpi, 3), "frac": round(2.0 / cpi, 4)})
+        binding.update({"valu_insts_per_kmer": round(per_base, 2), "cycles_per_valu_inst": round(cpi, 3), "frac": round(ceil_nominal / cpi, 4),
+                        "frac_of_isolated_rates": round(ceil_measured / cpi, 4)})
     traffic = hbm_bytes(pm)
     del seq
     torch.cuda.empty_cache()
