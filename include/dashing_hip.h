@@ -323,8 +323,11 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * byte-identical output over their ranges): "kc" (0 auto | 16 | 32 | 64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
- * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
- * "assembler_permille", "shard_c0_x10"; what-if only: "pair_mfma" (never the default).
+ * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles" (0|1: a tile's 128 rows on one XCD),
+ * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "colindex_split" (0 auto | 1 | 2 | 4
+ * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
+ * "assembler_permille", "shard_c0_x10"; profiling only: "finalize_timing" (the stamped instance of k_finalize, same results);
+ * what-if only: "pair_mfma" (refused unless the library was built with `make WHATIF=1`).
  * "finalize_stop" (1..4) is a profiling aid that DOES change results (k_finalize leaves after a phase and stores a dummy):
  * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);

@@ -566,7 +566,7 @@ def test_set_triple_measures(ctx, oracle, rt):
     assert np.allclose(rect[f2], wr[f2], rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("p", [9, 10, 12, 13])
+@pytest.mark.parametrize("p", [9, 10, 12, 13, 14])
 def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
     """round 4: the position index keeps a bucket's first 7 (p <= 12, lists of <= 256 entries) or 3 entries inside its
     record; list caps beyond 256 entries switch a small-p collection to the narrow records and four look-up rounds; the
@@ -586,6 +586,9 @@ def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
                 ctx.set_option("finalize_xcd_tiles", xcd)
                 assert ctx.dist_rows().tobytes() == base.tobytes(), (p, emax, elow, xcd)
             assert ctx.dist_rows(estim=dashing_amd.ESTIM_ORIGINAL).tobytes() != b""  # (runs; checked against the oracle below)
+        for split in (1, 2, 4, 0):  # workgroups per column block of the index build (each owns a range of the buckets)
+            ctx.set_option("colindex_split", split)
+            assert ctx.dist_rows().tobytes() == base.tobytes(), (p, "colindex_split", split)
         ctx.set_option("emax", 255)
         ctx.set_option("elow", 255)
         for estim in (0, 1, 2):  # every estimator on the narrow-record path of a small p
@@ -595,6 +598,7 @@ def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
         ctx.set_option("emax", -1)
         ctx.set_option("elow", -1)
         ctx.set_option("finalize_xcd_tiles", 1)
+        ctx.set_option("colindex_split", 0)
 
 
 @pytest.mark.parametrize("p", [8, 11, 15])
