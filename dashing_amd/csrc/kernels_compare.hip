@@ -51,7 +51,7 @@ namespace dsh {
 // (k_build_colindex), nothing walks them in order.
 // key = bad << 31 | hi << 18 | T << 12 | L << 6 | lo.
 template <typename PT>
-__global__ __launch_bounds__(256) void k_selfhist_card(const uint8_t *__restrict__ regs, uint64_t first,
+__global__ __launch_bounds__(256, 4) void k_selfhist_card(const uint8_t *__restrict__ regs, uint64_t first,
                                                         uint64_t n, int p, int estim, int emax, int elow,
                                                         uint32_t *__restrict__ hist_out,
                                                         PT *__restrict__ exc,

@@ -601,6 +601,26 @@ def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
         ctx.set_option("colindex_split", 0)
 
 
+@pytest.mark.parametrize("p", [16, 22, 23])
+def test_constant_sketches_at_large_p(ctx, oracle, p):
+    """Sketches whose registers are all equal (or of two values) at 2^16 ... 2^23 registers: every count of the per-sketch
+    histogram lands in one or two bins -- the case that overflows a counter narrower than the sketch is long, and the
+    one in which every LDS atomic of a wave hits the same address."""
+    regs = np.empty((3, 1 << p), np.uint8)
+    regs[0] = 5
+    regs[1] = 6
+    regs[2] = 5
+    regs[2, ::2] = 4
+    ctx.set_sketches(regs)
+    for estim in (0, 2):
+        got = ctx.cardinalities(estim)
+        want = oracle.cardinalities(regs, estim)
+        assert np.allclose(got, want, rtol=1e-12, atol=0), (p, estim, got, want)
+    got = ctx.dist_rows()
+    want = oracle.dist_tri(regs)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-15)
+
+
 @pytest.mark.parametrize("p", [8, 11, 15])
 def test_adversarial_registers(ctx, oracle, p):
     """Register arrays that do NOT follow the HLL law: uniform random over the whole value range
