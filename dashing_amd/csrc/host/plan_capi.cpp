@@ -206,6 +206,7 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
         if (sa != bd.second) return E.fail("segments of band %zu end at %zu, not %zu", bi, sa, bd.second);
         // items of the band cover every tile's chunk range exactly once
         const auto &bi_ = pp.band_items[bi];
+        if (band_item_count(tu, pp, bi) != bi_.second - bi_.first) return E.fail("band %zu: band_item_count disagrees with the items built", bi);
         std::vector<uint32_t> next(bd.second - bd.first);
         for (size_t t = bd.first; t < bd.second; ++t) next[t - bd.first] = pp.chunks[t].x;
         std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per(bd.second - bd.first);

@@ -285,7 +285,7 @@ static void tile_vrange(const Layout &L, const U4 &t, int &lo, int &hi)
     if (hi < lo) hi = lo;  // (blocks of padding only)
 }
 
-bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPlan &pp)
+bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPlan &pp)
 {
     std::vector<U4> &T = pp.T;
     T.clear();
@@ -299,17 +299,27 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     const uint32_t NT = L.Npad / kTile;
     // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes
     // v in (max(min lo of its two blocks), max threshold of its two blocks]
-    auto tile_of = [&](uint32_t ti, uint32_t tj) {
-        int pb, pe;
-        tile_planes(L, ti, tj, pb, pe);
-        return U4{ti, tj, (uint32_t)pb, (uint32_t)pe};
+    // (a row of tiles at a time, the row block's statistics in registers: at 100 000 sketches this loop writes 306 000
+    // tiles and the host's planning is not hidden behind anything the GPU does -- profiles/r4y)
+    const uint8_t *bLo = L.blk_lo.data(), *bL = L.blk_L.data(), *bT = L.blk_T.data();
+    const int pbase = L.pbase;
+    auto tile_row = [&](uint32_t ti, uint32_t c0, uint32_t c1) {
+        const size_t at = T.size();
+        T.resize(at + (c1 - c0));
+        U4 *out = T.data() + at;
+        const int lo_i = bLo[ti], L_i = bL[ti], T_i = bT[ti];
+        for (uint32_t tj = c0; tj < c1; ++tj) {  // tile_planes(), inlined
+            const int lo_t = std::max(std::max<int>(lo_i, bLo[tj]), std::min<int>(L_i, bL[tj]));
+            const int pb = std::max(0, lo_t - pbase), pe = std::max(pb, std::max<int>(T_i, bT[tj]) - pbase);
+            *out++ = U4{ti, tj, (uint32_t)pb, (uint32_t)pe};
+        }
     };
     if (job.rect) {
         if (job.row_begin >= job.row_end || job.col_begin >= job.col_end) return false;
         const uint32_t r0 = (uint32_t)(job.row_begin / kTile), r1 = (uint32_t)((job.row_end + kTile - 1) / kTile);
         const uint32_t c0 = (uint32_t)(job.col_begin / kTile), c1 = (uint32_t)((job.col_end + kTile - 1) / kTile);
-        for (uint32_t ti = r0; ti < r1; ++ti)
-            for (uint32_t tj = c0; tj < c1; ++tj) T.push_back(tile_of(ti, tj));
+        T.reserve((size_t)(r1 - r0) * (c1 - c0));
+        for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, c0, c1);
     } else {
         if (job.row_begin >= job.row_end) return false;
         uint32_t r0 = 0, r1 = NT;
@@ -319,8 +329,8 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
         } else {  // the wanted rows are the first re - rb columns
             r1 = std::min<uint32_t>(NT, (uint32_t)((L.re - L.rb + kTile - 1) / kTile));
         }
-        for (uint32_t ti = r0; ti < r1; ++ti)
-            for (uint32_t tj = ti; tj < NT; ++tj) T.push_back(tile_of(ti, tj));
+        if (r1 > r0) T.reserve((size_t)(r1 - r0) * (NT - r0) - (size_t)(r1 - r0) * (r1 - r0 - 1) / 2);
+        for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, ti, NT);
     }
     if (T.empty()) return false;
     // bands bounded by the cum scratch budget
@@ -388,47 +398,90 @@ bool build_pairs(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     if (tu.xcd_swizzle)
         for (auto &sv : pp.segs)
             for (auto &sg : sv) xcd_order(T, rank, sg.b, sg.e, tu.lockstep ? 2 : 1);
-    // work items per band: {tile index in band, chunk begin, chunk end}
+    // chunk range of every tile (the work items of a band are cut from these: build_band_items)
     const uint32_t KC = (uint32_t)tu.kc;
-    std::vector<U4> &I = pp.items;
     const uint32_t cpp = tu.W >= KC ? tu.W / KC : 1;  // chunks per plane when a plane spans chunks
-    std::vector<U2> &CR = pp.chunks;  // chunk range of every tile, computed once
+    std::vector<U2> &CR = pp.chunks;
     CR.resize(T.size());
-    for (size_t t = 0; t < T.size(); ++t)
-        CR[t] = U2{(uint32_t)(((uint64_t)T[t].z * tu.W) / KC), (uint32_t)(((uint64_t)T[t].w * tu.W + KC - 1) / KC)};
-    for (auto &bd : pp.bands) {
-        const size_t nt = bd.second - bd.first;
-        pp.max_band = std::max(pp.max_band, nt);
-        uint64_t tot = 0;
-        for (size_t t = bd.first; t < bd.second; ++t) tot += CR[t].y - CR[t].x;
-        // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
-        uint64_t piece = tu.nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + tu.nsplit - 1) / tu.nsplit)
-                                       : std::max<uint64_t>(1, tot / (16 * 512));
-        if (tu.nsplit == 0 && tu.lockstep)  // equal, short items: the two items of a workgroup run in lockstep
-            piece = std::min<uint64_t>(piece, std::max<uint64_t>(cpp, (uint64_t)tu.ls_item_chunks));
-        piece = (piece + cpp - 1) / cpp * cpp;
-        const size_t i0 = I.size();
-        uint32_t maxpieces = 0;
-        for (size_t t = bd.first; t < bd.second; ++t)
-            maxpieces = std::max<uint32_t>(maxpieces, (uint32_t)((CR[t].y - CR[t].x + piece - 1) / piece));
-        for (uint32_t s = 0; s < maxpieces; ++s) {  // piece-major so neighbours in launch order share planes
-            const size_t g0 = I.size();
-            uint32_t lmin = ~0u, lmax = 0;
-            for (size_t t = bd.first; t < bd.second; ++t) {
-                const uint64_t b0 = CR[t].x + (uint64_t)s * piece;
-                if (b0 >= CR[t].y) continue;
-                const uint32_t e0 = (uint32_t)std::min<uint64_t>(CR[t].y, b0 + piece);
-                I.push_back(U4{(uint32_t)(t - bd.first), (uint32_t)b0, e0, 0});
-                lmin = std::min<uint32_t>(lmin, e0 - (uint32_t)b0);
-                lmax = std::max<uint32_t>(lmax, e0 - (uint32_t)b0);
-            }
-            // the lockstep kernel pairs consecutive items: keep equal lengths together (only a tile's last piece can be
-            // shorter; with whole-plane pieces every item of the group is the same length and there is nothing to do)
-            if (tu.lockstep && tu.ls_sort_items && lmin != lmax)
-                std::stable_sort(I.begin() + g0, I.end(), [](const U4 &x, const U4 &y) { return x.z - x.y > y.z - y.y; });
-        }
-        pp.band_items.emplace_back(i0, I.size());
+    if (tu.W >= KC) {  // whole chunks per plane (both powers of two)
+        for (size_t t = 0; t < T.size(); ++t) CR[t] = U2{T[t].z * cpp, T[t].w * cpp};
+    } else {
+        for (size_t t = 0; t < T.size(); ++t)
+            CR[t] = U2{(uint32_t)(((uint64_t)T[t].z * tu.W) / KC), (uint32_t)(((uint64_t)T[t].w * tu.W + KC - 1) / KC)};
     }
+    for (auto &bd : pp.bands) pp.max_band = std::max(pp.max_band, bd.second - bd.first);
+    return true;
+}
+
+// work items of band bi, appended to pp.items (bands in order): {tile index in band, chunk begin, chunk end}
+void build_band_items(const Tuning &tu, PairPlan &pp, size_t bi)
+{
+    const auto &bd = pp.bands[bi];
+    const std::vector<U2> &CR = pp.chunks;
+    std::vector<U4> &I = pp.items;
+    const uint32_t KC = (uint32_t)tu.kc;
+    const uint32_t cpp = tu.W >= KC ? tu.W / KC : 1;
+    const size_t nt = bd.second - bd.first;
+    uint64_t tot = 0;
+    uint32_t maxlen = 0;
+    for (size_t t = bd.first; t < bd.second; ++t) {
+        const uint32_t len = CR[t].y - CR[t].x;
+        tot += len;
+        maxlen = std::max(maxlen, len);
+    }
+    // piece size: whole planes, aiming at >= 16 items per resident workgroup slot (512)
+    uint64_t piece = tu.nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + tu.nsplit - 1) / tu.nsplit)
+                                   : std::max<uint64_t>(1, tot / (16 * 512));
+    if (tu.nsplit == 0 && tu.lockstep)  // equal, short items: the two items of a workgroup run in lockstep
+        piece = std::min<uint64_t>(piece, std::max<uint64_t>(cpp, (uint64_t)tu.ls_item_chunks));
+    piece = (piece + cpp - 1) / cpp * cpp;
+    const size_t i0 = I.size();
+    const uint32_t maxpieces = (uint32_t)((maxlen + piece - 1) / piece);
+    // Piece-major, so that neighbours in launch order share planes.  The lockstep kernel pairs consecutive items: inside
+    // a group of pieces equal lengths are kept together, longest first, tiles in order (only a tile's last piece can be
+    // shorter; with whole-plane pieces every item of the group has the same length and nothing moves).  One counting
+    // pass, one placing pass: at 100 000 sketches the host plans 306 000 tiles and nothing hides it (profiles/r4y).
+    const bool by_length = tu.lockstep && tu.ls_sort_items && piece <= 65536;
+    std::vector<uint32_t> &first = pp.sort_first;
+    for (uint32_t s = 0; s < maxpieces; ++s) {
+        const size_t g0 = I.size();
+        const uint64_t off = (uint64_t)s * piece;
+        size_t cnt = 0;
+        uint32_t lmin = ~0u, lmax = 0;
+        if (by_length) first.assign((size_t)piece + 2, 0);
+        for (size_t t = bd.first; t < bd.second; ++t) {
+            const uint64_t b0 = CR[t].x + off;
+            if (b0 >= CR[t].y) continue;
+            const uint32_t len = (uint32_t)std::min<uint64_t>(CR[t].y - b0, piece);
+            ++cnt;
+            lmin = std::min(lmin, len);
+            lmax = std::max(lmax, len);
+            if (by_length) ++first[piece - len + 1];
+        }
+        I.resize(g0 + cnt);
+        U4 *out = I.data() + g0;
+        const bool place = by_length && lmin != lmax;
+        if (place)
+            for (size_t v = 1; v < first.size(); ++v) first[v] += first[v - 1];
+        for (size_t t = bd.first; t < bd.second; ++t) {
+            const uint64_t b0 = CR[t].x + off;
+            if (b0 >= CR[t].y) continue;
+            const uint32_t len = (uint32_t)std::min<uint64_t>(CR[t].y - b0, piece);
+            const U4 it{(uint32_t)(t - bd.first), (uint32_t)b0, (uint32_t)b0 + len, 0};
+            if (place) out[first[piece - len]++] = it;
+            else *out++ = it;
+        }
+        if (!by_length && tu.lockstep && tu.ls_sort_items && lmin != lmax)
+            std::stable_sort(I.begin() + g0, I.end(), [](const U4 &x, const U4 &y) { return x.z - x.y > y.z - y.y; });
+    }
+    if (pp.band_items.size() <= bi) pp.band_items.resize(bi + 1);
+    pp.band_items[bi] = std::make_pair(i0, I.size());
+}
+
+bool build_pairs(const Layout &L, const PairQuery &q, const Tuning &t, PairPlan &pp)
+{
+    if (!build_tiles(L, q, t, pp)) return false;
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi) build_band_items(t, pp, bi);
     return true;
 }
 
@@ -443,21 +496,45 @@ void emit_tile_lists(const Layout &L, const PairPlan &pp, U4 *pinT, U4 *pinF)
     // L2.  Walking a tile row's tiles one after the other keeps that row's lines in L2 until they are complete (the 128
     // rows of a tile row are 5 MB at C3, spread over the 8 L2s); in the tile kernel's interleaved order 8 tile rows were
     // in flight at once, lines left the L2 partly written and WRITE_SIZE was 6x the output (profiles/r3a, r3i).
+    for (size_t bi = 0; bi < pp.bands.size(); ++bi) emit_band_lists(L, pp, bi, pinT, pinF);
+}
+
+void emit_band_lists(const Layout &L, const PairPlan &pp, size_t bi, U4 *pinT, U4 *pinF)
+{
     const std::vector<U4> &T = pp.T;
-    for (size_t t = 0; t < T.size(); ++t) {
-        int lo, hi;
-        tile_vrange(L, T[t], lo, hi);
-        pinT[t] = U4{T[t].x, T[t].y, T[t].z | (T[t].w << 8), (uint32_t)lo | ((uint32_t)hi << 8)};
+    const size_t b0 = pp.bands[bi].first;
+    for (const Seg &sg : pp.segs[bi])
+        for (size_t t = sg.b; t < sg.e; ++t) {
+            int lo, hi;
+            tile_vrange(L, T[t], lo, hi);
+            const uint32_t pl = T[t].z | (T[t].w << 8);
+            pinT[t] = U4{T[t].x, T[t].y, pl, (uint32_t)lo | ((uint32_t)hi << 8)};
+            const size_t at = pp.finalize_rowmajor ? sg.b + pp.rank[t] : t;
+            pinF[at] = U4{T[t].x, T[t].y, pl | ((uint32_t)lo << 16) | ((uint32_t)hi << 24), (uint32_t)(t - b0)};
+        }
+}
+
+uint64_t band_item_count(const Tuning &tu, const PairPlan &pp, size_t bi)
+{
+    // (the arithmetic of build_band_items, without writing anything: the device and staging buffers are sized before the
+    // first band is launched)
+    const auto &bd = pp.bands[bi];
+    const std::vector<U2> &CR = pp.chunks;
+    const uint32_t KC = (uint32_t)tu.kc;
+    const uint32_t cpp = tu.W >= KC ? tu.W / KC : 1;
+    const size_t nt = bd.second - bd.first;
+    uint64_t tot = 0;
+    for (size_t t = bd.first; t < bd.second; ++t) tot += CR[t].y - CR[t].x;
+    uint64_t piece = tu.nsplit > 0 ? std::max<uint64_t>(1, (tot / std::max<size_t>(nt, 1) + tu.nsplit - 1) / tu.nsplit)
+                                   : std::max<uint64_t>(1, tot / (16 * 512));
+    if (tu.nsplit == 0 && tu.lockstep) piece = std::min<uint64_t>(piece, std::max<uint64_t>(cpp, (uint64_t)tu.ls_item_chunks));
+    piece = (piece + cpp - 1) / cpp * cpp;
+    uint64_t cnt = 0;
+    for (size_t t = bd.first; t < bd.second; ++t) {
+        const uint64_t len = CR[t].y - CR[t].x;
+        cnt += len <= piece ? (len ? 1 : 0) : (len + piece - 1) / piece;
     }
-    for (size_t bi = 0; bi < pp.bands.size(); ++bi)
-        for (const Seg &sg : pp.segs[bi])
-            for (size_t t = sg.b; t < sg.e; ++t) {
-                int lo, hi;
-                tile_vrange(L, T[t], lo, hi);
-                const size_t at = pp.finalize_rowmajor ? sg.b + pp.rank[t] : t;
-                pinF[at] = U4{T[t].x, T[t].y, T[t].z | (T[t].w << 8) | ((uint32_t)lo << 16) | ((uint32_t)hi << 24),
-                              (uint32_t)(t - pp.bands[bi].first)};
-            }
+    return cnt;
 }
 
 }  // namespace plan

@@ -129,14 +129,24 @@ struct PairPlan {
     size_t max_band = 0;                                 // tiles of the largest band
     uint32_t nparts = 0;                                 // parts that get an event (0 without want_parts)
     int finalize_rowmajor = 1;
+    std::vector<uint32_t> sort_first;                    // scratch of the item sort
+    std::vector<U4> sort_tmp;
 };
 
 // returns false when there is nothing to compute
 bool build_pairs(const Layout &L, const PairQuery &q, const Tuning &t, PairPlan &pp);
+// the same in two steps, so that a caller can launch band b while it plans band b + 1 (engine.hip): tiles, bands,
+// segments and chunk ranges of the whole job, then the work items of one band at a time (in band order)
+bool build_tiles(const Layout &L, const PairQuery &q, const Tuning &t, PairPlan &pp);
+void build_band_items(const Tuning &t, PairPlan &pp, size_t band);
 // the two device lists: the tile kernel's {row block, col block, pb | pe << 8, lo | hi << 8} in launch order and
 // k_finalize's {row block, col block, pb | pe << 8 | lo << 16 | hi << 24, index of the tile's C(v) block in its band},
 // every segment row-major
 void emit_tile_lists(const Layout &L, const PairPlan &pp, U4 *tiles_out, U4 *ftiles_out);
+// one band's entries of the two lists (the same arrays, the band's own index range)
+void emit_band_lists(const Layout &L, const PairPlan &pp, size_t band, U4 *tiles_out, U4 *ftiles_out);
+// how many items build_band_items will append for the band
+uint64_t band_item_count(const Tuning &t, const PairPlan &pp, size_t band);
 
 }  // namespace plan
 }  // namespace dsh

@@ -45,6 +45,6 @@ for opts in os.environ.get("SETS", "").split(";"):
     if ref is None:
         ref = out.clone()
     print(json.dumps({"n": n, "p": p, "options": opts, "step_ms": round(best * 1e3, 3), "prepare_ms": round(km["prepare_ms"], 3),
-                      "pair_ms": round(km["pair_ms"], 3), "finalize_ms": round(km["finalize_ms"], 3), "bands": ctx.info("bands"),
+                      "pair_ms": round(km["pair_ms"], 3), "finalize_ms": round(km["finalize_ms"], 3), "bands": ctx.info("bands"), "host_us": {k: ctx.info("host_" + k + "_us") for k in ("keys_wait", "layout", "lists")},
                       "same_as_first": bool(torch.equal(out, ref))}), flush=True)
     ctx.close()
