@@ -145,16 +145,18 @@ void sort_rows_by_key(const uint32_t *k32, uint64_t lo, uint64_t hi, uint32_t *d
     const uint64_t cnt_ = hi - lo;
     if (a.size() < 2 * cnt_) a.resize(2 * cnt_);  // [indices after the first digit | sort keys]
     uint32_t *const ks = a.data() + cnt_;
-    for (uint64_t i = 0; i < cnt_; ++i) ks[i] = skey(lo + i);
-    uint32_t cnt[513];
-    std::memset(cnt, 0, sizeof cnt);
-    for (uint64_t i = 0; i < cnt_; ++i) cnt[(ks[i] & 511u) + 1u]++;
-    for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
-    for (uint64_t i = 0; i < cnt_; ++i) a[cnt[ks[i] & 511u]++] = (uint32_t)i;
-    std::memset(cnt, 0, sizeof cnt);
-    for (uint64_t i = 0; i < cnt_; ++i) cnt[((ks[a[i]] >> 9) & 511u) + 1u]++;
-    for (int k = 1; k < 513; ++k) cnt[k] += cnt[k - 1];
-    for (uint64_t i = 0; i < cnt_; ++i) dst[cnt[(ks[a[i]] >> 9) & 511u]++] = (uint32_t)(lo + a[i]);
+    uint32_t c0[513], c1[513];  // both digits counted in the pass that makes the sort keys
+    std::memset(c0, 0, sizeof c0);
+    std::memset(c1, 0, sizeof c1);
+    for (uint64_t i = 0; i < cnt_; ++i) {
+        const uint32_t k = skey(lo + i);
+        ks[i] = k;
+        c0[(k & 511u) + 1u]++;
+        c1[(k >> 9) + 1u]++;
+    }
+    for (int k = 1; k < 513; ++k) c0[k] += c0[k - 1], c1[k] += c1[k - 1];
+    for (uint64_t i = 0; i < cnt_; ++i) a[c0[ks[i] & 511u]++] = (uint32_t)i;
+    for (uint64_t i = 0; i < cnt_; ++i) dst[c1[ks[a[i]] >> 9]++] = (uint32_t)(lo + a[i]);
 }
 
 void rowsorted_offsets(uint64_t n, const uint32_t *order, uint64_t cnt, std::vector<uint64_t> &rowoff)
@@ -238,14 +240,22 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     L.blk_L.assign(NT, 255);
     L.blk_hi.assign(NT, 0);
     int pbase = vr[2];
-    for (uint64_t s = 0; s < ncols; ++s) {
-        const uint32_t key = k32[L.perm[s]];
-        const uint32_t b = (uint32_t)(s / kTile);
-        L.blk_T[b] = std::max<uint8_t>(L.blk_T[b], (uint8_t)key_T(key));
-        L.blk_lo[b] = std::min<uint8_t>(L.blk_lo[b], (uint8_t)key_lo(key));
-        L.blk_L[b] = std::min<uint8_t>(L.blk_L[b], (uint8_t)key_L(key));
-        L.blk_hi[b] = std::max<uint8_t>(L.blk_hi[b], (uint8_t)key_hi(key));
-        pbase = std::min<int>(pbase, key_L(key));
+    const uint32_t *perm = L.perm.data();
+    for (uint32_t b = 0; b < NT; ++b) {  // (a block at a time, its four statistics in registers)
+        const uint64_t s0 = (uint64_t)b * kTile, s1 = std::min<uint64_t>(ncols, s0 + kTile);
+        int bt = 0, blo = 255, bl = 255, bhi = 0;
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint32_t key = k32[perm[s]];
+            bt = std::max(bt, key_T(key));
+            blo = std::min(blo, key_lo(key));
+            bl = std::min(bl, key_L(key));
+            bhi = std::max(bhi, key_hi(key));
+        }
+        L.blk_T[b] = (uint8_t)bt;
+        L.blk_lo[b] = (uint8_t)blo;
+        L.blk_L[b] = (uint8_t)bl;
+        L.blk_hi[b] = (uint8_t)bhi;
+        pbase = std::min(pbase, bl);
     }
     // dense planes cover v in (pbase, Tmax]: below the smallest low threshold every C(v) comes from the list join
     L.pbase = pbase;
