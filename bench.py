@@ -445,8 +445,11 @@ def run(args, backend, world, rank, line, dist_on):
         rccl_info = {"library": path, "nccl_version_code": ver, "available_on_rank0": dashing_amd.comm_available(),
                      "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
                      "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None}
-        if backend == "nccl" and os.environ.get("DSH_BENCH_EXCHANGE", "cabi") == "cabi":
-            flag = torch.tensor([1 if dashing_amd.comm_available() else 0], device=dev)
+        # (DSH_BENCH_EXCHANGE=cabi-mock with the gloo dry run: the C-ABI exchange between the ranks sharing cuda:0 over the
+        # stand-in transport of tests/mock_rccl, DSH_RCCL_LIB -- the code path of a real run, never a reported number)
+        want_x = os.environ.get("DSH_BENCH_EXCHANGE", "cabi")
+        if (backend == "nccl" and want_x == "cabi") or (backend == "gloo" and want_x == "cabi-mock"):
+            flag = torch.tensor([1 if dashing_amd.comm_available() else 0], device=cpu_or_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item()) == 1
             why = None if ok else "librccl not loadable by libdashing_hip.so on at least one rank (%s)" % path
@@ -456,7 +459,7 @@ def run(args, backend, world, rank, line, dist_on):
                 except Exception as e:  # noqa: BLE001
                     ok, why = False, "dsh_comm_init failed on rank %d: %s" % (rank, e)
                 mine_ok = ok
-                flag = torch.tensor([1 if ok else 0], device=dev)
+                flag = torch.tensor([1 if ok else 0], device=cpu_or_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks or none
                 if int(flag.item()) == 0:
                     if mine_ok:

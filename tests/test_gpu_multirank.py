@@ -331,3 +331,26 @@ def test_exchange_protocol_other_destination_and_ragged_ranges(tmp_path):
     """the destination need not be rank 0, a rank may own no rows at all, another a single row"""
     run_mock_world(tmp_path, 4, 1700, 12, 3, "exchange", dst=2, bounds=[0, 0, 640, 1699, 1700])
     run_mock_world(tmp_path, 3, 1700, 12, 2, "parts", dst=1, bounds=[0, 900, 900, 1700])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
+    """`python bench.py --gpus 2`, the multi-rank step of the driver's scaling run (dsh_exchange_rows_device_async +
+    dsh_exchange_collect_async + dsh_comm_wait per step), on the one-GPU box: two ranks on cuda:0, the library's RCCL calls
+    served by tests/mock_rccl.  The line names the exchange that ran and the assembled matrix equals the single-GPU one."""
+    import json
+
+    if not os.path.exists(MOCK):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(MOCK)])
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+               {"DSH_BENCH_BACKEND": "gloo", "DSH_BENCH_EXCHANGE": "cabi-mock", "DSH_RCCL_LIB": MOCK, "DSH_BENCH_N": "3000",
+                "MOCK_RCCL_TIMEOUT_S": "240"}, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    line = json.loads(lines[0])
+    mg = line["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["exchange"].startswith("c-abi rccl"), mg
+    assert "mock_rccl" in mg["exchange_library"]["library"]
+    assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
