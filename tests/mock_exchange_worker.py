@@ -34,7 +34,7 @@ def main():
     else:
         t0 = time.time()
         while not os.path.exists(idf):
-            assert time.time() - t0 < 60, "rank 0 never wrote the id"
+            assert time.time() - t0 < 300, "rank 0 never wrote the id"
             time.sleep(0.01)
         uid = open(idf, "rb").read()
     regs = torch.from_numpy(synth.survey_sketches(n, p, seed=0xE0C)[0]).cuda()

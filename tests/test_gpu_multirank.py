@@ -284,7 +284,7 @@ MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
 MOCK_WORKER = os.path.join(ROOT, "tests", "mock_exchange_worker.py")
 
 
-def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=420):
+def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=900):
     """`world` processes on the one GPU, the library's RCCL calls served by tests/mock_rccl (messages as files, matched
     by order, peer and exact size)"""
     if not os.path.exists(MOCK):
