@@ -54,7 +54,8 @@ static void release_ctx(dsh_ctx *c)
     c->pin_rowoff.release();
     c->pin_xch.release();
     for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab}) {
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_band_tiles,
+                          &c->ev_band_aux}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
     }
@@ -88,7 +89,9 @@ int dsh_create(int device, dsh_ctx **out)
         create_copy_stream(&c->copy_stream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_band_tiles, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_band_aux, hipEventDisableTiming) != hipSuccess) {
         release_ctx(c);
         delete c;
         return DSH_EIO;
@@ -822,6 +825,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     }
     if (!std::strcmp(name, "ls_sort_items")) {
         c->ls_sort_items = v != 0;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_two_streams")) {
+        c->finalize_two_streams = v != 0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "colindex_split")) {

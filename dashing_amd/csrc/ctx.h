@@ -84,6 +84,7 @@ struct dsh_ctx {
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // prepare(): the column index is built next to the bit-plane transform
     hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    hipEvent_t ev_band_tiles = nullptr, ev_band_aux = nullptr;  // a band's C(v) ready / its k_finalize launches on the second stream done
     bool aux_join_pending = false;
     DevBuf outbuf2[2];
     hipEvent_t ev_filled[2] = {nullptr, nullptr};  // kernels of the call that filled outbuf2[b] done (recorded on stream)
@@ -149,6 +150,7 @@ struct dsh_ctx {
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int ls_sort_items = 1;
+    int finalize_two_streams = 1;  // the k_finalize launches of a call with parts alternate between the two streams (profiles/r5f)
     int colindex_split = 0;  // workgroups per column block of k_build_colindex (0: automatic)
     int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto

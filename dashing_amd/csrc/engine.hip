@@ -338,7 +338,20 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                          L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
+        // (option finalize_two_streams) the k_finalize launches of a band with several segments alternate between the ctx
+        // stream and the second stream: the tail of one launch runs beside the head of the next.  The second stream starts
+        // behind the band's tile kernel and the ctx stream joins it again before the band's C(v) scratch is overwritten.
+        const bool two = c->finalize_two_streams && pp.segs[bi].size() > 1;
+        bool aux_used = false;
+        if (two) {
+            HIPCHK(c, hipEventRecord(c->ev_band_tiles, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_band_tiles, 0));
+        }
+        size_t seg_no = 0;
         for (const plan::Seg &sg : pp.segs[bi]) {
+            const bool on_aux = two && (seg_no++ & 1);
+            hipStream_t fst = on_aux ? c->aux_stream : c->stream;
+            aux_used = aux_used || on_aux;
             FinalizeLaunch f;
             f.cum = c->cum.ptr;  // the band's C(v); a tile's block is named by its descriptor
             f.cum_bytes = c->cum_bytes;
@@ -381,11 +394,11 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.col_end = job.col_end;
             f.base_index = job.base_index;
             f.out = job.d_out;
-            if (c->aux_join_pending) {
+            if (c->aux_join_pending && !on_aux) {  // (the second stream is behind the index build by stream order)
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
                 c->aux_join_pending = false;
             }
-            HIPCHK(c, launch_finalize(c->stream, f));
+            HIPCHK(c, launch_finalize(fst, f));
             if (sg.part >= 0) {  // this segment completes a part: its span of the matrix is final
                 const size_t qp = (size_t)sg.part;
                 while (c->ev_part.size() <= qp) {
@@ -393,9 +406,13 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                     HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
                     c->ev_part.push_back(e);
                 }
-                HIPCHK(c, hipEventRecord(c->ev_part[qp], c->stream));
+                HIPCHK(c, hipEventRecord(c->ev_part[qp], fst));
                 c->parts_done = (uint32_t)qp + 1;
             }
+        }
+        if (aux_used) {  // the ctx stream goes on (next band's tile kernel, the end of the call) behind the second stream
+            HIPCHK(c, hipEventRecord(c->ev_band_aux, c->aux_stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_band_aux, 0));
         }
         if (d) (void)hipEventRecord(d, c->stream);
         if (a && b && d) {

@@ -324,7 +324,8 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
  * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles" (0|1: a tile's 128 rows on one XCD),
- * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "colindex_split" (0 auto | 1 | 2 | 4
+ * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "finalize_two_streams" (0|1: the
+ * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4
  * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
  * "assembler_permille", "shard_c0_x10"; profiling only: "finalize_timing" (the stamped instance of k_finalize, same results);
  * what-if only: "pair_mfma" (refused unless the library was built with `make WHATIF=1`).

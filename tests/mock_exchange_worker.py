@@ -39,6 +39,9 @@ def main():
         uid = open(idf, "rb").read()
     regs = torch.from_numpy(synth.survey_sketches(n, p, seed=0xE0C)[0]).cuda()
     ctx = dashing_amd.Context(0)
+    for kv in filter(None, os.environ.get("OPTS", "").split(",")):
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     ctx.attach_device(regs.data_ptr(), n, p)
     ctx.comm_init(uid, rank, world)
     assert ctx.comm_rank() == (rank, world)

@@ -284,14 +284,14 @@ MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
 MOCK_WORKER = os.path.join(ROOT, "tests", "mock_exchange_worker.py")
 
 
-def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=900):
+def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=900, opts=""):
     """`world` processes on the one GPU, the library's RCCL calls served by tests/mock_rccl (messages as files, matched
     by order, peer and exact size)"""
     if not os.path.exists(MOCK):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(MOCK)])
     env = dict(os.environ, DSH_RCCL_LIB=MOCK, WORLD=str(world), N=str(n), P=str(p), NPARTS=str(nparts), MODE=mode, DST=str(dst),
                ID_FILE=str(tmp_path / ("id_%s_%d" % (mode, world))), MOCK_RCCL_TIMEOUT_S="240", DSH_COMM_TIMEOUT_S="300",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OPTS=opts)
     if bounds:
         env["BOUNDS"] = ",".join(str(b) for b in bounds)
     procs = [subprocess.Popen([sys.executable, MOCK_WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -354,3 +354,13 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
     assert mg["ranks"] == 2 and mg["exchange"].startswith("c-abi rccl"), mg
     assert "mock_rccl" in mg["exchange_library"]["library"]
     assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+
+
+@pytest.mark.gpu
+def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
+    """By default the k_finalize launches of the parts alternate between the ctx stream and the second stream (a part's
+    event is recorded on the stream that finished it); finalize_two_streams = 0 keeps them on one.  Bands cut per part
+    (part_band_tiles) put several tile-kernel launches between them.  The exchange sees the same parts either way."""
+    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_two_streams=0")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_two_streams=1,part_band_tiles=200")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_two_streams=0,part_band_tiles=200")
