@@ -4,6 +4,7 @@ sharded all-pairs -> gather -> un-permute), see tests/e2e_multigpu_worker.py.  A
 (b) two and three ranks sharing cuda:0 over gloo.  Real multi-GPU RCCL runs only in the driver's bench."""
 import os
 import socket
+import uuid
 import subprocess
 import sys
 
@@ -290,7 +291,7 @@ def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, time
     if not os.path.exists(MOCK):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(MOCK)])
     env = dict(os.environ, DSH_RCCL_LIB=MOCK, WORLD=str(world), N=str(n), P=str(p), NPARTS=str(nparts), MODE=mode, DST=str(dst),
-               ID_FILE=str(tmp_path / ("id_%s_%d" % (mode, world))), MOCK_RCCL_TIMEOUT_S="240", DSH_COMM_TIMEOUT_S="300",
+               ID_FILE=str(tmp_path / ("id_" + uuid.uuid4().hex)), MOCK_RCCL_TIMEOUT_S="240", DSH_COMM_TIMEOUT_S="300",  # (a file per run)
                HSA_ENABLE_IPC_MODE_LEGACY="0", OPTS=opts)
     if bounds:
         env["BOUNDS"] = ",".join(str(b) for b in bounds)
