@@ -179,6 +179,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     c->sent.assign(nranks, 0);
     c->received.assign(nranks, 0);
     mkdir(c->dir.c_str(), 0700);  // (whoever comes first)
+    if (std::getenv("MOCK_RCCL_DEBUG")) std::fprintf(stderr, "mock_rccl: rank %d of %d joins %s\n", rank, nranks, c->dir.c_str());
     char b[32];
     std::snprintf(b, sizeof b, "/joined_%d", rank);
     FILE *f = std::fopen((c->dir + b).c_str(), "wb");
@@ -190,10 +191,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     for (int r = 0; r < nranks; ++r) {  // every rank has to join, as with the real thing
         std::snprintf(b, sizeof b, "/joined_%d", r);
         if (!wait_for(c->dir + b)) {
+            std::fprintf(stderr, "mock_rccl: rank %d of %d: rank %d never joined %s\n", rank, nranks, r, c->dir.c_str());
             delete c;
             return ncclSystemError;
         }
     }
+    if (std::getenv("MOCK_RCCL_DEBUG")) std::fprintf(stderr, "mock_rccl: rank %d of %d: all joined\n", rank, nranks);
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
@@ -202,10 +205,26 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c) return ncclSuccess;
+    // (a rank that is done must not take its "joined" mark away: a slower rank may still be counting the marks inside
+    // ncclCommInitRank.  Everyone leaves a "left" mark instead; whoever finds all of them there clears the directory.)
     char b[32];
-    std::snprintf(b, sizeof b, "/joined_%d", c->rank);
-    unlink((c->dir + b).c_str());
-    rmdir(c->dir.c_str());  // (succeeds for the last one out)
+    std::snprintf(b, sizeof b, "/left_%d", c->rank);
+    if (FILE *f = std::fopen((c->dir + b).c_str(), "wb")) std::fclose(f);
+    bool all = true;
+    struct stat st;
+    for (int r = 0; r < c->world && all; ++r) {
+        std::snprintf(b, sizeof b, "/left_%d", r);
+        all = stat((c->dir + b).c_str(), &st) == 0;
+    }
+    if (all) {
+        for (int r = 0; r < c->world; ++r) {
+            std::snprintf(b, sizeof b, "/left_%d", r);
+            unlink((c->dir + b).c_str());
+            std::snprintf(b, sizeof b, "/joined_%d", r);
+            unlink((c->dir + b).c_str());
+        }
+        rmdir(c->dir.c_str());
+    }
     delete c;
     return ncclSuccess;
 }

@@ -278,6 +278,24 @@ def test_rccl_collect_path_matches_plain(genomes, tmp_path):
     assert r.returncode != 0  # two ranks on one GPU: RCCL refuses, the CLI reports it instead of hanging
 
 
+def test_cli_devices_collect_over_the_stand_in_transport(genomes, tmp_path):
+    """`dist --devices 0,0,0` with an output one writer emits in order: three THREADS of the CLI, a context each on GPU 0,
+    dsh_comm_init + dsh_dist_collect with three ranks -- served by tests/mock_rccl (DSH_RCCL_LIB), since RCCL itself refuses
+    several ranks on one device.  Every format equals the single-device run byte for byte."""
+    mock = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+    if not os.path.exists(mock):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(mock)])
+    d, paths, seqs = genomes
+    env = dict(os.environ, DSH_RCCL_LIB=mock, MOCK_RCCL_TIMEOUT_S="120")
+    for flags in ([], ["-U", "-M"], ["-T"]):
+        a, b = tmp_path / "plain.out", tmp_path / "three.out"
+        run("dist", "--avoid-sorting", *flags, "-O", a, "-o", os.devnull, *paths)
+        r = subprocess.run([CLI, "dist", "--avoid-sorting", "--devices", "0,0,0", *flags, "-O", str(b), "-o", os.devnull, *paths],
+                           capture_output=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert a.read_bytes() == b.read_bytes(), flags
+
+
 def test_multi_device_presketched_large(oracle, tmp_path):
     """700 presketched sketches (several 128-row tile rows per device): 3 contexts vs 1, and vs the oracle."""
     import ctypes as C
