@@ -28,7 +28,7 @@ SYMBOLS = [
     "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_exchange_mode", "dsh_exchange_rows_device_async",
     "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
-    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_alloc_host", "dsh_free_host",
+    "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_balance_rowsets", "dsh_rowsets_from_bounds", "dsh_rowsets_rank", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
@@ -112,10 +112,13 @@ def load_library():
     lib.dsh_comm_available.argtypes = []
     lib.dsh_comm_library.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i32)]
     lib.dsh_comm_wait.argtypes = [vp]
-    lib.dsh_exchange_mode.argtypes = [u64, vp, i32, i32, C.c_uint32, i32, C.POINTER(i32), C.POINTER(C.c_uint32)]
-    lib.dsh_exchange_rows_device_async.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_uint32, i32, vp]
+    lib.dsh_exchange_mode.argtypes = [u64, vp, i32, C.c_uint32, i32, C.POINTER(i32), C.POINTER(C.c_uint32), C.POINTER(u64)]
+    lib.dsh_exchange_rows_device_async.argtypes = [vp, i32, i32, i32, vp, i32, C.c_uint32, i32, vp]
     lib.dsh_exchange_collect_async.argtypes = [vp, u64, vp, C.c_uint32, vp, vp, i32]
-    lib.dsh_exchange_place_device.argtypes = [vp, vp, i32, i32, C.c_uint32, i32, vp, vp]
+    lib.dsh_exchange_place_device.argtypes = [vp, vp, i32, C.c_uint32, i32, vp, vp]
+    lib.dsh_balance_rowsets.argtypes = [u64, C.c_uint32, i32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.dsh_rowsets_from_bounds.argtypes = [vp, C.c_uint32, vp]
+    lib.dsh_rowsets_rank.argtypes = [u64, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), C.POINTER(u64)]
     lib.dsh_finalize_phase_cycles.argtypes = [vp, vp]
     lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.dsh_comm_destroy.argtypes = [vp]
@@ -185,14 +188,75 @@ def comm_library():
     return buf.value.decode(errors="replace"), int(v.value)
 
 
-def exchange_mode(n, bounds, rank, nparts, dst=0):
-    """(rowsorted, parts) of rank `rank`'s buffer under dsh_exchange_* (dsh_exchange_mode)"""
+class RowSets:
+    """A partition of the triangle's rows over the ranks as a row-set table (include/dashing_hip.h): row segments with
+    owners.  `table` is the uint64 array the C-ABI takes; rows(r) the segments of rank r, pairs(r) / tiles(r) its work."""
+
+    def __init__(self, n, table):
+        self.n = int(n)
+        self.table = np.ascontiguousarray(table, np.uint64)
+        self.world = int(self.table[0])
+
+    def _rank(self, r):
+        segs = np.zeros(2 * max(int(self.table[1]), 1), np.uint64)
+        ns, pairs, tiles = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        rc = load_library().dsh_rowsets_rank(self.n, self.table.ctypes.data, r, segs.ctypes.data, len(segs) // 2, C.byref(ns),
+                                             C.byref(pairs), C.byref(tiles))
+        if rc:
+            raise DshError(rc, "dsh_rowsets_rank: malformed row-set table")
+        return [(int(segs[2 * i]), int(segs[2 * i + 1])) for i in range(ns.value)], int(pairs.value), int(tiles.value)
+
+    def rows(self, r):
+        return self._rank(r)[0]
+
+    def pairs(self, r):
+        return self._rank(r)[1]
+
+    def tiles(self, r):
+        return self._rank(r)[2]
+
+    def describe(self):
+        return [{"rank": r, "rows": self.rows(r), "pairs": self.pairs(r), "tiles": self.tiles(r)} for r in range(self.world)]
+
+
+def balance_rowsets(n, world, prep_permille=-1):
+    """Main ranges + top-up tile rows from the bottom of the triangle, one row set per rank (dsh_balance_rowsets)."""
+    lib = load_library()
+    words = C.c_uint32()
+    rc = lib.dsh_balance_rowsets(n, world, prep_permille, None, 0, C.byref(words))
+    if rc:
+        raise DshError(rc, "dsh_balance_rowsets")
+    tab = np.zeros(words.value, np.uint64)
+    rc = lib.dsh_balance_rowsets(n, world, prep_permille, tab.ctypes.data, len(tab), C.byref(words))
+    if rc:
+        raise DshError(rc, "dsh_balance_rowsets")
+    return RowSets(n, tab)
+
+
+def rowsets_from_bounds(n, bounds):
+    """contiguous row ranges bounds[world + 1] as a row-set table (dsh_rowsets_from_bounds)"""
     b = np.ascontiguousarray(bounds, np.uint64)
-    rs, k = C.c_int(), C.c_uint32()
-    rc = load_library().dsh_exchange_mode(n, b.ctypes.data, len(b) - 1, rank, nparts, dst, C.byref(rs), C.byref(k))
+    tab = np.zeros(3 + 2 * (len(b) - 1), np.uint64)
+    rc = load_library().dsh_rowsets_from_bounds(b.ctypes.data, len(b) - 1, tab.ctypes.data)
+    if rc:
+        raise DshError(rc, "dsh_rowsets_from_bounds")
+    return RowSets(n, tab)
+
+
+def _table(n, rows):
+    """the C-ABI table of `rows`: a RowSets, or contiguous bounds [world + 1]"""
+    return (rows if isinstance(rows, RowSets) else rowsets_from_bounds(n, rows)).table
+
+
+def exchange_mode(n, rows, rank, nparts, dst=0, want_floats=False):
+    """(rowsorted, parts[, floats of the rank's buffer]) of rank `rank` under dsh_exchange_* (dsh_exchange_mode); `rows` is a
+    RowSets or contiguous bounds"""
+    t = _table(n, rows)
+    rs, k, fl = C.c_int(), C.c_uint32(), C.c_uint64()
+    rc = load_library().dsh_exchange_mode(n, t.ctypes.data, rank, nparts, dst, C.byref(rs), C.byref(k), C.byref(fl))
     if rc:
         raise DshError(rc, "dsh_exchange_mode")
-    return bool(rs.value), int(k.value)
+    return (bool(rs.value), int(k.value), int(fl.value)) if want_floats else (bool(rs.value), int(k.value))
 
 
 def range_parts(n, rb, re, nparts):
@@ -434,17 +498,18 @@ class Context:
         self._ck(self._lib.dsh_finalize_phase_cycles(self._h, out.ctypes.data))
         return [int(x) for x in out]
 
-    def exchange_rows_device_async(self, out_ptr, bounds, rank, nparts, dst=0, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
-        b = np.ascontiguousarray(bounds, np.uint64)
-        self._ck(self._lib.dsh_exchange_rows_device_async(self._h, estim, result_type, k, b.ctypes.data, len(b) - 1, rank, nparts, dst, C.c_void_p(out_ptr)))
+    # (`rows` below: a RowSets -- balance_rowsets() -- or contiguous bounds [world + 1])
+    def exchange_rows_device_async(self, out_ptr, rows, rank, nparts, dst=0, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
+        t = _table(self.n, rows)
+        self._ck(self._lib.dsh_exchange_rows_device_async(self._h, estim, result_type, k, t.ctypes.data, rank, nparts, dst, C.c_void_p(out_ptr)))
 
-    def exchange_collect_async(self, n, bounds, nparts, local_ptr, final_ptr, dst=0):
-        b = np.ascontiguousarray(bounds, np.uint64)
-        self._ck(self._lib.dsh_exchange_collect_async(self._h, n, b.ctypes.data, nparts, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
+    def exchange_collect_async(self, n, rows, nparts, local_ptr, final_ptr, dst=0):
+        t = _table(n, rows)
+        self._ck(self._lib.dsh_exchange_collect_async(self._h, n, t.ctypes.data, nparts, C.c_void_p(local_ptr), C.c_void_p(final_ptr), dst))
 
-    def exchange_place_device(self, bounds, src, nparts, src_local_ptr, final_ptr, dst=0):
-        b = np.ascontiguousarray(bounds, np.uint64)
-        self._ck(self._lib.dsh_exchange_place_device(self._h, b.ctypes.data, len(b) - 1, src, nparts, dst, C.c_void_p(src_local_ptr), C.c_void_p(final_ptr)))
+    def exchange_place_device(self, rows, src, nparts, src_local_ptr, final_ptr, dst=0):
+        t = _table(self.n, rows)
+        self._ck(self._lib.dsh_exchange_place_device(self._h, t.ctypes.data, src, nparts, dst, C.c_void_p(src_local_ptr), C.c_void_p(final_ptr)))
 
     def comm_wait(self):
         """dsh_wait with a deadline on the RCCL traffic (DSH_COMM_TIMEOUT_S): an error instead of a hang"""
@@ -471,13 +536,14 @@ class Context:
         self._ck(self._lib.dsh_allgather_device(self._h, C.c_void_p(send_ptr), bytes_per_rank, C.c_void_p(recv_ptr)))
 
     def dist_collect(self, bounds, dst=0, estim=ESTIM_ERTL_MLE, result_type=JI, k=31):
-        """this rank's rows computed, every span delivered to `dst`; returns the packed matrix there, None elsewhere"""
-        b = np.ascontiguousarray(bounds, np.uint64)
+        """this rank's rows computed, every span delivered to `dst`; returns the packed matrix there, None elsewhere.
+        bounds = None: the library partitions the rows itself (balanced row sets, the pipelined exchange pair)"""
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.uint64)
         me = self.comm_rank()
         out = None
         if me is None or me[0] == dst:
             out = np.zeros(max(tri_span(self.n, 0, self.n), 1), np.float32)
-        self._ck(self._lib.dsh_dist_collect(self._h, estim, result_type, k, b.ctypes.data, dst,
+        self._ck(self._lib.dsh_dist_collect(self._h, estim, result_type, k, None if b is None else b.ctypes.data, dst,
                                             out.ctypes.data if out is not None else None))
         return None if out is None else out[: tri_span(self.n, 0, self.n)]
 

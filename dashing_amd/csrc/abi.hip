@@ -43,7 +43,7 @@ static void release_ctx(dsh_ctx *c)
         if (s) (void)hipStreamSynchronize(s);
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
-                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->perm, &c->items, &c->cum, &c->tiles,
+                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->place_tab, &c->perm, &c->items, &c->cum, &c->tiles,
                       &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc})
         b->release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
@@ -770,6 +770,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "lockstep")) *out = c->planes_valid && use_lockstep(c) ? 1 : 0;
     else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->pp.T.size();
     else if (!std::strcmp(name, "bands")) *out = (int64_t)c->last_bands;
+    else if (!std::strcmp(name, "items")) *out = (int64_t)c->pp.items.size();  // work items of the tile kernel (rounds of 512)
     else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
         uint64_t tot = 0;

@@ -99,6 +99,7 @@ struct dsh_ctx {
     DevBuf gather_full, gather_local;   // dsh_dist_collect: the assembled matrix on the destination rank / this rank's span
     // dsh_exchange_*: on the destination, the row-sorted spans as they arrive and the sources' key order + row offsets
     DevBuf xch_stage, xch_tab;
+    DevBuf place_tab;                   // dsh_exchange_place_device's own tables (ctx stream; xch_tab belongs to the copy stream)
     PinBuf pin_xch;
     hipEvent_t ev_xch_tab = nullptr;
     bool xch_tab_in_flight = false;
@@ -249,12 +250,13 @@ struct PairJob {
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *d_out;
+    std::vector<uint64_t> extra;  // (with nparts) further row segments {b0, e0, ...} behind row_end: a row set (plan.h)
 };
 
 // cardinalities + thresholds/lists + planes + position index for the current sketch matrix.  want_sorted < 0: whatever
 // is cached.  card_only: the per-sketch pass alone.
 int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only = false, uint64_t want_rb = 0,
-            uint64_t want_re = ~0ull, uint32_t nparts = 1, int rowsorted = 0);
+            uint64_t want_re = ~0ull, uint32_t nparts = 1, int rowsorted = 0, const std::vector<uint64_t> *extra = nullptr);
 int run_pairs(dsh_ctx *c, const PairJob &job);
 
 // exchange.hip: waits for both streams of the communicator's traffic and destroys it (no-op without one)

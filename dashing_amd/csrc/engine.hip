@@ -11,8 +11,11 @@
 namespace dsh {
 
 int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t want_rb, uint64_t want_re, uint32_t nparts,
-            int rowsorted)
+            int rowsorted, const std::vector<uint64_t> *extra_in)
 {
+    static const std::vector<uint64_t> kNoExtra;
+    std::vector<uint64_t> extra_cached;
+    const std::vector<uint64_t> *extra = extra_in ? extra_in : &kNoExtra;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     if (estim < 0 || estim > 2) return fail(c, DSH_EINVAL, "bad estimator %d", estim);
     if (want_sorted < 0) {  // "whatever is cached"
@@ -20,15 +23,21 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         want_rb = c->lay.rb;
         want_re = c->lay.re;
         rowsorted = 0;
+        extra_cached = c->lay.extra;
+        extra = &extra_cached;
     }
-    if (!want_sorted) rowsorted = 0;
+    if (!want_sorted) rowsorted = 0, extra = &kNoExtra;
     if (want_re > c->n) want_re = c->n;
     if (!want_sorted) want_rb = 0, want_re = c->n;
     if (want_rb > want_re) want_rb = want_re;
     const uint64_t n = c->n;
     std::vector<uint64_t> parts, rs_pos;
-    if (want_sorted && !rowsorted) plan::range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
-    if (rowsorted) plan::rowsorted_part_positions(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), rs_pos);
+    if (want_rb >= want_re) extra = &kNoExtra;
+    if (want_sorted && !rowsorted) {
+        if (extra->empty()) plan::range_parts(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), parts);
+        else parts = {want_rb, want_re};  // (a range with extra segments is ONE part)
+    }
+    if (rowsorted) plan::rowsorted_part_positions(n, want_rb, want_re, std::max<uint32_t>(nparts, 1), rs_pos, extra);
     const int emax_new = c->emax_opt >= 0 ? std::min<int>(c->emax_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, true);
     const int elow_new = c->elow_opt >= 0 ? std::min<int>(c->elow_opt, (int)kMaxListSide) : plan::auto_list_cap(c->p, false);
     if (emax_new != c->emax || elow_new != c->elow) {  // thresholds and lists (hence planes) depend on them
@@ -41,7 +50,7 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
     // per-sketch pass that is current -- another estimator or other list caps start a new pass)
     const bool same_layout = c->planes_valid && c->lay_gen == c->pass_gen && c->lay.sorted == want_sorted &&
                              (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.rowsorted == rowsorted &&
-                                               (rowsorted ? c->lay.part_pos == rs_pos : c->lay.parts == parts)));
+                                               c->lay.extra == *extra && (rowsorted ? c->lay.part_w == rs_pos : c->lay.parts == parts)));
     // sketches the per-sketch pass has to cover: a row range of the triangle never looks at the sketches before it
     const uint64_t need_from = (card_only || !want_sorted || c->pass_from_zero) ? 0 : want_rb;
     const bool have_pass = c->card_estim == estim && c->card_from <= need_from;
@@ -111,7 +120,8 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
                             (unsigned long long)i, 64 - c->p + 1, c->p);
         c->planes_valid = false;  // (the cached layout is overwritten from here on)
         plan::Layout &L = c->lay;
-        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0);
+        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0,
+                           extra->empty() ? nullptr : extra);
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
@@ -238,7 +248,11 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         lre = jre;
     }
     c->parts_done = 0;
-    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, with_parts ? job.nparts : 1, with_parts && job.rowsorted);
+    // extra segments (row sets, plan.h): only with a key-ordered layout of the range and parts (the exchange)
+    const bool with_extra = want_sorted && with_parts && !job.extra.empty() && lre > lrb;
+    if (!job.extra.empty() && !with_extra) return fail(c, DSH_EINVAL, "internal: extra row segments need a key-ordered range with parts");
+    int rc = prepare(c, job.estim, want_sorted, false, lrb, lre, with_parts ? job.nparts : 1, with_parts && job.rowsorted,
+                     with_extra ? &job.extra : nullptr);
     if (rc) return rc;
     if (job.result_type < 0 || job.result_type > 8)
         return fail(c, DSH_EINVAL, "unsupported result_type %d", job.result_type);
@@ -389,7 +403,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.knn_ld = job.knn_ld;
             f.knn_rows = job.knn_rows;
             f.row_begin = job.row_begin;
-            f.row_end = job.row_end;
+            // (with extra segments every pair of a launched tile is this rank's: the runs of the layout lie in row order and
+            // whole 128-column blocks are wanted or not, plan.h)
+            f.row_end = with_extra ? c->n : job.row_end;
             f.col_begin = job.col_begin;
             f.col_end = job.col_end;
             f.base_index = job.base_index;

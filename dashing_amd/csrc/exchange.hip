@@ -196,33 +196,44 @@ int dsh_comm_init(dsh_ctx *c, const void *unique_id, int rank, int world)
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
     // ncclCommInitRank blocks until every rank has joined.  It runs on a helper thread so that a rank that never
-    // arrives costs this one DSH_COMM_INIT_TIMEOUT_S (default 90 s) and an error, not a hang.  (On expiry the helper
-    // stays blocked inside RCCL and is left behind; the context works on without a communicator.)
+    // arrives costs this one DSH_COMM_INIT_TIMEOUT_S (default 90 s) and an error, not a hang.  On expiry the helper
+    // stays blocked inside RCCL and is left behind; the context works on without a communicator, and should the peers
+    // arrive after all, the helper ABORTS the communicator it then gets (the peers would otherwise see a
+    // successful init and stall until their exchange deadline).  All ranks must treat an init timeout as fatal.
     struct Shared {
         std::mutex mu;
         std::condition_variable cv;
         bool done = false;
+        bool abandoned = false;
         ncclResult_t res = ncclSuccess;
         ncclComm_t comm = nullptr;
     };
     auto sh = std::make_shared<Shared>();
     const int device = c->device;
     auto init = r->CommInitRank;
-    std::thread([sh, device, init, world, id, rank] {
+    auto abort_ = r->CommAbort;
+    std::thread([sh, device, init, abort_, world, id, rank] {
         ncclComm_t comm = nullptr;
         ncclResult_t res = hipSetDevice(device) == hipSuccess ? init(&comm, world, id, rank) : ncclUnhandledCudaError;
-        std::lock_guard<std::mutex> lk(sh->mu);
-        sh->res = res;
-        sh->comm = comm;
-        sh->done = true;
-        sh->cv.notify_all();
+        bool orphan = false;
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            sh->res = res;
+            sh->comm = comm;
+            sh->done = true;
+            orphan = sh->abandoned;
+            sh->cv.notify_all();
+        }
+        if (orphan && res == ncclSuccess && comm) (void)abort_(comm);  // nobody will ever use or destroy it
     }).detach();
     const double limit = env_seconds("DSH_COMM_INIT_TIMEOUT_S", 90.0);
     {
         std::unique_lock<std::mutex> lk(sh->mu);
-        if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; }))
+        if (!sh->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return sh->done; })) {
+            sh->abandoned = true;
             return fail(c, DSH_EIO, "ncclCommInitRank(rank %d of %d) did not return within %.0f s (DSH_COMM_INIT_TIMEOUT_S): "
                                     "not every rank joined", rank, world, limit);
+        }
         if (sh->res != ncclSuccess) return fail(c, DSH_EIO, "ncclCommInitRank: %s", r->GetErrorString(sh->res));
         c->comm = sh->comm;
     }
@@ -374,79 +385,144 @@ int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint
 
 }  // extern "C"
 
-/* ---- the exchange-aware pair: every rank's buffer laid out for the exchange (plan.h: row-sorted parts) ---------------- */
+/* ---- the exchange-aware pair: every rank's buffer laid out for the exchange (plan.h: row sets, row-sorted parts) ------ */
 namespace {
 
-// what rank r does under dsh_exchange_*: the destination keeps its rows in place as ONE part; a short range goes in
-// row-sorted parts (key-ordered as one run, homogeneous tiles); a long one in parts of consecutive rows
+// what rank r does under dsh_exchange_*: the destination keeps its rows in place as ONE part; a short range, or any rank
+// with extra segments, goes in row-sorted parts (every wanted segment key-ordered as one run, homogeneous tiles); a long
+// range in parts of consecutive rows
 struct XMode {
     bool rowsorted = false;
-    std::vector<uint64_t> cut;  // rowsorted: positions of the key order; else row boundaries (range_parts)
+    uint64_t rb = 0, re = 0;      // the rank's main range
+    std::vector<uint64_t> extra;  // its extra segments {b0, e0, ...}
+    std::vector<uint64_t> cut;    // rowsorted: counts of wanted rows (layout order); else row boundaries (range_parts)
     size_t nparts() const { return cut.empty() ? 0 : cut.size() - 1; }
+    uint64_t span(uint64_t n) const { return plan::rowset_span(n, rb, re, extra); }
 };
 
-XMode xmode(uint64_t n, const uint64_t *bounds, int r, uint32_t nparts, int dst)
+XMode xmode(uint64_t n, const plan::RowSets &rs, int r, uint32_t nparts, int dst)
 {
     XMode m;
-    const uint64_t rb = bounds[r], re = bounds[r + 1];
-    if (rb >= re) return m;
+    rs.rank_rows((uint32_t)r, m.rb, m.re, m.extra);
+    if (m.rb >= m.re) return m;
     if (r == dst) {
-        m.cut = {rb, re};
-    } else if (plan::rowsorted_rule(n, rb, re, nparts)) {
+        m.cut = {m.rb, m.re};
+    } else if (!m.extra.empty() || plan::rowsorted_rule(n, m.rb, m.re, nparts)) {
         m.rowsorted = true;
-        plan::rowsorted_part_positions(n, rb, re, nparts, m.cut);
+        plan::rowsorted_part_positions(n, m.rb, m.re, nparts, m.cut, &m.extra);
     } else {
-        plan::range_parts(n, rb, re, nparts, m.cut);
+        plan::range_parts(n, m.rb, m.re, nparts, m.cut);
     }
     return m;
 }
 
-// the key order and the row offsets of rank r's row-sorted buffer, from THIS context's host copy of the keys (every rank
-// holds every sketch, the per-sketch pass is deterministic: the destination derives what the source used)
-int rowsorted_tables(dsh_ctx *c, uint64_t n, uint64_t rb, uint64_t re, std::vector<uint32_t> &order, std::vector<uint64_t> &rowoff,
+int parse_table(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, int dst, plan::RowSets &rs)
+{
+    if (const char *why = plan::parse_rowsets(rowsets, n, rs)) return fail(c, DSH_EINVAL, "%s", why);
+    if (dst < 0 || (uint32_t)dst >= rs.world) return fail(c, DSH_EINVAL, "bad destination rank %d (world %u)", dst, rs.world);
+    return DSH_OK;
+}
+
+// the key order and the row offsets of a rank's row-sorted buffer (wanted rows: main range, then the extra segments, each
+// key-ordered as one run), from THIS context's host copy of the keys (every rank holds every sketch, the per-sketch pass
+// is deterministic: the destination derives what the source used)
+int rowsorted_tables(dsh_ctx *c, uint64_t n, const XMode &m, std::vector<uint32_t> &order, std::vector<uint64_t> &rowoff,
                      std::vector<uint32_t> &scratch)
 {
-    if (!c->hk32_valid || c->card_from > rb)
+    if (!c->hk32_valid || c->card_from > m.rb)
         return fail(c, DSH_ESTATE, "the per-sketch pass of this context does not cover the rows from %llu on (compute this rank's rows first)",
-                    (unsigned long long)rb);
-    order.resize(re - rb);
-    plan::sort_rows_by_key(c->hk32, rb, re, order.data(), scratch);
-    plan::rowsorted_offsets(n, order.data(), re - rb, rowoff);
+                    (unsigned long long)m.rb);
+    const uint64_t cnt = plan::rowset_rows(m.rb, m.re, m.extra);
+    order.resize(cnt);
+    plan::sort_rows_by_key(c->hk32, m.rb, m.re, order.data(), scratch);
+    uint64_t at = m.re - m.rb;
+    for (size_t x = 0; x + 1 < m.extra.size(); x += 2) {
+        plan::sort_rows_by_key(c->hk32, m.extra[x], m.extra[x + 1], order.data() + at, scratch);
+        at += m.extra[x + 1] - m.extra[x];
+    }
+    plan::rowsorted_offsets(n, order.data(), cnt, rowoff);
     return DSH_OK;
+}
+
+// the destination's own rows, computed relative to its first row: every segment of them to its place in the final matrix
+// (a no-op when they were computed in place)
+int place_own_rows(dsh_ctx *c, uint64_t n, const XMode &m, const void *d_local, void *d_final, hipStream_t st)
+{
+    const uint64_t base = dsh_tri_span(n, 0, m.rb);
+    if (!d_local || (const float *)d_local == (float *)d_final + base) return DSH_OK;
+    auto seg = [&](uint64_t b, uint64_t e) -> int {
+        const uint64_t off = dsh_tri_span(n, 0, b), cnt = dsh_tri_span(n, b, e);
+        if (cnt)
+            HIPCHK(c, hipMemcpyAsync((float *)d_final + off, (const float *)d_local + (off - base), cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return DSH_OK;
+    };
+    int rc = seg(m.rb, m.re);
+    for (size_t x = 0; !rc && x + 1 < m.extra.size(); x += 2) rc = seg(m.extra[x], m.extra[x + 1]);
+    return rc;
 }
 
 }  // namespace
 
 extern "C" {
 
-int dsh_exchange_mode(uint64_t n, const uint64_t *bounds, int world, int rank, uint32_t nparts, int dst, int *rowsorted,
-                      uint32_t *nparts_out)
+int dsh_exchange_mode(uint64_t n, const uint64_t *rowsets, int rank, uint32_t nparts, int dst, int *rowsorted, uint32_t *nparts_out,
+                      uint64_t *local_floats_out)
 {
-    if (!bounds || world < 1 || rank < 0 || rank >= world || nparts == 0) return DSH_EINVAL;
-    const XMode m = xmode(n, bounds, rank, nparts, dst);
+    plan::RowSets rs;
+    if (nparts == 0 || plan::parse_rowsets(rowsets, n, rs) || rank < 0 || (uint32_t)rank >= rs.world || dst < 0 || (uint32_t)dst >= rs.world)
+        return DSH_EINVAL;
+    const XMode m = xmode(n, rs, rank, nparts, dst);
     if (rowsorted) *rowsorted = m.rowsorted ? 1 : 0;
     if (nparts_out) *nparts_out = (uint32_t)m.nparts();
+    if (local_floats_out) {
+        // the destination computes relative to its first row (in place in the final matrix, or a buffer that reaches to
+        // the end of its last segment); every other rank's buffer holds exactly its rows
+        if (m.rb >= m.re) *local_floats_out = 0;
+        else if (rank == dst) *local_floats_out = dsh_tri_span(n, m.rb, m.extra.empty() ? m.re : m.extra.back());
+        else *local_floats_out = m.span(n);
+    }
     return DSH_OK;
 }
 
-int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *bounds, int world, int rank,
-                                   uint32_t nparts, int dst, void *d_local)
+int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *rowsets, int rank, uint32_t nparts,
+                                   int dst, void *d_local)
 {
-    if (!c || !bounds || nparts == 0 || world < 1 || rank < 0 || rank >= world) return DSH_EINVAL;
+    if (!c || !rowsets || nparts == 0 || rank < 0) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
-    if ((rc = validate_bounds(c, c->n, bounds, world, dst))) return rc;
+    plan::RowSets rs;
+    if ((rc = parse_table(c, c->n, rowsets, dst, rs))) return rc;
+    if ((uint32_t)rank >= rs.world) return fail(c, DSH_EINVAL, "bad rank %d (world %u)", rank, rs.world);
     reset_prof(c);
     c->parts_done = 0;
-    const uint64_t rb = bounds[rank], re = bounds[rank + 1];
-    if (rb >= re || c->n < 2) return DSH_OK;
-    if (!d_local) return DSH_EINVAL;
-    const XMode m = xmode(c->n, bounds, rank, nparts, dst);
-    // the destination places the row-sorted spans of the others: its per-sketch pass must cover their rows too
-    c->pass_from_zero = false;
+    if (c->n < 2) return DSH_OK;
+    const XMode m = xmode(c->n, rs, rank, nparts, dst);
+    // the destination places the row-sorted spans of the others: its per-sketch pass must cover their rows too -- also
+    // when it holds no rows itself (it used to return before any pass and fail later in the collect, with the
+    // peers' sends already posted)
+    bool from_zero = false;
+    uint64_t first_needed = m.rb < m.re ? m.rb : c->n;
     if (rank == dst)
-        for (int r = 0; r < rank; ++r) c->pass_from_zero = c->pass_from_zero || xmode(c->n, bounds, r, nparts, dst).rowsorted;
+        for (uint32_t r = 0; r < rs.world; ++r) {
+            if ((int)r == dst) continue;
+            const XMode o = xmode(c->n, rs, (int)r, nparts, dst);
+            if (o.rowsorted && o.rb < first_needed) from_zero = true;
+        }
+    if (m.rb >= m.re) {
+        if (!from_zero) return DSH_OK;
+        c->pass_from_zero = true;
+        rc = prepare(c, estim, -1, /*card_only=*/true);
+        c->pass_from_zero = false;
+        if (rc) return rc;
+        if (!c->hk32_valid) {  // (a cardinality pass does not wait for its keys: the collect's tables need them)
+            HIPCHK(c, hipEventSynchronize(c->ev_keys));
+            c->hk32_valid = true;
+        }
+        return DSH_OK;
+    }
+    if (!d_local) return DSH_EINVAL;
+    c->pass_from_zero = from_zero;
     PairJob j;
     j.estim = estim;
     j.result_type = result_type;
@@ -454,10 +530,11 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
     j.rect = 0;
     j.nparts = rank == dst ? 1 : nparts;
     j.rowsorted = m.rowsorted ? 1 : 0;
-    j.row_begin = rb;
-    j.row_end = re;
+    j.row_begin = m.rb;
+    j.row_end = m.re;
+    j.extra = m.extra;
     j.col_begin = j.col_end = 0;
-    j.base_index = dsh_tri_span(c->n, 0, rb);
+    j.base_index = dsh_tri_span(c->n, 0, m.rb);
     j.d_out = (float *)d_local;
     rc = run_pairs(c, j);
     c->pass_from_zero = false;
@@ -466,7 +543,7 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
 
 // rank `src`'s parts, as they lie in its buffer: offset and length of part q (floats), and where a part of consecutive
 // rows lands in the final matrix
-static void part_span(uint64_t n, const XMode &m, const std::vector<uint64_t> &rowoff, uint64_t rb, size_t q, uint64_t &off, uint64_t &cnt,
+static void part_span(uint64_t n, const XMode &m, const std::vector<uint64_t> &rowoff, size_t q, uint64_t &off, uint64_t &cnt,
                       uint64_t &final_off)
 {
     if (m.rowsorted) {
@@ -474,26 +551,28 @@ static void part_span(uint64_t n, const XMode &m, const std::vector<uint64_t> &r
         cnt = rowoff[m.cut[q + 1]] - off;
         final_off = 0;
     } else {
-        off = dsh_tri_span(n, rb, m.cut[q]);
+        off = dsh_tri_span(n, m.rb, m.cut[q]);
         cnt = dsh_tri_span(n, m.cut[q], m.cut[q + 1]);
         final_off = dsh_tri_span(n, 0, m.cut[q]);
     }
 }
 
-int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local, void *d_final,
+int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, uint32_t nparts, const void *d_local, void *d_final,
                                int dst)
 {
-    if (!c || !bounds || nparts == 0) return DSH_EINVAL;
+    if (!c || !rowsets || nparts == 0) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
+    plan::RowSets rs;
+    if ((rc = parse_table(c, n, rowsets, dst, rs))) return rc;
     const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
-    if (!c->comm && !(bounds[0] == 0 && bounds[1] == n)) return fail(c, DSH_ESTATE, "dsh_comm_init first");
-    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;
+    if (!c->comm && rs.world != 1) return fail(c, DSH_ESTATE, "dsh_comm_init first");
+    if ((int)rs.world != world) return fail(c, DSH_EINVAL, "the row-set table is for %u ranks, the communicator has %d", rs.world, world);
     if (rank == dst && !d_final) return DSH_EINVAL;
     std::vector<XMode> modes((size_t)world);
     size_t maxparts = 0;
     for (int r = 0; r < world; ++r) {
-        modes[r] = xmode(n, bounds, r, nparts, dst);
+        modes[r] = xmode(n, rs, r, nparts, dst);
         maxparts = std::max(maxparts, modes[r].nparts());
     }
     const XMode &mine = modes[rank];
@@ -508,11 +587,11 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, u
     std::vector<uint64_t> stage_off((size_t)world, 0), tab_off((size_t)world, 0);
     uint64_t stage_total = 0, tab_bytes = 0;
     if (rank != dst) {
-        if (mine.rowsorted) rowoff[rank] = c->lay.rowoff;
+        if (mine.rowsorted) rowoff[rank] = c->lay.rowoff_w;
     } else {
         for (int r = 0; r < world; ++r) {
             if (r == dst || !modes[r].rowsorted) continue;
-            if ((rc = rowsorted_tables(c, n, bounds[r], bounds[r + 1], order[r], rowoff[r], c->lay.sort_a))) return rc;
+            if ((rc = rowsorted_tables(c, n, modes[r], order[r], rowoff[r], c->lay.sort_a))) return rc;
             stage_off[r] = stage_total;
             stage_total += rowoff[r].back();
             tab_off[r] = tab_bytes;
@@ -542,12 +621,8 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, u
         // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
         // there while the ctx stream computes part q+1
         if (q < mine.nparts()) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
-        if (rank == dst && q < mine.nparts() && d_local) {  // (the destination's own rows: one part, normally in place)
-            float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[rank]);
-            const uint64_t cnt = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
-            if (cnt && (const float *)d_local != own)
-                HIPCHK(c, hipMemcpyAsync(own, d_local, cnt * sizeof(float), hipMemcpyDeviceToDevice, c->copy_stream));
-        }
+        if (rank == dst && q < mine.nparts())  // (the destination's own rows: one part, normally in place)
+            if ((rc = place_own_rows(c, n, mine, d_local, d_final, c->copy_stream))) return rc;
         if (world == 1) continue;
         NCCLCHK(c, rc_->GroupStart());
         ncclResult_t e = ncclSuccess;
@@ -555,13 +630,13 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, u
             for (int src = 0; src < world && e == ncclSuccess; ++src) {
                 if (src == dst || q >= modes[src].nparts()) continue;
                 uint64_t off, cnt, foff;
-                part_span(n, modes[src], rowoff[src], bounds[src], q, off, cnt, foff);
+                part_span(n, modes[src], rowoff[src], q, off, cnt, foff);
                 float *to = modes[src].rowsorted ? (float *)c->xch_stage.ptr + stage_off[src] + off : (float *)d_final + foff;
                 if (cnt) e = rc_->Recv(to, cnt, ncclFloat32, src, c->comm, c->copy_stream);
             }
         } else if (q < mine.nparts()) {
             uint64_t off, cnt, foff;
-            part_span(n, mine, rowoff[rank], bounds[rank], q, off, cnt, foff);
+            part_span(n, mine, rowoff[rank], q, off, cnt, foff);
             if (cnt) {
                 if (!d_local) e = ncclInvalidArgument;
                 else e = rc_->Send((const float *)d_local + off, cnt, ncclFloat32, dst, c->comm, c->copy_stream);
@@ -584,36 +659,36 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, u
     return DSH_OK;
 }
 
-int dsh_exchange_place_device(dsh_ctx *c, const uint64_t *bounds, int world, int src, uint32_t nparts, int dst, const void *d_src_local,
+int dsh_exchange_place_device(dsh_ctx *c, const uint64_t *rowsets, int src, uint32_t nparts, int dst, const void *d_src_local,
                               void *d_final)
 {
-    if (!c || !bounds || nparts == 0 || world < 1 || src < 0 || src >= world || !d_final) return DSH_EINVAL;
+    if (!c || !rowsets || nparts == 0 || src < 0 || !d_final) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     const uint64_t n = c->n;
-    if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;
-    const XMode m = xmode(n, bounds, src, nparts, dst);
-    const uint64_t span = dsh_tri_span(n, bounds[src], bounds[src + 1]);
-    if (!span) return DSH_OK;
+    plan::RowSets rs;
+    if ((rc = parse_table(c, n, rowsets, dst, rs))) return rc;
+    if ((uint32_t)src >= rs.world) return fail(c, DSH_EINVAL, "bad source rank %d (world %u)", src, rs.world);
+    const XMode m = xmode(n, rs, src, nparts, dst);
+    if (!m.span(n)) return DSH_OK;
     if (!d_src_local) return DSH_EINVAL;
-    if (!m.rowsorted) {  // final order already: the span goes to its place
-        float *own = (float *)d_final + dsh_tri_span(n, 0, bounds[src]);
-        if ((const float *)d_src_local != own)
-            HIPCHK(c, hipMemcpyAsync(own, d_src_local, span * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    // (its own table buffer, on the ctx stream: dsh_exchange_collect_async keeps xch_tab busy on the copy stream -- ADVICE r4)
+    if (!m.rowsorted) {  // final order already (relative to the rank's first row): every segment goes to its place
+        if ((rc = place_own_rows(c, n, m, d_src_local, d_final, c->stream))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return DSH_OK;
     }
     std::vector<uint32_t> order;
     std::vector<uint64_t> rowoff;
-    if ((rc = rowsorted_tables(c, n, bounds[src], bounds[src + 1], order, rowoff, c->lay.sort_a))) return rc;
+    if ((rc = rowsorted_tables(c, n, m, order, rowoff, c->lay.sort_a))) return rc;
     const size_t ro_bytes = rowoff.size() * sizeof(uint64_t), bytes = ro_bytes + order.size() * sizeof(uint32_t);
-    HIPCHK(c, c->xch_tab.ensure(bytes));
-    HIPCHK(c, hipMemcpyAsync(c->xch_tab.ptr, rowoff.data(), ro_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->xch_tab.ptr + ro_bytes, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->place_tab.ensure(bytes));
+    HIPCHK(c, hipMemcpyAsync(c->place_tab.ptr, rowoff.data(), ro_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->place_tab.ptr + ro_bytes, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     for (size_t q = 0; q + 1 < m.cut.size(); ++q)
         HIPCHK(c, launch_row_place(c->stream, (const float *)d_src_local, (float *)d_final,
-                                   (const uint32_t *)((const uint8_t *)c->xch_tab.ptr + ro_bytes), (const uint64_t *)c->xch_tab.ptr,
+                                   (const uint32_t *)((const uint8_t *)c->place_tab.ptr + ro_bytes), (const uint64_t *)c->place_tab.ptr,
                                    m.cut[q], m.cut[q + 1], n));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (the pageable tables must outlive their copies)
     return DSH_OK;
@@ -631,12 +706,44 @@ int dsh_allgather_device(dsh_ctx *c, const void *d_send, uint64_t bytes_per_rank
 
 int dsh_dist_collect(dsh_ctx *c, int estim, int result_type, int k, const uint64_t *bounds, int dst, float *out)
 {
-    if (!c || !bounds) return DSH_EINVAL;
+    if (!c) return DSH_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
     if (!c->have_sketches) return fail(c, DSH_ESTATE, "no sketches loaded");
     const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
     const uint64_t n = c->n, total = dsh_tri_span(n, 0, n);
+    if (!bounds) {
+        // the library's own partition: balanced row sets (range + top-up tile rows, dsh_balance_rowsets) through the
+        // pipelined exchange pair -- what bench.py --gpus N times, for a host without device pointers
+        if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d (world %d)", dst, world);
+        plan::RowSets rs;
+        plan::balance_rowsets(n, (uint32_t)world, rs);
+        std::vector<uint64_t> tab(rs.words());
+        rs.write(tab.data());
+        constexpr uint32_t kParts = 8;
+        uint64_t local_floats = 0;
+        if ((rc = dsh_exchange_mode(n, tab.data(), rank, kParts, dst, nullptr, nullptr, &local_floats))) return fail(c, rc, "internal: row-set table");
+        void *d_loc = nullptr;
+        if (rank == dst) {
+            if (total && !out) return DSH_EINVAL;
+            HIPCHK(c, c->gather_full.ensure(std::max<uint64_t>(total, 1) * sizeof(float)));
+            uint64_t rb = 0, re = 0;
+            std::vector<uint64_t> ex;
+            rs.rank_rows((uint32_t)rank, rb, re, ex);
+            d_loc = (float *)c->gather_full.ptr + dsh_tri_span(n, 0, rb);  // computed in place
+        } else {
+            HIPCHK(c, c->gather_local.ensure(std::max<uint64_t>(local_floats, 1) * sizeof(float)));
+            d_loc = c->gather_local.ptr;
+        }
+        if ((rc = dsh_exchange_rows_device_async(c, estim, result_type, k, tab.data(), rank, kParts, dst, d_loc))) return rc;
+        if ((rc = dsh_exchange_collect_async(c, n, tab.data(), kParts, rank == dst ? nullptr : d_loc, rank == dst ? c->gather_full.ptr : nullptr, dst)))
+            return rc;
+        if ((rc = sync_guarded(c, c->stream, "dsh_dist_collect (ctx stream)"))) return rc;
+        if ((rc = sync_guarded(c, c->copy_stream, "dsh_dist_collect (copy stream)"))) return rc;
+        if (rank == dst && total)
+            HIPCHK(c, hipMemcpyAsync(out, c->gather_full.ptr, total * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        return sync_guarded(c, c->stream, "dsh_dist_collect");
+    }
     if ((rc = validate_bounds(c, n, bounds, world, dst))) return rc;  // before anything is sized by them
     const uint64_t mine = dsh_tri_span(n, bounds[rank], bounds[rank + 1]);
     void *d_local = nullptr;

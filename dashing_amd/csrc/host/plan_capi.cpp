@@ -32,15 +32,14 @@ struct Err {
 
 }  // namespace
 
-extern "C" {
-
 // mode: 0 triangle rows [rb, re) (want_sorted decides the layout), 1 rectangle rows [rb,re) x cols [cb,ce) (identity
 // layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN), 3 triangle
 // rows in ROW-SORTED parts (the wanted rows one key-ordered run, parts = runs of whole tile rows of that order).
 // stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P.
-int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
-                    uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
-                    int ls_item_chunks, uint64_t *stats, char *err, size_t cap)
+// extra: further wanted segments {b0, e0, ...} (plan.h, row sets; modes 0 and 3 with a sorted layout only)
+static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
+                      uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
+                      int ls_item_chunks, const std::vector<uint64_t> &extra, uint64_t *stats, char *err, size_t cap)
 {
     Err E{err, cap};
     if (re > n) re = n;
@@ -52,23 +51,42 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
     uint64_t lrb = 0, lre = n;
     if (want_sorted && mode == 0) lrb = rb, lre = re;
     if (want_sorted && !rowsorted) range_parts(n, lrb, lre, std::max<uint32_t>(want_parts ? nparts : 1, 1), parts);
+    if (!extra.empty() && !(want_sorted && mode == 0)) return E.fail("extra segments need a sorted triangle layout");
     Layout L;
-    build_layout(keys, n, want_sorted, lrb, lre, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0);
-    if (rowsorted) {  // one key-ordered run, cuts on whole tile rows of it, row offsets of the rank's buffer
+    build_layout(keys, n, want_sorted, lrb, lre, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0, extra.empty() ? nullptr : &extra);
+    // the wanted segments, main range first
+    std::vector<std::pair<uint64_t, uint64_t>> wsegs;
+    if (lre > lrb) wsegs.emplace_back(lrb, lre);
+    for (size_t x = 0; x + 1 < extra.size(); x += 2) wsegs.emplace_back(extra[x], extra[x + 1]);
+    auto in_rows = [&](uint64_t i) {
+        for (auto &w : wsegs)
+            if (i >= w.first && i < w.second) return true;
+        return false;
+    };
+    uint64_t nw = 0, wspan = 0;
+    for (auto &w : wsegs) nw += w.second - w.first, wspan += tri_span(n, w.first, w.second);
+    if (want_sorted && mode == 0 && L.nwanted != nw) return E.fail("nwanted %llu != %llu", (unsigned long long)L.nwanted, (unsigned long long)nw);
+    if (rowsorted) {  // one key-ordered run per wanted segment, cuts on whole tile rows of the wanted order, row offsets of the rank's buffer
         auto skey = [&](uint32_t g) { return ((uint32_t)key_T(keys[g]) << 12) | ((uint32_t)key_L(keys[g]) << 6) | (uint32_t)key_hi(keys[g]); };
-        for (uint64_t s = 1; s < lre - lrb; ++s)
-            if (skey(L.perm[s - 1]) > skey(L.perm[s])) return E.fail("row-sorted: the wanted rows are not one key-ordered run at %llu", (unsigned long long)s);
-        if (L.part_pos.empty() || L.part_pos.front() != 0 || L.part_pos.back() != lre - lrb) return E.fail("row-sorted: part positions do not span the rows");
-        for (size_t q = 1; q + 1 < L.part_pos.size(); ++q)
-            if (L.part_pos[q] % kTile || L.part_pos[q] <= L.part_pos[q - 1]) return E.fail("row-sorted: cut %zu at %llu", q, (unsigned long long)L.part_pos[q]);
-        if (L.part_pos.size() - 1 > std::max<uint32_t>(nparts, 1)) return E.fail("row-sorted: more parts than asked for");
-        uint64_t acc = 0;
-        if (L.rowoff.size() != lre - lrb + 1) return E.fail("row-sorted: rowoff size");
-        for (uint64_t s = 0; s < lre - lrb; ++s) {
-            if (L.rowoff[s] != acc) return E.fail("row-sorted: rowoff[%llu]", (unsigned long long)s);
-            acc += n - 1 - L.perm[s];
-        }
-        if (L.rowoff.back() != acc || acc != tri_span(n, lrb, lre)) return E.fail("row-sorted: the rows do not add up to the span");
+        for (auto &w : wsegs)
+            for (uint64_t s = w.first - lrb + 1; s < w.second - lrb; ++s)
+                if (skey(L.perm[s - 1]) > skey(L.perm[s])) return E.fail("row-sorted: a wanted segment is not one key-ordered run at %llu", (unsigned long long)s);
+        if (L.part_w.empty() || L.part_w.front() != 0 || L.part_w.back() != nw) return E.fail("row-sorted: part cuts do not span the wanted rows");
+        if (L.part_pos.size() != L.part_w.size()) return E.fail("row-sorted: part positions and cuts differ in number");
+        for (size_t q = 1; q + 1 < L.part_w.size(); ++q)
+            if (L.part_w[q] % kTile || L.part_w[q] <= L.part_w[q - 1] || L.part_pos[q] % kTile || L.part_pos[q] <= L.part_pos[q - 1])
+                return E.fail("row-sorted: cut %zu at %llu", q, (unsigned long long)L.part_w[q]);
+        if (L.part_w.size() - 1 > std::max<uint32_t>(nparts, 1)) return E.fail("row-sorted: more parts than asked for");
+        uint64_t acc = 0, w_ = 0;
+        if (L.rowoff_w.size() != nw + 1) return E.fail("row-sorted: rowoff_w size");
+        for (auto &w : wsegs)
+            for (uint64_t s = w.first - lrb; s < w.second - lrb; ++s, ++w_) {
+                if (s >= L.rowoff.size() || L.rowoff[s] != acc || L.rowoff_w[w_] != acc) return E.fail("row-sorted: rowoff[%llu]", (unsigned long long)s);
+                for (size_t q = 0; q < L.part_w.size(); ++q)
+                    if (L.part_w[q] == w_ && L.part_pos[q] != s) return E.fail("row-sorted: part %zu starts at position %llu, not %llu", q, (unsigned long long)L.part_pos[q], (unsigned long long)s);
+                acc += n - 1 - L.perm[s];
+            }
+        if (L.rowoff_w.back() != acc || acc != wspan) return E.fail("row-sorted: the rows do not add up to the span");
     }
     // ---- layout: perm is a permutation of the columns; the parts hold exactly their rows; block stats are right
     const uint64_t col0 = want_sorted ? lrb : 0;
@@ -86,12 +104,23 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
             for (uint64_t r = L.parts[q]; r < L.parts[q + 1]; ++r, ++s)
                 if (L.perm[s] < L.parts[q] || L.perm[s] >= L.parts[q + 1])
                     return E.fail("column %llu holds sketch %u, not a row of part %zu", (unsigned long long)s, L.perm[s], q);
-        if (L.part_pos.size() != (rowsorted ? L.part_pos.size() : L.parts.size())) return E.fail("part positions and parts differ in number");
-        if (!rowsorted)
+        if (!rowsorted && extra.empty()) {
+            if (L.part_pos.size() != L.parts.size()) return E.fail("part positions and parts differ in number");
             for (size_t q = 0; q < L.parts.size(); ++q)
                 if (L.part_pos[q] != L.parts[q] - lrb) return E.fail("part position %zu", q);
+        }
         for (; s < L.ncols; ++s)
             if (L.perm[s] < lre) return E.fail("column %llu (after the wanted rows) holds wanted row %u", (unsigned long long)s, L.perm[s]);
+        // every run holds exactly its rows: a wanted segment's positions hold its rows; every block is wanted or not as a whole
+        for (auto &w : wsegs)
+            for (uint64_t s2 = w.first - lrb; s2 < w.second - lrb; ++s2)
+                if (L.perm[s2] < w.first || L.perm[s2] >= w.second) return E.fail("position %llu of a wanted segment holds row %u", (unsigned long long)s2, L.perm[s2]);
+        if (!extra.empty())
+            for (uint64_t s2 = 0; s2 < L.ncols; ++s2) {
+                // rows to the right of a position are larger unless they share its run: position order = row order between runs
+                const uint64_t b = s2 / kTile * kTile;
+                if (in_rows(L.perm[s2]) != in_rows(L.perm[b])) return E.fail("block %llu mixes wanted and other rows", (unsigned long long)(b / kTile));
+            }
         if (L.whole)
             for (uint64_t i = 0; i < n; ++i)
                 if (L.perm[n + L.perm[i]] != i) return E.fail("inverse permutation wrong at %llu", (unsigned long long)i);
@@ -129,6 +158,8 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
     } else {
         hit.assign(n * n, 0);
         for (uint64_t i = rb; i < re; ++i) wanted += n - 1 - i;
+        for (size_t x = 0; x + 1 < extra.size(); x += 2)
+            for (uint64_t i = extra[x]; i < extra[x + 1]; ++i) wanted += n - 1 - i;
         if (mode == 2) {
             wanted = 0;
             for (uint64_t si = rb; si < re; ++si) wanted += n - 1 - si;
@@ -157,9 +188,12 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
                     active = si < sj && si >= rb && si < re;
                     slot = si * n + sj;
                 } else {
+                    // (k_finalize: with extra segments run_pairs hands it the rows [rb, n) -- every pair of a launched tile)
                     const uint64_t oi = std::min(i, j), oj = std::max(i, j);
-                    active = si < sj && oi >= rb && oi < re;
+                    active = si < sj && oi >= rb && oi < (extra.empty() ? re : n);
                     slot = oi * n + oj;
+                    if (active && !extra.empty() && !in_rows(oi))
+                        return E.fail("tile (%u,%u) computes the pair (%llu,%llu) of a row this rank does not hold", t.x, t.y, (unsigned long long)oi, (unsigned long long)oj);
                 }
                 if (!active) continue;
                 if (hit[slot]++) return E.fail("pair slot %llu computed twice (tile %u,%u)", (unsigned long long)slot, t.x, t.y);
@@ -259,6 +293,33 @@ int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted,
     stats[3] = pp.nparts;
     stats[4] = T.empty() ? 0 : planes_sum * 100 / T.size();
     return 0;
+}
+
+extern "C" {
+
+int dshh_plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
+                    uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
+                    int ls_item_chunks, uint64_t *stats, char *err, size_t cap)
+{
+    return plan_check(n, keys, mode, want_sorted, rb, re, cb, ce, nparts, want_parts, p, cum_budget, lockstep, nsplit, ls_item_chunks,
+                      std::vector<uint64_t>(), stats, err, cap);
+}
+
+// the rows of ONE rank of a row-set table (plan.h): main range + extra segments, row-sorted parts (rowsorted != 0: what a
+// source rank of the exchange computes) or one part in final order (the destination)
+int dshh_plan_check_rowset(uint64_t n, const uint32_t *keys, const uint64_t *tab, uint32_t rank, int rowsorted, uint32_t nparts, int p,
+                           uint64_t cum_budget, uint64_t *stats, char *err, size_t cap)
+{
+    Err E{err, cap};
+    RowSets rs;
+    if (const char *why = parse_rowsets(tab, n, rs)) return E.fail("%s", why);
+    if (rank >= rs.world) return E.fail("rank %u of %u", rank, rs.world);
+    uint64_t rb, re;
+    std::vector<uint64_t> extra;
+    rs.rank_rows(rank, rb, re, extra);
+    for (int i = 0; i < 7; ++i) stats[i] = 0;
+    if (rb >= re) return 0;
+    return plan_check(n, keys, rowsorted ? 3 : 0, 1, rb, re, 0, 0, rowsorted ? nparts : 1, 1, p, cum_budget, 1, 0, 64, extra, stats, err, cap);
 }
 
 }  // extern "C"

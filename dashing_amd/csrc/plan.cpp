@@ -114,23 +114,220 @@ bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts)
     return re - rb < (uint64_t)1024 * nparts && tri_span(n, rb, re) * sizeof(float) <= ((uint64_t)1 << 30);
 }
 
-void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos)
+// tiles of every wanted tile row of a row set, in layout order: the block at layout block index b meets the NTc - b
+// blocks from itself to the right (the runs of the layout lie in row order, plan.h)
+static void wanted_tile_rows(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<uint64_t> &cnt)
+{
+    cnt.clear();
+    if (re > n) re = n;
+    if (rb >= re) return;
+    const uint64_t NTc = (n - rb + kTile - 1) / kTile;
+    auto add = [&](uint64_t b, uint64_t e) {
+        for (uint64_t t = (b - rb) / kTile, t1 = (e - rb + kTile - 1) / kTile; t < t1; ++t) cnt.push_back(NTc - t);
+    };
+    add(rb, re);
+    if (extra)
+        for (size_t x = 0; x + 1 < extra->size(); x += 2) add((*extra)[x], std::min<uint64_t>((*extra)[x + 1], n));
+}
+
+uint64_t rowset_rows(uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra)
+{
+    uint64_t r = re > rb ? re - rb : 0;
+    for (size_t x = 0; x + 1 < extra.size(); x += 2) r += extra[x + 1] - extra[x];
+    return r;
+}
+
+uint64_t rowset_span(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra)
+{
+    uint64_t s = tri_span(n, rb, re);
+    for (size_t x = 0; x + 1 < extra.size(); x += 2) s += tri_span(n, extra[x], extra[x + 1]);
+    return s;
+}
+
+uint64_t rowset_tiles(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra)
+{
+    std::vector<uint64_t> cnt;
+    wanted_tile_rows(n, rb, re, &extra, cnt);
+    uint64_t t = 0;
+    for (uint64_t c : cnt) t += c;
+    return t;
+}
+
+void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos,
+                              const std::vector<uint64_t> *extra)
 {
     pos.assign(1, 0);
     if (re > n) re = n;
     if (rb >= re) return;
-    const uint64_t R = re - rb, TR = (R + kTile - 1) / kTile, NTc = (n - rb + kTile - 1) / kTile;
-    // tile row t of the layout holds NTc - t tiles; cut after the tile row that reaches q / nparts of them
+    const uint64_t R = rowset_rows(rb, re, extra ? *extra : std::vector<uint64_t>());
+    // cut after the wanted tile row that reaches q / nparts of the tiles (only the last wanted tile row can hold fewer
+    // than 128 wanted rows: a rank with extra segments has all its boundaries on multiples of 128 or at n)
+    std::vector<uint64_t> cnt;
+    wanted_tile_rows(n, rb, re, extra, cnt);
+    const uint64_t TR = cnt.size();
     uint64_t total = 0;
-    for (uint64_t t = 0; t < TR; ++t) total += NTc - t;
+    for (uint64_t c : cnt) total += c;
     uint64_t acc = 0, t = 0;
     for (uint32_t q = 1; q < nparts && t < TR; ++q) {
         const uint64_t t0 = t;
-        while (t < TR && (acc * nparts < total * q || t == t0)) acc += NTc - t++;
+        while (t < TR && (acc * nparts < total * q || t == t0)) acc += cnt[t++];
         if (t >= TR) break;
         pos.push_back(t * kTile);
     }
     pos.push_back(R);
+}
+
+// ---- row sets --------------------------------------------------------------------------------------------------------
+void RowSets::write(uint64_t *tab) const
+{
+    const size_t ns = owner.size();
+    tab[0] = world;
+    tab[1] = ns;
+    for (size_t s = 0; s <= ns; ++s) tab[2 + s] = seg[s];
+    for (size_t s = 0; s < ns; ++s) tab[3 + ns + s] = owner[s];
+}
+
+void RowSets::rank_rows(uint32_t r, uint64_t &rb, uint64_t &re, std::vector<uint64_t> &extra) const
+{
+    rb = re = 0;
+    extra.clear();
+    bool have = false;
+    for (size_t s = 0; s < owner.size(); ++s) {
+        if (owner[s] != r || seg[s] >= seg[s + 1]) continue;
+        if (!have) {
+            rb = seg[s], re = seg[s + 1], have = true;
+        } else if (extra.empty() ? seg[s] == re : seg[s] == extra.back()) {  // adjacent: one segment
+            if (extra.empty()) re = seg[s + 1];
+            else extra.back() = seg[s + 1];
+        } else {
+            extra.push_back(seg[s]);
+            extra.push_back(seg[s + 1]);
+        }
+    }
+}
+
+const char *parse_rowsets(const uint64_t *tab, uint64_t n, RowSets &rs)
+{
+    if (!tab) return "the row-set table is NULL";
+    if (tab[0] == 0 || tab[0] > 65536) return "row-set table: bad number of ranks";
+    if (tab[1] > ((uint64_t)1 << 24)) return "row-set table: bad number of segments";
+    rs.world = (uint32_t)tab[0];
+    const size_t ns = (size_t)tab[1];
+    rs.seg.assign(tab + 2, tab + 3 + ns);
+    rs.owner.resize(ns);
+    if (rs.seg.front() != 0 || rs.seg.back() != n) return "row-set table: the segments must run from 0 to n";
+    for (size_t s = 0; s < ns; ++s) {
+        if (rs.seg[s] > rs.seg[s + 1]) return "row-set table: segment boundaries not monotone";
+        if (tab[3 + ns + s] >= rs.world) return "row-set table: a segment's owner is not a rank";
+        rs.owner[s] = (uint32_t)tab[3 + ns + s];
+    }
+    // a rank with extra segments: every boundary of its segments on a multiple of 128 (or at n)
+    std::vector<uint64_t> extra;
+    for (uint32_t r = 0; r < rs.world; ++r) {
+        uint64_t rb, re;
+        rs.rank_rows(r, rb, re, extra);
+        if (extra.empty()) continue;
+        auto ok = [n](uint64_t x) { return x % kTile == 0 || x == n; };
+        if (!ok(rb) || !ok(re)) return "row-set table: a rank with extra segments needs all its boundaries on multiples of 128";
+        for (uint64_t x : extra)
+            if (!ok(x)) return "row-set table: a rank with extra segments needs all its boundaries on multiples of 128";
+    }
+    return nullptr;
+}
+
+void rowsets_from_bounds(const uint64_t *bounds, uint32_t world, RowSets &rs)
+{
+    rs.world = world;
+    rs.seg.assign(bounds, bounds + world + 1);
+    rs.owner.resize(world);
+    for (uint32_t r = 0; r < world; ++r) rs.owner[r] = r;
+}
+
+void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille)
+{
+    const uint64_t NT = (n + kTile - 1) / kTile;
+    std::vector<uint64_t> cb(world + 1);
+    balance_rows(n, world, cb.data());
+    rowsets_from_bounds(cb.data(), world, rs);
+    if (world < 2 || n > kTopupMaxRows || NT < 2 * (uint64_t)world) return;
+    // The cost of a rank = its tiles + its own prepare (balance_rows: kPrepPerTileRow per 128 columns of its plane matrix,
+    // which starts at its first row).  For a limit: main ranges filled from the top, none above the limit; the tile rows
+    // left over at the bottom (NT - t tiles each) are dealt in RUNS of consecutive tile rows -- the rank furthest below
+    // the limit takes rows from the top of what is left while it stays under the limit, then the next rank (a run of
+    // consecutive rows is ONE extra segment, key-ordered as one run of the rank's layout; single rows dealt round-robin
+    // would each be a 128-row block in no key order); whatever is left then goes row by row to the cheapest rank.  Two
+    // sweeps over the limits: the smallest maximum any limit reaches, then, among the limits within half a percent of
+    // it, the one with the fewest segments.
+    const double kPrepPerTileRow = prep_permille == ~0u ? 0.9 : (double)prep_permille / 1000.0;
+    std::vector<uint64_t> start(world), stop(world);
+    std::vector<double> cost(world);
+    std::vector<uint32_t> deal, best_deal, byneed(world);
+    std::vector<uint64_t> best_start, best_stop;
+    double best_max = -1;
+    uint64_t best_t = NT + 1;
+    size_t best_segs = 0;
+    const double total = (double)NT * (double)(NT + 1) / 2.0;
+    const double lo = total / world, hi = total / world + kPrepPerTileRow * (double)NT + (double)NT;
+    const int steps = 800;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const double accept = best_max * 1.005;
+        for (int it = 0; it <= steps; ++it) {
+            const double limit = lo + (hi - lo) * it / steps;
+            uint64_t t = 0;
+            for (uint32_t r = 0; r < world; ++r) {
+                start[r] = t;
+                double acc = kPrepPerTileRow * (double)(NT - t);
+                while (t < NT && acc + (double)(NT - t) <= limit) acc += (double)(NT - t++);
+                stop[r] = t;
+                cost[r] = stop[r] > start[r] ? acc : 0.0;
+            }
+            const uint64_t t_pool = t;
+            deal.assign(NT - t_pool, ~0u);
+            for (uint32_t r = 0; r < world; ++r) byneed[r] = r;
+            std::stable_sort(byneed.begin(), byneed.end(), [&](uint32_t a, uint32_t b) { return cost[a] < cost[b]; });
+            uint64_t u = t_pool;
+            for (uint32_t k = 0; k < world && u < NT; ++k) {
+                const uint32_t r = byneed[k];
+                // (a rank without a main range would start its plane matrix at the dealt row: it pays that prepare)
+                if (cost[r] == 0) cost[r] = kPrepPerTileRow * (double)(NT - u);
+                while (u < NT && cost[r] + (double)(NT - u) <= limit) cost[r] += (double)(NT - u), deal[u++ - t_pool] = r;
+            }
+            for (; u < NT; ++u) {
+                uint32_t to = 0;
+                for (uint32_t r = 1; r < world; ++r)
+                    if (cost[r] < cost[to]) to = r;
+                cost[to] += (double)(NT - u);
+                deal[u - t_pool] = to;
+            }
+            double mx = 0;
+            for (uint32_t r = 0; r < world; ++r) mx = std::max(mx, cost[r]);
+            size_t segs = 0;
+            for (size_t d = 0; d < deal.size(); ++d) segs += d == 0 || deal[d] != deal[d - 1];
+            if (sweep == 0) {
+                if (best_max < 0 || mx < best_max) best_max = mx;
+            } else if (mx <= accept && (best_t == NT + 1 || segs < best_segs)) {
+                best_t = t_pool;
+                best_segs = segs;
+                best_deal = deal;
+                best_start = start;
+                best_stop = stop;
+            }
+        }
+    }
+    if (best_t >= NT) return;  // nothing dealt: the contiguous ranges
+    // a rank that holds dealt rows needs aligned boundaries: all main boundaries are multiples of 128 by construction
+    rs.seg.clear();
+    rs.owner.clear();
+    rs.seg.push_back(0);
+    auto push = [&](uint64_t end_row, uint32_t who) {
+        if (end_row <= rs.seg.back()) return;
+        if (!rs.owner.empty() && rs.owner.back() == who) rs.seg.back() = end_row;
+        else rs.seg.push_back(end_row), rs.owner.push_back(who);
+    };
+    for (uint32_t r = 0; r < world; ++r) push(std::min<uint64_t>(n, best_stop[r] * kTile), r);
+    for (uint64_t u = best_t; u < NT; ++u) push(std::min<uint64_t>(n, (u + 1) * kTile), best_deal[u - best_t]);
+    if (rs.owner.empty()) rs.owner.push_back(0), rs.seg.push_back(n);
+    rs.seg.back() = n;
 }
 
 void sort_rows_by_key(const uint32_t *k32, uint64_t lo, uint64_t hi, uint32_t *dst, std::vector<uint32_t> &a)
@@ -179,11 +376,13 @@ void tile_planes(const Layout &L, uint32_t ti, uint32_t tj, int &pb, int &pe)
 }
 
 void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
-                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts)
+                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts, const std::vector<uint64_t> *extra_in)
 {
     if (re > n) re = n;
     if (!want_sorted) rb = 0, re = n;
     if (rb > re) rb = re;
+    static const std::vector<uint64_t> kNoExtra;
+    const std::vector<uint64_t> &extra = (want_sorted && extra_in && rb < re) ? *extra_in : kNoExtra;
     // the plane matrix holds the sketches col0 .. n-1 (a row range [rb,re) of the triangle never looks at
     // sketches before rb); value range and thresholds are taken over those only
     const uint64_t col0 = want_sorted ? rb : 0;
@@ -200,7 +399,8 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     L.rb = rb;
     L.re = re;
     L.rowsorted = want_sorted && rowsorted_nparts > 0;
-    if (L.rowsorted) L.parts = {rb, re};  // ONE key-ordered run
+    L.extra = extra;
+    if (L.rowsorted || !extra.empty()) L.parts = {rb, re};  // ONE key-ordered run
     else L.parts = want_sorted ? parts : std::vector<uint64_t>();
     L.n = n;
     L.vlo = vr[0];
@@ -215,14 +415,49 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     // then the later rows; each part is key-ordered on its own.
     L.perm.resize(ncols);
     L.part_pos.clear();
+    L.part_w.clear();
     L.rowoff.clear();
+    L.rowoff_w.clear();
+    L.wtr.clear();
+    L.nwanted = want_sorted ? rowset_rows(rb, re, extra) : n;
     if (want_sorted) {
+        // the runs, in row order (a run of rows [lo, hi) lies at the positions [lo - rb, hi - rb)): the parts of the
+        // wanted range, then the later rows -- cut into [gap | extra segment | gap ...] where extra segments lie
         for (size_t q = 0; q + 1 < L.parts.size(); ++q)
             sort_rows_by_key(k32, L.parts[q], L.parts[q + 1], L.perm.data() + (L.parts[q] - rb), L.sort_a);
-        sort_rows_by_key(k32, re, n, L.perm.data() + (re - rb), L.sort_a);
+        uint64_t at = re;
+        for (size_t x = 0; x + 1 < extra.size(); x += 2) {
+            if (extra[x] > at) sort_rows_by_key(k32, at, extra[x], L.perm.data() + (at - rb), L.sort_a);
+            sort_rows_by_key(k32, extra[x], extra[x + 1], L.perm.data() + (extra[x] - rb), L.sort_a);
+            at = extra[x + 1];
+        }
+        if (at < n) sort_rows_by_key(k32, at, n, L.perm.data() + (at - rb), L.sort_a);
+        // tile rows that hold wanted rows
+        if (re > rb) L.wtr.emplace_back(0u, (uint32_t)((re - rb + kTile - 1) / kTile));
+        for (size_t x = 0; x + 1 < extra.size(); x += 2)
+            L.wtr.emplace_back((uint32_t)((extra[x] - rb) / kTile), (uint32_t)((extra[x + 1] - rb + kTile - 1) / kTile));
+        const uint64_t wend = extra.empty() ? re - rb : extra.back() - rb;  // position behind the last wanted row
         if (L.rowsorted) {
-            rowsorted_part_positions(n, rb, re, rowsorted_nparts, L.part_pos);
-            rowsorted_offsets(n, L.perm.data(), re - rb, L.rowoff);
+            rowsorted_part_positions(n, rb, re, rowsorted_nparts, L.part_w, &extra);
+            // compact order of the wanted rows -> their rows' offsets in the rank's buffer, and the same by position
+            L.rowoff_w.resize(L.nwanted + 1);
+            L.rowoff.assign(wend + 1, 0);
+            std::vector<uint64_t> wpos(L.nwanted + 1);  // layout position of the w-th wanted row
+            uint64_t acc = 0, w = 0;
+            auto walk = [&](uint64_t b, uint64_t e) {
+                for (uint64_t s = b - rb; s < e - rb; ++s, ++w) {
+                    wpos[w] = s;
+                    L.rowoff_w[w] = L.rowoff[s] = acc;
+                    acc += n - 1 - L.perm[s];
+                }
+            };
+            walk(rb, re);
+            for (size_t x = 0; x + 1 < extra.size(); x += 2) walk(extra[x], extra[x + 1]);
+            wpos[L.nwanted] = wend;
+            L.rowoff_w[L.nwanted] = L.rowoff[wend] = acc;
+            for (uint64_t c : L.part_w) L.part_pos.push_back(wpos[c]);
+        } else if (!extra.empty()) {
+            L.part_pos = {0, wend};
         } else {
             for (uint64_t r : L.parts) L.part_pos.push_back(r - rb);
         }
@@ -332,15 +567,19 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
         for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, c0, c1);
     } else {
         if (job.row_begin >= job.row_end) return false;
-        uint32_t r0 = 0, r1 = NT;
         if (!L.sorted || job.sorted_rows) {  // rows index plane columns: only their tile rows
-            r0 = (uint32_t)(job.row_begin / kTile);
-            r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
-        } else {  // the wanted rows are the first re - rb columns
-            r1 = std::min<uint32_t>(NT, (uint32_t)((L.re - L.rb + kTile - 1) / kTile));
+            const uint32_t r0 = (uint32_t)(job.row_begin / kTile);
+            const uint32_t r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
+            if (r1 > r0) T.reserve((size_t)(r1 - r0) * (NT - r0) - (size_t)(r1 - r0) * (r1 - r0 - 1) / 2);
+            for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, ti, NT);
+        } else {  // the tile rows of the wanted runs (the first re - rb columns, and the extra segments' blocks)
+            size_t cnt = 0;
+            for (const auto &w : L.wtr)
+                for (uint32_t ti = w.first; ti < std::min(w.second, NT); ++ti) cnt += NT - ti;
+            T.reserve(cnt);
+            for (const auto &w : L.wtr)
+                for (uint32_t ti = w.first; ti < std::min(w.second, NT); ++ti) tile_row(ti, ti, NT);
         }
-        if (r1 > r0) T.reserve((size_t)(r1 - r0) * (NT - r0) - (size_t)(r1 - r0) * (r1 - r0 - 1) / 2);
-        for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, ti, NT);
     }
     if (T.empty()) return false;
     // bands bounded by the cum scratch budget
@@ -570,6 +809,48 @@ int dsh_balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds)
 {
     if (!bounds || nparts == 0) return DSH_EINVAL;
     dsh::plan::balance_rows(n, nparts, bounds);
+    return DSH_OK;
+}
+
+int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, uint64_t *tab_out, uint32_t cap_words, uint32_t *words_out)
+{
+    if (world == 0 || (!tab_out && cap_words)) return DSH_EINVAL;
+    dsh::plan::RowSets rs;
+    dsh::plan::balance_rowsets(n, world, rs, prep_permille < 0 ? ~0u : (uint32_t)prep_permille);
+    if (words_out) *words_out = (uint32_t)rs.words();
+    if (!tab_out) return DSH_OK;  // (size query)
+    if (rs.words() > cap_words) return DSH_EINVAL;
+    rs.write(tab_out);
+    return DSH_OK;
+}
+
+int dsh_rowsets_from_bounds(const uint64_t *bounds, uint32_t world, uint64_t *tab_out)
+{
+    if (!bounds || !tab_out || world == 0) return DSH_EINVAL;
+    dsh::plan::RowSets rs;
+    dsh::plan::rowsets_from_bounds(bounds, world, rs);
+    rs.write(tab_out);
+    return DSH_OK;
+}
+
+int dsh_rowsets_rank(uint64_t n, const uint64_t *tab, uint32_t rank, uint64_t *segs_out, uint32_t cap_segs, uint32_t *nsegs_out,
+                     uint64_t *pairs_out, uint64_t *tiles_out)
+{
+    dsh::plan::RowSets rs;
+    if (dsh::plan::parse_rowsets(tab, n, rs) || rank >= rs.world) return DSH_EINVAL;
+    uint64_t rb, re;
+    std::vector<uint64_t> extra;
+    rs.rank_rows(rank, rb, re, extra);
+    const uint32_t ns = (rb < re ? 1u : 0u) + (uint32_t)(extra.size() / 2);
+    if (nsegs_out) *nsegs_out = ns;
+    if (pairs_out) *pairs_out = dsh::plan::rowset_span(n, rb, re, extra);
+    if (tiles_out) *tiles_out = dsh::plan::rowset_tiles(n, rb, re, extra);
+    if (segs_out) {
+        if (ns > cap_segs) return DSH_EINVAL;
+        uint32_t at = 0;
+        if (rb < re) segs_out[at++] = rb, segs_out[at++] = re;
+        for (uint64_t x : extra) segs_out[at++] = x;
+    }
     return DSH_OK;
 }
 

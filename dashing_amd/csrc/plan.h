@@ -42,6 +42,41 @@ void balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds);
 // tile rows after rb (fewer parts if the range has fewer tile rows); out gets the boundaries
 void range_parts(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &out);
 
+// ---- row sets: a rank's rows as a range plus top-up tile rows --------------------------------------------------------
+// Contiguous row ranges on 128-row boundaries cannot give every rank the same number of tiles when the ranges are a
+// few tile rows long (10 000 sketches over 8 ranks: tile rows hold 79 ... 1 tiles, a rank ~395): the short tile rows
+// at the BOTTOM of the triangle are therefore dealt one by one to the ranks whose range falls short of the mean.  The
+// partition is a table of row segments with owners (include/dashing_hip.h, dsh_balance_rowsets):
+//   tab[0] = world, tab[1] = nseg, tab[2 .. 2 + nseg] = the nseg + 1 segment boundaries from 0 to n,
+//   tab[3 + nseg .. 3 + 2 nseg) = the owner of every segment.
+// A rank's rows are the segments it owns, adjacent ones merged: the first is its MAIN range [rb, re) -- its plane matrix
+// holds the sketches rb .. n-1 -- the others are its EXTRA segments.  A rank with extra segments must have all its
+// segment boundaries on multiples of 128 (or n): the runs of its layout are then whole 128-column blocks.
+struct RowSets {
+    uint32_t world = 0;
+    std::vector<uint64_t> seg;    // nseg + 1 boundaries
+    std::vector<uint32_t> owner;  // nseg
+    size_t words() const { return 3 + 2 * owner.size(); }
+    void write(uint64_t *tab) const;
+    // the rows of rank r: main range (rb == re: none) and the extra segments, flat {b0, e0, b1, e1, ...}
+    void rank_rows(uint32_t r, uint64_t &rb, uint64_t &re, std::vector<uint64_t> &extra) const;
+};
+// nullptr when the table is well-formed for n rows, else what is wrong with it
+const char *parse_rowsets(const uint64_t *tab, uint64_t n, RowSets &rs);
+void rowsets_from_bounds(const uint64_t *bounds, uint32_t world, RowSets &rs);
+// main ranges as balance_rows() makes them over the top of the triangle + the bottom tile rows dealt as top-ups, so
+// that the largest cost of any rank (tiles + its own prepare) is smallest; plain balance_rows() ranges when the
+// collection is large (n > kTopupMaxRows: a tile row is then a small fraction of a rank's work and the row-sorted
+// exchange would have to stage gigabytes) or a rank would get fewer than two tile rows
+constexpr uint64_t kTopupMaxRows = 32768;
+// prep_permille: the weight of a rank's own prepare, in thousandths of a tile per 128 columns of its plane matrix
+// (~0u: the default)
+void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille = ~0u);
+// tiles a rank with these rows computes, and the rows it holds
+uint64_t rowset_tiles(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
+uint64_t rowset_rows(uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
+uint64_t rowset_span(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
+
 // default caps of the two listed tails (profiles/r3f/list_cap_sweep.jsonl)
 int auto_list_cap(int p, bool upper);
 
@@ -53,21 +88,33 @@ int auto_list_cap(int p, bool upper);
 // destination puts the rows of a received part into place (k_row_place).
 // rowsorted_rule: a range of fewer than 1024 rows per part whose span is at most 1 GiB (the destination stages it).
 bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts);
-// cut positions (multiples of 128 rows of the key order, front() = 0, back() = re - rb) of about equal tile counts
-void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos);
+// cut positions (multiples of 128 rows of the key order, front() = 0, back() = number of wanted rows) of about equal
+// tile counts.  With extra segments the positions count WANTED rows only (main range first, then the extra segments
+// in row order): the compact order the rank's buffer and the destination's tables use.
+void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos,
+                              const std::vector<uint64_t> *extra = nullptr);
 // the key order of the rows [lo, hi): dst[0 .. hi - lo) = their indices, stable by (T, L, hi) of the per-sketch keys
 void sort_rows_by_key(const uint32_t *keys, uint64_t lo, uint64_t hi, uint32_t *dst, std::vector<uint32_t> &scratch);
 // offsets of the rows of a row-sorted buffer: rowoff[s] = sum over s' < s of (n - 1 - order[s']), rowoff[cnt] = span
 void rowsorted_offsets(uint64_t n, const uint32_t *order, uint64_t cnt, std::vector<uint64_t> &rowoff);
 
 // ---- column layout of the plane matrix ------------------------------------------------------------------------------
+// The columns of a sorted layout are RUNS of consecutive original rows in row order, each key-ordered on its own: the
+// parts of the wanted range [rb, re), then -- without extra segments -- the later rows as one run; with extra segments
+// the later rows are cut where the extra segments lie: [gap | extra | gap | extra | ...], so that the tile rows of an
+// extra segment only meet the columns to their right, i.e. the later rows (every pair they compute is theirs).
 struct Layout {
     int sorted = 0;               // 0: identity over all n sketches.  1: the sub-collection {rb .. n-1}, key-ordered
     uint64_t rb = 0, re = 0;      // wanted rows of a sorted layout (rb = 0, re = n: the whole collection)
+    std::vector<uint64_t> extra;  // further wanted segments {b0, e0, ...} after re (plan.h, row sets), all on 128-row boundaries
+    std::vector<std::pair<uint32_t, uint32_t>> wtr;  // the tile rows (128-column blocks) that hold wanted rows, as block ranges
+    uint64_t nwanted = 0;         // wanted rows in all
+    std::vector<uint64_t> part_w;    // (rowsorted) the parts as counts of wanted rows, front() = 0, back() = nwanted
+    std::vector<uint64_t> rowoff_w;  // (rowsorted) offset of the w-th wanted row (layout order) in the rank's buffer, [nwanted + 1]
     std::vector<uint64_t> parts;  // row boundaries of the parts of the wanted rows, front() = rb, back() = re
     int rowsorted = 0;            // the wanted rows are ONE key-ordered run; the parts are runs of whole tile rows of that order
     std::vector<uint64_t> part_pos;  // the parts as positions of the layout, front() = 0, back() = re - rb
-    std::vector<uint64_t> rowoff;    // (rowsorted) offset of the row at position s in the rank's buffer, [re - rb + 1]
+    std::vector<uint64_t> rowoff;    // (rowsorted) offset of the row at layout position s in the rank's buffer (unwanted positions: 0)
     uint64_t n = 0, ncols = 0;    // sketches in the collection; real columns of the plane matrix
     uint32_t Npad = 0;            // ncols padded to whole 128-column blocks
     bool whole = false;           // sorted over the whole collection: perm also holds its inverse at [n, 2n)
@@ -82,8 +129,10 @@ struct Layout {
 // keys: the n per-sketch keys (only [rb, n) is read for a sorted layout).  `parts` as range_parts() gives them
 // (ignored for the identity layout).
 // rowsorted_nparts > 0 (sorted layouts only): row-sorted parts, `parts` is ignored.
+// extra (sorted layouts only): further wanted segments; the wanted range is then ONE part (`parts` is ignored).
 void build_layout(const uint32_t *keys, uint64_t n, int want_sorted, uint64_t rb, uint64_t re,
-                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts = 0);
+                  const std::vector<uint64_t> &parts, Layout &L, uint32_t rowsorted_nparts = 0,
+                  const std::vector<uint64_t> *extra = nullptr);
 
 // dense plane range of the tile (ti, tj): C(v) is needed for v in (max(larger of the two minima, smaller of the two
 // low thresholds), larger of the two high thresholds] -- below that every C(v) is 0 or comes from the low-list join

@@ -227,6 +227,8 @@ int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_
  *   dsh_dist_collect     the whole multi-GPU dist step for a host without device pointers: computes this rank's row
  *                        range, delivers the spans to `dst`, which gets the full packed matrix in `out` (host,
  *                        n(n-1)/2 floats; ignored on other ranks).  Without a communicator (world = 1) it is dsh_dist_rows.
+ *                        bounds = NULL: the library partitions the rows itself (dsh_balance_rowsets) and runs the
+ *                        pipelined exchange pair below.
  * Pipelined form (the exchange hidden behind the compute): dsh_dist_rows_parts_device_async computes a row range in
  * `nparts` consecutive parts (dsh_range_parts: about equal pair counts, cuts on whole 128-row tile rows; the plane
  * matrix keeps every part key-ordered on its own) and marks the completion of each part on the ctx stream;
@@ -235,6 +237,15 @@ int dsh_unpermute_blocks_device(dsh_ctx *ctx, const void *d_stage, const uint64_
  * with the same bounds / nparts; dsh_comm_wait (or dsh_wait / a ticket) completes them.  A range of any length works: a
  * call with parts always lays its range out in exactly the parts dsh_range_parts reports (a short range: one part),
  * and a rank without rows simply takes no part in the rounds.
+ * ENVIRONMENT INPUTS of the library (all read by the exchange only):
+ *   DSH_RCCL_LIB             path of the RCCL library to dlopen instead of librccl.so.1.  A CODE-LOADING TRUST BOUNDARY:
+ *                            whatever it names runs inside the process that called dsh_comm_* (the tests load the
+ *                            stand-in transport tests/mock_rccl through it).  A set-uid / privileged host must clear it.
+ *                            If set and not loadable, dsh_comm_available reports DSH_ENODEV (never a silent fallback).
+ *   DSH_COMM_INIT_TIMEOUT_S  seconds dsh_comm_init waits for ncclCommInitRank (default 90).  A timeout is FATAL for the
+ *                            job: the helper thread stays inside RCCL, and should the peers arrive later the orphan
+ *                            communicator is aborted, so that they fail too instead of waiting for this rank.
+ *   DSH_COMM_TIMEOUT_S       seconds dsh_comm_wait and the blocking exchange calls wait (default 120)
  * Failure behaviour (a multi-rank job must end with an error, not hang):
  *   dsh_comm_available   DSH_OK if librccl can be loaded here (DSH_ENODEV otherwise) -- local, no communication: let
  *                        every rank check it and agree BEFORE the collective dsh_comm_init
@@ -250,26 +261,46 @@ int dsh_dist_rows_parts_device_async(dsh_ctx *ctx, int estim, int result_type, i
                                      void *d_out, uint32_t nparts);
 int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
                             void *d_final, int dst);
-/* The exchange-aware pair (round 4).  Parts of consecutive rows are key-ordered each on its own, so a SHORT range cut into
- * many parts loses the ordering its tiles live on (one 128-row block per part: 10 planes per tile instead of 8.7 at
- * BASELINE configs[2] over 8 ranks).  Here the layout of every rank's buffer follows from (bounds, nparts, dst) alone:
- *   - the destination computes its own rows in place (d_local = d_final + its offset) as ONE part;
- *   - a range of fewer than 1024 rows per part (span <= 1 GiB) is key-ordered as ONE run, its parts are runs of whole tile
- *     rows of that order, d_local holds the rows in key order; the destination stages what it receives and puts the rows
- *     of every part into place (one contiguous copy per row) behind the part's transfer;
+/* The exchange-aware pair.  Parts of consecutive rows are key-ordered each on its own, so a SHORT range cut into many
+ * parts loses the ordering its tiles live on (one 128-row block per part: 10 planes per tile instead of 8.7 at BASELINE
+ * configs[2] over 8 ranks), and contiguous ranges on 128-row boundaries cannot give every rank the same number of tiles
+ * when a range is only a few tile rows long (tile rows hold 79 ... 1 tiles there, a rank ~395).  So the partition is a
+ * ROW-SET TABLE -- row segments with owners:
+ *     tab[0] = world, tab[1] = nseg, tab[2 .. 2 + nseg] = the nseg + 1 segment boundaries from 0 to n,
+ *     tab[3 + nseg .. 3 + 2 nseg) = the owning rank of every segment                       (3 + 2 nseg words)
+ * A rank's rows are the segments it owns (adjacent ones merged): the first is its MAIN range, the others EXTRA segments
+ * ("top-ups"); a rank with extra segments must have all its boundaries on multiples of 128 (or at n).
+ *   dsh_balance_rowsets      main ranges over the top of the triangle + the short tile rows at its bottom dealt, in runs
+ *                            of consecutive tile rows, to the ranks that fall short of the mean: the largest cost of any
+ *                            rank (tiles + its own prepare, prep_permille/1000 tiles per 128 columns of its plane matrix;
+ *                            < 0: the default) is smallest.  Plain dsh_balance_rows ranges when n > 32 768 or a rank would
+ *                            hold fewer than two tile rows.  tab_out = NULL: only the size (words_out).
+ *   dsh_rowsets_from_bounds  contiguous bounds[world + 1] as a table (3 + 2 world words): any alignment
+ *   dsh_rowsets_rank         the segments {b0, e0, b1, e1, ...} of one rank, its pairs and its 128 x 128 tiles
+ * The layout of every rank's buffer follows from (table, nparts, dst) alone:
+ *   - the destination computes its own rows in place (d_local = d_final + the offset of its first row) as ONE part;
+ *   - a rank with extra segments, or with a range of fewer than 1024 rows per part (span <= 1 GiB), goes ROW-SORTED: every
+ *     segment key-ordered as one run, its parts are runs of whole tile rows of that order, d_local holds the rows in that
+ *     order; the destination stages what it receives and puts the rows of every part into place (one contiguous copy
+ *     per row) behind the part's transfer;
  *   - longer ranges go in parts of consecutive rows, received in place, as with dsh_collect_parts_async.
  * dsh_exchange_rows_device_async computes rank `rank`'s rows (enqueued; an event per part), dsh_exchange_collect_async
  * enqueues the rounds of grouped ncclSend/ncclRecv on the copy stream; every rank calls both with the same arguments;
- * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts).
- * dsh_exchange_place_device does, for ONE source rank and without a communicator, what the destination does with that
- * rank's buffer (tests and single-GPU timing of an N-rank plan). */
-int dsh_exchange_mode(uint64_t n, const uint64_t *bounds, int world, int rank, uint32_t nparts, int dst, int *rowsorted,
-                      uint32_t *nparts_out);
-int dsh_exchange_rows_device_async(dsh_ctx *ctx, int estim, int result_type, int k, const uint64_t *bounds, int world, int rank,
+ * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts) and how
+ * many floats d_local must hold.  dsh_exchange_place_device does, for ONE source rank and without a communicator, what
+ * the destination does with that rank's buffer (tests and single-GPU timing of an N-rank plan).
+ * dsh_dist_collect(bounds = NULL) runs this pair over dsh_balance_rowsets' table. */
+int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, uint64_t *tab_out, uint32_t cap_words, uint32_t *words_out);
+int dsh_rowsets_from_bounds(const uint64_t *bounds, uint32_t world, uint64_t *tab_out /* [3 + 2 world] */);
+int dsh_rowsets_rank(uint64_t n, const uint64_t *rowsets, uint32_t rank, uint64_t *segs_out /* [2 cap_segs] or NULL */, uint32_t cap_segs,
+                     uint32_t *nsegs_out, uint64_t *pairs_out, uint64_t *tiles_out);
+int dsh_exchange_mode(uint64_t n, const uint64_t *rowsets, int rank, uint32_t nparts, int dst, int *rowsorted,
+                      uint32_t *nparts_out, uint64_t *local_floats_out);
+int dsh_exchange_rows_device_async(dsh_ctx *ctx, int estim, int result_type, int k, const uint64_t *rowsets, int rank,
                                    uint32_t nparts, int dst, void *d_local);
-int dsh_exchange_collect_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, uint32_t nparts, const void *d_local,
+int dsh_exchange_collect_async(dsh_ctx *ctx, uint64_t n, const uint64_t *rowsets, uint32_t nparts, const void *d_local,
                                void *d_final, int dst);
-int dsh_exchange_place_device(dsh_ctx *ctx, const uint64_t *bounds, int world, int src, uint32_t nparts, int dst,
+int dsh_exchange_place_device(dsh_ctx *ctx, const uint64_t *rowsets, int src, uint32_t nparts, int dst,
                               const void *d_src_local, void *d_final);
 int dsh_comm_available(void);
 int dsh_comm_library(char *path_out, size_t cap, int *version_out);

@@ -3,8 +3,9 @@ library's exchange on a box with one GPU.  Every rank is a process of its own on
 tests/mock_rccl/libmock_rccl.so (DSH_RCCL_LIB) instead of librccl: the same dsh_comm_* / dsh_exchange_* / dsh_collect_*
 calls a real multi-GPU run makes, with messages that only match when both sides agree on order, peer and size.
 
-env: RANK, WORLD, N, P, NPARTS, MODE (exchange | parts | spans | collect | allgather), ID_FILE (rank 0 leaves the unique id
-there), DST.  Rank DST checks the assembled matrix against its own single-GPU result, byte for byte."""
+env: RANK, WORLD, N, P, NPARTS, MODE (exchange | parts | spans | collect | collect-auto | allgather), ID_FILE (rank 0 leaves
+the unique id there), DST, ROWSETS=1 (MODE exchange: the balanced row-set table -- ranges + top-up tile rows -- instead of
+contiguous bounds).  Rank DST checks the assembled matrix against its own single-GPU result, byte for byte."""
 import os
 import sys
 import time
@@ -50,17 +51,25 @@ def main():
     if os.environ.get("BOUNDS"):  # ragged ranges, empty ones included
         bounds = [int(x) for x in os.environ["BOUNDS"].split(",")]
     span = dashing_amd.tri_span(n, bounds[rank], bounds[rank + 1])
+    first_row = bounds[rank]
+    rows = bounds
+    if os.environ.get("ROWSETS") and mode == "exchange":
+        rows = dashing_amd.balance_rowsets(n, world)
+        span = dashing_amd.exchange_mode(n, rows, rank, nparts, dst, want_floats=True)[2]
+        first_row = rows.rows(rank)[0][0] if rows.rows(rank) else 0
+        if os.environ.get("EXPECT_TOPUPS"):
+            assert any(len(rows.rows(r)) > 1 for r in range(world)), "this case is meant to exercise top-up segments"
     final = torch.zeros(max(total, 1), dtype=torch.float32, device="cuda") if rank == dst else None
     in_place = rank == dst and mode in ("exchange", "parts", "spans")
-    local = final[dashing_amd.tri_span(n, 0, bounds[rank]):] if in_place else torch.zeros(max(span, 1), dtype=torch.float32, device="cuda")
+    local = final[dashing_amd.tri_span(n, 0, first_row):] if in_place else torch.zeros(max(span, 1), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     lp, fp = local.data_ptr(), (final.data_ptr() if rank == dst else 0)
     got = None
     if mode == "exchange":  # what bench.py --gpus N runs
         for _ in range(2):  # twice: the second call reuses staging, tables and events
             ctx.attach_device(regs.data_ptr(), n, p)
-            ctx.exchange_rows_device_async(lp, bounds, rank, nparts, dst)
-            ctx.exchange_collect_async(n, bounds, nparts, 0 if rank == dst else lp, fp, dst)
+            ctx.exchange_rows_device_async(lp, rows, rank, nparts, dst)
+            ctx.exchange_collect_async(n, rows, nparts, 0 if rank == dst else lp, fp, dst)
             ctx.comm_wait()
         got = final
     elif mode == "parts":
@@ -74,6 +83,9 @@ def main():
         got = final
     elif mode == "collect":  # the whole step for a host without device pointers
         out = ctx.dist_collect(bounds, dst)
+        got = torch.from_numpy(np.asarray(out)).cuda() if rank == dst else None
+    elif mode == "collect-auto":  # the same with the library's own partition (balanced row sets, the pipelined pair)
+        out = ctx.dist_collect(None, dst)
         got = torch.from_numpy(np.asarray(out)).cuda() if rank == dst else None
     elif mode == "allgather":
         m = 1 << p

@@ -281,11 +281,61 @@ def test_exchange_pair_virtual_ranks_row_sorted_parts(ctx):
     assert not rs and k == 2
 
 
+def test_exchange_pair_virtual_ranks_row_sets(ctx):
+    """the same with dsh_balance_rowsets' tables: ranges + top-up tile rows.  Every rank's pairs are its own (sorted values
+    equal those of its rows in the single-GPU matrix), the tiles it computes are the table's count, and the destination's
+    placement assembles the single-GPU matrix byte for byte; worlds 2..8, destinations first / middle / last."""
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    n, p = 3300, 12
+    regs = torch.from_numpy(synth.survey_sketches(n, p, seed=14)[0]).cuda()
+    ctx.attach_device(regs.data_ptr(), n, p)
+    total = n * (n - 1) // 2
+    want = torch.empty(total, dtype=torch.float32, device="cuda")
+    ctx.dist_rows_device(want.data_ptr(), 0, n)
+    ctx.synchronize()
+    topups = 0
+    for world, dst, nparts in ((2, 0, 8), (3, 1, 2), (4, 3, 4), (8, 0, 8), (8, 7, 3), (5, 2, 1)):
+        rows = dashing_amd.balance_rowsets(n, world)
+        final = torch.full((total,), -7.0, dtype=torch.float32, device="cuda")
+        order = [dst] + [r for r in range(world) if r != dst]
+        tiles = 0
+        for r in order:
+            segs = rows.rows(r)
+            topups += len(segs) > 1
+            rs, k, floats = dashing_amd.exchange_mode(n, rows, r, nparts, dst, want_floats=True)
+            if not segs:
+                continue
+            if r == dst:
+                assert not rs and k == 1
+                local = final[dashing_amd.tri_span(n, 0, segs[0][0]):]
+            else:
+                assert floats == rows.pairs(r)
+                assert rs == (len(segs) > 1 or (nparts >= 2 and segs[0][1] - segs[0][0] < 1024 * nparts))
+                local = torch.full((max(floats, 1),), -3.0, dtype=torch.float32, device="cuda")
+            ctx.attach_device(regs.data_ptr(), n, p)
+            ctx.exchange_rows_device_async(local.data_ptr(), rows, r, nparts, dst)
+            ctx.synchronize()
+            assert ctx.info("parts_done") == k and ctx.info("tiles") == rows.tiles(r), (world, dst, nparts, r)
+            tiles += rows.tiles(r)
+            if r != dst:
+                mine = torch.cat([want[dashing_amd.tri_span(n, 0, b):dashing_amd.tri_span(n, 0, e)] for b, e in segs])
+                assert torch.equal(torch.sort(local[:floats])[0], torch.sort(mine)[0]), (world, dst, nparts, r)
+                ctx.exchange_place_device(rows, r, nparts, local.data_ptr(), final.data_ptr(), dst)
+        assert torch.equal(final, want), (world, dst, nparts)
+        nt = (n + 127) // 128
+        assert tiles == nt * (nt + 1) // 2  # nothing computed twice, nothing for another rank's rows
+    assert topups >= 6, "these cases are meant to exercise top-up segments"
+
+
 MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
 MOCK_WORKER = os.path.join(ROOT, "tests", "mock_exchange_worker.py")
 
 
-def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=900, opts=""):
+def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, timeout=900, opts="", rowsets=False, expect_topups=False):
     """`world` processes on the one GPU, the library's RCCL calls served by tests/mock_rccl (messages as files, matched
     by order, peer and exact size)"""
     if not os.path.exists(MOCK):
@@ -295,6 +345,10 @@ def run_mock_world(tmp_path, world, n, p, nparts, mode, dst=0, bounds=None, time
                HSA_ENABLE_IPC_MODE_LEGACY="0", OPTS=opts)
     if bounds:
         env["BOUNDS"] = ",".join(str(b) for b in bounds)
+    if rowsets:
+        env["ROWSETS"] = "1"
+    if expect_topups:
+        env["EXPECT_TOPUPS"] = "1"
     procs = [subprocess.Popen([sys.executable, MOCK_WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = []
@@ -332,6 +386,29 @@ def test_exchange_protocol_other_destination_and_ragged_ranges(tmp_path):
     """the destination need not be rank 0, a rank may own no rows at all, another a single row"""
     run_mock_world(tmp_path, 4, 1700, 12, 3, "exchange", dst=2, bounds=[0, 0, 640, 1699, 1700])
     run_mock_world(tmp_path, 3, 1700, 12, 2, "parts", dst=1, bounds=[0, 900, 900, 1700])
+    # ADVICE r4: the DESTINATION owns no rows while the sources are row-sorted -- it used to return before any per-sketch
+    # pass and fail in the collect with the peers' sends already posted
+    run_mock_world(tmp_path, 3, 1700, 12, 2, "exchange", dst=0, bounds=[0, 0, 900, 1700])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,p,nparts,dst", [
+    (8, 4000, 10, 8, 0),   # the shape of the driver's 8-rank run, scaled: ranges of 2-6 tile rows + top-ups
+    (4, 3000, 12, 3, 2),   # the destination itself holds top-up segments (computed in place, in final order)
+    (3, 1400, 12, 8, 1),   # more parts asked for than a rank has tile rows
+])
+def test_exchange_protocol_row_sets_between_processes(tmp_path, world, n, p, nparts, dst):
+    """the balanced partition -- a rank's rows are a range plus top-up tile rows from the bottom of the
+    triangle (dsh_balance_rowsets) -- through the real exchange code between processes: every source row-sorted (each
+    segment one key-ordered run), staged and placed row by row; the destination's matrix equals the single-GPU one."""
+    run_mock_world(tmp_path, world, n, p, nparts, "exchange", dst=dst, rowsets=True, expect_topups=True)
+
+
+@pytest.mark.gpu
+def test_dist_collect_with_the_librarys_own_partition(tmp_path):
+    """dsh_dist_collect(bounds = NULL): balanced row sets + the pipelined exchange pair, for a host without device pointers"""
+    run_mock_world(tmp_path, 4, 2200, 10, 1, "collect-auto")
+    run_mock_world(tmp_path, 3, 1500, 12, 1, "collect-auto", dst=2)
 
 
 @pytest.mark.gpu

@@ -179,3 +179,131 @@ def test_triangle_arithmetic_and_partitions(host):
     nt = (n + 127) // 128
     tiles = [sum(nt - t for t in range(int(b[r]) // 128, (int(b[r + 1]) + 127) // 128)) for r in range(world)]
     assert max(tiles) <= 1.15 * sum(tiles) / world, tiles
+
+
+# ---- row sets: a rank's rows as a range + top-up tile rows (plan.h; dsh_balance_rowsets) ---------------------------------
+def _rowset_api(host):
+    u64, u32, vp = C.c_uint64, C.c_uint32, C.c_void_p
+    host.dsh_balance_rowsets.argtypes = [u64, u32, C.c_int, vp, u32, C.POINTER(u32)]
+    host.dsh_rowsets_from_bounds.argtypes = [vp, u32, vp]
+    host.dsh_rowsets_rank.argtypes = [u64, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    host.dshh_plan_check_rowset.argtypes = [u64, vp, vp, u32, C.c_int, u32, C.c_int, u64, vp, C.c_char_p, C.c_size_t]
+    return host
+
+
+def balance_rowsets(host, n, world, prep=-1):
+    _rowset_api(host)
+    words = C.c_uint32(0)
+    assert host.dsh_balance_rowsets(n, world, prep, None, 0, C.byref(words)) == 0
+    tab = np.zeros(words.value, np.uint64)
+    assert host.dsh_balance_rowsets(n, world, prep, tab.ctypes.data, len(tab), C.byref(words)) == 0
+    return tab
+
+
+def rank_rows(host, n, tab, r):
+    segs = np.zeros(2 * 64, np.uint64)
+    ns, pairs, tiles = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    assert host.dsh_rowsets_rank(n, tab.ctypes.data, r, segs.ctypes.data, 64, C.byref(ns), C.byref(pairs), C.byref(tiles)) == 0
+    return [(int(segs[2 * i]), int(segs[2 * i + 1])) for i in range(ns.value)], pairs.value, tiles.value
+
+
+def check_rowset(host, keys, tab, rank, rowsorted, nparts, p=12, budget=8 << 30):
+    stats = np.zeros(8, np.uint64)
+    err = C.create_string_buffer(512)
+    rc = host.dshh_plan_check_rowset(len(keys), keys.ctypes.data, tab.ctypes.data, rank, rowsorted, nparts, p, budget,
+                                     stats.ctypes.data, err, 512)
+    assert rc == 0, err.value.decode()
+    return dict(tiles=int(stats[0]), parts=int(stats[3]), planes_x100=int(stats[4]))
+
+
+def test_balanced_rowsets_partition_every_row_once(host):
+    """every row has exactly one owner, every rank's segments are tile-aligned when it has more than one, the pairs of the
+    ranks add up to the triangle, and the largest cost of any rank (tiles + 0.9 per 128 columns of its plane matrix: its own
+    prepare) is never above the contiguous balance's"""
+    _rowset_api(host)
+    rng = np.random.default_rng(11)
+    cases = [(10000, 8), (10000, 4), (10000, 2), (10000, 3), (1000, 8), (5000, 8), (32768, 8), (40000, 8), (300, 8), (129, 2)]
+    cases += [(int(rng.integers(2, 30000)), int(rng.integers(1, 17))) for _ in range(60)]
+    for n, world in cases:
+        tab = balance_rowsets(host, n, world)
+        assert int(tab[0]) == world
+        ns = int(tab[1])
+        seg, own = tab[2:3 + ns], tab[3 + ns:3 + 2 * ns]
+        assert seg[0] == 0 and seg[-1] == n and np.all(np.diff(seg.astype(np.int64)) >= 0) and np.all(own < world)
+        owner_of = np.full(n, -1, np.int64)
+        tot_pairs, tiles, cost = 0, [], []
+        nt = (n + 127) // 128
+        for r in range(world):
+            segs, pairs, t = rank_rows(host, n, tab, r)
+            cost.append(t + 0.9 * (nt - segs[0][0] // 128) if segs else 0.0)
+            for b, e in segs:
+                assert np.all(owner_of[b:e] == -1)
+                owner_of[b:e] = r
+                if len(segs) > 1:
+                    assert b % 128 == 0 and (e % 128 == 0 or e == n)
+            assert pairs == sum(host.dsh_tri_span(n, b, e) for b, e in segs)
+            tot_pairs += pairs
+            tiles.append(t)
+        assert np.all(owner_of >= 0) and tot_pairs == n * (n - 1) // 2
+        b = np.zeros(world + 1, np.uint64)
+        host.dsh_balance_rows(n, world, b.ctypes.data)
+        contiguous = [sum(nt - t for t in range(int(b[r]) // 128, (int(b[r + 1]) + 127) // 128)) for r in range(world)]
+        ccost = [contiguous[r] + (0.9 * (nt - int(b[r]) // 128) if b[r + 1] > b[r] else 0.0) for r in range(world)]
+        assert sum(tiles) == nt * (nt + 1) // 2 or sum(tiles) == sum(contiguous)
+        assert max(cost) <= max(ccost) + 1e-6, (n, world, cost, ccost)
+
+
+def test_balanced_rowsets_c3_over_8_ranks_is_level(host):
+    """the case the top-ups exist for (BASELINE configs[2] over 8 GPUs): 3 160 tiles, 395 per rank -- contiguous 128-row
+    ranges leave the largest rank at 432+; with the bottom tile rows dealt every rank is within a few tiles of the others
+    once its own prepare (0.9 tile-equivalents per 128 columns of its plane matrix) is counted"""
+    n, world = 10000, 8
+    tab = balance_rowsets(host, n, world)
+    nt = (n + 127) // 128
+    cost = []
+    for r in range(world):
+        segs, _, tiles = rank_rows(host, n, tab, r)
+        cost.append(tiles + 0.9 * (nt - segs[0][0] // 128))
+    assert max(cost) - min(cost) <= 12, cost
+    assert max(cost) <= 1.02 * (sum(cost) / world), cost
+    assert any(len(rank_rows(host, n, tab, r)[0]) > 1 for r in range(world))
+
+
+def test_rowset_plans_cover_every_pair_exactly_once(host):
+    """every rank of a balanced row-set table, as a SOURCE of the exchange (row-sorted parts) and as the DESTINATION (one
+    part in final order): each of its pairs owned by exactly one (tile, lane), no pair of another rank's row computed,
+    parts complete in order; over all ranks the tiles add up to the whole triangle's"""
+    rng = np.random.default_rng(12)
+    for n, world, nparts in [(1500, 4, 3), (2000, 4, 8), (1100, 3, 2), (2000, 5, 4), (1400, 2, 8), (2500, 4, 2)]:
+        keys = make_keys(rng, n, 12)
+        tab = balance_rowsets(host, n, world)
+        tiles = 0
+        multi = 0
+        for r in range(world):
+            segs, _, t = rank_rows(host, n, tab, r)
+            multi += len(segs) > 1
+            for rowsorted in (1, 0):
+                st = check_rowset(host, keys, tab, r, rowsorted, nparts)
+                assert st["tiles"] == t
+                if rowsorted and t:
+                    assert 1 <= st["parts"] <= nparts
+            tiles += t
+        nt = (n + 127) // 128
+        assert tiles == nt * (nt + 1) // 2
+        assert multi > 0, "no rank of this case holds a top-up segment: the case does not test what it is for"
+
+
+def test_rowset_tables_reject_unaligned_extra_segments(host):
+    _rowset_api(host)
+    n = 1000
+    # rank 0: [0,300) and [700,1000); rank 1: [300,700) -- rank 0 has an extra segment on a non-multiple of 128
+    tab = np.array([2, 3, 0, 300, 700, 1000, 0, 1, 0], np.uint64)
+    ns = C.c_uint32(0)
+    assert host.dsh_rowsets_rank(n, tab.ctypes.data, 0, None, 0, C.byref(ns), None, None) != 0
+    tab = np.array([2, 3, 0, 256, 768, 1000, 0, 1, 0], np.uint64)
+    assert host.dsh_rowsets_rank(n, tab.ctypes.data, 0, None, 0, C.byref(ns), None, None) == 0 and ns.value == 2
+    # contiguous bounds as a table: any alignment
+    b = np.array([0, 301, 1000], np.uint64)
+    t2 = np.zeros(3 + 2 * 2, np.uint64)
+    assert host.dsh_rowsets_from_bounds(b.ctypes.data, 2, t2.ctypes.data) == 0
+    assert host.dsh_rowsets_rank(n, t2.ctypes.data, 1, None, 0, C.byref(ns), None, None) == 0 and ns.value == 1
