@@ -47,6 +47,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 CLOCK_HZ = 2.4e9       # max shader clock (same guide); cycle figures below are "wall time x 2.4 GHz"
 N_SIMD = 256 * 4
 GATHER_LIMIT_BYTES = 2 << 30  # larger outputs stay on the ranks that computed them (default; --exchange overrides)
+PARITY_NOTE = ("vs the CPU restatement (oracle/dsh_oracle.c); upstream arithmetic unpinned (bonsai / sketch submodules absent from the reference tree). "
+               "The contract is 1e-6 relative; exact_float32_matches is OBSERVED, not guaranteed (the recurrence's division is one Newton step, "
+               "correctly rounded unless the quotient lies within 2^-97 of a rounding midpoint: DESIGN.md 3.4)")
 
 DEVICE_SOURCES = ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
                   "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
@@ -91,8 +94,12 @@ def measure_kernels(ctx, regs_d, n, p, calls, reps=3):
     acc = {"pair_ms": 0.0, "finalize_ms": 0.0, "prepare_ms": 0.0, "pair_launches": 0}
     for _ in range(reps):
         ctx.attach_device(regs_d.data_ptr(), n, p)
-        for (ptr, rb, re) in calls:
-            ctx.dist_rows_device(ptr, rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        for call in calls:
+            if callable(call):  # (the exchange-aware call of an N-rank run: a row set, not a range)
+                call()
+            else:
+                ptr, rb, re = call
+                ctx.dist_rows_device(ptr, rb, re, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             ctx.synchronize()
             k = ctx.last_kernel_ms()
             for key in acc:
@@ -476,6 +483,14 @@ def run(args, backend, world, rank, line, dist_on):
         exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_exchange_rows_device_async + dsh_exchange_collect_async)" % NPARTS
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
+    # the C-ABI exchange partitions the rows into ROW SETS: a range per rank plus top-up tile rows from the bottom of the
+    # triangle (dsh_balance_rowsets), so that every rank computes about the same number of tiles; the torch.distributed
+    # fallback keeps the contiguous ranges (its spans are received in place)
+    rows_of = dashing_amd.balance_rowsets(n, world, int(os.environ.get("DSH_BENCH_PREP_PERMILLE", "-1"))) if use_cabi else None
+    my_floats = None
+    if rows_of is not None:
+        sizes = [rows_of.pairs(r) for r in range(world)]
+        my_floats = dashing_amd.exchange_mode(n, rows_of, rank, NPARTS, 0, want_floats=True)[2]
     my_pairs = sizes[rank] if multi else total_pairs
     host_stage = backend == "gloo" and multi
     gather = not multi or args.exchange == "gather" or (args.exchange == "auto" and 4 * total_pairs <= GATHER_LIMIT_BYTES)
@@ -484,7 +499,7 @@ def run(args, backend, world, rank, line, dist_on):
     def alloc_buffers(with_final):
         buf["final"] = torch.empty(max(total_pairs, 1), dtype=torch.float32, device=dev) if (rank == 0 and with_final) else None
         # rank 0 computes in place (its rows are the head of the matrix); the others into a span-sized buffer
-        buf["local"] = buf["final"] if buf["final"] is not None else torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
+        buf["local"] = buf["final"] if buf["final"] is not None else torch.empty(max(my_floats or my_pairs, 1), dtype=torch.float32, device=dev)
         buf["final_h"] = torch.empty(max(total_pairs, 1), dtype=torch.float32) if host_stage and rank == 0 and with_final else None
 
     alloc_buffers(gather)
@@ -499,9 +514,9 @@ def run(args, backend, world, rank, line, dist_on):
             # pipelined: the rank's rows in <= NPARTS parts (short ranges: row-sorted parts, placed row by row on rank 0);
             # part q travels to rank 0 (copy stream, grouped ncclSend/ncclRecv behind the part's event) while the later
             # parts are still being finalized on the ctx stream
-            ctx.exchange_rows_device_async(local.data_ptr(), bounds, rank, NPARTS, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.exchange_rows_device_async(local.data_ptr(), rows_of, rank, NPARTS, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
             computed = ctx.event_record()  # (a ticket orders nothing between the streams: the transfers are not held back)
-            ctx.exchange_collect_async(n, bounds, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
+            ctx.exchange_collect_async(n, rows_of, NPARTS, 0 if rank == 0 else local.data_ptr(), final.data_ptr() if rank == 0 else 0, 0)
             ctx.event_wait(computed)
             t1 = time.perf_counter()
             ctx.comm_wait()  # (with a deadline: a missing peer is an error, not a hang)
@@ -510,7 +525,10 @@ def run(args, backend, world, rank, line, dist_on):
                 phase["compute"] += t1 - t0
                 phase["exchange"] += t2 - t1  # what is left of the exchange after the last kernel
             return final
-        ctx.dist_rows_device(local.data_ptr(), bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        if rows_of is not None:  # (every rank keeps its rows: the same exchange-aware layout, no transfer)
+            ctx.exchange_rows_device_async(local.data_ptr(), rows_of, rank, NPARTS, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        else:
+            ctx.dist_rows_device(local.data_ptr(), bounds[rank], bounds[rank + 1], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
         ctx.synchronize()
         t1 = time.perf_counter()
         if multi and do_gather:
@@ -547,6 +565,7 @@ def run(args, backend, world, rank, line, dist_on):
         fence()
         dt_ = time.perf_counter() - t0
         ph = [phase["compute"] / max(args.steps, 1) * 1e3, phase["exchange"] / max(args.steps, 1) * 1e3]
+        phase["mine_ms"] = list(ph)  # (this rank's own; `ph` becomes the max over ranks below)
         if multi:
             t = torch.tensor([dt_] + ph, dtype=torch.float64, device=cpu_or_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -571,7 +590,10 @@ def run(args, backend, world, rank, line, dist_on):
 
     # ---- kernel phases: HIP events on the library stream, outside the timed region
     reps = 3
-    km = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), bounds[rank], bounds[rank + 1])], reps)
+    if rows_of is not None:
+        km = measure_kernels(ctx, regs_d, n, p, [lambda: ctx.exchange_rows_device_async(local.data_ptr(), rows_of, rank, NPARTS, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)], reps)
+    else:
+        km = measure_kernels(ctx, regs_d, n, p, [(local.data_ptr(), bounds[rank], bounds[rank + 1])], reps)
     pair_ms, fin_ms, prep_ms, launches = km["pair_ms"], km["finalize_ms"], km["prepare_ms"], km["pair_launches"]
     kphase = [pair_ms / reps, fin_ms / reps, prep_ms / reps]
     cyc, pbind = pair_binding(ctx, pair_ms / reps)
@@ -623,17 +645,28 @@ def run(args, backend, world, rank, line, dist_on):
     achieved = my_pairs * reps * b_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
     avg_launch_ms = pair_ms / max(launches, 1)
     fbind = finalize_binding(kphase[1], my_pairs, pmc.get("C3_finalize"))
+    # `bound` / `frac` name the resource that BINDS the kernel -- integer VALU issue of its (v_and_b32, v_bcnt_u32_b32) pairs --
+    # in the contract's shape (achieved / peak in wave-instruction pairs per second over the whole chip).  The SURVEY 8d
+    # streaming figure (2*2^p + 4 bytes per pair against the HBM peak) exceeds 1 for an LDS-tiled kernel (each staged sketch
+    # is reused 128x): it lives under `streaming_model`, never under the key a reader takes for efficiency.
+    slots_per_pass = pair_slots(ctx)
+    ach_pairs = slots_per_pass / (pair_ms / reps * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    peak_pairs = N_SIMD * CLOCK_HZ / 6.0 / 1e9
     roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-        # the resource that actually bounds the kernel: `frac` above is the SURVEY 8d streaming model and exceeds 1 for an
-        # LDS-tiled kernel -- read `binding.frac` for how close the kernel is to its ceiling
+        "bound": "int VALU issue", "achieved": round(ach_pairs, 2), "peak": round(peak_pairs, 2),
+        "unit": "G wave64 (v_and_b32 + v_bcnt_u32_b32) pairs/s, whole chip (peak = 1024 SIMDs x 2.4 GHz / 6 issue cycles)",
+        "frac": pbind["frac"], "traffic": traffic, "traffic_note": traffic_note,
         "binding": pbind,
         "kernel": "k_pair_counts_ls" if lockstep else "k_pair_counts", "launches_per_step": launches // reps,
         "avg_launch_ms": round(avg_launch_ms, 4),
-        "bytes_per_pair": b_pair, "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
+        "pairs_per_launch_avg": my_pairs * reps // max(launches, 1),
         **rinfo,
-        "note": "SURVEY 8d streaming-model bytes (2*2^p+4 per pair, the reference's own traffic): frac > 1 only says the LDS-tiled kernel is not HBM-bound (each staged sketch is reused 128x); the binding resource is integer VALU issue, see binding / valu_int; physical HBM is physical_hbm_gbs",
+        "streaming_model": {
+            "bytes_per_pair": b_pair, "achieved_gbs": round(achieved, 1), "hbm_peak_gbs": HBM_PEAK_GBS,
+            "frac_of_hbm": round(achieved / HBM_PEAK_GBS, 4),
+            "note": "SURVEY 8d algorithmic bytes (2*2^p+4 per pair, the reference's own traffic) / the tile kernel's launch time: a fraction above 1 only says the LDS-tiled kernel is not HBM-bound"},
+        "streaming_model_frac_of_hbm": round(achieved / HBM_PEAK_GBS, 4),
+        "note": "the tile kernel issues one v_and_b32 + one v_bcnt_u32_b32 per 32 pair-bits and nothing else per k-row (64 + 64 + 4 ds_read_b128 + 1 s_barrier): frac = 6 issue cycles / measured wall-cycles per pair; physical HBM is physical_hbm_gbs (PMC)",
         "physical_hbm_gbs": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and pair_ms > 0 else None,
         "physical_hbm_frac_of_peak": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pair_ms > 0 else None,
         "compulsory_bytes_per_step": n * m + 4 * total_pairs,
@@ -673,23 +706,29 @@ def run(args, backend, world, rank, line, dist_on):
         else:
             parity = {"assembled_equals_single_gpu": None, "note": "spans kept on their ranks (not gathered): rank 0's own span is checked against the CPU oracle"}
     if rank == 0 and not args.no_cpu_baseline and (not multi or not gather):
-        cpu, par2 = cpu_baseline(regs_h, full, n, p, args.cpu_seconds if not multi else min(args.cpu_seconds, 4.0), max_rows=bounds[1])
+        cpu, par2 = cpu_baseline(regs_h, full, n, p, args.cpu_seconds if not multi else min(args.cpu_seconds, 4.0),
+                                 max_rows=rows_of.rows(0)[0][1] if rows_of is not None else bounds[1])
         parity = par2 if parity is None else {**parity, "rank0_span_vs_cpu": par2}
 
     line.update({
         "config": {"workload": "BASELINE configs[2]: %d synthetic sketches, p=%d (%d B each), all-pairs dist on MI355X" % (n, p, m),
                    "n_sketches": n, "p": p, "k": K, "estimator": "ERTL_MLE", "result": "JI",
-                   "sharding": "tile-count-balanced row ranges of the final triangle, one per rank (plane matrix laid out per range); point-to-point send of each span into place on rank 0, no un-permute" if multi else "single GPU"},
+                   "sharding": ("row sets: a tile-aligned row range of the final triangle per rank + top-up tile rows from its bottom (dsh_balance_rowsets: equal tiles + prepare per rank), plane matrix laid out per rank; pipelined point-to-point send of each rank's parts to rank 0, which puts the rows into place; no un-permute" if rows_of is not None else
+                                "tile-count-balanced row ranges of the final triangle, one per rank (plane matrix laid out per range); point-to-point send of each span into place on rank 0, no un-permute") if multi else "single GPU"},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_vs_cpu": parity,
         "kernel_source_sha256": src,
     })
     if multi:
+        diag = multi_gpu_diagnostics(ctx, torch, dist, dashing_amd, multigpu, dev, regs_d, n, p, rank, world, rows_of, bounds, NPARTS, use_cabi,
+                                     km, reps, phase.get("mine_ms", [0.0, 0.0]), my_pairs, ms_per_step, buf, gather)
         line["multi_gpu"] = {
+            **diag,
             "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
             "exchange": exchange if gather else "none: every rank keeps its span (output %.1f GB > %.1f GB; --exchange gather collects it)" % (4 * total_pairs / 1e9, GATHER_LIMIT_BYTES / 1e9),
-            "exchange_library": rccl_info, "row_bounds": bounds, "pairs_per_rank": sizes,
+            "exchange_library": rccl_info, "row_bounds": bounds if rows_of is None else None,
+            "row_sets": rows_of.describe() if rows_of is not None else None, "pairs_per_rank": sizes,
             "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange" if not use_cabi else "exchange_exposed_after_last_kernel": round(phases[1], 4),
                                         "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},
             "exchange_bytes_into_rank0": 4 * (total_pairs - sizes[0]) if gather else 0,
@@ -709,7 +748,7 @@ def run(args, backend, world, rank, line, dist_on):
 
         guarded("BASELINE configs[1] shape", lambda: config_sketch(ctx, torch, dev, dashing_amd, pmc.get("sketch")))
         cfgs.append({"workload": line["config"]["workload"], "pairs_per_s": value, "ms_per_step": ms_per_step,
-                     "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": roofline["frac"], "physical_hbm_gbs": roofline["physical_hbm_gbs"]},
+                     "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": roofline["streaming_model_frac_of_hbm"], "physical_hbm_gbs": roofline["physical_hbm_gbs"]},
                      "cpu_baseline": None if cpu is None else {"value": cpu["value"], "cores": cpu["cores"], "sample": cpu["sample"]},
                      "parity": parity, "note": "the headline: full detail at top level"})
         guarded("BASELINE configs[3] shape", lambda: config_c4(ctx, torch, dev, dashing_amd, regs4_h, pmc, args))
@@ -725,6 +764,116 @@ def run(args, backend, world, rank, line, dist_on):
     if single and args.what_if:
         line["what_if_mfma"] = what_if_mfma(ctx, torch, dashing_amd, regs_d, full, local, n, p, total_pairs)
     ctx.close()
+
+
+def link_ping(ctx, torch, dist, dashing_amd, dev, rank, world, mb):
+    """Measured point-to-point rate of the library's own communicator (dsh_collect_spans: grouped ncclSend/ncclRecv into
+    rank 0): `mb` MB from ONE source at a time (every source in turn) and from all sources at once.  GB/s as seen by rank 0
+    (barrier, then the blocking call; best of 3 after a warm-up that also pays RCCL's channel set-up)."""
+    floats = mb * (1 << 20) // 4
+
+    def tri_n(f):  # smallest n whose triangle holds f floats
+        n_ = int((2 * f) ** 0.5)
+        while n_ * (n_ - 1) // 2 < f:
+            n_ += 1
+        return n_
+
+    n1, nc = tri_n(floats), tri_n(floats * world)
+    bc = dashing_amd.partition_rows(nc, world, 1)
+    span_c = [dashing_amd.tri_span(nc, bc[r], bc[r + 1]) for r in range(world)]
+    tot1, totc = n1 * (n1 - 1) // 2, nc * (nc - 1) // 2
+    fin = torch.zeros(max(tot1, totc), dtype=torch.float32, device=dev) if rank == 0 else None
+    loc = torch.ones(max(tot1, max(span_c)), dtype=torch.float32, device=dev) if rank != 0 else None
+    torch.cuda.synchronize()
+
+    def timed(nn, b):
+        best = None
+        for it in range(4):
+            dist.barrier()
+            t0 = time.perf_counter()
+            ctx.collect_spans(nn, b, 0 if rank == 0 else loc.data_ptr(), fin.data_ptr() if rank == 0 else 0, 0, wait=True)
+            dt_ = time.perf_counter() - t0
+            if it and (best is None or dt_ < best):
+                best = dt_
+        return best
+
+    single = {}
+    for src in range(1, world):
+        b = [0] * (src + 1) + [n1] * (world - src)
+        t = timed(n1, b)
+        single[str(src)] = round(4 * tot1 / t / 1e9, 2)
+    t = timed(nc, bc)
+    into0 = 4 * (totc - span_c[0])
+    conc = into0 / t / 1e9
+    ok = bool(rank != 0 or float(fin[span_c[0]:totc].min().item()) == 1.0)  # (what arrived is what was sent)
+    return {"message_MB": mb, "single_GBs_by_source": single, "single_GBs_min": min(single.values()), "single_GBs_max": max(single.values()),
+            "concurrent_total_GBs": round(conc, 2), "concurrent_per_link_GBs": round(conc / (world - 1), 2), "payload_intact": ok,
+            "how": "dsh_collect_spans (grouped ncclSend/ncclRecv on the ctx stream) into rank 0, wall time on rank 0 behind a barrier, best of 3"}
+
+
+def multi_gpu_diagnostics(ctx, torch, dist, dashing_amd, multigpu, dev, regs_d, n, p, rank, world, rows_of, bounds, nparts, use_cabi,
+                          km, reps, mine_ms, my_pairs, ms_per_step, buf, gather):
+    """What makes an N-rank line readable on its own: every rank's phases (not only the max), the link
+    rate measured through the library's communicator, and the step tools/shard_model.py's pipeline model predicts for THESE
+    per-rank times at THAT rate -- prediction and measurement side by side."""
+    if rows_of is not None:
+        rs, k, _ = dashing_amd.exchange_mode(n, rows_of, rank, nparts, 0, want_floats=True)
+        my_rows = rows_of.rows(rank)
+    else:
+        rs, k, my_rows = False, 1, [(bounds[rank], bounds[rank + 1])]
+    items = ctx.info("items")
+    ctx.set_profiling(True)  # one more pass for the parts' completion times (events; outside the timed loop)
+    ctx.attach_device(regs_d.data_ptr(), n, p)
+    if rows_of is not None:
+        ctx.exchange_rows_device_async(buf["local"].data_ptr(), rows_of, rank, nparts, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+    pinfo = ctx.last_part_info() if rows_of is not None else []
+    ctx.set_profiling(False)
+    mine = {"rank": rank, "part_info": [(round(a, 4), b) for a, b in pinfo], "rows": my_rows, "pairs": my_pairs, "span_bytes": 4 * my_pairs, "tiles": ctx.info("tiles"), "items": items,
+            "rounds_of_512": -(-items // 512), "planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0, "parts": k, "rowsorted": rs,
+            "bands": ctx.info("bands"), "prepare_ms": round(km["prepare_ms"] / reps, 4), "pair_ms": round(km["pair_ms"] / reps, 4),
+            "finalize_ms": round(km["finalize_ms"] / reps, 4), "wall_ms": round(mine_ms[0], 4), "exposed_exchange_ms": round(mine_ms[1], 4)}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    out = {"per_rank": allr,
+           "per_rank_note": "wall_ms = attach + prepare + tile kernel + k_finalize of the rank's rows per step (host clock); exposed_exchange_ms = what is left of the exchange after the rank's last kernel; prepare/pair/finalize_ms = HIP events outside the timed loop"}
+    ping = None
+    if use_cabi and world > 1 and not os.environ.get("DSH_BENCH_NO_PING"):
+        try:
+            ping = link_ping(ctx, torch, dist, dashing_amd, dev, rank, world, int(os.environ.get("DSH_BENCH_PING_MB", "64")))
+        except Exception as e:  # noqa: BLE001
+            ping = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["link_gbs_measured"] = ping if ping is not None else {"skipped": "the library's communicator is not in use (torch.distributed exchange) or one rank"}
+    # the destination's placement rate of a row-sorted source (rank 1's rows computed here, then put into place)
+    place_rate = None
+    if rank == 0 and rows_of is not None and world > 1 and gather and buf["final"] is not None:
+        rs1, _, fl1 = dashing_amd.exchange_mode(n, rows_of, 1, nparts, 0, want_floats=True)
+        if rs1 and fl1:
+            tmp = torch.empty(fl1, dtype=torch.float32, device=dev)
+            ctx.attach_device(regs_d.data_ptr(), n, p)
+            ctx.exchange_rows_device_async(tmp.data_ptr(), rows_of, 1, nparts, 0, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.exchange_place_device(rows_of, 1, nparts, tmp.data_ptr(), buf["final"].data_ptr(), 0)  # (the values it already holds)
+                best = min(best, time.perf_counter() - t0)
+            place_rate = 4 * fl1 / best
+            del tmp
+    if rank == 0 and world > 1:
+        def predict(g):
+            ms, worst = multigpu.pipeline_model(allr, place_rate, g)
+            return {"step_model_ms": round(ms, 4), "bound_by": "link/placement of rank %d" % worst if worst else "compute (slowest rank)"}
+
+        model = {"what": "dashing_amd.multigpu.pipeline_model (the model of tools/shard_model.py) over the per-rank times above: every source's parts over its own link into rank 0, a part ready after its share of k_finalize, 20 us per round, row-sorted parts placed at place_rate",
+                 "place_rate_GBs": round(place_rate / 1e9, 2) if place_rate else None,
+                 "sensitivity_by_assumed_link_GBs": {"%g" % g: predict(g) for g in (30.0, 45.0, 60.0)},
+                 "measured_ms_per_step": round(ms_per_step, 4)}
+        if ping and "concurrent_per_link_GBs" in ping and ping["concurrent_per_link_GBs"] > 0:
+            model["at_measured_link_rate"] = {"link_GBs": ping["concurrent_per_link_GBs"], **predict(ping["concurrent_per_link_GBs"])}
+            model["measured_over_predicted"] = round(ms_per_step / model["at_measured_link_rate"]["step_model_ms"], 3)
+        out["model"] = model
+    return out
 
 
 def what_if_mfma(ctx, torch, dashing_amd, regs_d, full, local, n, p, total_pairs):
@@ -1000,7 +1149,8 @@ def cpu_baseline(regs_h, gpu_full, n, p, seconds, max_rows=None):
            "scalar_histogram_value": ref_s.size / t_s,
            "note": "CPU restatement of the reference's algorithm and schedule in its SIMD form (Makefile:159-190); the reference itself is not buildable (bonsai/sketch submodules absent)"}
     parity = {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6,
-              "exact_float32_matches": int((got == ref).sum())}
+              "exact_float32_matches": int((got == ref).sum()),
+              "note": PARITY_NOTE}
     try:
         os.unlink(native)
     except OSError:

@@ -29,7 +29,7 @@ SYMBOLS = [
     "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_balance_rowsets", "dsh_rowsets_from_bounds", "dsh_rowsets_rank", "dsh_alloc_host", "dsh_free_host",
-    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
+    "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_last_part_info", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library():
     lib.dsh_rowsets_from_bounds.argtypes = [vp, C.c_uint32, vp]
     lib.dsh_rowsets_rank.argtypes = [u64, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), C.POINTER(u64)]
     lib.dsh_finalize_phase_cycles.argtypes = [vp, vp]
+    lib.dsh_last_part_info.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.dsh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.dsh_comm_destroy.argtypes = [vp]
     lib.dsh_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
@@ -491,6 +492,14 @@ class Context:
 
     def comm_destroy(self):
         self._ck(self._lib.dsh_comm_destroy(self._h))
+
+    def last_part_info(self):
+        """[(ready_ms, bytes)] of the parts of the last call with parts under profiling (dsh_last_part_info)"""
+        k = C.c_uint32()
+        self._ck(self._lib.dsh_last_part_info(self._h, None, None, 0, C.byref(k)))
+        ms, fl = np.zeros(max(k.value, 1), np.float64), np.zeros(max(k.value, 1), np.uint64)
+        self._ck(self._lib.dsh_last_part_info(self._h, ms.ctypes.data, fl.ctypes.data, k.value, C.byref(k)))
+        return [(float(ms[q]), 4 * int(fl[q])) for q in range(k.value)]
 
     def finalize_phase_cycles(self):
         """per-phase cycle sums of the last call with the option finalize_timing (dsh_finalize_phase_cycles)"""

@@ -727,6 +727,19 @@ int dsh_last_kernel_ms(dsh_ctx *c, double *pair_ms, double *fin_ms, double *prep
     return DSH_OK;
 }
 
+int dsh_last_part_info(dsh_ctx *c, double *ready_ms, uint64_t *floats, uint32_t cap, uint32_t *nparts_out)
+{
+    if (!c || !nparts_out) return DSH_EINVAL;
+    const uint32_t k = (uint32_t)c->part_ready_ms.size();
+    *nparts_out = k;
+    if (k > cap && (ready_ms || floats)) return DSH_EINVAL;
+    for (uint32_t q = 0; q < k; ++q) {
+        if (ready_ms) ready_ms[q] = c->part_ready_ms[q];
+        if (floats) floats[q] = c->part_floats[q];
+    }
+    return DSH_OK;
+}
+
 int dsh_finalize_phase_cycles(dsh_ctx *c, uint64_t *out16)
 {
     if (!c || !out16) return DSH_EINVAL;
@@ -881,6 +894,16 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "part_band_tiles")) {
         if (v < 1 || v > (1 << 30)) return fail(c, DSH_EINVAL, "part_band_tiles out of range");
         c->part_band_tiles = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "xch_tail_bands")) {
+        if (v < 0 || v > 8) return fail(c, DSH_EINVAL, "xch_tail_bands out of range");
+        c->tail_bands = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "xch_tail_permille")) {
+        if (v < 1 || v > 900) return fail(c, DSH_EINVAL, "xch_tail_permille out of range");
+        c->tail_permille = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "finalize_xcd_tiles")) {

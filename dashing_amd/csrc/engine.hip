@@ -248,6 +248,14 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         lre = jre;
     }
     c->parts_done = 0;
+    c->part_ready_ms.clear();
+    c->part_floats.clear();
+    hipEvent_t e_call0 = nullptr;
+    std::vector<std::pair<size_t, hipEvent_t>> ev_part_t;  // (profiling) part -> a timing event behind its last segment
+    if (c->profiling && with_parts) {
+        e_call0 = next_event(c);
+        if (e_call0) (void)hipEventRecord(e_call0, c->stream);
+    }
     // extra segments (row sets, plan.h): only with a key-ordered layout of the range and parts (the exchange)
     const bool with_extra = want_sorted && with_parts && !job.extra.empty() && lre > lrb;
     if (!job.extra.empty() && !with_extra) return fail(c, DSH_EINVAL, "internal: extra row segments need a key-ordered range with parts");
@@ -280,6 +288,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     tu.xcd_swizzle = c->xcd_swizzle;
     tu.finalize_rowmajor = c->finalize_rowmajor;
     tu.part_band_tiles = (uint32_t)c->part_band_tiles;
+    tu.tail_bands = (uint32_t)c->tail_bands;
+    tu.tail_permille = (uint32_t)c->tail_permille;
     // Tiles, bands and segments of the whole job first; the work items and the two device lists are made, uploaded and
     // launched BAND BY BAND: the host plans band b + 1 while the GPU runs band b (at 100 000 x p=10 the plan of 306 000
     // tiles took the host 8 ms that nothing hid, round 4 / profiles/r4y).
@@ -424,6 +434,13 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                 }
                 HIPCHK(c, hipEventRecord(c->ev_part[qp], fst));
                 c->parts_done = (uint32_t)qp + 1;
+                if (e_call0) {
+                    hipEvent_t te = next_event(c);
+                    if (te) {
+                        (void)hipEventRecord(te, fst);
+                        ev_part_t.emplace_back(qp, te);
+                    }
+                }
             }
         }
         if (aux_used) {  // the ctx stream goes on (next band's tile kernel, the end of the call) behind the second stream
@@ -449,6 +466,23 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e.first, e.second);
             c->fin_ms += ms;
+        }
+        // when every part of the call was final (from the start of the call, prepare included) and how many floats of the
+        // rank's buffer it holds: what a model of the pipelined exchange needs (dsh_last_part_info)
+        if (e_call0 && !ev_part_t.empty()) {
+            if (c->aux_stream) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+            c->part_ready_ms.assign(c->parts_done, 0.0);
+            c->part_floats.assign(c->parts_done, 0);
+            for (auto &pe : ev_part_t) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e_call0, pe.second);
+                if (pe.first < c->part_ready_ms.size()) c->part_ready_ms[pe.first] = ms;
+            }
+            for (size_t q = 0; q < c->part_floats.size(); ++q) {
+                if (L.rowsorted && q + 1 < L.part_w.size()) c->part_floats[q] = L.rowoff_w[L.part_w[q + 1]] - L.rowoff_w[L.part_w[q]];
+                else if (!L.rowsorted && L.extra.empty() && q + 1 < L.parts.size()) c->part_floats[q] = plan::tri_span(c->n, L.parts[q], L.parts[q + 1]);
+                else if (!L.rowsorted) c->part_floats[q] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
+            }
         }
     }
     return DSH_OK;

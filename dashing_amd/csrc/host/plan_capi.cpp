@@ -35,7 +35,8 @@ struct Err {
 // mode: 0 triangle rows [rb, re) (want_sorted decides the layout), 1 rectangle rows [rb,re) x cols [cb,ce) (identity
 // layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN), 3 triangle
 // rows in ROW-SORTED parts (the wanted rows one key-ordered run, parts = runs of whole tile rows of that order).
-// stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P.
+// stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P,
+// [7] rounds of 512 items summed over the bands.
 // extra: further wanted segments {b0, e0, ...} (plan.h, row sets; modes 0 and 3 with a sorted layout only)
 static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
                       uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
@@ -144,7 +145,7 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     q.col_end = ce;
     PairPlan pp;
     const bool any = build_pairs(L, q, tu, pp);
-    for (int i = 0; i < 7; ++i) stats[i] = 0;
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
     stats[5] = L.Npad;
     stats[6] = L.P;
     // ---- every wanted pair is owned by exactly one (tile, lane) -- the `active` predicate of k_finalize
@@ -292,6 +293,9 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     stats[2] = pp.items.size();
     stats[3] = pp.nparts;
     stats[4] = T.empty() ? 0 : planes_sum * 100 / T.size();
+    // rounds of the lockstep tile kernel over all bands (a band of k items takes ceil(k / round_items) rounds)
+    stats[7] = 0;
+    for (auto &bi_ : pp.band_items) stats[7] += (bi_.second - bi_.first + tu.round_items - 1) / tu.round_items;
     return 0;
 }
 
@@ -317,7 +321,7 @@ int dshh_plan_check_rowset(uint64_t n, const uint32_t *keys, const uint64_t *tab
     uint64_t rb, re;
     std::vector<uint64_t> extra;
     rs.rank_rows(rank, rb, re, extra);
-    for (int i = 0; i < 7; ++i) stats[i] = 0;
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
     if (rb >= re) return 0;
     return plan_check(n, keys, rowsorted ? 3 : 0, 1, rb, re, 0, 0, rowsorted ? nparts : 1, 1, p, cum_budget, 1, 0, 64, extra, stats, err, cap);
 }

@@ -612,12 +612,52 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     auto part_of_tile = [&](size_t t) -> size_t {
         return (size_t)(std::upper_bound(pstart.begin(), pstart.end() - 1, t) - pstart.begin()) - 1;
     };
+    // tail bands (plan.h, Tuning): cuts of the tile list at whole rounds of the tile kernel
+    std::vector<size_t> cuts;
+    if (parts_on && tu.tail_bands > 0 && tu.lockstep && tu.W >= (uint32_t)tu.kc && tu.nsplit == 0 && tu.round_items > 0) {
+        const uint64_t RI = tu.round_items;
+        uint64_t items = 0;  // one item per plane of a tile while the job is small (build_band_items: piece = one plane)
+        for (const U4 &t : T) items += t.w - t.z;
+        const uint64_t R = (items + RI - 1) / RI;
+        if (items <= 16 * RI && R >= 3) {
+            std::vector<uint64_t> tails;  // rounds of the tail bands, last band first
+            uint64_t left = R;
+            for (uint32_t b = 0; b < tu.tail_bands; ++b) {
+                const uint64_t r = std::max<uint64_t>(1, (left * tu.tail_permille + 500) / 1000);
+                if (left < r + 2) break;
+                tails.push_back(r);
+                left -= r;
+            }
+            // the head takes `left` rounds, then the tails in reverse; a band ends at the last tile that still fits
+            std::vector<uint64_t> quota{left};
+            for (size_t b = tails.size(); b-- > 0;) quota.push_back(tails[b]);
+            uint64_t target = 0, acc = 0, rounds = 0, band_items = 0;
+            size_t t = 0;
+            for (size_t b = 0; b + 1 < quota.size(); ++b) {
+                target += quota[b] * RI;
+                while (t < T.size() && acc + (T[t].w - T[t].z) <= target) {
+                    acc += T[t].w - T[t].z;
+                    band_items += T[t].w - T[t].z;
+                    ++t;
+                }
+                if (t == 0 || t >= T.size() || (!cuts.empty() && cuts.back() == t)) continue;
+                cuts.push_back(t);
+                rounds += (band_items + RI - 1) / RI;
+                band_items = 0;
+            }
+            rounds += (items - acc + band_items + RI - 1) / RI;
+            if (rounds != R) cuts.clear();  // (a cut that costs a round is worse than none)
+        }
+    }
+    size_t next_cut = 0;
     for (size_t b = 0; b < T.size();) {
         size_t e = std::min<size_t>(T.size(), b + max_tiles);
         if (parts_on) {  // a large part also ends the band
             const size_t q = part_of_tile(b);
             if (pstart[q + 1] - pstart[q] >= kPartBandTiles) e = std::min(e, pstart[q + 1]);
         }
+        while (next_cut < cuts.size() && cuts[next_cut] <= b) ++next_cut;
+        if (next_cut < cuts.size()) e = std::min(e, cuts[next_cut]);
         pp.bands.emplace_back(b, e);
         b = e;
     }

@@ -158,6 +158,15 @@ struct Tuning {
     int xcd_swizzle = 1;
     int finalize_rowmajor = 1;
     uint32_t part_band_tiles = 2048;  // a part of at least this many tiles also ends the band of the tile kernel
+    // Tail bands (jobs with parts = the exchange; small jobs only: at most 16 rounds of one-plane items).  The lockstep
+    // tile kernel runs in ROUNDS of round_items work items (2 per workgroup, one workgroup per CU); a rank's parts only
+    // become final during k_finalize, i.e. after the whole tile kernel, and its link then needs longer for them than
+    // k_finalize takes.  So the tile kernel is cut into a head band and `tail_bands` tail bands at multiples of a round
+    // (a cut elsewhere rounds every band up: +1 round, profiles/r4i): the head's parts travel while the tails compute.
+    // Each tail takes tail_permille of the rounds left; no cut is made if it would add a round.
+    uint32_t round_items = 512;
+    uint32_t tail_bands = 1;
+    uint32_t tail_permille = 280;
 };
 
 struct Seg {

@@ -206,3 +206,37 @@ class PipelinedShards:
         self.works = []
         _host_sync(self.outs[0] if self.outs else None)
         return (self.stage, self.block_off) if self.rank == self.dst else None
+
+
+def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02):
+    """The N-rank step predicted from per-rank compute times (tools/shard_model.py measures them on one GPU, bench.py
+    --gpus N on the ranks themselves): every source's parts go to rank 0 over that source's own xGMI link at `link_gbs`
+    + `round_ms` per round; a link carries one part at a time; rank 0 places a row-sorted part behind its arrival at
+    `place_rate` bytes/s.  rows[r]: rank, wall_ms, rowsorted, and either part_info = [(ready_ms, bytes)] -- when every
+    part was final, measured with events (dsh_last_part_info; shifted so that the last part ends with the rank's wall) --
+    or the older estimate from prepare_ms, pair_ms, finalize_ms, parts, bands, span_bytes: part q ready after prepare, the
+    tile kernel and (q+1)/parts of k_finalize.  rows[0] is the destination.
+    Returns (step ms, the rank that bounds it; 0: compute)."""
+    step_ms, worst = max(x["wall_ms"] for x in rows), 0
+    for x in rows[1:]:
+        parts = x.get("part_info")
+        if parts:
+            shift = max(0.0, x["wall_ms"] - parts[-1][0])  # (host time of the call: counted in front of the kernels)
+            parts = [(r + shift, b) for r, b in parts]
+        else:
+            k = max(x["parts"], 1)
+            parts = []
+            for q in range(k):
+                if x["bands"] >= k > 1:  # the tile kernel is cut per part
+                    ready = x["prepare_ms"] + (x["pair_ms"] + x["finalize_ms"]) * (q + 1) / k
+                else:
+                    ready = x["prepare_ms"] + x["pair_ms"] + x["finalize_ms"] * (q + 1) / k
+                parts.append((max(ready, x["wall_ms"]) if q == k - 1 else ready, x["span_bytes"] / k))
+        done = 0.0
+        for ready, by in parts:
+            done = max(ready, done) + by / (link_gbs * 1e9) * 1e3 + round_ms
+        if x["rowsorted"] and place_rate and parts:
+            done += parts[-1][1] / place_rate * 1e3  # the last part's rows put into place
+        if done > step_ms:
+            step_ms, worst = done, x["rank"]
+    return step_ms, worst

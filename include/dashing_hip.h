@@ -344,6 +344,11 @@ void dsh_free_host(void *p);
 int dsh_set_profiling(dsh_ctx *ctx, int enable);
 int dsh_last_kernel_ms(dsh_ctx *ctx, double *pair_kernel_ms, double *finalize_kernel_ms,
                        double *prepare_ms, uint32_t *pair_kernel_launches);
+/* (profiling on) the parts of the last call with parts (dsh_exchange_rows_device_async, dsh_dist_rows_parts_device_async):
+ * when each became final, in ms from the start of the call (prepare included), and how many floats of the rank's buffer it
+ * holds -- what a model of the pipelined exchange needs (tools/shard_model.py, bench.py --gpus N). */
+int dsh_last_part_info(dsh_ctx *ctx, double *ready_ms /* [cap] or NULL */, uint64_t *floats /* [cap] or NULL */, uint32_t cap,
+                       uint32_t *nparts_out);
 /* Profiling aid: after a compare call with dsh_set_profiling(ctx, 1) and the option "finalize_timing" = 1 (the
  * s_memtime-stamped instance of k_finalize; results unchanged), out16 = shader-clock cycles summed over the waves that
  * finished, per phase [0..5] {prologue + loads issued, histogram columns, list joins, fix-ups, estimator, result + store};
@@ -355,7 +360,9 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
  * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
  * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles" (0|1: a tile's 128 rows on one XCD),
- * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "finalize_two_streams" (0|1: the
+ * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "xch_tail_bands" (0..8, default 1) /
+ * "xch_tail_permille" (default 280): a small job with parts (at most 16 rounds of 512 one-plane work items) has its tile kernel cut
+ * at whole rounds into a head and tail launches, so that the head's parts travel while the tails compute, "finalize_two_streams" (0|1: the
  * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4
  * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
  * "assembler_permille", "shard_c0_x10"; profiling only: "finalize_timing" (the stamped instance of k_finalize, same results);
@@ -364,7 +371,7 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
- * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands",
+ * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands", "items" (work items of the tile kernel),
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.

@@ -48,7 +48,7 @@ def check(host, keys, mode=0, sorted_=1, rb=0, re=None, cb=0, ce=0, nparts=1, wa
                               chunks, stats.ctypes.data, err, 512)
     assert rc == 0, err.value.decode()
     return dict(tiles=int(stats[0]), bands=int(stats[1]), items=int(stats[2]), parts=int(stats[3]), planes_x100=int(stats[4]),
-                npad=int(stats[5]), P=int(stats[6]))
+                npad=int(stats[5]), P=int(stats[6]), rounds=int(stats[7]))
 
 
 def test_full_triangle_sorted_and_identity(host):
@@ -213,7 +213,7 @@ def check_rowset(host, keys, tab, rank, rowsorted, nparts, p=12, budget=8 << 30)
     rc = host.dshh_plan_check_rowset(len(keys), keys.ctypes.data, tab.ctypes.data, rank, rowsorted, nparts, p, budget,
                                      stats.ctypes.data, err, 512)
     assert rc == 0, err.value.decode()
-    return dict(tiles=int(stats[0]), parts=int(stats[3]), planes_x100=int(stats[4]))
+    return dict(tiles=int(stats[0]), bands=int(stats[1]), items=int(stats[2]), parts=int(stats[3]), planes_x100=int(stats[4]), rounds=int(stats[7]))
 
 
 def test_balanced_rowsets_partition_every_row_once(host):
@@ -307,3 +307,22 @@ def test_rowset_tables_reject_unaligned_extra_segments(host):
     t2 = np.zeros(3 + 2 * 2, np.uint64)
     assert host.dsh_rowsets_from_bounds(b.ctypes.data, 2, t2.ctypes.data) == 0
     assert host.dsh_rowsets_rank(n, t2.ctypes.data, 1, None, 0, C.byref(ns), None, None) == 0 and ns.value == 1
+
+
+def test_tail_bands_cut_the_tile_kernel_at_whole_rounds(host):
+    """a small job with parts (the exchange): the tile kernel is cut into a head and a tail launch so that the head's parts
+    can travel while the tail computes -- at a multiple of a round of 512 work items, never at the cost of a round"""
+    rng = np.random.default_rng(21)
+    cut = 0
+    for n, world in [(2000, 2), (1900, 2), (2100, 3), (2000, 1)]:
+        keys = make_keys(rng, n, 14, spread=8)
+        tab = balance_rowsets(host, n, world)
+        for r in range(world):
+            st = check_rowset(host, keys, tab, r, 1 if world > 1 else 0, 8, p=14)
+            if not st["tiles"]:
+                continue
+            assert st["rounds"] == -(-st["items"] // 512), (n, world, r, st)  # no band rounds up on its own
+            if st["items"] > 2 * 512 and st["items"] <= 16 * 512 and world > 1:
+                assert st["bands"] >= 2, (n, world, r, st)
+                cut += 1
+    assert cut >= 2

@@ -23,30 +23,9 @@ import torch  # noqa: E402
 
 import dashing_amd  # noqa: E402
 from dashing_amd import synth  # noqa: E402
+from dashing_amd.multigpu import pipeline_model  # noqa: E402
 
 LINKS = [float(x) for x in os.environ.get("LINK_GBS", "30,45,60").split(",")]
-
-
-def pipeline_model(rows, place_rate, link_gbs):
-    """modelled step (ms) and the rank that bounds it (0: compute)"""
-    step_ms, worst = max(x["wall_ms"] for x in rows), 0
-    for x in rows[1:]:
-        k = max(x["parts"], 1)
-        done = 0.0
-        for q in range(k):
-            by = x["span_bytes"] / k
-            if x["bands"] >= k > 1:  # the tile kernel is cut per part: part q is ready after (q+1)/k of tile kernel + finalize
-                ready = x["prepare_ms"] + (x["pair_ms"] + x["finalize_ms"]) * (q + 1) / k
-            else:
-                ready = x["prepare_ms"] + x["pair_ms"] + x["finalize_ms"] * (q + 1) / k
-            if q == k - 1:
-                ready = max(ready, x["wall_ms"])
-            done = max(ready, done) + by / (link_gbs * 1e9) * 1e3 + 0.02
-        if x["rowsorted"]:
-            done += x["span_bytes"] / k / place_rate * 1e3  # the last part's rows put into place
-        if done > step_ms:
-            step_ms, worst = done, x["rank"]
-    return step_ms, worst
 
 
 def model_partition(ctx, regs, n, p, G, NPARTS, part, final, want, t1):
@@ -72,12 +51,14 @@ def model_partition(ctx, regs, n, p, G, NPARTS, part, final, want, t1):
         step()
         step()
         km = ctx.last_kernel_ms()
+        pinfo = ctx.last_part_info()
         ctx.set_profiling(False)
         items = ctx.info("items")
         rows.append({"rank": r, "rows": rows_of.rows(r), "rowsorted": rs, "parts": k, "span_bytes": 4 * rows_of.pairs(r), "tiles": ctx.info("tiles"),
                      "items": items, "rounds_of_512": -(-items // 512), "bands": ctx.info("bands"),
                      "wall_ms": round(best * 1e3, 3), "prepare_ms": round(km["prepare_ms"], 3), "pair_ms": round(km["pair_ms"], 3),
-                     "finalize_ms": round(km["finalize_ms"], 3), "planes_per_tile": ctx.info("avg_tile_planes_x100") / 100})
+                     "finalize_ms": round(km["finalize_ms"], 3), "planes_per_tile": ctx.info("avg_tile_planes_x100") / 100,
+                     "part_info": [(round(a, 4), b) for a, b in pinfo]})
     # rank 0 places what it received: all sources, timed together (its per-sketch pass covers every sketch: redo rank 0's step)
     final.fill_(-1.0)
     ctx.attach_device(regs.data_ptr(), n, p)
