@@ -423,7 +423,7 @@ int parse_table(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, int dst, plan::
     return DSH_OK;
 }
 
-// the key order and the row offsets of a rank's row-sorted buffer (wanted rows: main range, then the extra segments, each
+// the key order and the row offsets of a rank's row-sorted buffer (wanted rows: the extra segments, then the main range, each
 // key-ordered as one run), from THIS context's host copy of the keys (every rank holds every sketch, the per-sketch pass
 // is deterministic: the destination derives what the source used)
 int rowsorted_tables(dsh_ctx *c, uint64_t n, const XMode &m, std::vector<uint32_t> &order, std::vector<uint64_t> &rowoff,
@@ -434,11 +434,12 @@ int rowsorted_tables(dsh_ctx *c, uint64_t n, const XMode &m, std::vector<uint32_
                     (unsigned long long)m.rb);
     const uint64_t cnt = plan::rowset_rows(m.rb, m.re, m.extra);
     order.resize(cnt);
-    plan::sort_rows_by_key(c->hk32, m.rb, m.re, order.data(), scratch);
-    uint64_t at = m.re - m.rb;
-    for (size_t x = 0; x + 1 < m.extra.size(); x += 2) {
-        plan::sort_rows_by_key(c->hk32, m.extra[x], m.extra[x + 1], order.data() + at, scratch);
-        at += m.extra[x + 1] - m.extra[x];
+    std::vector<std::pair<uint64_t, uint64_t>> segs;  // the wanted order: extra segments first, then the main range
+    plan::wanted_order(n, m.rb, m.re, &m.extra, segs);
+    uint64_t at = 0;
+    for (auto &sg : segs) {
+        plan::sort_rows_by_key(c->hk32, sg.first, sg.second, order.data() + at, scratch);
+        at += sg.second - sg.first;
     }
     plan::rowsorted_offsets(n, order.data(), cnt, rowoff);
     return DSH_OK;

@@ -56,9 +56,8 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     Layout L;
     build_layout(keys, n, want_sorted, lrb, lre, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0, extra.empty() ? nullptr : &extra);
     // the wanted segments, main range first
-    std::vector<std::pair<uint64_t, uint64_t>> wsegs;
-    if (lre > lrb) wsegs.emplace_back(lrb, lre);
-    for (size_t x = 0; x + 1 < extra.size(); x += 2) wsegs.emplace_back(extra[x], extra[x + 1]);
+    std::vector<std::pair<uint64_t, uint64_t>> wsegs;  // (the wanted order: extra segments first, then the main range)
+    wanted_order(n, lrb, lre, &extra, wsegs);
     auto in_rows = [&](uint64_t i) {
         for (auto &w : wsegs)
             if (i >= w.first && i < w.second) return true;
@@ -73,18 +72,22 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
             for (uint64_t s = w.first - lrb + 1; s < w.second - lrb; ++s)
                 if (skey(L.perm[s - 1]) > skey(L.perm[s])) return E.fail("row-sorted: a wanted segment is not one key-ordered run at %llu", (unsigned long long)s);
         if (L.part_w.empty() || L.part_w.front() != 0 || L.part_w.back() != nw) return E.fail("row-sorted: part cuts do not span the wanted rows");
-        if (L.part_pos.size() != L.part_w.size()) return E.fail("row-sorted: part positions and cuts differ in number");
-        for (size_t q = 1; q + 1 < L.part_w.size(); ++q)
-            if (L.part_w[q] % kTile || L.part_w[q] <= L.part_w[q - 1] || L.part_pos[q] % kTile || L.part_pos[q] <= L.part_pos[q - 1])
-                return E.fail("row-sorted: cut %zu at %llu", q, (unsigned long long)L.part_w[q]);
+        for (size_t q = 1; q + 1 < L.part_w.size(); ++q) {  // every cut at the start of a tile row of the wanted order
+            if (L.part_w[q] <= L.part_w[q - 1]) return E.fail("row-sorted: cut %zu at %llu", q, (unsigned long long)L.part_w[q]);
+            uint64_t w0 = 0;
+            bool ok = false;
+            for (auto &w : wsegs) {
+                if (L.part_w[q] >= w0 && L.part_w[q] < w0 + (w.second - w.first)) ok = (L.part_w[q] - w0) % kTile == 0;
+                w0 += w.second - w.first;
+            }
+            if (!ok) return E.fail("row-sorted: cut %zu at %llu is not at a tile row of the wanted order", q, (unsigned long long)L.part_w[q]);
+        }
         if (L.part_w.size() - 1 > std::max<uint32_t>(nparts, 1)) return E.fail("row-sorted: more parts than asked for");
         uint64_t acc = 0, w_ = 0;
         if (L.rowoff_w.size() != nw + 1) return E.fail("row-sorted: rowoff_w size");
         for (auto &w : wsegs)
             for (uint64_t s = w.first - lrb; s < w.second - lrb; ++s, ++w_) {
                 if (s >= L.rowoff.size() || L.rowoff[s] != acc || L.rowoff_w[w_] != acc) return E.fail("row-sorted: rowoff[%llu]", (unsigned long long)s);
-                for (size_t q = 0; q < L.part_w.size(); ++q)
-                    if (L.part_w[q] == w_ && L.part_pos[q] != s) return E.fail("row-sorted: part %zu starts at position %llu, not %llu", q, (unsigned long long)L.part_pos[q], (unsigned long long)s);
                 acc += n - 1 - L.perm[s];
             }
         if (L.rowoff_w.back() != acc || acc != wspan) return E.fail("row-sorted: the rows do not add up to the span");
@@ -229,12 +232,14 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
                     return E.fail("part %d completed out of order or twice", sg.part);
                 last_part = sg.part;
             }
-            // every tile of the segment belongs to the part that is current
+            // every tile of the segment belongs to the part that is current (parts are runs of the WANTED order)
             if (q.want_parts)
                 for (size_t t = sg.b; t < sg.e; ++t) {
-                    const uint64_t pos0 = (uint64_t)T[t].x * kTile;
+                    uint64_t pos0 = ~0ull;  // wanted rows in front of the tile's row block
+                    for (size_t k = 0; k < L.wtr.size(); ++k)
+                        if (T[t].x >= L.wtr[k].first && T[t].x < L.wtr[k].second) pos0 = L.wtr_w[k] + (uint64_t)(T[t].x - L.wtr[k].first) * kTile;
                     const int cur = last_part + (sg.part >= 0 ? 0 : 1);
-                    if (cur < 0 || (size_t)cur + 1 >= L.part_pos.size() || pos0 < L.part_pos[cur] || pos0 >= L.part_pos[cur + 1])
+                    if (cur < 0 || (size_t)cur + 1 >= L.part_w.size() || pos0 < L.part_w[cur] || pos0 >= L.part_w[cur + 1])
                         return E.fail("tile row %u is not in part %d", T[t].x, cur);
                 }
         }
@@ -265,7 +270,7 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     if (at != T.size()) return E.fail("bands end at %zu of %zu tiles", at, T.size());
     for (uint32_t qd = 0; qd < pp.nparts; ++qd)
         if (part_done[qd] != 1) return E.fail("part %u never completes", qd);
-    if (q.want_parts && pp.nparts + 1 != L.part_pos.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.part_pos.size() - 1);
+    if (q.want_parts && pp.nparts + 1 != L.part_w.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.part_w.size() - 1);
     // ---- the two device lists describe the same tiles
     std::vector<U4> dt(T.size()), df(T.size());
     emit_tile_lists(L, pp, dt.data(), df.data());
@@ -283,10 +288,19 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
                 const int lo = (int)((f.z >> 16) & 0xFFu), hi = (int)(f.z >> 24);
                 if (hi - lo + 1 > sg.hist_bins) return E.fail("segment hist_bins %d too small for tile %zu", sg.hist_bins, src);
             }
-            if (pp.finalize_rowmajor)  // row-major inside the segment
-                for (size_t t = sg.b + 1; t < sg.e; ++t)
-                    if (df[t - 1].x > df[t].x || (df[t - 1].x == df[t].x && df[t - 1].y >= df[t].y))
-                        return E.fail("finalize list of a segment is not row-major at %zu", t);
+            if (pp.finalize_rowmajor) {  // tile row by tile row inside the segment, columns ascending (the tile rows come in the
+                                          // wanted order: the extra segments' first)
+                std::vector<uint32_t> rows_seen;
+                for (size_t t = sg.b + 1; t < sg.e; ++t) {
+                    if (df[t - 1].x == df[t].x) {
+                        if (df[t - 1].y >= df[t].y) return E.fail("finalize list of a segment is not row-major at %zu", t);
+                    } else {
+                        rows_seen.push_back(df[t - 1].x);
+                        if (std::find(rows_seen.begin(), rows_seen.end(), df[t].x) != rows_seen.end())
+                            return E.fail("finalize list of a segment returns to tile row %u at %zu", df[t].x, t);
+                    }
+                }
+            }
         }
     stats[0] = T.size();
     stats[1] = pp.bands.size();

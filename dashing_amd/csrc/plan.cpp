@@ -116,18 +116,26 @@ bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts)
 
 // tiles of every wanted tile row of a row set, in layout order: the block at layout block index b meets the NTc - b
 // blocks from itself to the right (the runs of the layout lie in row order, plan.h)
+void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs)
+{
+    segs.clear();
+    if (re > n) re = n;
+    if (rb >= re) return;
+    if (extra)
+        for (size_t x = 0; x + 1 < extra->size(); x += 2) segs.emplace_back((*extra)[x], std::min<uint64_t>((*extra)[x + 1], n));
+    segs.emplace_back(rb, re);
+}
+
 static void wanted_tile_rows(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<uint64_t> &cnt)
 {
     cnt.clear();
     if (re > n) re = n;
     if (rb >= re) return;
     const uint64_t NTc = (n - rb + kTile - 1) / kTile;
-    auto add = [&](uint64_t b, uint64_t e) {
-        for (uint64_t t = (b - rb) / kTile, t1 = (e - rb + kTile - 1) / kTile; t < t1; ++t) cnt.push_back(NTc - t);
-    };
-    add(rb, re);
-    if (extra)
-        for (size_t x = 0; x + 1 < extra->size(); x += 2) add((*extra)[x], std::min<uint64_t>((*extra)[x + 1], n));
+    std::vector<std::pair<uint64_t, uint64_t>> segs;
+    wanted_order(n, rb, re, extra, segs);
+    for (auto &sg : segs)
+        for (uint64_t t = (sg.first - rb) / kTile, t1 = (sg.second - rb + kTile - 1) / kTile; t < t1; ++t) cnt.push_back(NTc - t);
 }
 
 uint64_t rowset_rows(uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra)
@@ -160,19 +168,38 @@ void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t npa
     if (re > n) re = n;
     if (rb >= re) return;
     const uint64_t R = rowset_rows(rb, re, extra ? *extra : std::vector<uint64_t>());
-    // cut after the wanted tile row that reaches q / nparts of the tiles (only the last wanted tile row can hold fewer
-    // than 128 wanted rows: a rank with extra segments has all its boundaries on multiples of 128 or at n)
+    // cut after the wanted tile row (in the wanted order) that reaches q / nparts of the tiles.  The extra segments come
+    // FIRST: their tile rows are short (the bottom of the triangle), and several of them share a part -- a part is a
+    // message of its own in the exchange and a launch of k_finalize, a row of 3 tiles is worth neither; the rank's last
+    // part is then ONE tile row of its main range, which is what stays exposed behind its last kernel.  (Only the last
+    // tile row of a segment that ends at n can hold fewer than 128 rows: a rank with extra segments has all its
+    // boundaries on multiples of 128 or at n; its positions count whole tile rows of 128 all the same, see below.)
     std::vector<uint64_t> cnt;
     wanted_tile_rows(n, rb, re, extra, cnt);
     const uint64_t TR = cnt.size();
     uint64_t total = 0;
     for (uint64_t c : cnt) total += c;
+    // rows in front of the wanted tile row t of the wanted order
+    std::vector<std::pair<uint64_t, uint64_t>> segs;
+    wanted_order(n, rb, re, extra, segs);
+    std::vector<uint64_t> rows_before(TR + 1, 0);
+    {
+        size_t t = 0;
+        uint64_t acc_rows = 0;
+        for (auto &sg : segs)
+            for (uint64_t b = sg.first; b < sg.second; b += kTile) {
+                rows_before[t++] = acc_rows;
+                acc_rows += std::min<uint64_t>(kTile, sg.second - b);
+            }
+        rows_before[TR] = acc_rows;
+    }
     uint64_t acc = 0, t = 0;
-    for (uint32_t q = 1; q < nparts && t < TR; ++q) {
+    for (uint32_t q = 1; q < nparts && t < TR;) {
         const uint64_t t0 = t;
         while (t < TR && (acc * nparts < total * q || t == t0)) acc += cnt[t++];
         if (t >= TR) break;
-        pos.push_back(t * kTile);
+        pos.push_back(rows_before[t]);
+        q = std::max<uint32_t>(q + 1, (uint32_t)(acc * nparts / std::max<uint64_t>(total, 1)) + 1);  // (no part of a few tiles)
     }
     pos.push_back(R);
 }
@@ -258,7 +285,11 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
     // would each be a 128-row block in no key order); whatever is left then goes row by row to the cheapest rank.  Two
     // sweeps over the limits: the smallest maximum any limit reaches, then, among the limits within half a percent of
     // it, the one with the fewest segments.
-    const double kPrepPerTileRow = prep_permille == ~0u ? 0.9 : (double)prep_permille / 1000.0;
+    // the weight of a rank's own prepare.  Measured on BASELINE configs[2] over 8 ranks (profiles/rd5b): prepare costs 2.9 us
+    // per 128 columns against 4.8 us per tile (tile kernel + k_finalize), i.e. 0.6 tiles; the default leans towards equal
+    // TILE counts because the tile kernel's time moves in whole rounds of 512 work items (7 or 8 at that size) and the
+    // ranks with the cheap prepare are the ones that would spill into another round
+    const double kPrepPerTileRow = prep_permille == ~0u ? 0.4 : (double)prep_permille / 1000.0;
     std::vector<uint64_t> start(world), stop(world);
     std::vector<double> cost(world);
     std::vector<uint32_t> deal, best_deal, byneed(world);
@@ -419,6 +450,7 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     L.rowoff.clear();
     L.rowoff_w.clear();
     L.wtr.clear();
+    L.wtr_w.clear();
     L.nwanted = want_sorted ? rowset_rows(rb, re, extra) : n;
     if (want_sorted) {
         // the runs, in row order (a run of rows [lo, hi) lies at the positions [lo - rb, hi - rb)): the parts of the
@@ -432,35 +464,37 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
             at = extra[x + 1];
         }
         if (at < n) sort_rows_by_key(k32, at, n, L.perm.data() + (at - rb), L.sort_a);
-        // tile rows that hold wanted rows
-        if (re > rb) L.wtr.emplace_back(0u, (uint32_t)((re - rb + kTile - 1) / kTile));
-        for (size_t x = 0; x + 1 < extra.size(); x += 2)
-            L.wtr.emplace_back((uint32_t)((extra[x] - rb) / kTile), (uint32_t)((extra[x + 1] - rb + kTile - 1) / kTile));
+        // tile rows that hold wanted rows, in the WANTED ORDER (extra segments first, then the main range: the order of the
+        // tile list, of the parts and of a row-sorted buffer), and the wanted rows in front of each of these ranges
+        std::vector<std::pair<uint64_t, uint64_t>> wsegs;
+        wanted_order(n, rb, re, &extra, wsegs);
+        uint64_t wrows = 0;
+        for (auto &sg : wsegs) {
+            L.wtr.emplace_back((uint32_t)((sg.first - rb) / kTile), (uint32_t)((sg.second - rb + kTile - 1) / kTile));
+            L.wtr_w.push_back(wrows);
+            wrows += sg.second - sg.first;
+        }
         const uint64_t wend = extra.empty() ? re - rb : extra.back() - rb;  // position behind the last wanted row
         if (L.rowsorted) {
             rowsorted_part_positions(n, rb, re, rowsorted_nparts, L.part_w, &extra);
-            // compact order of the wanted rows -> their rows' offsets in the rank's buffer, and the same by position
+            // wanted order -> the rows' offsets in the rank's buffer, and the same by layout position
             L.rowoff_w.resize(L.nwanted + 1);
             L.rowoff.assign(wend + 1, 0);
-            std::vector<uint64_t> wpos(L.nwanted + 1);  // layout position of the w-th wanted row
             uint64_t acc = 0, w = 0;
-            auto walk = [&](uint64_t b, uint64_t e) {
-                for (uint64_t s = b - rb; s < e - rb; ++s, ++w) {
-                    wpos[w] = s;
+            for (auto &sg : wsegs)
+                for (uint64_t s = sg.first - rb; s < sg.second - rb; ++s, ++w) {
                     L.rowoff_w[w] = L.rowoff[s] = acc;
                     acc += n - 1 - L.perm[s];
                 }
-            };
-            walk(rb, re);
-            for (size_t x = 0; x + 1 < extra.size(); x += 2) walk(extra[x], extra[x + 1]);
-            wpos[L.nwanted] = wend;
-            L.rowoff_w[L.nwanted] = L.rowoff[wend] = acc;
-            for (uint64_t c : L.part_w) L.part_pos.push_back(wpos[c]);
+            L.rowoff_w[L.nwanted] = acc;
         } else if (!extra.empty()) {
-            L.part_pos = {0, wend};
+            L.part_w = {0, L.nwanted};
         } else {
-            for (uint64_t r : L.parts) L.part_pos.push_back(r - rb);
+            for (uint64_t r : L.parts) L.part_w.push_back(r - rb);
         }
+        // (layout positions of the cuts: only meaningful where the wanted order is the layout order -- no extra segments)
+        if (extra.empty()) L.part_pos = L.part_w;
+        else L.part_pos = {0, wend};
         // (whole collection only) the inverse for the un-permute of the shard path
         if (L.whole) {
             L.perm.resize(2 * n);
@@ -559,6 +593,8 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
             *out++ = U4{ti, tj, (uint32_t)pb, (uint32_t)pe};
         }
     };
+    std::vector<size_t> trow_first;   // (wanted tile rows of a sorted layout) first tile of the tile row ...
+    std::vector<uint64_t> trow_w;     // ... and the wanted rows in front of it (wanted order)
     if (job.rect) {
         if (job.row_begin >= job.row_end || job.col_begin >= job.col_end) return false;
         const uint32_t r0 = (uint32_t)(job.row_begin / kTile), r1 = (uint32_t)((job.row_end + kTile - 1) / kTile);
@@ -572,13 +608,17 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
             const uint32_t r1 = std::min<uint32_t>(NT, (uint32_t)((job.row_end + kTile - 1) / kTile));
             if (r1 > r0) T.reserve((size_t)(r1 - r0) * (NT - r0) - (size_t)(r1 - r0) * (r1 - r0 - 1) / 2);
             for (uint32_t ti = r0; ti < r1; ++ti) tile_row(ti, ti, NT);
-        } else {  // the tile rows of the wanted runs (the first re - rb columns, and the extra segments' blocks)
+        } else {  // the tile rows of the wanted runs, in the wanted order (extra segments' blocks first, then the main range)
             size_t cnt = 0;
             for (const auto &w : L.wtr)
                 for (uint32_t ti = w.first; ti < std::min(w.second, NT); ++ti) cnt += NT - ti;
             T.reserve(cnt);
-            for (const auto &w : L.wtr)
-                for (uint32_t ti = w.first; ti < std::min(w.second, NT); ++ti) tile_row(ti, ti, NT);
+            for (size_t k = 0; k < L.wtr.size(); ++k)
+                for (uint32_t ti = L.wtr[k].first; ti < std::min(L.wtr[k].second, NT); ++ti) {
+                    trow_first.push_back(T.size());
+                    trow_w.push_back(L.wtr_w[k] + (uint64_t)(ti - L.wtr[k].first) * kTile);
+                    tile_row(ti, ti, NT);
+                }
         }
     }
     if (T.empty()) return false;
@@ -594,18 +634,17 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     // the compute instead of after the whole tile kernel); small parts (C3 / 8 ranks: ~50-400 tiles) only cut k_finalize.
     // A layout with ONE part (a short range) still gets its event: the exchange of every rank looks the same.
     const size_t kPartBandTiles = tu.part_band_tiles;
-    const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.part_pos.size() >= 2;
-    // first tile of every part: T is row-major and a part is a run of whole tile rows, so the part of a tile is monotone
+    const bool parts_on = job.want_parts && !job.rect && !job.sorted_rows && L.sorted && L.part_w.size() >= 2;
+    // first tile of every part: T holds the wanted tile rows in the wanted order and a part is a run of whole tile rows of
+    // that order, so the part of a tile is monotone
     std::vector<size_t> pstart{0};
     if (parts_on) {
         size_t q = 0;
-        for (size_t t = 0; t < T.size(); ++t) {
-            const uint64_t pos = (uint64_t)T[t].x * kTile;
-            while (q + 2 < L.part_pos.size() && pos >= L.part_pos[q + 1]) {
+        for (size_t r = 0; r < trow_first.size(); ++r)
+            while (q + 2 < L.part_w.size() && trow_w[r] >= L.part_w[q + 1]) {
                 ++q;
-                pstart.push_back(t);
+                pstart.push_back(trow_first[r]);
             }
-        }
         pp.nparts = (uint32_t)pstart.size();
     }
     pstart.push_back(T.size());
@@ -614,15 +653,16 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     };
     // tail bands (plan.h, Tuning): cuts of the tile list at whole rounds of the tile kernel
     std::vector<size_t> cuts;
-    if (parts_on && tu.tail_bands > 0 && tu.lockstep && tu.W >= (uint32_t)tu.kc && tu.nsplit == 0 && tu.round_items > 0) {
+    // (a call with ONE part has nothing to send early: the destination of an exchange computes its rows that way)
+    if (parts_on && pp.nparts >= 2 && tu.tail_bands > 0 && tu.lockstep && tu.W >= (uint32_t)tu.kc && tu.nsplit == 0 && tu.round_items > 0) {
         const uint64_t RI = tu.round_items;
         uint64_t items = 0;  // one item per plane of a tile while the job is small (build_band_items: piece = one plane)
         for (const U4 &t : T) items += t.w - t.z;
         const uint64_t R = (items + RI - 1) / RI;
-        if (items <= 16 * RI && R >= 3) {
+        for (uint32_t ntails = tu.tail_bands; ntails >= 1 && cuts.empty() && items <= 16 * RI && R >= 3; --ntails) {
             std::vector<uint64_t> tails;  // rounds of the tail bands, last band first
             uint64_t left = R;
-            for (uint32_t b = 0; b < tu.tail_bands; ++b) {
+            for (uint32_t b = 0; b < ntails; ++b) {
                 const uint64_t r = std::max<uint64_t>(1, (left * tu.tail_permille + 500) / 1000);
                 if (left < r + 2) break;
                 tails.push_back(r);

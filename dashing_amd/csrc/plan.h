@@ -72,6 +72,8 @@ constexpr uint64_t kTopupMaxRows = 32768;
 // prep_permille: the weight of a rank's own prepare, in thousandths of a tile per 128 columns of its plane matrix
 // (~0u: the default)
 void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille = ~0u);
+// the wanted segments in the WANTED ORDER: the extra segments (row order) first, then the main range
+void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs);
 // tiles a rank with these rows computes, and the rows it holds
 uint64_t rowset_tiles(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
 uint64_t rowset_rows(uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
@@ -107,13 +109,14 @@ struct Layout {
     int sorted = 0;               // 0: identity over all n sketches.  1: the sub-collection {rb .. n-1}, key-ordered
     uint64_t rb = 0, re = 0;      // wanted rows of a sorted layout (rb = 0, re = n: the whole collection)
     std::vector<uint64_t> extra;  // further wanted segments {b0, e0, ...} after re (plan.h, row sets), all on 128-row boundaries
-    std::vector<std::pair<uint32_t, uint32_t>> wtr;  // the tile rows (128-column blocks) that hold wanted rows, as block ranges
+    std::vector<std::pair<uint32_t, uint32_t>> wtr;  // the tile rows (128-column blocks) that hold wanted rows, as block ranges in the WANTED ORDER
+    std::vector<uint64_t> wtr_w;  // wanted rows in front of each of these ranges (wanted order: extra segments first, then the main range)
     uint64_t nwanted = 0;         // wanted rows in all
-    std::vector<uint64_t> part_w;    // (rowsorted) the parts as counts of wanted rows, front() = 0, back() = nwanted
+    std::vector<uint64_t> part_w;    // the parts as counts of wanted rows in the wanted order, front() = 0, back() = nwanted
     std::vector<uint64_t> rowoff_w;  // (rowsorted) offset of the w-th wanted row (layout order) in the rank's buffer, [nwanted + 1]
     std::vector<uint64_t> parts;  // row boundaries of the parts of the wanted rows, front() = rb, back() = re
     int rowsorted = 0;            // the wanted rows are ONE key-ordered run; the parts are runs of whole tile rows of that order
-    std::vector<uint64_t> part_pos;  // the parts as positions of the layout, front() = 0, back() = re - rb
+    std::vector<uint64_t> part_pos;  // the parts as positions of the layout (without extra segments: = part_w)
     std::vector<uint64_t> rowoff;    // (rowsorted) offset of the row at layout position s in the rank's buffer (unwanted positions: 0)
     uint64_t n = 0, ncols = 0;    // sketches in the collection; real columns of the plane matrix
     uint32_t Npad = 0;            // ncols padded to whole 128-column blocks
@@ -166,7 +169,7 @@ struct Tuning {
     // Each tail takes tail_permille of the rounds left; no cut is made if it would add a round.
     uint32_t round_items = 512;
     uint32_t tail_bands = 1;
-    uint32_t tail_permille = 280;
+    uint32_t tail_permille = 100;
 };
 
 struct Seg {

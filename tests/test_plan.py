@@ -182,6 +182,9 @@ def test_triangle_arithmetic_and_partitions(host):
 
 
 # ---- row sets: a rank's rows as a range + top-up tile rows (plan.h; dsh_balance_rowsets) ---------------------------------
+PREP = 0.4  # dsh_balance_rowsets' default weight of a rank's own prepare: tiles per 128 columns of its plane matrix
+
+
 def _rowset_api(host):
     u64, u32, vp = C.c_uint64, C.c_uint32, C.c_void_p
     host.dsh_balance_rowsets.argtypes = [u64, u32, C.c_int, vp, u32, C.POINTER(u32)]
@@ -218,7 +221,7 @@ def check_rowset(host, keys, tab, rank, rowsorted, nparts, p=12, budget=8 << 30)
 
 def test_balanced_rowsets_partition_every_row_once(host):
     """every row has exactly one owner, every rank's segments are tile-aligned when it has more than one, the pairs of the
-    ranks add up to the triangle, and the largest cost of any rank (tiles + 0.9 per 128 columns of its plane matrix: its own
+    ranks add up to the triangle, and the largest cost of any rank (tiles + 0.4 per 128 columns of its plane matrix: its own
     prepare) is never above the contiguous balance's"""
     _rowset_api(host)
     rng = np.random.default_rng(11)
@@ -235,7 +238,7 @@ def test_balanced_rowsets_partition_every_row_once(host):
         nt = (n + 127) // 128
         for r in range(world):
             segs, pairs, t = rank_rows(host, n, tab, r)
-            cost.append(t + 0.9 * (nt - segs[0][0] // 128) if segs else 0.0)
+            cost.append(t + PREP * (nt - segs[0][0] // 128) if segs else 0.0)
             for b, e in segs:
                 assert np.all(owner_of[b:e] == -1)
                 owner_of[b:e] = r
@@ -248,7 +251,7 @@ def test_balanced_rowsets_partition_every_row_once(host):
         b = np.zeros(world + 1, np.uint64)
         host.dsh_balance_rows(n, world, b.ctypes.data)
         contiguous = [sum(nt - t for t in range(int(b[r]) // 128, (int(b[r + 1]) + 127) // 128)) for r in range(world)]
-        ccost = [contiguous[r] + (0.9 * (nt - int(b[r]) // 128) if b[r + 1] > b[r] else 0.0) for r in range(world)]
+        ccost = [contiguous[r] + (PREP * (nt - int(b[r]) // 128) if b[r + 1] > b[r] else 0.0) for r in range(world)]
         assert sum(tiles) == nt * (nt + 1) // 2 or sum(tiles) == sum(contiguous)
         assert max(cost) <= max(ccost) + 1e-6, (n, world, cost, ccost)
 
@@ -256,14 +259,14 @@ def test_balanced_rowsets_partition_every_row_once(host):
 def test_balanced_rowsets_c3_over_8_ranks_is_level(host):
     """the case the top-ups exist for (BASELINE configs[2] over 8 GPUs): 3 160 tiles, 395 per rank -- contiguous 128-row
     ranges leave the largest rank at 432+; with the bottom tile rows dealt every rank is within a few tiles of the others
-    once its own prepare (0.9 tile-equivalents per 128 columns of its plane matrix) is counted"""
+    once its own prepare (0.4 tile-equivalents per 128 columns of its plane matrix, the default weight) is counted"""
     n, world = 10000, 8
     tab = balance_rowsets(host, n, world)
     nt = (n + 127) // 128
     cost = []
     for r in range(world):
         segs, _, tiles = rank_rows(host, n, tab, r)
-        cost.append(tiles + 0.9 * (nt - segs[0][0] // 128))
+        cost.append(tiles + PREP * (nt - segs[0][0] // 128))
     assert max(cost) - min(cost) <= 12, cost
     assert max(cost) <= 1.02 * (sum(cost) / world), cost
     assert any(len(rank_rows(host, n, tab, r)[0]) > 1 for r in range(world))
