@@ -185,6 +185,15 @@ def pmc_child():
             ctx.synchronize()
         del regs_d, out
         torch.cuda.empty_cache()
+    if os.environ.get("DSH_BENCH_PMC_BAND"):  # one band of the configs[4]-shaped collection (a compare pass of its own)
+        b = C5_BAND
+        regs5 = c5_sketches(torch, dev, synth, b["n"], b["p"], b["nbase"])
+        out = torch.empty(dashing_amd.tri_span(b["n"], 0, b["rows"]), dtype=torch.float32, device=dev)
+        ctx.attach_device(regs5.data_ptr(), b["n"], b["p"])
+        ctx.dist_rows_device(out.data_ptr(), 0, b["rows"], dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        del regs5, out
+        torch.cuda.empty_cache()
     sketch_workload(ctx, torch, dev, PMC_SKETCH_GENOMES, 5_000_000, 10, 1)
     ctx.close()
 
@@ -219,7 +228,7 @@ def live_pmc(n, p, cache_env):
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
                 env.pop(k, None)
             try:
-                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                r = subprocess.run(argv, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
             except (OSError, subprocess.TimeoutExpired) as e:
                 return None, "rocprofv3 --pmc %s pass did not finish (%s)" % (counters[0], type(e).__name__)
             rows = []
@@ -242,6 +251,8 @@ def live_pmc(n, p, cache_env):
                 last["C3"] = passes[2]
             if len(passes) >= 5:
                 last["C4"] = passes[4]
+            if len(passes) >= 6 and cache_env.get("DSH_BENCH_PMC_BAND"):
+                last["C5"] = passes[5]
             for wl, prow in last.items():
                 for row in prow:
                     kn = row["Kernel_Name"]
@@ -613,6 +624,8 @@ def run(args, backend, world, rank, line, dist_on):
     want_cfg = single and not args.no_secondary and (n, p) == (10000, 14)
     regs4_h = synth.survey_sketches(100_000, 10, seed=0x5EED0000)[0] if want_cfg else None
     if single and not args.no_pmc and not os.environ.get("DSH_BENCH_NO_PMC"):
+        if want_cfg:
+            cache_env["DSH_BENCH_PMC_BAND"] = "1"
         for tag, arr in (("C3", regs_h), ("C4", regs4_h)):
             if arr is not None:
                 path = "/tmp/dsh_bench_%s_%d.npy" % (tag, os.getpid())
@@ -746,14 +759,14 @@ def run(args, backend, world, rank, line, dist_on):
                 sys.stderr.write(traceback.format_exc())
                 cfgs.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
 
-        guarded("BASELINE configs[1] shape", lambda: config_sketch(ctx, torch, dev, dashing_amd, pmc.get("sketch")))
+        guarded("BASELINE configs[1]", lambda: config_sketch(ctx, torch, dev, dashing_amd, pmc.get("sketch"), args))
         cfgs.append({"workload": line["config"]["workload"], "pairs_per_s": value, "ms_per_step": ms_per_step,
                      "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": roofline["streaming_model_frac_of_hbm"], "physical_hbm_gbs": roofline["physical_hbm_gbs"]},
                      "cpu_baseline": None if cpu is None else {"value": cpu["value"], "cores": cpu["cores"], "sample": cpu["sample"]},
                      "parity": parity, "note": "the headline: full detail at top level"})
         guarded("BASELINE configs[3] shape", lambda: config_c4(ctx, torch, dev, dashing_amd, regs4_h, pmc, args))
         regs4_h = None
-        guarded("BASELINE configs[4] shape, one band", lambda: config_c5_band(ctx, torch, dev, dashing_amd, synth))
+        guarded("BASELINE configs[4] shape, one band", lambda: config_c5_band(ctx, torch, dev, dashing_amd, synth, pmc, args))
         line["configs"] = cfgs
         line["secondary"] = next((c for c in cfgs if c.get("workload", "").startswith("BASELINE configs[3]") and "error" not in c), None)
         try:
@@ -901,35 +914,120 @@ def what_if_mfma(ctx, torch, dashing_amd, regs_d, full, local, n, p, total_pairs
             "k_pair_counts_mfma_ms": round(kw["pair_ms"], 3), "output_identical_to_valu_path": same}
 
 
-def config_sketch(ctx, torch, dev, dashing_amd, pm, G=200, L=5_000_000, p=10):
-    """BASELINE configs[1] shape: the sketch kernel (hot loop 1, src/sketch_and_cmp.h:314-360's replacement) on G x 5 Mbp
-    genomes resident in HBM, k=31, p=10: bases/s, fraction of HBM at 1 B/base, VALU-issue fraction, CPU oracle, parity."""
+def cli_end_to_end(torch, dev, seq, G, L, p, want_tri, threads):
+    """`dashing-amd dist -b` from FASTA files (80-column lines) on a RAM-backed file system: the whole of configs[1] as a user
+    runs it -- process start, context creation, FASTA parsing on the host cores, batched upload + k_sketch, dist, the
+    binary matrix written.  Host-bound (the parser), labelled so; the matrix must equal the in-process one."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    need = int(G * L * 1.02) + (64 << 20)
+    where = None
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            if shutil.disk_usage(cand).free > 2 * need + (4 << 30):
+                where = cand
+                break
+        except OSError:
+            pass
+    if where is None:
+        return {"skipped": "no file system with %.1f GB free for the FASTA files" % (2 * need / 1e9)}
+    cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
+    d = tempfile.mkdtemp(prefix="dsh_c1_", dir=where)
+    try:
+        t0 = time.perf_counter()
+        nl = torch.full((G * L // 80, 1), 10, dtype=torch.uint8, device=dev)
+        fa = torch.cat([seq[: G * L].view(-1, 80), nl], dim=1).view(G, L // 80 * 81)  # the line breaks, inserted on the device
+        paths = []
+        for g_ in range(G):
+            pth = os.path.join(d, "g%04d.fna" % g_)
+            with open(pth, "wb") as f:
+                f.write(b">genome%d\n" % g_)
+                f.write(fa[g_].cpu().numpy().tobytes())
+            paths.append(pth)
+        del fa, nl
+        lst = os.path.join(d, "paths.txt")
+        with open(lst, "w") as f:
+            f.write("\n".join(paths) + "\n")
+        t_write = time.perf_counter() - t0
+        out = os.path.join(d, "dist.bin")
+        walls = []
+        for _ in range(2):
+            time.sleep(0.5)  # (the driver tears the previous process down: its dsh_create otherwise takes 0.24 s instead of 0.07)
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "dist", "-k", str(K), "-S", str(p), "-p", str(threads), "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst],
+                               capture_output=True, timeout=300)
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"error": "dashing-amd dist: rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+        raw = np.fromfile(out, np.uint8)
+        got = raw[9:].view(np.float32)
+        same = bool(got.size == want_tri.size and (got == want_tri).all())
+        wall = min(walls)
+        return {"what": "wall time of `dashing-amd dist -k%d -S%d -p%d -b --avoid-sorting -F <%d FASTA files of %d bp, 80-column lines, on %s>`: process start + context + host FASTA parsing + upload + k_sketch + dist + the binary matrix" % (K, p, threads, G, L, where),
+                "wall_s": round(wall, 4), "wall_s_runs": [round(w, 4) for w in walls], "bases_per_s": G * L / wall, "host_threads": threads,
+                "matrix_equals_in_process_result": same, "fasta_write_s_not_counted": round(t_write, 2), "bound": "HOST (FASTA parsing on %d cores)" % threads}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def config_sketch(ctx, torch, dev, dashing_amd, pm, args, G=1000, L=5_000_000, p=10):
+    """BASELINE configs[1] at its stated size and scope: 1 000 synthetic 5 Mbp genomes resident in HBM, k=31, p=10 -- k_sketch
+    (hot loop 1, src/sketch_and_cmp.h:314-360's replacement) + dist of the 1 000 sketches: bases/s of the kernel, the
+    sketch+dist step, fraction of HBM at 1 B/base, VALU-issue fraction, the CPU oracle on >= 1 s of the same genomes,
+    registers of 20 sampled genomes bit-exact, the distances within 1e-6; then the same job through the CLI from FASTA."""
     from oracle import oracle_c
 
     seq, wall_s, kernel_ms, regs = sketch_workload(ctx, torch, dev, G, L, p, 3)
     bases = G * L
-    # registers bit-exact on a sample of genomes (two decorated ones among them)
-    sample = [0, 1, 10, 57, G - 1]
-    exact = True
-    for g_ in sample:
-        host = seq[g_ * L:(g_ + 1) * L].cpu().numpy()
-        want = oracle_c.sketch_batch(host, np.array([0, L], np.uint64), K, p, True)
-        exact = exact and bool((regs[g_] == want[0]).all())
+    offs = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+    total = G * (G - 1) // 2
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    # sketch + dist, one step: clear, k_sketch over all genomes, all-pairs dist of the fresh sketches
+    steps = []
+    for _ in range(3):
+        ctx.clear()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.sketch_batch_device(seq.data_ptr(), offs, 0, K, True)
+        ctx.dist_rows_device(out.data_ptr(), 0, G, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+        ctx.synchronize()
+        steps.append(time.perf_counter() - t0)
+    step_s = min(steps)
+    tri = out.cpu().numpy()
+    # registers bit-exact on 20 sampled genomes (decorated ones among them: every 10th holds an N run and a lowercase kilobase)
     cores = oracle_c.effective_cpus()
     oracle_c.load(threads=cores)
+    rng = np.random.default_rng(11)
+    sample = sorted(set([0, 10, G - 1] + [int(x) for x in rng.choice(G, 17, replace=False)]))
+    hs = torch.cat([seq[g_ * L:(g_ + 1) * L] for g_ in sample]).cpu().numpy()
+    want = oracle_c.sketch_batch(hs, np.arange(len(sample) + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
+    exact = bool((regs[sample] == want).all())
+    # distances of all 499 500 pairs against the oracle's estimator on the device's registers (bit-exact to the oracle's own
+    # on the sample above)
+    ref = oracle_c.dist_tri(regs)
+    rel = np.abs(tri.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
+    # CPU oracle on >= 1 s of the same genomes, one genome per thread (src/sketch_and_cmp.h:314-360)
     nc = min(G, 2 * cores)
-    hs = seq[: nc * L].cpu().numpy()
+    h0 = seq[: nc * L].cpu().numpy()
     t0 = time.perf_counter()
-    oracle_c.sketch_batch(hs, np.arange(nc + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
+    oracle_c.sketch_batch(h0, np.arange(nc + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
+    rate = nc * L / (time.perf_counter() - t0)
+    nc = int(min(G, max(nc, np.ceil(1.3 * rate / L / cores) * cores)))
+    h0 = seq[: nc * L].cpu().numpy()
+    t0 = time.perf_counter()
+    oracle_c.sketch_batch(h0, np.arange(nc + 1, dtype=np.uint64) * np.uint64(L), K, p, True)
     tc = time.perf_counter() - t0
+    del h0
     ksec = kernel_ms * 1e-3
-    # the kernel's static mix (tools/isa_mix.py kernels_sketch.hip _ZN3dsh8k_sketchILb0ELb1EEE: 1299 of its 2302 VALU
-    # instructions are full-rate VOP1/VOP2 moves, logic, adds and compares, 1003 are shifts, VOP3 forms, multiplies and the 64-bit
-    # ops of the Wang hash): nominal issue 2 / 4 cycles per wave64 instruction, measured alone 2.5 / 4.4 (profiles/ubench)
-    full_share = 0.5643
+    # the kernel's static mix (tools/sketch_instr.py / tools/isa_mix.py on k_sketch<false,true,1>): two thirds of the unrolled
+    # loop's VALU instructions are full-rate VOP1/VOP2 (2 issue cycles per wave64 instruction), the rest -- the 64-bit shifts
+    # and v_mad_u64_u32 of the Wang hash, the funnel shifts -- take 4; measured alone 2.5 / 4.4 (profiles/ubench)
+    full_share = 0.664
     ceil_nominal = 2.0 * full_share + 4.0 * (1 - full_share)
     ceil_measured = 2.5 * full_share + 4.4 * (1 - full_share)
-    binding = {"resource": "int VALU issue (the 64-bit Wang hash: v_mad_u64_u32 / v_lshrrev_b64 / v_lshlrev_b64, fixed by the bit-exactness contract, are 44 % half-rate instructions)",
+    binding = {"resource": "int VALU issue (24 of the ~43 instructions per k-mer are the 64-bit Wang hash, fixed by the bit-exactness contract)",
                "frac": None, "valu_insts_per_kmer": None, "ceiling_cycles_per_valu_inst": round(ceil_nominal, 3),
                "ceiling_note": "mix-aware: %.1f %% full-rate (2 cycles per wave64 instruction) + %.1f %% half-rate (4); measured alone 2.5 / 4.4 -> %.2f" % (
                    100 * full_share, 100 * (1 - full_share), ceil_measured)}
@@ -940,17 +1038,30 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, G=200, L=5_000_000, p=10):
         binding.update({"valu_insts_per_kmer": round(per_base, 2), "cycles_per_valu_inst": round(cpi, 3), "frac": round(ceil_nominal / cpi, 4),
                         "frac_of_isolated_rates": round(ceil_measured / cpi, 4)})
     traffic = hbm_bytes(pm)
-    del seq
+    e2e = None
+    if not args.no_secondary and not os.environ.get("DSH_BENCH_NO_CLI"):
+        try:
+            e2e = cli_end_to_end(torch, dev, seq, G, L, p, tri, cores)
+            if e2e and "wall_s" in e2e:
+                e2e["gpu_idle_fraction"] = round(1.0 - step_s / e2e["wall_s"], 4)
+                e2e["gpu_idle_note"] = "1 - (the in-process sketch+dist step, %.1f ms) / wall: the GPU waits for the host's parser" % (step_s * 1e3)
+        except Exception as e:  # noqa: BLE001
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
+    del seq, out
     torch.cuda.empty_cache()
-    return {"workload": "BASELINE configs[1] shape: k_sketch on %d synthetic %d bp genomes resident in HBM, k=%d, p=%d (canonical k-mers)" % (G, L, K, p),
+    return {"workload": "BASELINE configs[1]: %d synthetic %d bp genomes resident in HBM, k=%d, p=%d (canonical k-mers): k_sketch, then dist of the %d sketches" % (G, L, K, p, G),
             "bases_per_s": bases / ksec, "ms_per_step": kernel_ms, "wall_ms_per_call": wall_s * 1e3, "steps": 3,
-            "roofline": {"bound": "hbm", "achieved": round(bases / ksec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bases / ksec / 1e9 / HBM_PEAK_GBS, 4),
-                         "bytes_per_base": 1, "binding": binding,
-                         "physical_hbm_bytes_per_base": round(traffic / (PMC_SKETCH_GENOMES * L), 3) if traffic else None,
-                         "note": "HBM is the nominal roof at 1 B/base (SURVEY 8d); the kernel is bound by integer VALU issue"},
+            "sketch_plus_dist": {"ms_per_step": round(step_s * 1e3, 3), "bases_per_s": bases / step_s, "pairs": total,
+                                 "what": "clear + k_sketch over the %d genomes + all-pairs dist (Ertl-MLE JI) of the fresh sketches, wall" % G},
+            "roofline": {"bound": "int VALU issue", "frac": binding["frac"], "binding": binding,
+                         "streaming_model": {"bytes_per_base": 1, "achieved_gbs": round(bases / ksec / 1e9, 1), "frac_of_hbm": round(bases / ksec / 1e9 / HBM_PEAK_GBS, 4),
+                                             "note": "HBM is the nominal roof at 1 B/base (SURVEY 8d); the kernel is bound by integer VALU issue"},
+                         "physical_hbm_bytes_per_base": round(traffic / (PMC_SKETCH_GENOMES * L), 3) if traffic else None},
             "cpu_baseline": {"value": nc * L / tc, "unit": "bases/s", "cores": cores, "kind": "port",
                              "sample": "%d of the same genomes (%d bases) in %.2f s; oracle/dsh_oracle.c dsho_sketch_batch, one genome per thread as src/sketch_and_cmp.h:314-360" % (nc, nc * L, tc)},
-            "parity": {"registers_bit_exact": exact, "genomes_checked": len(sample)}}
+            "parity": {"registers_bit_exact": exact, "genomes_checked": len(sample), "dist_pairs_checked": int(ref.size), "dist_max_rel_diff": float(rel.max()),
+                       "tolerance": 1e-6, "note": PARITY_NOTE},
+            "end_to_end_cli": e2e}
 
 
 def config_c4(ctx, torch, dev, dashing_amd, regs, pmc, args, n=100_000, p=10):
@@ -1010,12 +1121,12 @@ def config_c4(ctx, torch, dev, dashing_amd, regs, pmc, args, n=100_000, p=10):
     return res
 
 
-def config_c5_band(ctx, torch, dev, dashing_amd, synth, n=300_000, p=14, rows=2048, nbase=4000):
-    """configs[4] shape (300 000 x p=14): ONE row range of the triangle on one GPU, extrapolated to the full matrix by pair
-    count and labelled so.  Sketch g >= nbase = max(base[a_g], base[b_g]): unions of two base sketches, built on the device
-    (as tests/test_gpu_configs.py); parity on sampled pairs of the band against the CPU oracle."""
-    from oracle import oracle_c
+C5_BAND = {"n": 300_000, "p": 14, "rows": 2048, "nbase": 4000}
 
+
+def c5_sketches(torch, dev, synth, n, p, nbase):
+    """configs[4]-shaped collection built on the device: sketch g >= nbase = max(base[a_g], base[b_g]), unions of two base
+    sketches (as tests/test_gpu_configs.py)"""
     base = synth.survey_sketches(nbase, p, seed=0x5EED0000)[0]
     bd = torch.from_numpy(base).to(dev)
     regs = torch.empty((n, 1 << p), dtype=torch.uint8, device=dev)
@@ -1026,6 +1137,17 @@ def config_c5_band(ctx, torch, dev, dashing_amd, synth, n=300_000, p=14, rows=20
         e0 = min(n - nbase, s0 + (1 << 14))
         regs[nbase + s0: nbase + e0] = torch.maximum(bd[a[s0:e0]], bd[b2[s0:e0]])
     del bd
+    torch.cuda.synchronize()
+    return regs
+
+
+def config_c5_band(ctx, torch, dev, dashing_amd, synth, pmc, args, n=C5_BAND["n"], p=C5_BAND["p"], rows=C5_BAND["rows"], nbase=C5_BAND["nbase"]):
+    """configs[4] shape (300 000 x p=14): ONE row range of the triangle on one GPU, extrapolated to the full matrix by pair
+    count and labelled so; parity on sampled pairs of the band against the CPU oracle, the CPU oracle timed on >= 1e7 pairs
+    of the band itself, physical HBM of the band's kernels from the PMC child."""
+    from oracle import oracle_c
+
+    regs = c5_sketches(torch, dev, synth, n, p, nbase)
     span = dashing_amd.tri_span(n, 0, rows)
     out = torch.empty(span, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -1054,14 +1176,40 @@ def config_c5_band(ctx, torch, dev, dashing_amd, synth, n=300_000, p=14, rows=20
     ref = oracle_c.dist_rect(q_h, c_h)
     got = np.stack([out[torch.from_numpy(np.array([dashing_amd.tri_index(n, i, int(j)) for j in cols], np.int64)).to(dev)].cpu().numpy() for i in qi])
     rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-9)
+    # the CPU oracle on >= 1e7 pairs of the band itself: the band's first rows against a run of its columns
+    cpu = None
+    if not args.no_cpu_baseline:
+        cores = oracle_c.effective_cpus()
+        lib = oracle_c.load(threads=cores)
+        level = oracle_c.simd_level(lib)
+        oracle_c.set_simd(level, lib)
+        qn, cn = 64, 160_000
+        q2 = regs[:qn].cpu().numpy()
+        c2 = regs[rows: rows + cn].cpu().numpy()
+        t0 = time.perf_counter()
+        ref2 = oracle_c.dist_rect(q2, c2)  # (the library loaded above: every core, the SIMD histogram)
+        tc = time.perf_counter() - t0
+        oracle_c.set_simd(0, lib)
+        idx = torch.from_numpy(np.array([dashing_amd.tri_index(n, i, rows) for i in range(qn)], np.int64)).to(dev)
+        got2 = torch.stack([out[int(i0): int(i0) + cn] for i0 in idx.tolist()]).cpu().numpy()
+        rel2 = np.abs(got2.astype(np.float64) - ref2) / np.maximum(np.abs(ref2), 1e-9)
+        cpu = {"value": ref2.size / tc, "unit": "pairs/s", "cores": cores, "kind": "port",
+               "sample": "rows [0,%d) x columns [%d,%d) of the band = %d pairs in %.2f s (oracle/dsh_oracle.c, %s histogram-of-max)" % (
+                   qn, rows, rows + cn, ref2.size, tc, {0: "scalar", 1: "avx2", 2: "avx512bw"}[level]),
+               "max_rel_diff_on_the_sample": float(rel2.max())}
+        del q2, c2
+    phys_p, phys_f = hbm_bytes(pmc.get("C5_pair")), hbm_bytes(pmc.get("C5_finalize"))
     res = {"workload": "BASELINE configs[4] shape, ONE BAND: rows [0,%d) of %d synthetic sketches, p=%d (%.2e of the matrix's %.2e pairs) on one GPU" % (rows, n, p, span, total),
            "pairs_per_s": span / t, "ms_band": t * 1e3, "pairs_in_band": span,
            "extrapolated_full_matrix_s": round(total / (span / t), 2),
            "extrapolation": "full matrix = pairs / (band pairs per second); the band pays the per-sketch pass and the bit-plane transform of ALL %d columns (%.1f ms of %.1f), which a full pass pays once per row range of its own columns: pessimistic" % (n, k["prepare_ms"], t * 1e3),
            "kernel_ms": {"k_pair_counts": round(k["pair_ms"], 3), "k_finalize": round(k["finalize_ms"], 3), "prepare": round(k["prepare_ms"], 3)},
            "avg_planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0,
-           "roofline": {"binding": pbind, "streaming_model_frac_of_hbm": round(span * (2 * (1 << p) + 4) / t / 1e9 / HBM_PEAK_GBS, 4), "physical_hbm_gbs": None},
-           "cpu_baseline": None,
+           "roofline": {"bound": "int VALU issue", "frac": pbind["frac"], "binding": pbind,
+                        "streaming_model_frac_of_hbm": round(span * (2 * (1 << p) + 4) / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "physical_hbm_bytes_per_band": {"k_pair_counts": phys_p, "k_finalize": phys_f},
+                        "physical_hbm_gbs": round((phys_p + phys_f) / t / 1e9, 1) if phys_p and phys_f else None},
+           "cpu_baseline": cpu,
            "parity": {"pairs_checked": int(ref.size), "max_rel_diff": float(rel.max()), "tolerance": 1e-6, "exact_float32_matches": int((got == ref).sum())},
            "note": "the full 300 000 x p=14 matrix (45e9 pairs, 180 GB) is computed twice on one GPU by tests/test_gpu_configs.py::test_config4_full_300k_p14_eight_ranges; CPU rate per pair at p=14: see the headline's cpu_baseline"}
     del out, regs

@@ -139,7 +139,7 @@ struct dsh_ctx {
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
     int part_band_tiles = 2048;       // a part of at least this many tiles gets its own launch of the tile kernel (plan.cpp)
-    int tail_bands = 1, tail_permille = 100;  // small jobs with parts: the tile kernel cut at whole rounds (plan.h, Tuning)
+    int tail_bands = 1, tail_permille = 100, tail_permille2 = 0;  // small jobs with parts: the tile kernel cut at whole rounds (plan.h, Tuning)
     std::vector<double> part_ready_ms;  // (profiling) when each part of the last call with parts was final, from the call's start
     std::vector<uint64_t> part_floats;  // and the floats of the rank's buffer it holds
     int finalize_xcd_tiles = 1;       // k_finalize: block -> tile mapping that keeps a tile's 128 rows on one XCD (option, A/B)
@@ -155,6 +155,7 @@ struct dsh_ctx {
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int ls_sort_items = 1;
     int finalize_two_streams = 1;  // the k_finalize launches of a call with parts alternate between the two streams (profiles/r5f)
+    int sketch_variant = 1;  // k_sketch: 1 the trimmed instruction stream, 0 the kernel of rounds 1-4 (A/B; same registers)
     int colindex_split = 0;  // workgroups per column block of k_build_colindex (0: automatic)
     int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto

@@ -73,6 +73,49 @@ __device__ __forceinline__ void pack32(const uint4 lo, const uint4 hi, uint64_t 
     }
 }
 
+// ---- the trimmed pack (VAR = 1; round 5, profiles/rd5*/sketch_instr.json) -----------------------------------------------
+// One v_perm_b32 is an 8-entry byte table looked up for 4 bases at once: index = (byte >> 1) & 7 is 0 1 2 3 for A C T G
+// in either case; the table of EXPECTED upper-case letters compared with the case-folded byte validates the base (any
+// other byte either indexes 4..7 -> 0xFF, or differs from the letter its index stands for), a second table gives the
+// 2-bit code.  27 -> 9 instructions per 4 bases for the validity, 3 -> 1 for the code.  The reverse strand is not packed
+// at all: R = the bit-pair reversal of ~F (v_bfrev_b32 + one swap of neighbouring bits per 32-bit half).
+__device__ __forceinline__ void pack4_perm(uint32_t x, uint32_t &be8, uint32_t &v4)
+{
+    const uint32_t up = x & 0xDFDFDFDFu;
+    const uint32_t idx = (x >> 1) & 0x07070707u;
+    // selector bytes 0..3 pick the bytes of the second source, 4..7 those of the first
+    const uint32_t expect = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, idx);  // 'A' 'C' 'T' 'G', else 0xFF
+    const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, idx);             //  0   1   3   2
+    const uint32_t ok = zero_bytes(expect ^ up);
+    v4 = ((ok >> 7) * 0x01020408u) >> 24;     // bit k = byte k valid
+    be8 = (code * 0x40100401u) >> 24;         // c0<<6 | c1<<4 | c2<<2 | c3
+}
+
+// the 16 two-bit fields of x in reverse order
+__device__ __forceinline__ uint32_t pairrev32(uint32_t x)
+{
+    const uint32_t y = __builtin_bitreverse32(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+__device__ __forceinline__ void pack32_perm(const uint4 lo, const uint4 hi, uint64_t &F, uint64_t &R, uint32_t &V)
+{
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t fh = 0, fl = 0;
+    V = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t be, v;
+        pack4_perm(w[k], be, v);
+        if (k < 4) fh |= be << (24 - 8 * k);
+        else fl |= be << (56 - 8 * k);
+        V |= v << (4 * k);
+    }
+    F = ((uint64_t)fh << 32) | fl;
+    // R: complement codes, little-endian (base 0 in the lowest two bits) = the pair-reversal of ~F
+    R = ((uint64_t)pairrev32(~fl) << 32) | pairrev32(~fh);
+}
+
 __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
 {
     // bytes < 128: bit7 of (a|0x80)-b set iff a_byte >= b_byte
@@ -99,7 +142,10 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
     return acc;
 }
 
-template <bool GLOBAL, bool CANON>
+// VAR: 0 = the kernel of rounds 1-4 (kept for the A/B of tools/bench_sketch.py, option "sketch_variant"), 1 = the trimmed
+// instruction stream (perm-table pack, R from F, index and leading-zero count from 32-bit halves, one validity test per
+// 32 start positions when all of them are valid).  Same registers, bit for bit.
+template <bool GLOBAL, bool CANON, int VAR>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, uint8_t *__restrict__ regs)
@@ -125,7 +171,8 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         F = 0; R = 0; V = 0;
         if (B >= wk.gend) return;
         const uint4 *src = reinterpret_cast<const uint4 *>(seq + B);
-        pack32(src[0], src[1], F, R, V);
+        if (VAR == 0) pack32(src[0], src[1], F, R, V);
+        else pack32_perm(src[0], src[1], F, R, V);
         const uint64_t lo = wk.gbeg > B ? wk.gbeg - B : 0;
         const uint64_t hi = wk.gend - B;  // > 0
         uint32_t rmask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1);
@@ -152,13 +199,11 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         const uint64_t V = (uint64_t)V0 | ((uint64_t)xV[tid + 1] << 32);
         const uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
         if (ok == 0) continue;  // (barriers are at the top of the loop body: safe to skip the rest)
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            if (!(ok & (1u << j))) continue;
-            // 64-bit windows of (F0:F1) << 2j and (R1:R0) >> 2j, one v_alignbit_b32 per 32-bit half
-            // (j is a constant after unrolling, so the word selection folds away)
-            const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
-            const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
+        const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
+        const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
+        // the k-mer that starts at base B + j (j a constant after unrolling, so the word selection folds away): 64-bit
+        // windows of (F0:F1) << 2j and (R1:R0) >> 2j, one v_alignbit_b32 per 32-bit half
+        auto kmer_at = [&](const int j) {
             const int q = (2 * j) >> 5, r = (2 * j) & 31;
             const uint32_t fhi = r ? __builtin_amdgcn_alignbit(fwv[q], fwv[q + 1], 32 - r) : fwv[q];
             const uint32_t flo = r ? __builtin_amdgcn_alignbit(fwv[q + 1], fwv[q + 2], 32 - r) : fwv[q + 1];
@@ -170,14 +215,29 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             const uint64_t rc = rl & kmask;
             const uint64_t km = (CANON && rc < fw) ? rc : fw;
             const uint64_t h = wang64(km);
-            const uint32_t idx = (uint32_t)(h >> (64 - p));
-            // value = clz of the 64-p bits after the index, guard bit below them, + 1
-            const uint64_t t = (h << p) | guard;
-            uint32_t lz = (uint32_t)__builtin_clzll(t);
+            uint32_t idx, lz;
+            if (VAR == 0) {
+                idx = (uint32_t)(h >> (64 - p));
+                // value = clz of the 64-p bits after the index, guard bit below them, + 1
+                const uint64_t t = (h << p) | guard;
+                lz = (uint32_t)__builtin_clzll(t);
+            } else {
+                // the same from the halves (4 <= p <= 24 < 32): the index is the top of the high word; t = (h << p) | guard
+                // has its high word from one funnel shift, its low word from one shift-or (the guard bit p - 1 lies there);
+                // v_ffbh_u32 gives -1 for 0, so min() picks the right half
+                const uint32_t hhi = (uint32_t)(h >> 32), hlo = (uint32_t)h;
+                idx = hhi >> (32 - p);
+                const uint32_t thi = __builtin_amdgcn_alignbit(hhi, hlo, 32 - p);
+                const uint32_t tlo = (hlo << p) | (uint32_t)guard;
+                uint32_t zh, zl;
+                asm("v_ffbh_u32 %0, %1" : "=v"(zh) : "v"(thi));
+                asm("v_ffbh_u32 %0, %1" : "=v"(zl) : "v"(tlo));
+                lz = zh < zl + 32u ? zh : zl + 32u;
+            }
             asm("" : "+v"(lz));  // keep the comparison below in 32 bits (hipcc otherwise widens it to u64)
             const uint32_t val = lz + 1u;
             // filter with a plain byte read: almost no k-mer can raise its register
-            if (reinterpret_cast<const uint8_t *>(lregs)[idx] > lz) continue;
+            if (reinterpret_cast<const uint8_t *>(lregs)[idx] > lz) return;
             uint32_t *wp = &lregs[idx >> 2];
             const uint32_t sh = (idx & 3u) * 8u;
             uint32_t old = *wp;
@@ -187,6 +247,14 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                 if (prev == old) break;
                 old = prev;
             }
+        };
+        if (VAR != 0 && __all(ok == 0xFFFFFFFFu)) {  // (the common case: no N, no record edge -- no per-position test)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) kmer_at(j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (ok & (1u << j)) kmer_at(j);
         }
     }
     if (GLOBAL) return;
@@ -206,27 +274,33 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     }
 }
 
-hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
-                         uint32_t nwork, int k, int p, int canon, uint8_t *regs)
+template <bool GLOBAL, int VAR>
+static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
+                                  uint8_t *regs, size_t lds)
 {
-    if (nwork == 0) return hipSuccess;
-    const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
-    if (p > kMaxPLds) {
-        if (canon) hipLaunchKernelGGL((k_sketch<true, true>), dim3(nwork), dim3(256), xch, st, seq, work, k, p, regs);
-        else hipLaunchKernelGGL((k_sketch<true, false>), dim3(nwork), dim3(256), xch, st, seq, work, k, p, regs);
-        return hipGetLastError();
-    }
-    // registers (2^p bytes, 16-byte aligned) + the exchange slots
-    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
     if (lds > (48u << 10)) {  // per launch: the attribute is per device
-        hipError_t e = hipFuncSetAttribute(canon ? reinterpret_cast<const void *>(k_sketch<false, true>)
-                                                 : reinterpret_cast<const void *>(k_sketch<false, false>),
+        hipError_t e = hipFuncSetAttribute(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, VAR>)
+                                                 : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (canon) hipLaunchKernelGGL((k_sketch<false, true>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
-    else hipLaunchKernelGGL((k_sketch<false, false>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, VAR>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, VAR>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
+}
+
+hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
+                         uint32_t nwork, int k, int p, int canon, uint8_t *regs, int variant)
+{
+    if (nwork == 0) return hipSuccess;
+    const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
+    if (p > kMaxPLds)
+        return variant ? launch_sketch_v<true, 1>(st, seq, work, nwork, k, p, canon, regs, xch)
+                       : launch_sketch_v<true, 0>(st, seq, work, nwork, k, p, canon, regs, xch);
+    // registers (2^p bytes, 16-byte aligned) + the exchange slots
+    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
+    return variant ? launch_sketch_v<false, 1>(st, seq, work, nwork, k, p, canon, regs, lds)
+                   : launch_sketch_v<false, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
 }
 
 }  // namespace dsh

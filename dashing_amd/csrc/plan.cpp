@@ -663,7 +663,8 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
             std::vector<uint64_t> tails;  // rounds of the tail bands, last band first
             uint64_t left = R;
             for (uint32_t b = 0; b < ntails; ++b) {
-                const uint64_t r = std::max<uint64_t>(1, (left * tu.tail_permille + 500) / 1000);
+                const uint64_t pm = b == 0 || tu.tail_permille2 == 0 ? tu.tail_permille : tu.tail_permille2;
+                const uint64_t r = std::max<uint64_t>(1, (left * pm + 500) / 1000);
                 if (left < r + 2) break;
                 tails.push_back(r);
                 left -= r;

@@ -170,6 +170,7 @@ struct Tuning {
     uint32_t round_items = 512;
     uint32_t tail_bands = 1;
     uint32_t tail_permille = 100;
+    uint32_t tail_permille2 = 0;  // share of the rounds left for the tails in front of the last one (0: tail_permille)
 };
 
 struct Seg {
