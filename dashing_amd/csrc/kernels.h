@@ -119,4 +119,8 @@ struct SketchWork {
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs, int variant = 1);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (kernel, device) instead of on every launch
+// (ADVICE r4): remembers the largest size granted so far and only calls the runtime for a larger one.
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 }  // namespace dsh

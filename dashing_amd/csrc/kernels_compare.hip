@@ -1709,7 +1709,7 @@ hipError_t launch_topk_merge(hipStream_t st, const float *vals, uint64_t ld, int
     const uint64_t nrows = mode == 0 ? rows : (ncols > b0 + 1 ? ncols - b0 - 1 : 0);
     if (nrows == 0 || nn == 0) return hipSuccess;
     const size_t lds = (size_t)4 * 2 * nn * sizeof(uint32_t);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_topk_merge), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_topk_merge, dim3((uint32_t)((nrows + 3) / 4)), dim3(256), lds, st, vals, ld, mode, b0, rows, ncols,
                        perm, descending, nn, st_idx, st_val);
@@ -1762,6 +1762,12 @@ hipError_t launch_card_from_hist(hipStream_t st, const uint32_t *hist, const uin
     return hipGetLastError();
 }
 
+// Memory and LDS of the position index: the bucket records take nblocks x nbuckets x (RK + 1) x 4 bytes
+// (nbuckets = 2 x min(2^p, 2^14); 16-byte records from p = 13, 32-byte below): 512 KiB per 128-column block at p >= 14, i.e.
+// 0.4 GB at 100 000 columns and 4 GB at 1 000 000 -- against the 288 GB of the device, and bounded per call by the
+// columns of the layout.  A workgroup counts nbuckets / G buckets in dynamic LDS: 128 KiB at p >= 14 when G = 1 (more
+// than 255 column blocks), which the 160 KiB of a gfx950 CU hold; this library is gfx950-only (dsh_create refuses
+// other devices), so no smaller-LDS fallback exists.
 hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c)
 {
     if (c.nblocks == 0) return hipSuccess;
@@ -1772,8 +1778,7 @@ hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c)
     const size_t lds = (size_t)(c.nbuckets / G) * sizeof(uint32_t);
 #define DSH_COLINDEX(PT, RK)                                                                                                  \
     do {                                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_colindex<PT, RK>),                          \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_build_colindex<PT, RK>), lds);                     \
         if (e != hipSuccess) return e;                                                                                        \
         hipLaunchKernelGGL((k_build_colindex<PT, RK>), dim3(c.nblocks, G), dim3(1024), lds, st, (const PT *)c.exc, c.excv,    \
                            c.exc_n, c.keys, c.card, c.tailhist, c.perm, c.ncols, c.p, c.nbuckets, c.ent_stride, c.E, c.rec,    \
@@ -1810,8 +1815,7 @@ static hipError_t launch_pc(hipStream_t st, const uint32_t *planes, uint32_t Npa
 {
     const size_t lds = (size_t)KC * 2048;
     // per launch, not cached in a static: the attribute is per device and a process may own several
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts<KC, U, CT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_pair_counts<KC, U, CT>), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pair_counts<KC, U, CT>), dim3(nitems), dim3(256), lds, st, planes, Npad,
                        Kpad, W, P, tiles, items, reinterpret_cast<CT *>(cum), nslots);
@@ -1857,8 +1861,7 @@ static hipError_t launch_pcl(hipStream_t st, const uint32_t *planes, uint32_t Np
                              uint64_t nslots)
 {
     const size_t lds = (size_t)KC * 4096;  // two halves, each double-buffered A|B
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_counts_ls<KC, CT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_pair_counts_ls<KC, CT>), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pair_counts_ls<KC, CT>), dim3((nitems + 1) / 2), dim3(512), lds, st, planes, Npad, Kpad, W,
                        P, tiles, items, nitems, reinterpret_cast<CT *>(cum), nslots);

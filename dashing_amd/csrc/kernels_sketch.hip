@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <vector>
+
 #include "kernels.h"
 
 namespace dsh {
@@ -274,14 +277,36 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     }
 }
 
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    // (a handful of kernels x devices: a small table under a mutex; the CLI's one-thread-per-device path gets here from
+    // several threads)
+    struct Ent { const void *k; int dev; size_t granted; };
+    static std::mutex mu;
+    static std::vector<Ent> tab;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    for (Ent &t : tab)
+        if (t.k == kernel && t.dev == dev) {
+            if (bytes <= t.granted) return hipSuccess;
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) t.granted = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) tab.push_back(Ent{kernel, dev, bytes});
+    return e;
+}
+
 template <bool GLOBAL, int VAR>
 static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
                                   uint8_t *regs, size_t lds)
 {
-    if (lds > (48u << 10)) {  // per launch: the attribute is per device
-        hipError_t e = hipFuncSetAttribute(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, VAR>)
-                                                 : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > (48u << 10)) {
+        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, VAR>)
+                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, VAR>), lds);
         if (e != hipSuccess) return e;
     }
     if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, VAR>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);

@@ -756,6 +756,34 @@ def test_extreme_histograms_smallest_and_largest_precision(ctx, oracle, p):
             assert (err <= 1e-6 * np.maximum(np.abs(want[fin]), 1e-9)).all(), (estim, rt, err.max())
 
 
+@pytest.mark.parametrize("p", [8, 10, 12, 14])
+def test_mle_division_against_the_oracle_over_the_operand_range(ctx, oracle, p):
+    """the division of the MLE's inner recurrence takes ONE Newton step (div_inner, estimators.h): correctly
+    rounded unless the exact quotient lies within 2^-97 of a rounding midpoint, so identity with a CPU `/` is statistical,
+    not by construction.  This pins it: sketches whose cardinalities sweep eleven decades (the recurrence's operands
+    x' in [2^-k, 2) x every histogram shape from nearly empty to nearly saturated), unions of very unequal sets, every
+    pair's Jaccard / sizes against the oracle -- the contract 1e-6, and (observed, asserted loosely) float32-identical in
+    all but a vanishing share of the pairs."""
+    m = 1 << p
+    rng = np.random.default_rng(1000 + p)
+    cards = np.unique(np.round(np.logspace(0, 11, 90) * (0.5 + rng.random(90))).astype(np.int64))
+    regs = np.stack([synth.hll_registers(int(rng.integers(1, 1 << 30)), int(c), p) for c in cards])
+    ctx.set_sketches(regs)
+    n = len(regs)
+    for rt in (dashing_amd.JI, dashing_amd.SIZES):
+        want = oracle.dist_tri(regs, dashing_amd.ESTIM_ERTL_MLE, rt, 31)
+        got = ctx.dist_rows(estim=dashing_amd.ESTIM_ERTL_MLE, result_type=rt, k=31)
+        fin = np.isfinite(want)
+        assert (np.isfinite(got) == fin).all()
+        err = np.abs(got[fin].astype(np.float64) - want[fin]) / np.maximum(np.abs(want[fin].astype(np.float64)), 1e-9)
+        assert err.max() <= 1e-6, (p, rt, err.max())
+        assert (got[fin] == want[fin]).mean() >= 0.999, (p, rt, (got[fin] != want[fin]).sum(), n)
+    want_c = oracle.cardinalities(regs, dashing_amd.ESTIM_ERTL_MLE)
+    got_c = ctx.cardinalities(dashing_amd.ESTIM_ERTL_MLE)
+    fin = np.isfinite(want_c)
+    assert np.allclose(got_c[fin], want_c[fin], rtol=1e-12)
+
+
 def test_out_of_range_registers_are_refused(ctx):
     """uploaded registers above 64 - p + 1 (corrupt / foreign sketches) make the compare entry points fail loudly
     instead of aliasing into wrong histogram bins"""

@@ -422,7 +422,7 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(MOCK)])
     r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"],
                {"DSH_BENCH_BACKEND": "gloo", "DSH_BENCH_EXCHANGE": "cabi-mock", "DSH_RCCL_LIB": MOCK, "DSH_BENCH_N": "3000",
-                "MOCK_RCCL_TIMEOUT_S": "240"}, timeout=600)
+                "MOCK_RCCL_TIMEOUT_S": "240", "DSH_BENCH_PING_MB": "4"}, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
@@ -432,6 +432,21 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
     assert mg["ranks"] == 2 and mg["exchange"].startswith("c-abi rccl"), mg
     assert "mock_rccl" in mg["exchange_library"]["library"]
     assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+    # the line is self-diagnosing: the row sets, every rank's phases, the link rate measured through
+    # the library's communicator, and the pipeline model's prediction for these times at that rate beside the measurement
+    assert [d["rank"] for d in mg["row_sets"]] == [0, 1] and sum(d["pairs"] for d in mg["row_sets"]) == 3000 * 2999 // 2
+    assert any(len(d["rows"]) > 1 for d in mg["row_sets"]), "n = 3000 over 2 ranks is meant to exercise a top-up segment"
+    assert [r_["rank"] for r_ in mg["per_rank"]] == [0, 1]
+    for r_ in mg["per_rank"]:
+        assert {"prepare_ms", "pair_ms", "finalize_ms", "wall_ms", "exposed_exchange_ms", "tiles", "items", "rounds_of_512", "part_info"} <= set(r_)
+        assert r_["wall_ms"] > 0 and r_["pair_ms"] > 0
+    assert len(mg["per_rank"][1]["part_info"]) == mg["per_rank"][1]["parts"] >= 1
+    ping = mg["link_gbs_measured"]
+    assert ping["payload_intact"] is True and ping["single_GBs_min"] > 0 and ping["concurrent_per_link_GBs"] > 0, ping
+    model = mg["model"]
+    assert set(model["sensitivity_by_assumed_link_GBs"]) == {"30", "45", "60"}
+    assert model["at_measured_link_rate"]["step_model_ms"] > 0 and model["measured_over_predicted"] > 0
+    assert line["roofline"]["bound"] == "int VALU issue" and 0 < line["roofline"]["frac"] <= 1
 
 
 @pytest.mark.gpu
