@@ -255,7 +255,7 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
     HIPCHK(c, launch_sketch(c->stream, d_seq, (const SketchWork *)c->workbuf.ptr,
-                            (uint32_t)work.size(), k, c->p, canon, (uint8_t *)c->regs_own.ptr, c->sketch_variant));
+                            (uint32_t)work.size(), k, c->p, canon, (uint8_t *)c->regs_own.ptr));
     if (e0 && e1) {
         (void)hipEventRecord(e1, c->stream);
         (void)hipEventSynchronize(e1);
@@ -894,11 +894,6 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "part_band_tiles")) {
         if (v < 1 || v > (1 << 30)) return fail(c, DSH_EINVAL, "part_band_tiles out of range");
         c->part_band_tiles = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "sketch_variant")) {
-        if (v != 0 && v != 1) return fail(c, DSH_EINVAL, "sketch_variant is 0 or 1");
-        c->sketch_variant = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "xch_tail_bands")) {

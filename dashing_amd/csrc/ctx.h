@@ -155,7 +155,6 @@ struct dsh_ctx {
     double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
     int ls_sort_items = 1;
     int finalize_two_streams = 1;  // the k_finalize launches of a call with parts alternate between the two streams (profiles/r5f)
-    int sketch_variant = 1;  // k_sketch: 1 the trimmed instruction stream, 0 the kernel of rounds 1-4 (A/B; same registers)
     int colindex_split = 0;  // workgroups per column block of k_build_colindex (0: automatic)
     int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
     // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto

@@ -832,10 +832,11 @@ static int dist_main(int argc, char **argv)
         for (auto &w : workers) w.join();
     } else if (o.devices.size() > 1 || o.rccl) {
         // Several GPUs, output that one writer has to emit in order (text formats, or -b to a pipe): every device
-        // computes its row range (dsh_balance_rows: one contiguous span of the packed matrix each) and the spans are
-        // delivered to the first device over RCCL / xGMI inside the library (dsh_dist_collect: grouped ncclSend/ncclRecv
-        // straight into place), which hands the whole matrix to this process -- dashing's single writer
-        // (src/sketch_and_cmp.h:804-849) fed by G GPUs.  One thread per device, as RCCL wants for one process.
+        // computes its rows -- the library partitions them itself (dsh_dist_collect with bounds = NULL: a row range per
+        // device plus top-up tile rows from the bottom of the triangle, dsh_balance_rowsets) -- and the rows are delivered
+        // to the first device over RCCL / xGMI inside the library (pipelined grouped ncclSend/ncclRecv, part by part),
+        // which hands the whole matrix to this process -- dashing's single writer (src/sketch_and_cmp.h:804-849) fed by
+        // G GPUs.  One thread per device, as RCCL wants for one process.
         const size_t G = std::max<size_t>(o.devices.size(), 1), m = (size_t)1 << o.S;
         uint8_t uid[DSH_UNIQUE_ID_BYTES];
         if (int rc = dsh_comm_unique_id(uid)) die("[dashing-amd] RCCL is not available (dsh_comm_unique_id = %d)", rc);
@@ -844,8 +845,6 @@ static int dist_main(int argc, char **argv)
             all.resize(n * m);
             DSH(ctx, dsh_download_sketches(ctx, 0, n, all.data()));
         }
-        std::vector<uint64_t> bounds(G + 1);
-        if (dsh_balance_rows(n, (uint32_t)G, bounds.data())) die("dsh_balance_rows failed");
         std::vector<float> tri(std::max<uint64_t>(total, 1));
         std::vector<std::thread> workers;
         for (size_t d = 0; d < G; ++d)
@@ -857,7 +856,7 @@ static int dist_main(int argc, char **argv)
                     DSH(c, dsh_upload_sketches(c, all.data(), 0, n));
                 }
                 DSH(c, dsh_comm_init(c, uid, (int)d, (int)G));
-                DSH(c, dsh_dist_collect(c, o.estim, o.result_type, o.k, bounds.data(), 0, d == 0 ? tri.data() : nullptr));
+                DSH(c, dsh_dist_collect(c, o.estim, o.result_type, o.k, /*bounds=*/nullptr, 0, d == 0 ? tri.data() : nullptr));
                 DSH(c, dsh_comm_destroy(c));
                 if (d > 0) dsh_destroy(c);
             });

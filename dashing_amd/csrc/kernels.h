@@ -115,9 +115,8 @@ struct SketchWork {
     uint32_t nsub;   // number of 8192-base sub-chunks this workgroup walks
     uint32_t slot;   // row of the resident sketch matrix
 };
-// variant: 1 = the trimmed instruction stream (default), 0 = the kernel of rounds 1-4 (A/B only; same registers)
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
-                         uint32_t nwork, int k, int p, int canon, uint8_t *regs, int variant = 1);
+                         uint32_t nwork, int k, int p, int canon, uint8_t *regs);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (kernel, device) instead of on every launch
 // (ADVICE r4): remembers the largest size granted so far and only calls the runtime for a larger one.

@@ -47,36 +47,8 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t v)
     return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
 }
 
-// 4 ASCII bases (byte 0 = first base) -> 8 bits big-endian codes, 8 bits little-endian
-// complement codes, 4 validity bits.  A0 C1 G2 T3, case-folded; anything else invalid.
-__device__ __forceinline__ void pack4(uint32_t x, uint32_t &be8, uint32_t &le8c, uint32_t &v4)
-{
-    const uint32_t up = x & 0xDFDFDFDFu;
-    const uint32_t ok = zero_bytes(up ^ 0x41414141u) | zero_bytes(up ^ 0x43434343u) |
-                        zero_bytes(up ^ 0x47474747u) | zero_bytes(up ^ 0x54545454u);
-    v4 = ((ok >> 7) * 0x01020408u) >> 24;  // bit k = byte k valid (upper bits are junk-free)
-    const uint32_t t = (x >> 1) & 0x03030303u;                 // A0 C1 T2 G3
-    const uint32_t code = t ^ ((t >> 1) & 0x01010101u);        // A0 C1 G2 T3
-    be8 = (code * 0x40100401u) >> 24;                          // c0<<6 | c1<<4 | c2<<2 | c3
-    le8c = ((code ^ 0x03030303u) * 0x01041040u) >> 24;         // (3-c0) | (3-c1)<<2 | ...
-}
-
-__device__ __forceinline__ void pack32(const uint4 lo, const uint4 hi, uint64_t &F, uint64_t &R,
-                                       uint32_t &V)
-{
-    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    F = 0; R = 0; V = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        uint32_t be, le, v;
-        pack4(w[k], be, le, v);
-        F |= (uint64_t)be << (56 - 8 * k);
-        R |= (uint64_t)le << (8 * k);
-        V |= (v & 0xFu) << (4 * k);
-    }
-}
-
-// ---- the trimmed pack (VAR = 1; round 5, profiles/rd5*/sketch_instr.json) -----------------------------------------------
+// ---- pack: 4 ASCII bases (byte 0 = first base) -> 8 bits of big-endian 2-bit codes + 4 validity bits; A0 C1 G2 T3,
+// case-folded, anything else invalid (round 5; profiles/rd5d/sketch_instr.json: 425 -> 301 instructions per 32 bases).
 // One v_perm_b32 is an 8-entry byte table looked up for 4 bases at once: index = (byte >> 1) & 7 is 0 1 2 3 for A C T G
 // in either case; the table of EXPECTED upper-case letters compared with the case-folded byte validates the base (any
 // other byte either indexes 4..7 -> 0xFF, or differs from the letter its index stands for), a second table gives the
@@ -145,10 +117,7 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
     return acc;
 }
 
-// VAR: 0 = the kernel of rounds 1-4 (kept for the A/B of tools/bench_sketch.py, option "sketch_variant"), 1 = the trimmed
-// instruction stream (perm-table pack, R from F, index and leading-zero count from 32-bit halves, one validity test per
-// 32 start positions when all of them are valid).  Same registers, bit for bit.
-template <bool GLOBAL, bool CANON, int VAR>
+template <bool GLOBAL, bool CANON>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, uint8_t *__restrict__ regs)
@@ -174,8 +143,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         F = 0; R = 0; V = 0;
         if (B >= wk.gend) return;
         const uint4 *src = reinterpret_cast<const uint4 *>(seq + B);
-        if (VAR == 0) pack32(src[0], src[1], F, R, V);
-        else pack32_perm(src[0], src[1], F, R, V);
+        pack32_perm(src[0], src[1], F, R, V);
         const uint64_t lo = wk.gbeg > B ? wk.gbeg - B : 0;
         const uint64_t hi = wk.gend - B;  // > 0
         uint32_t rmask = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1);
@@ -218,25 +186,17 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             const uint64_t rc = rl & kmask;
             const uint64_t km = (CANON && rc < fw) ? rc : fw;
             const uint64_t h = wang64(km);
-            uint32_t idx, lz;
-            if (VAR == 0) {
-                idx = (uint32_t)(h >> (64 - p));
-                // value = clz of the 64-p bits after the index, guard bit below them, + 1
-                const uint64_t t = (h << p) | guard;
-                lz = (uint32_t)__builtin_clzll(t);
-            } else {
-                // the same from the halves (4 <= p <= 24 < 32): the index is the top of the high word; t = (h << p) | guard
-                // has its high word from one funnel shift, its low word from one shift-or (the guard bit p - 1 lies there);
-                // v_ffbh_u32 gives -1 for 0, so min() picks the right half
-                const uint32_t hhi = (uint32_t)(h >> 32), hlo = (uint32_t)h;
-                idx = hhi >> (32 - p);
-                const uint32_t thi = __builtin_amdgcn_alignbit(hhi, hlo, 32 - p);
-                const uint32_t tlo = (hlo << p) | (uint32_t)guard;
-                uint32_t zh, zl;
-                asm("v_ffbh_u32 %0, %1" : "=v"(zh) : "v"(thi));
-                asm("v_ffbh_u32 %0, %1" : "=v"(zl) : "v"(tlo));
-                lz = zh < zl + 32u ? zh : zl + 32u;
-            }
+            // index and register value from the 32-bit halves of h (4 <= p <= 24 < 32): the index is the top of the high
+            // word; t = (h << p) | guard has its high word from one funnel shift, its low word from one shift-or (the guard
+            // bit p - 1 lies there); value - 1 = clz(t); v_ffbh_u32 gives -1 for 0, so min() picks the right half
+            const uint32_t hhi = (uint32_t)(h >> 32), hlo = (uint32_t)h;
+            const uint32_t idx = hhi >> (32 - p);
+            const uint32_t thi = __builtin_amdgcn_alignbit(hhi, hlo, 32 - p);
+            const uint32_t tlo = (hlo << p) | (uint32_t)guard;
+            uint32_t zh, zl;
+            asm("v_ffbh_u32 %0, %1" : "=v"(zh) : "v"(thi));
+            asm("v_ffbh_u32 %0, %1" : "=v"(zl) : "v"(tlo));
+            uint32_t lz = zh < zl + 32u ? zh : zl + 32u;
             asm("" : "+v"(lz));  // keep the comparison below in 32 bits (hipcc otherwise widens it to u64)
             const uint32_t val = lz + 1u;
             // filter with a plain byte read: almost no k-mer can raise its register
@@ -251,7 +211,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                 old = prev;
             }
         };
-        if (VAR != 0 && __all(ok == 0xFFFFFFFFu)) {  // (the common case: no N, no record edge -- no per-position test)
+        if (__all(ok == 0xFFFFFFFFu)) {  // (the common case: no N, no record edge -- no per-position test)
 #pragma unroll
             for (int j = 0; j < 32; ++j) kmer_at(j);
         } else {
@@ -300,32 +260,29 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
     return e;
 }
 
-template <bool GLOBAL, int VAR>
+template <bool GLOBAL>
 static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
                                   uint8_t *regs, size_t lds)
 {
     if (lds > (48u << 10)) {
-        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, VAR>)
-                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, VAR>), lds);
+        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true>)
+                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false>), lds);
         if (e != hipSuccess) return e;
     }
-    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, VAR>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
-    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, VAR>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<GLOBAL, false>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
 }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
-                         uint32_t nwork, int k, int p, int canon, uint8_t *regs, int variant)
+                         uint32_t nwork, int k, int p, int canon, uint8_t *regs)
 {
     if (nwork == 0) return hipSuccess;
     const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
-    if (p > kMaxPLds)
-        return variant ? launch_sketch_v<true, 1>(st, seq, work, nwork, k, p, canon, regs, xch)
-                       : launch_sketch_v<true, 0>(st, seq, work, nwork, k, p, canon, regs, xch);
+    if (p > kMaxPLds) return launch_sketch_v<true>(st, seq, work, nwork, k, p, canon, regs, xch);
     // registers (2^p bytes, 16-byte aligned) + the exchange slots
     const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
-    return variant ? launch_sketch_v<false, 1>(st, seq, work, nwork, k, p, canon, regs, lds)
-                   : launch_sketch_v<false, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
+    return launch_sketch_v<false>(st, seq, work, nwork, k, p, canon, regs, lds);
 }
 
 }  // namespace dsh

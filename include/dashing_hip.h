@@ -364,7 +364,7 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * "xch_tail_permille" (default 100: one round of the tile kernel of a rank of BASELINE configs[2] over 8) / "xch_tail_permille2" (the
  * share of the tails in front of the last one; 0 = the same): a small job with parts (at most 16 rounds of 512 one-plane work items) has its tile kernel cut
  * at whole rounds into a head and tail launches, so that the head's parts travel while the tails compute, "finalize_two_streams" (0|1: the
- * k_finalize launches of a call with parts alternate between two streams), "sketch_variant" (1 | 0: k_sketch's trimmed instruction stream or the kernel of rounds 1-4, A/B only), "colindex_split" (0 auto | 1 | 2 | 4
+ * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4
  * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
  * "assembler_permille", "shard_c0_x10"; profiling only: "finalize_timing" (the stamped instance of k_finalize, same results);
  * what-if only: "pair_mfma" (refused unless the library was built with `make WHATIF=1`).

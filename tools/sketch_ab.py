@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of k_sketch's two instruction streams (option sketch_variant: 0 = the kernel of rounds 1-4, 1 = the trimmed one) on
+"""(Needs the tree of commit 1383876, which carried BOTH instruction streams behind the option sketch_variant; the result is
+profiles/rd5d/sketch_ab.jsonl, after which the old stream was removed.)
+A/B of k_sketch's two instruction streams (option sketch_variant: 0 = the kernel of rounds 1-4, 1 = the trimmed one) on
 the bench's configs[1]-shaped input (G x 5 Mbp resident in HBM, k=31, p=10): kernel ms by HIP events, alternating the
 variants; the registers must be identical between the variants and equal to the CPU oracle's on sampled genomes.
 

@@ -5,7 +5,8 @@ straight-line code, so its phases can be read off the listing).
 
   python tools/sketch_instr.py            # both variants of the LDS / canonical instance, JSON on stdout
 
-For VAR = 0 (the kernel of rounds 1-4) and VAR = 1 (the trimmed stream) of k_sketch<GLOBAL=false, CANON=true>:
+For k_sketch<GLOBAL=false, CANON=true> (profiles/rd5d/sketch_instr.json holds the table of commit 1383876, where the kernel
+of rounds 1-4 was still present as variant 0 next to the trimmed stream, variant 1 = the kernel of this tree):
   * per k-mer, the unrolled body between two filter reads (median over the 32 start positions), split in order into
     validity test | window (funnel shifts, k-mer mask) | canonical (64-bit compare + select) | Wang hash | register rule
     (index, leading zeros) | filter (LDS address, compare) -- and the CAS path behind the filter, which almost no k-mer takes;
@@ -75,7 +76,8 @@ def phases(block):
 
 
 def analyse(lines, var):
-    body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELi%dEEE" % var)
+    body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELi%dEEE" % var if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELi") for l in lines)
+                   else "_ZN3dsh8k_sketchILb0ELb1EEE")
     reads = [i for i, l in enumerate(body) if l.startswith("ds_read_u8")]
     # a k-mer's code ends where the exec mask narrowed by its filter (and its validity test) is restored: the
     # `s_or_b64 exec, exec, s[..]` that is NOT part of the CAS retry loop (those are followed by an s_and_b64)
@@ -111,7 +113,8 @@ def analyse(lines, var):
 
 def main():
     lines = listing()
-    res = {"kernel": "k_sketch<GLOBAL=false, CANON=true, VAR>", "variants": [analyse(lines, 0), analyse(lines, 1)],
+    both = any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELi") for l in lines)
+    res = {"kernel": "k_sketch<GLOBAL=false, CANON=true>", "variants": [analyse(lines, 0), analyse(lines, 1)] if both else [analyse(lines, 1)],
            "note": "static counts of the unrolled body (median over start positions); per 32 bases the pack + window test add pack_and_prologue/32 per k-mer for every lane and once more for the 64 lanes that pack the sub-chunk's right neighbour"}
     print(json.dumps(res, indent=1))
 
