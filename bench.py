@@ -492,19 +492,20 @@ def run(args, backend, world, rank, line, dist_on):
     NPARTS = int(os.environ.get("DSH_BENCH_PARTS", "8"))
     if use_cabi:
         exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_exchange_rows_device_async + dsh_exchange_collect_async)" % NPARTS
+    gather = not multi or args.exchange == "gather" or (args.exchange == "auto" and 4 * total_pairs <= GATHER_LIMIT_BYTES)
     bounds = dashing_amd.balance_rows(n, world) if multi else [0, n]
     sizes = multigpu.span_sizes(n, bounds)
     # the C-ABI exchange partitions the rows into ROW SETS: a range per rank plus top-up tile rows from the bottom of the
     # triangle (dsh_balance_rowsets), so that every rank computes about the same number of tiles; the torch.distributed
     # fallback keeps the contiguous ranges (its spans are received in place)
-    rows_of = dashing_amd.balance_rowsets(n, world, int(os.environ.get("DSH_BENCH_PREP_PERMILLE", "-1"))) if use_cabi else None
+    rows_of = dashing_amd.balance_rowsets(n, world, int(os.environ.get("DSH_BENCH_PREP_PERMILLE", "-1")), 0 if gather else -1,
+                                          int(os.environ.get("DSH_BENCH_DST_BONUS_PERMILLE", "-1"))) if use_cabi else None
     my_floats = None
     if rows_of is not None:
         sizes = [rows_of.pairs(r) for r in range(world)]
         my_floats = dashing_amd.exchange_mode(n, rows_of, rank, NPARTS, 0, want_floats=True)[2]
     my_pairs = sizes[rank] if multi else total_pairs
     host_stage = backend == "gloo" and multi
-    gather = not multi or args.exchange == "gather" or (args.exchange == "auto" and 4 * total_pairs <= GATHER_LIMIT_BYTES)
     buf = {"final": None, "local": None, "final_h": None}
 
     def alloc_buffers(with_final):

@@ -116,7 +116,7 @@ def load_library():
     lib.dsh_exchange_rows_device_async.argtypes = [vp, i32, i32, i32, vp, i32, C.c_uint32, i32, vp]
     lib.dsh_exchange_collect_async.argtypes = [vp, u64, vp, C.c_uint32, vp, vp, i32]
     lib.dsh_exchange_place_device.argtypes = [vp, vp, i32, C.c_uint32, i32, vp, vp]
-    lib.dsh_balance_rowsets.argtypes = [u64, C.c_uint32, i32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.dsh_balance_rowsets.argtypes = [u64, C.c_uint32, i32, i32, i32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.dsh_rowsets_from_bounds.argtypes = [vp, C.c_uint32, vp]
     lib.dsh_rowsets_rank.argtypes = [u64, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), C.POINTER(u64)]
     lib.dsh_finalize_phase_cycles.argtypes = [vp, vp]
@@ -220,15 +220,16 @@ class RowSets:
         return [{"rank": r, "rows": self.rows(r), "pairs": self.pairs(r), "tiles": self.tiles(r)} for r in range(self.world)]
 
 
-def balance_rowsets(n, world, prep_permille=-1):
-    """Main ranges + top-up tile rows from the bottom of the triangle, one row set per rank (dsh_balance_rowsets)."""
+def balance_rowsets(n, world, prep_permille=-1, dst=-1, dst_bonus_permille=-1):
+    """Main ranges + top-up tile rows from the bottom of the triangle, one row set per rank (dsh_balance_rowsets); dst >= 0:
+    the rank that receives the others' rows takes a bonus of work (it sends nothing)."""
     lib = load_library()
     words = C.c_uint32()
-    rc = lib.dsh_balance_rowsets(n, world, prep_permille, None, 0, C.byref(words))
+    rc = lib.dsh_balance_rowsets(n, world, prep_permille, dst, dst_bonus_permille, None, 0, C.byref(words))
     if rc:
         raise DshError(rc, "dsh_balance_rowsets")
     tab = np.zeros(words.value, np.uint64)
-    rc = lib.dsh_balance_rowsets(n, world, prep_permille, tab.ctypes.data, len(tab), C.byref(words))
+    rc = lib.dsh_balance_rowsets(n, world, prep_permille, dst, dst_bonus_permille, tab.ctypes.data, len(tab), C.byref(words))
     if rc:
         raise DshError(rc, "dsh_balance_rowsets")
     return RowSets(n, tab)

@@ -718,7 +718,7 @@ int dsh_dist_collect(dsh_ctx *c, int estim, int result_type, int k, const uint64
         // pipelined exchange pair -- what bench.py --gpus N times, for a host without device pointers
         if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d (world %d)", dst, world);
         plan::RowSets rs;
-        plan::balance_rowsets(n, (uint32_t)world, rs);
+        plan::balance_rowsets(n, (uint32_t)world, rs, ~0u, dst);
         std::vector<uint64_t> tab(rs.words());
         rs.write(tab.data());
         constexpr uint32_t kParts = 8;

@@ -270,7 +270,7 @@ void rowsets_from_bounds(const uint64_t *bounds, uint32_t world, RowSets &rs)
     for (uint32_t r = 0; r < world; ++r) rs.owner[r] = r;
 }
 
-void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille)
+void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille, int dst, uint32_t dst_bonus_permille)
 {
     const uint64_t NT = (n + kTile - 1) / kTile;
     std::vector<uint64_t> cb(world + 1);
@@ -290,15 +290,23 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
     // TILE counts because the tile kernel's time moves in whole rounds of 512 work items (7 or 8 at that size) and the
     // ranks with the cheap prepare are the ones that would spill into another round
     const double kPrepPerTileRow = prep_permille == ~0u ? 0.4 : (double)prep_permille / 1000.0;
+    // The DESTINATION of an exchange sends nothing: every other rank's step ends when its last part has ARRIVED, i.e. its
+    // compute + what stays exposed of its transfer (the last part's 4.6 MB + the rounds' latency: ~0.2 of 2.2 ms at
+    // BASELINE configs[2] over 8 ranks, profiles/rd5c), the destination's with its last kernel.  So the destination takes
+    // a bonus of work, as a share of a rank's mean tile count: every rank's cost below is its tiles + prepare, minus the
+    // bonus for the destination.
+    const double total = (double)NT * (double)(NT + 1) / 2.0;
+    const double bonus = dst >= 0 && (uint32_t)dst < world ? total / world * (dst_bonus_permille == ~0u ? 0.09 : (double)dst_bonus_permille / 1000.0) : 0.0;
+    auto handicap = [&](uint32_t r) { return (int)r == dst ? -bonus : 0.0; };
     std::vector<uint64_t> start(world), stop(world);
     std::vector<double> cost(world);
+    std::vector<uint8_t> has(world);
     std::vector<uint32_t> deal, best_deal, byneed(world);
     std::vector<uint64_t> best_start, best_stop;
     double best_max = -1;
     uint64_t best_t = NT + 1;
     size_t best_segs = 0;
-    const double total = (double)NT * (double)(NT + 1) / 2.0;
-    const double lo = total / world, hi = total / world + kPrepPerTileRow * (double)NT + (double)NT;
+    const double lo = total / world - bonus, hi = total / world + kPrepPerTileRow * (double)NT + (double)NT;
     const int steps = 800;
     for (int sweep = 0; sweep < 2; ++sweep) {
         const double accept = best_max * 1.005;
@@ -307,10 +315,11 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
             uint64_t t = 0;
             for (uint32_t r = 0; r < world; ++r) {
                 start[r] = t;
-                double acc = kPrepPerTileRow * (double)(NT - t);
+                double acc = kPrepPerTileRow * (double)(NT - t) + handicap(r);
                 while (t < NT && acc + (double)(NT - t) <= limit) acc += (double)(NT - t++);
                 stop[r] = t;
-                cost[r] = stop[r] > start[r] ? acc : 0.0;
+                has[r] = stop[r] > start[r];
+                cost[r] = has[r] ? acc : handicap(r);
             }
             const uint64_t t_pool = t;
             deal.assign(NT - t_pool, ~0u);
@@ -320,7 +329,7 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
             for (uint32_t k = 0; k < world && u < NT; ++k) {
                 const uint32_t r = byneed[k];
                 // (a rank without a main range would start its plane matrix at the dealt row: it pays that prepare)
-                if (cost[r] == 0) cost[r] = kPrepPerTileRow * (double)(NT - u);
+                if (!has[r]) cost[r] = kPrepPerTileRow * (double)(NT - u) + handicap(r), has[r] = 1;
                 while (u < NT && cost[r] + (double)(NT - u) <= limit) cost[r] += (double)(NT - u), deal[u++ - t_pool] = r;
             }
             for (; u < NT; ++u) {
@@ -893,11 +902,13 @@ int dsh_balance_rows(uint64_t n, uint32_t nparts, uint64_t *bounds)
     return DSH_OK;
 }
 
-int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, uint64_t *tab_out, uint32_t cap_words, uint32_t *words_out)
+int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, int dst, int dst_bonus_permille, uint64_t *tab_out,
+                        uint32_t cap_words, uint32_t *words_out)
 {
-    if (world == 0 || (!tab_out && cap_words)) return DSH_EINVAL;
+    if (world == 0 || (!tab_out && cap_words) || dst >= (int)world) return DSH_EINVAL;
     dsh::plan::RowSets rs;
-    dsh::plan::balance_rowsets(n, world, rs, prep_permille < 0 ? ~0u : (uint32_t)prep_permille);
+    dsh::plan::balance_rowsets(n, world, rs, prep_permille < 0 ? ~0u : (uint32_t)prep_permille, dst,
+                               dst_bonus_permille < 0 ? ~0u : (uint32_t)dst_bonus_permille);
     if (words_out) *words_out = (uint32_t)rs.words();
     if (!tab_out) return DSH_OK;  // (size query)
     if (rs.words() > cap_words) return DSH_EINVAL;

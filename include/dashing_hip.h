@@ -273,8 +273,11 @@ int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, ui
  *   dsh_balance_rowsets      main ranges over the top of the triangle + the short tile rows at its bottom dealt, in runs
  *                            of consecutive tile rows, to the ranks that fall short of the mean: the largest cost of any
  *                            rank (tiles + its own prepare, prep_permille/1000 tiles per 128 columns of its plane matrix;
- *                            < 0: the default) is smallest.  Plain dsh_balance_rows ranges when n > 32 768 or a rank would
- *                            hold fewer than two tile rows.  tab_out = NULL: only the size (words_out).
+ *                            < 0: the default) is smallest.  dst >= 0 names the rank that will RECEIVE the others' rows:
+ *                            it sends nothing, so it takes dst_bonus_permille (< 0: the default, 90) thousandths of a
+ *                            rank's mean tile count more than the others, whose step only ends when their last part has
+ *                            arrived; dst < 0: every rank keeps its rows.  Plain dsh_balance_rows ranges when n > 32 768
+ *                            or a rank would hold fewer than two tile rows.  tab_out = NULL: only the size (words_out).
  *   dsh_rowsets_from_bounds  contiguous bounds[world + 1] as a table (3 + 2 world words): any alignment
  *   dsh_rowsets_rank         the segments {b0, e0, b1, e1, ...} of one rank, its pairs and its 128 x 128 tiles
  * The layout of every rank's buffer follows from (table, nparts, dst) alone:
@@ -290,7 +293,8 @@ int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, ui
  * many floats d_local must hold.  dsh_exchange_place_device does, for ONE source rank and without a communicator, what
  * the destination does with that rank's buffer (tests and single-GPU timing of an N-rank plan).
  * dsh_dist_collect(bounds = NULL) runs this pair over dsh_balance_rowsets' table. */
-int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, uint64_t *tab_out, uint32_t cap_words, uint32_t *words_out);
+int dsh_balance_rowsets(uint64_t n, uint32_t world, int prep_permille, int dst, int dst_bonus_permille, uint64_t *tab_out,
+                        uint32_t cap_words, uint32_t *words_out);
 int dsh_rowsets_from_bounds(const uint64_t *bounds, uint32_t world, uint64_t *tab_out /* [3 + 2 world] */);
 int dsh_rowsets_rank(uint64_t n, const uint64_t *rowsets, uint32_t rank, uint64_t *segs_out /* [2 cap_segs] or NULL */, uint32_t cap_segs,
                      uint32_t *nsegs_out, uint64_t *pairs_out, uint64_t *tiles_out);

@@ -187,19 +187,19 @@ PREP = 0.4  # dsh_balance_rowsets' default weight of a rank's own prepare: tiles
 
 def _rowset_api(host):
     u64, u32, vp = C.c_uint64, C.c_uint32, C.c_void_p
-    host.dsh_balance_rowsets.argtypes = [u64, u32, C.c_int, vp, u32, C.POINTER(u32)]
+    host.dsh_balance_rowsets.argtypes = [u64, u32, C.c_int, C.c_int, C.c_int, vp, u32, C.POINTER(u32)]
     host.dsh_rowsets_from_bounds.argtypes = [vp, u32, vp]
     host.dsh_rowsets_rank.argtypes = [u64, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     host.dshh_plan_check_rowset.argtypes = [u64, vp, vp, u32, C.c_int, u32, C.c_int, u64, vp, C.c_char_p, C.c_size_t]
     return host
 
 
-def balance_rowsets(host, n, world, prep=-1):
+def balance_rowsets(host, n, world, prep=-1, dst=-1, bonus=-1):
     _rowset_api(host)
     words = C.c_uint32(0)
-    assert host.dsh_balance_rowsets(n, world, prep, None, 0, C.byref(words)) == 0
+    assert host.dsh_balance_rowsets(n, world, prep, dst, bonus, None, 0, C.byref(words)) == 0
     tab = np.zeros(words.value, np.uint64)
-    assert host.dsh_balance_rowsets(n, world, prep, tab.ctypes.data, len(tab), C.byref(words)) == 0
+    assert host.dsh_balance_rowsets(n, world, prep, dst, bonus, tab.ctypes.data, len(tab), C.byref(words)) == 0
     return tab
 
 
@@ -329,3 +329,29 @@ def test_tail_bands_cut_the_tile_kernel_at_whole_rounds(host):
                 assert st["bands"] >= 2, (n, world, r, st)
                 cut += 1
     assert cut >= 2
+
+
+def test_the_destination_of_an_exchange_takes_a_bonus(host):
+    """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~9 % (or the share asked for) more tiles
+    than the mean and the others correspondingly fewer -- still every row with one owner, every boundary aligned"""
+    n, world = 10000, 8
+    nt = (n + 127) // 128
+    base = [rank_rows(host, n, balance_rowsets(host, n, world), r)[2] for r in range(world)]
+    for dst, bonus in ((0, -1), (3, -1), (7, 150), (0, 0)):
+        tab = balance_rowsets(host, n, world, -1, dst, bonus)
+        tiles = [rank_rows(host, n, tab, r)[2] for r in range(world)]
+        assert sum(tiles) == nt * (nt + 1) // 2
+        mean = sum(tiles) / world
+        share = 0.09 if bonus < 0 else bonus / 1000.0
+        others = [t for r, t in enumerate(tiles) if r != dst]
+        if share == 0:
+            assert tiles == base
+        else:
+            assert tiles[dst] - sum(others) / len(others) >= 0.6 * share * mean, (dst, bonus, tiles)
+            assert max(others) <= max(base), (tiles, base)
+        owner = np.full(n, -1)
+        for r in range(world):
+            for b, e in rank_rows(host, n, tab, r)[0]:
+                assert np.all(owner[b:e] == -1)
+                owner[b:e] = r
+        assert np.all(owner >= 0)

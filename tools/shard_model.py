@@ -5,7 +5,8 @@ row-sorted parts timed on the same GPU, and a pipeline model of the transfers (N
 
   N=10000 P=14 G=8 NPARTS=8 python tools/shard_model.py
   PARTITIONS=contiguous,rowsets,rowsets:450 ...   which partitions to model: contiguous = dsh_balance_rows ranges (round 4),
-                                                  rowsets[:prep_permille] = dsh_balance_rowsets (range + top-up tile rows)
+                                                  rowsets[:prep_permille[:dst_bonus_permille]] = dsh_balance_rowsets (range + top-up
+                                                  tile rows; rank 0 receives and takes the bonus)
 
 Exchange model: every source's parts go to rank 0 over that source's own xGMI link at LINK_GBS + 20 us per round; part q
 of a rank is ready after its prepare, its tile kernel and (q+1)/parts of its finalize (small parts share one launch of
@@ -114,8 +115,10 @@ def main():
         if name == "contiguous":
             rows_of = dashing_amd.rowsets_from_bounds(n, dashing_amd.balance_rows(n, G))
         else:
-            prep = int(name.split(":")[1]) if ":" in name else -1
-            rows_of = dashing_amd.balance_rowsets(n, G, prep)
+            f = name.split(":")  # rowsets[:prep_permille[:dst_bonus_permille]] (-1 = the default; bonus 0 = none)
+            prep = int(f[1]) if len(f) > 1 else -1
+            bonus = int(f[2]) if len(f) > 2 else -1
+            rows_of = dashing_amd.balance_rowsets(n, G, prep, 0, bonus)
         out = model_partition(ctx, regs, n, p, G, NPARTS, {"name": name, "rows": rows_of}, final, want, t1)
         out["opts"] = os.environ.get("OPTS", "")
         print(json.dumps(out), flush=True)
