@@ -151,25 +151,25 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         V &= rmask;
     };
 
+    // Software pipeline over the sub-chunks: a lane packs the NEXT sub-chunk's 32 bases while this one's k-mers are
+    // processed (the global loads travel under the hash arithmetic), and lane 0's look-ahead IS the right neighbour of
+    // lane 255 -- no separate pack of the 32 bases behind the sub-chunk (round 4: wave 0 packed them on top of its own,
+    // 2.3 of 57.5 instructions per k-mer).  Behind the work item's last sub-chunk only wave 0 looks ahead.
+    uint64_t F0, R0;
+    uint32_t V0;
+    pack_at(wk.start + (uint64_t)tid * 32, F0, R0, V0);
     for (uint32_t s = 0; s < wk.nsub; ++s) {
-        const uint64_t B0 = wk.start + (uint64_t)s * kSketchSub;
-        const uint64_t B = B0 + (uint64_t)tid * 32;
-        uint64_t F0, R0;
-        uint32_t V0;
-        pack_at(B, F0, R0, V0);
+        const uint64_t Bn = wk.start + (uint64_t)(s + 1) * kSketchSub + (uint64_t)tid * 32;
+        uint64_t Fn = 0, Rn = 0;
+        uint32_t Vn = 0;
+        if (s + 1 < wk.nsub || tid < 64) pack_at(Bn, Fn, Rn, Vn);  // (wave-uniform)
         __syncthreads();  // previous sub-chunk's neighbour reads (and the register clear) are done
         xF[tid] = F0; xR[tid] = R0; xV[tid] = V0;
-        if (tid < 64) {  // one extra slot: the 32 bases after this sub-chunk (lane 0 of wave 0)
-            uint64_t Fe, Re;
-            uint32_t Ve;
-            pack_at(B0 + kSketchSub, Fe, Re, Ve);
-            if (tid == 0) { xF[256] = Fe; xR[256] = Re; xV[256] = Ve; }
-        }
+        if (tid == 0) { xF[256] = Fn; xR[256] = Rn; xV[256] = Vn; }
         __syncthreads();
         const uint64_t F1 = xF[tid + 1], R1 = xR[tid + 1];
         const uint64_t V = (uint64_t)V0 | ((uint64_t)xV[tid + 1] << 32);
         const uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
-        if (ok == 0) continue;  // (barriers are at the top of the loop body: safe to skip the rest)
         const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
         const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
         // the k-mer that starts at base B + j (j a constant after unrolling, so the word selection folds away): 64-bit
@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                 old = prev;
             }
         };
-        if (__all(ok == 0xFFFFFFFFu)) {  // (the common case: no N, no record edge -- no per-position test)
+        if (ok == 0) {
+            // (nothing starts in this lane's 32 positions)
+        } else if (__all(ok == 0xFFFFFFFFu)) {  // (the common case: no N, no record edge -- no per-position test)
 #pragma unroll
             for (int j = 0; j < 32; ++j) kmer_at(j);
         } else {
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             for (int j = 0; j < 32; ++j)
                 if (ok & (1u << j)) kmer_at(j);
         }
+        F0 = Fn; R0 = Rn; V0 = Vn;
     }
     if (GLOBAL) return;
     __syncthreads();

@@ -293,10 +293,11 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
     // The DESTINATION of an exchange sends nothing: every other rank's step ends when its last part has ARRIVED, i.e. its
     // compute + what stays exposed of its transfer (the last part's 4.6 MB + the rounds' latency: ~0.2 of 2.2 ms at
     // BASELINE configs[2] over 8 ranks, profiles/rd5c), the destination's with its last kernel.  So the destination takes
-    // a bonus of work, as a share of a rank's mean tile count: every rank's cost below is its tiles + prepare, minus the
-    // bonus for the destination.
+    // a bonus of work, as a share of a rank's mean tile count (default 12 %: profiles/rd5f -- 2 ranks 1.61 -> 1.72x, 4 ranks
+    // 3.09 -> 3.15x, 8 ranks 5.75 -> 5.81x modelled at 45 GB/s per link): every rank's cost below is its tiles + prepare,
+    // minus the bonus for the destination.
     const double total = (double)NT * (double)(NT + 1) / 2.0;
-    const double bonus = dst >= 0 && (uint32_t)dst < world ? total / world * (dst_bonus_permille == ~0u ? 0.09 : (double)dst_bonus_permille / 1000.0) : 0.0;
+    const double bonus = dst >= 0 && (uint32_t)dst < world ? total / world * (dst_bonus_permille == ~0u ? 0.12 : (double)dst_bonus_permille / 1000.0) : 0.0;
     auto handicap = [&](uint32_t r) { return (int)r == dst ? -bonus : 0.0; };
     std::vector<uint64_t> start(world), stop(world);
     std::vector<double> cost(world);

@@ -332,7 +332,7 @@ def test_tail_bands_cut_the_tile_kernel_at_whole_rounds(host):
 
 
 def test_the_destination_of_an_exchange_takes_a_bonus(host):
-    """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~9 % (or the share asked for) more tiles
+    """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~12 % (or the share asked for) more tiles
     than the mean and the others correspondingly fewer -- still every row with one owner, every boundary aligned"""
     n, world = 10000, 8
     nt = (n + 127) // 128
@@ -342,7 +342,7 @@ def test_the_destination_of_an_exchange_takes_a_bonus(host):
         tiles = [rank_rows(host, n, tab, r)[2] for r in range(world)]
         assert sum(tiles) == nt * (nt + 1) // 2
         mean = sum(tiles) / world
-        share = 0.09 if bonus < 0 else bonus / 1000.0
+        share = 0.12 if bonus < 0 else bonus / 1000.0
         others = [t for r, t in enumerate(tiles) if r != dst]
         if share == 0:
             assert tiles == base
