@@ -675,7 +675,9 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
             for (uint32_t b = 0; b < ntails; ++b) {
                 const uint64_t pm = b == 0 || tu.tail_permille2 == 0 ? tu.tail_permille : tu.tail_permille2;
                 const uint64_t r = std::max<uint64_t>(1, (left * pm + 500) / 1000);
-                if (left < r + 2) break;
+                // (a tail in front of the last one only pays where the head keeps enough rounds for its parts' transfer to
+                // hide behind it: 14 rounds -> 8 + 5 + 1, but 7 rounds -> 6 + 1, profiles/rd5d)
+                if (left < r + 2 || (b > 0 && left < r + tu.tail_head_min_rounds)) break;
                 tails.push_back(r);
                 left -= r;
             }

@@ -169,9 +169,10 @@ struct Tuning {
     // (a cut elsewhere rounds every band up: +1 round, profiles/r4i): the head's parts travel while the tails compute.
     // Each tail takes tail_permille of the rounds left; no cut is made if it would add a round.
     uint32_t round_items = 512;
-    uint32_t tail_bands = 1;
+    uint32_t tail_bands = 2;
     uint32_t tail_permille = 100;
-    uint32_t tail_permille2 = 0;  // share of the rounds left for the tails in front of the last one (0: tail_permille)
+    uint32_t tail_permille2 = 350;  // share of the rounds left for the tails in front of the last one (0: tail_permille)
+    uint32_t tail_head_min_rounds = 7;  // a tail in front of the last one must leave the head at least this many rounds
 };
 
 struct Seg {
