@@ -293,11 +293,14 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
     // The DESTINATION of an exchange sends nothing: every other rank's step ends when its last part has ARRIVED, i.e. its
     // compute + what stays exposed of its transfer (the last part's 4.6 MB + the rounds' latency: ~0.2 of 2.2 ms at
     // BASELINE configs[2] over 8 ranks, profiles/rd5c), the destination's with its last kernel.  So the destination takes
-    // a bonus of work, as a share of a rank's mean tile count (default 12 %: profiles/rd5f -- 2 ranks 1.61 -> 1.72x, 4 ranks
-    // 3.09 -> 3.15x, 8 ranks 5.75 -> 5.81x modelled at 45 GB/s per link): every rank's cost below is its tiles + prepare,
-    // minus the bonus for the destination.
+    // a bonus of work, as a share of a rank's mean tile count: every rank's cost below is its tiles + prepare, minus the
+    // bonus for the destination.  Default 12 % where a rank holds at least 16 tile rows (profiles/rd5f, rd5h: 2 ranks of
+    // BASELINE configs[2] 1.61 -> 1.72x, 4 ranks 3.09 -> 3.23x modelled at 45 GB/s per link), none below that: at 8 ranks
+    // (10 tile rows each) the tile kernel takes 7 rounds for 385 tiles and for 400, so taking tiles off the sources buys
+    // nothing while the destination spills into an 8th round and becomes the last to finish (5.75x -> 5.66-5.81x).
     const double total = (double)NT * (double)(NT + 1) / 2.0;
-    const double bonus = dst >= 0 && (uint32_t)dst < world ? total / world * (dst_bonus_permille == ~0u ? 0.12 : (double)dst_bonus_permille / 1000.0) : 0.0;
+    const double share = dst_bonus_permille != ~0u ? (double)dst_bonus_permille / 1000.0 : (NT >= 16 * (uint64_t)world ? 0.12 : 0.0);
+    const double bonus = dst >= 0 && (uint32_t)dst < world ? total / world * share : 0.0;
     auto handicap = [&](uint32_t r) { return (int)r == dst ? -bonus : 0.0; };
     std::vector<uint64_t> start(world), stop(world);
     std::vector<double> cost(world);
@@ -355,7 +358,8 @@ void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_perm
             }
         }
     }
-    if (best_t >= NT) return;  // nothing dealt: the contiguous ranges
+    if (best_t >= NT && bonus == 0.0) return;  // nothing dealt: the contiguous ranges of balance_rows
+    if (best_t > NT) return;                   // (no limit was accepted)
     // a rank that holds dealt rows needs aligned boundaries: all main boundaries are multiples of 128 by construction
     rs.seg.clear();
     rs.owner.clear();

@@ -71,7 +71,8 @@ void rowsets_from_bounds(const uint64_t *bounds, uint32_t world, RowSets &rs);
 constexpr uint64_t kTopupMaxRows = 32768;
 // prep_permille: the weight of a rank's own prepare, in thousandths of a tile per 128 columns of its plane matrix
 // (~0u: the default).  dst >= 0: the rank that RECEIVES the others' rows and sends nothing takes dst_bonus_permille
-// (~0u: the default, 120) thousandths of a rank's mean tile count more than the others.
+// (~0u: the default: 120 where a rank holds at least 16 tile rows, else 0) thousandths of a rank's mean tile count more than
+// the others.
 void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille = ~0u, int dst = -1, uint32_t dst_bonus_permille = ~0u);
 // the wanted segments in the WANTED ORDER: the extra segments (row order) first, then the main range
 void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs);

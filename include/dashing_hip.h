@@ -274,7 +274,7 @@ int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, ui
  *                            of consecutive tile rows, to the ranks that fall short of the mean: the largest cost of any
  *                            rank (tiles + its own prepare, prep_permille/1000 tiles per 128 columns of its plane matrix;
  *                            < 0: the default) is smallest.  dst >= 0 names the rank that will RECEIVE the others' rows:
- *                            it sends nothing, so it takes dst_bonus_permille (< 0: the default, 120) thousandths of a
+ *                            it sends nothing, so it takes dst_bonus_permille (< 0: the default -- 120 where a rank holds at least 16 tile rows, else 0) thousandths of a
  *                            rank's mean tile count more than the others, whose step only ends when their last part has
  *                            arrived; dst < 0: every rank keeps its rows.  Plain dsh_balance_rows ranges when n > 32 768
  *                            or a rank would hold fewer than two tile rows.  tab_out = NULL: only the size (words_out).

@@ -334,10 +334,13 @@ def test_tail_bands_cut_the_tile_kernel_at_whole_rounds(host):
 def test_the_destination_of_an_exchange_takes_a_bonus(host):
     """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~12 % (or the share asked for) more tiles
     than the mean and the others correspondingly fewer -- still every row with one owner, every boundary aligned"""
-    n, world = 10000, 8
+    n, world = 10000, 4
     nt = (n + 127) // 128
     base = [rank_rows(host, n, balance_rowsets(host, n, world), r)[2] for r in range(world)]
-    for dst, bonus in ((0, -1), (3, -1), (7, 150), (0, 0)):
+    # (the default applies where a rank holds at least 16 tile rows: 79 tile rows over 4 ranks, not over 8)
+    assert [rank_rows(host, n, balance_rowsets(host, n, 8, -1, 0, -1), r)[2] for r in range(8)] == \
+           [rank_rows(host, n, balance_rowsets(host, n, 8), r)[2] for r in range(8)]
+    for dst, bonus in ((0, -1), (2, -1), (3, 150), (0, 0)):
         tab = balance_rowsets(host, n, world, -1, dst, bonus)
         tiles = [rank_rows(host, n, tab, r)[2] for r in range(world)]
         assert sum(tiles) == nt * (nt + 1) // 2
