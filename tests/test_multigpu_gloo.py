@@ -219,3 +219,56 @@ def test_pipelined_shards_gloo(tmp_path, world, pieces):
     mp.spawn(_worker_pipe, args=(world, _free_port(), pieces, str(tmp_path)), nprocs=world, join=True)
     got = np.load(os.path.join(str(tmp_path), "pipe_%d_%d.npy" % (world, pieces)))
     assert (got == np.arange(got.size, dtype=np.float32)).all() and got.size >= 37
+
+
+def _worker_rowsets(rank, world, port, n, p, dst, outdir):
+    """every rank computes the rows of ITS ROW SET (dsh_balance_rowsets: a range + top-up tile rows), segment by segment
+    in final order, and sends each segment's span to `dst`, which puts it at dsh_tri_span(n, 0, first row)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dashing_amd
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    oracle_c.load(threads=2)
+    regs = synth.synthetic_sketches(n, p, seed=321)
+    rows = dashing_amd.balance_rowsets(n, world, dst=dst, dst_bonus_permille=100)  # (identical on every rank)
+    total = n * (n - 1) // 2
+    full = torch.full((total,), -1.0) if rank == dst else None
+    for r in range(world):
+        for b, e in rows.rows(r):
+            off, cnt = dashing_amd.tri_span(n, 0, b), dashing_amd.tri_span(n, b, e)
+            if r == rank:
+                seg = torch.from_numpy(oracle_c.dist_rows(regs, b, e))
+                assert seg.numel() == cnt
+                if rank == dst:
+                    full[off:off + cnt] = seg
+                else:
+                    dist.send(seg, dst)
+            elif rank == dst:
+                buf = torch.empty(cnt)
+                dist.recv(buf, r)
+                full[off:off + cnt] = buf
+    if rank == dst:
+        np.save(os.path.join(outdir, "rowsets_%d.npy" % world), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, 1)])
+def test_row_sets_assemble_the_matrix_gloo(tmp_path, world, dst):
+    """N > 1 on CPU: the balanced row sets (with a destination bonus) partition the triangle -- the segments of all ranks,
+    each placed at its span, are the single-rank matrix byte for byte; some rank holds a top-up segment"""
+    import dashing_amd
+
+    n, p = 1700, 8
+    assert any(len(dashing_amd.balance_rowsets(n, world, dst=dst, dst_bonus_permille=100).rows(r)) > 1 for r in range(world))
+    mp.spawn(_worker_rowsets, args=(world, _free_port(), n, p, dst, str(tmp_path)), nprocs=world, join=True)
+    from dashing_amd import synth
+    from oracle import oracle_c
+
+    want = oracle_c.dist_tri(synth.synthetic_sketches(n, p, seed=321))
+    got = np.load(os.path.join(str(tmp_path), "rowsets_%d.npy" % world))
+    assert got.tobytes() == want.tobytes()
