@@ -329,6 +329,19 @@ def test_exchange_pair_virtual_ranks_row_sets(ctx):
         nt = (n + 127) // 128
         assert tiles == nt * (nt + 1) // 2  # nothing computed twice, nothing for another rank's rows
     assert topups >= 6, "these cases are meant to exercise top-up segments"
+    # dsh_last_part_info (what the pipeline model of bench.py / tools/shard_model.py is fed with): under profiling every part
+    # of a source rank reports when it was final and how many bytes of the buffer it holds; the bytes add up to the buffer
+    rows = dashing_amd.balance_rowsets(n, 4)
+    rs, k, floats = dashing_amd.exchange_mode(n, rows, 1, 4, 0, want_floats=True)
+    local = torch.empty(floats, dtype=torch.float32, device="cuda")
+    ctx.set_profiling(True)
+    ctx.attach_device(regs.data_ptr(), n, p)
+    ctx.exchange_rows_device_async(local.data_ptr(), rows, 1, 4, 0)
+    ctx.synchronize()
+    info = ctx.last_part_info()
+    ctx.set_profiling(False)
+    assert len(info) == k >= 2 and sum(b for _, b in info) == 4 * floats
+    assert all(ms > 0 for ms, _ in info) and info[-1][0] == max(ms for ms, _ in info)
 
 
 MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
@@ -402,6 +415,16 @@ def test_exchange_protocol_row_sets_between_processes(tmp_path, world, n, p, npa
     triangle (dsh_balance_rowsets) -- through the real exchange code between processes: every source row-sorted (each
     segment one key-ordered run), staged and placed row by row; the destination's matrix equals the single-GPU one."""
     run_mock_world(tmp_path, world, n, p, nparts, "exchange", dst=dst, rowsets=True, expect_topups=True)
+
+
+@pytest.mark.gpu
+def test_exchange_protocol_row_sets_edge_shapes(tmp_path):
+    """row-set tables at the edges: more ranks than tile rows (ranks without rows, contiguous fall-back), ONE part per rank
+    with top-up segments, 32-bit C(v) counts (p = 16), a collection just above the top-up limit (plain ranges again)"""
+    run_mock_world(tmp_path, 8, 700, 10, 4, "exchange", dst=3, rowsets=True)           # 6 tile rows over 8 ranks
+    run_mock_world(tmp_path, 4, 2600, 12, 1, "exchange", dst=0, rowsets=True, expect_topups=True)  # one part each
+    run_mock_world(tmp_path, 3, 1100, 16, 3, "exchange", dst=2, rowsets=True, expect_topups=True)  # p = 16
+    run_mock_world(tmp_path, 2, 33000, 8, 4, "exchange", dst=1, rowsets=True)          # n > 32 768: contiguous ranges
 
 
 @pytest.mark.gpu
