@@ -670,10 +670,15 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     // (a call with ONE part has nothing to send early: the destination of an exchange computes its rows that way)
     if (parts_on && pp.nparts >= 2 && tu.tail_bands > 0 && tu.lockstep && tu.W >= (uint32_t)tu.kc && tu.nsplit == 0 && tu.round_items > 0) {
         const uint64_t RI = tu.round_items;
-        uint64_t items = 0;  // one item per plane of a tile while the job is small (build_band_items: piece = one plane)
+        // one item per plane of a tile while a BAND holds at most 16 rounds of them (build_band_items: piece = one plane);
+        // a longer launch takes pieces of 2-4 planes, i.e. longer rounds.  Jobs of up to 64 rounds are therefore cut into
+        // bands of at most 16: the head as well as the tails (2 ranks of BASELINE configs[2]: 27 rounds = 15 + 9 + 3
+        // instead of ONE launch of 15 two-plane rounds whose first part is final after 6 ms).
+        uint64_t items = 0;
         for (const U4 &t : T) items += t.w - t.z;
         const uint64_t R = (items + RI - 1) / RI;
-        for (uint32_t ntails = tu.tail_bands; ntails >= 1 && cuts.empty() && items <= 16 * RI && R >= 3; --ntails) {
+        constexpr uint64_t kBandRounds = 16;
+        for (uint32_t ntails = tu.tail_bands; ntails >= 1 && cuts.empty() && items <= 4 * kBandRounds * RI && R >= 3; --ntails) {
             std::vector<uint64_t> tails;  // rounds of the tail bands, last band first
             uint64_t left = R;
             for (uint32_t b = 0; b < ntails; ++b) {
@@ -685,9 +690,17 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
                 tails.push_back(r);
                 left -= r;
             }
-            // the head takes `left` rounds, then the tails in reverse; a band ends at the last tile that still fits
-            std::vector<uint64_t> quota{left};
-            for (size_t b = tails.size(); b-- > 0;) quota.push_back(tails[b]);
+            // the head takes `left` rounds (in bands of at most 16), then the tails in reverse; a band ends at the last
+            // tile that still fits
+            std::vector<uint64_t> quota;
+            {
+                const uint64_t nb = (left + kBandRounds - 1) / kBandRounds;
+                for (uint64_t b = 0; b < nb; ++b) quota.push_back(left / nb + (b < left % nb ? 1 : 0));
+            }
+            for (size_t b = tails.size(); b-- > 0;) {
+                const uint64_t nb = (tails[b] + kBandRounds - 1) / kBandRounds;
+                for (uint64_t x = 0; x < nb; ++x) quota.push_back(tails[b] / nb + (x < tails[b] % nb ? 1 : 0));
+            }
             uint64_t target = 0, acc = 0, rounds = 0, band_items = 0;
             size_t t = 0;
             for (size_t b = 0; b + 1 < quota.size(); ++b) {
@@ -703,7 +716,9 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
                 band_items = 0;
             }
             rounds += (items - acc + band_items + RI - 1) / RI;
-            if (rounds != R) cuts.clear();  // (a cut that costs a round is worse than none)
+            // a cut that costs a round is worse than none -- except for a long job, where one round in twenty buys parts that
+            // leave milliseconds earlier and one-plane rounds instead of two-plane ones
+            if (rounds != R && !(R > kBandRounds && rounds == R + 1)) cuts.clear();
         }
     }
     size_t next_cut = 0;

@@ -163,7 +163,7 @@ struct Tuning {
     int xcd_swizzle = 1;
     int finalize_rowmajor = 1;
     uint32_t part_band_tiles = 2048;  // a part of at least this many tiles also ends the band of the tile kernel
-    // Tail bands (jobs with parts = the exchange; small jobs only: at most 16 rounds of one-plane items).  The lockstep
+    // Tail bands (jobs with parts = the exchange; jobs of at most 64 rounds of one-plane items, in bands of at most 16).  The lockstep
     // tile kernel runs in ROUNDS of round_items work items (2 per workgroup, one workgroup per CU); a rank's parts only
     // become final during k_finalize, i.e. after the whole tile kernel, and its link then needs longer for them than
     // k_finalize takes.  So the tile kernel is cut into a head band and `tail_bands` tail bands at multiples of a round
