@@ -901,6 +901,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->tail_bands = (int)v;
         return DSH_OK;
     }
+    if (!std::strcmp(name, "xch_tail_head_min_rounds")) {
+        if (v < 2 || v > 64) return fail(c, DSH_EINVAL, "xch_tail_head_min_rounds out of range");
+        c->tail_head_min_rounds = (int)v;
+        return DSH_OK;
+    }
     if (!std::strcmp(name, "xch_tail_permille2")) {
         if (v < 0 || v > 900) return fail(c, DSH_EINVAL, "xch_tail_permille2 out of range");
         c->tail_permille2 = (int)v;

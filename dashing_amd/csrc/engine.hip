@@ -291,6 +291,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     tu.tail_bands = (uint32_t)c->tail_bands;
     tu.tail_permille = (uint32_t)c->tail_permille;
     tu.tail_permille2 = (uint32_t)c->tail_permille2;
+    tu.tail_head_min_rounds = (uint32_t)c->tail_head_min_rounds;
     // Tiles, bands and segments of the whole job first; the work items and the two device lists are made, uploaded and
     // launched BAND BY BAND: the host plans band b + 1 while the GPU runs band b (at 100 000 x p=10 the plan of 306 000
     // tiles took the host 8 ms that nothing hid, round 4 / profiles/r4y).

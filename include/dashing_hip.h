@@ -366,7 +366,8 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles" (0|1: a tile's 128 rows on one XCD),
  * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "xch_tail_bands" (0..8, default 2: the second only where the head keeps at least 7 rounds) /
  * "xch_tail_permille" (default 100: one round of the tile kernel of a rank of BASELINE configs[2] over 8) / "xch_tail_permille2" (the
- * share of the tails in front of the last one, default 350; 0 = the same): a job with parts of at most 64 rounds of 512 one-plane work items has its tile kernel cut
+ * share of the tails in front of the last one, default 350; 0 = the same) / "xch_tail_head_min_rounds" (such a tail must leave the head
+ * at least this many rounds, default 7): a job with parts of at most 64 rounds of 512 one-plane work items has its tile kernel cut
  * at whole rounds into head and tail launches of at most 16 rounds, so that the head's parts travel while the tails compute, "finalize_two_streams" (0|1: the
  * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4
  * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
