@@ -43,7 +43,7 @@ static void release_ctx(dsh_ctx *c)
         if (s) (void)hipStreamSynchronize(s);
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
-                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->place_tab, &c->perm, &c->items, &c->cum, &c->tiles,
+                      &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->place_tab, &c->sig, &c->perm, &c->items, &c->cum, &c->tiles,
                       &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc})
         b->release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
@@ -53,8 +53,9 @@ static void release_ctx(dsh_ctx *c)
     c->pin_keys.release();
     c->pin_rowoff.release();
     c->pin_xch.release();
+    c->pin_sig.release();
     for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_band_tiles,
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_sig, &c->ev_band_tiles,
                           &c->ev_band_aux}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
@@ -767,6 +768,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "kc")) *out = c->kc;
     else if (!std::strcmp(name, "tile")) *out = kTile;
     else if (!std::strcmp(name, "parts_done")) *out = c->parts_done;
+    else if (!std::strcmp(name, "parts_signalled")) *out = c->parts_signalled ? 1 : 0;
     else if (!std::strcmp(name, "sketch_kernel_us")) *out = (int64_t)(c->sketch_ms * 1000.0);
     else if (!std::strcmp(name, "whatif_mfma")) {
 #ifdef DSH_WHATIF_MFMA
@@ -899,6 +901,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "xch_tail_bands")) {
         if (v < 0 || v > 8) return fail(c, DSH_EINVAL, "xch_tail_bands out of range");
         c->tail_bands = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "finalize_signal")) {
+        if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "finalize_signal is -1 (auto), 0 or 1");
+        c->finalize_signal = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "xch_tail_head_min_rounds")) {

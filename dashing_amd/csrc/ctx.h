@@ -115,6 +115,17 @@ struct dsh_ctx {
     dsh::plan::PairPlan pp;
     std::vector<hipEvent_t> ev_part;    // part q complete (recorded on the ctx stream by the last call with parts)
     uint32_t parts_done = 0;            // parts of the last dsh_dist_rows_parts_device_async call
+    // part signalling (kernels.h kSig*): k_finalize announces the parts from inside ONE launch per band; the copy stream
+    // waits for a part's flag with hipStreamWaitValue32 instead of an event between launches
+    DevBuf sig;
+    PinBuf pin_sig;                     // the parts' tile totals on their way to the device
+    hipEvent_t ev_sig = nullptr;        // their upload has run (the staging is rewritten by the next call)
+    bool sig_in_flight = false;
+    uint32_t sig_gen = 0;               // generation of the last call with parts: the value its flags take
+    bool parts_signalled = false;       // the last call with parts used flags (else events)
+    int finalize_signal = -1;           // option: -1 auto (on where the device supports stream wait-value), 0 events, 1 flags
+    int can_wait_value = -1;            // hipDeviceAttributeCanUseStreamWaitValue, queried once
+    int wall_clock_khz = 0;
     PinBuf pin_keys;                    // host copy of the per-sketch keys (valid while the per-sketch pass is), page-locked:
     const uint32_t *hk32 = nullptr;     // the copy is a direct DMA and the host only waits for ev_keys
     bool hk32_valid = false;

@@ -252,9 +252,18 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     c->part_floats.clear();
     hipEvent_t e_call0 = nullptr;
     std::vector<std::pair<size_t, hipEvent_t>> ev_part_t;  // (profiling) part -> a timing event behind its last segment
+    if (with_parts) {  // the signal block of the parts (kernels.h kSig*; used when the call turns out to signal, below)
+        HIPCHK(c, c->sig.ensure((size_t)kSigWords * sizeof(uint32_t)));
+        if (c->sig_gen == 0) {  // (first use: the flags must not hold garbage that passes for a generation)
+            HIPCHK(c, hipMemsetAsync(c->sig.ptr, 0, (size_t)kSigTileCnt * sizeof(uint32_t), c->stream));
+            c->sig_gen = 1;
+        }
+    }
     if (c->profiling && with_parts) {
         e_call0 = next_event(c);
         if (e_call0) (void)hipEventRecord(e_call0, c->stream);
+        // the call's start on the device's wall clock: signalled parts stamp their completion on the same
+        HIPCHK(c, launch_wall_stamp(c->stream, reinterpret_cast<unsigned long long *>((uint32_t *)c->sig.ptr + kSigT0)));
     }
     // extra segments (row sets, plan.h): only with a key-ordered layout of the range and parts (the exchange)
     const bool with_extra = want_sorted && with_parts && !job.extra.empty() && lre > lrb;
@@ -319,6 +328,40 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     HIPCHK(c, c->cum.ensure(std::max<uint64_t>(pp.per_tile_bytes * pp.max_band, 256)));
     c->host_lists_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_l0).count();  // (until the first band can be planned)
 
+    // Part signalling (kernels.h, k_finalize_signal): with parts, ONE k_finalize launch per band; the parts' flags are
+    // written from inside it and the copy stream waits for them with hipStreamWaitValue32 (exchange.hip).  Not with the
+    // stamped / general instances (profiling aids, rectangles) and not where the device lacks stream wait-value.
+    bool signal = false;
+    if (with_parts && pp.nparts >= 1 && pp.nparts <= kSigMaxParts && !c->finalize_timing && !c->finalize_stop && c->finalize_signal != 0) {
+        if (c->can_wait_value < 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) v = 0;
+            c->can_wait_value = v;
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess) khz = 0;
+            c->wall_clock_khz = khz;
+        }
+        signal = c->can_wait_value == 1;
+        if (!signal && c->finalize_signal == 1) return fail(c, DSH_ENODEV, "option finalize_signal = 1, but the device does not support hipStreamWaitValue32");
+    }
+    c->parts_signalled = signal;
+    if (signal) {
+        ++c->sig_gen;
+        if (c->sig_gen == 0) c->sig_gen = 1;
+        // the parts' tile totals (host -> device through page-locked staging), their counters cleared
+        if (c->sig_in_flight) {
+            HIPCHK(c, hipEventSynchronize(c->ev_sig));
+            c->sig_in_flight = false;
+        }
+        HIPCHK(c, c->pin_sig.ensure(kSigMaxParts * sizeof(uint32_t)));
+        uint32_t *tot = (uint32_t *)c->pin_sig.ptr;
+        for (uint32_t qd = 0; qd < kSigMaxParts; ++qd) tot[qd] = qd < pp.part_tiles.size() ? pp.part_tiles[qd] : 0u;
+        HIPCHK(c, hipMemsetAsync((uint32_t *)c->sig.ptr + kSigPartCnt, 0, kSigMaxParts * sizeof(uint32_t), c->stream));
+        HIPCHK(c, launch_upload(c->stream, (uint32_t *)c->sig.ptr + kSigPartTotal, tot, kSigMaxParts * sizeof(uint32_t)));
+        if (!c->ev_sig) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sig, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_sig, c->stream));
+        c->sig_in_flight = true;
+    }
     const float ksinv_f = (float)(1. / (double)job.k);
     if (c->finalize_timing) {
         HIPCHK(c, c->phase_cyc.ensure(16 * sizeof(unsigned long long)));
@@ -367,14 +410,22 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         // (option finalize_two_streams) the k_finalize launches of a band with several segments alternate between the ctx
         // stream and the second stream: the tail of one launch runs beside the head of the next.  The second stream starts
         // behind the band's tile kernel and the ctx stream joins it again before the band's C(v) scratch is overwritten.
-        const bool two = c->finalize_two_streams && pp.segs[bi].size() > 1;
+        const bool two = !signal && c->finalize_two_streams && pp.segs[bi].size() > 1;
         bool aux_used = false;
+        // signal mode: ONE launch over the band's tiles; the parts announce themselves (k_finalize_signal)
+        std::vector<plan::Seg> one_seg;
+        if (signal) {
+            plan::Seg all{bd.first, bd.second, -1, 1};
+            for (const plan::Seg &sg : pp.segs[bi]) all.hist_bins = std::max(all.hist_bins, sg.hist_bins);
+            one_seg.push_back(all);
+            HIPCHK(c, hipMemsetAsync((uint32_t *)c->sig.ptr + kSigTileCnt, 0, (size_t)nt * sizeof(uint32_t), c->stream));
+        }
         if (two) {
             HIPCHK(c, hipEventRecord(c->ev_band_tiles, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_band_tiles, 0));
         }
         size_t seg_no = 0;
-        for (const plan::Seg &sg : pp.segs[bi]) {
+        for (const plan::Seg &sg : signal ? one_seg : pp.segs[bi]) {
             const bool on_aux = two && (seg_no++ & 1);
             hipStream_t fst = on_aux ? c->aux_stream : c->stream;
             aux_used = aux_used || on_aux;
@@ -422,6 +473,11 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.col_end = job.col_end;
             f.base_index = job.base_index;
             f.out = job.d_out;
+            if (signal) {
+                f.sig = (uint32_t *)c->sig.ptr;
+                f.sig_gen = c->sig_gen;
+                f.sig_stamp = c->profiling ? 1 : 0;
+            }
             if (c->aux_join_pending && !on_aux) {  // (the second stream is behind the index build by stream order)
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
                 c->aux_join_pending = false;
@@ -455,6 +511,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             evf.emplace_back(b, d);
         }
     }
+    if (signal) c->parts_done = pp.nparts;  // (every part's flag will be written by the launches above)
     // everything is enqueued; the blocking entry points synchronise, the *_async ones return here
     if (c->profiling) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -471,7 +528,20 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         }
         // when every part of the call was final (from the start of the call, prepare included) and how many floats of the
         // rank's buffer it holds: what a model of the pipelined exchange needs (dsh_last_part_info)
-        if (e_call0 && !ev_part_t.empty()) {
+        if (signal && e_call0 && c->wall_clock_khz > 0) {
+            std::vector<unsigned long long> st(kSigMaxParts + 1);
+            HIPCHK(c, hipMemcpy(st.data(), (uint32_t *)c->sig.ptr + kSigPartTime, kSigMaxParts * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&st[kSigMaxParts], (uint32_t *)c->sig.ptr + kSigT0, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            c->part_ready_ms.assign(c->parts_done, 0.0);
+            c->part_floats.assign(c->parts_done, 0);
+            for (size_t q = 0; q < c->part_ready_ms.size(); ++q)
+                c->part_ready_ms[q] = (double)(long long)(st[q] - st[kSigMaxParts]) / (double)c->wall_clock_khz;
+            for (size_t q = 0; q < c->part_floats.size(); ++q) {
+                if (L.rowsorted && q + 1 < L.part_w.size()) c->part_floats[q] = L.rowoff_w[L.part_w[q + 1]] - L.rowoff_w[L.part_w[q]];
+                else if (!L.rowsorted && L.extra.empty() && q + 1 < L.parts.size()) c->part_floats[q] = plan::tri_span(c->n, L.parts[q], L.parts[q + 1]);
+                else if (!L.rowsorted) c->part_floats[q] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
+            }
+        } else if (e_call0 && !ev_part_t.empty()) {
             if (c->aux_stream) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
             c->part_ready_ms.assign(c->parts_done, 0.0);
             c->part_floats.assign(c->parts_done, 0);

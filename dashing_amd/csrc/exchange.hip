@@ -123,6 +123,20 @@ int sync_guarded(dsh_ctx *c, hipStream_t st, const char *what)
     }
 }
 
+// the copy stream waits for part q of the last call with parts: for the flag k_finalize writes from inside its launch
+// (hipStreamWaitValue32: >= the call's generation) or, where the call marked its parts with events, for the event
+int wait_part(dsh_ctx *c, size_t q)
+{
+    if (c->parts_signalled) {
+        if (q >= kSigMaxParts || !c->sig.ptr) return fail(c, DSH_ESTATE, "internal: part %zu has no flag", q);
+        HIPCHK(c, hipStreamWaitValue32(c->copy_stream, (uint32_t *)c->sig.ptr + kSigPartFlag + q, c->sig_gen, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        return DSH_OK;
+    }
+    if (q >= c->ev_part.size()) return fail(c, DSH_ESTATE, "internal: part %zu has no event", q);
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+    return DSH_OK;
+}
+
 // bounds of `world` row ranges over n rows (dsh_balance_rows / dsh_partition_rows) and a destination rank: ONE check
 // for every entry point that takes them
 int validate_bounds(dsh_ctx *c, uint64_t n, const uint64_t *bounds, int world, int dst)
@@ -351,7 +365,7 @@ int dsh_collect_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *bounds, uint
     for (size_t q = 0; q < maxparts; ++q) {
         // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
         // there while the ctx stream computes part q+1
-        if (q < myparts) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+        if (q < myparts) { int rcw = wait_part(c, q); if (rcw) return rcw; }
         if (rank == dst && q < myparts && d_local) {
             const uint64_t o0 = dsh_tri_span(n, 0, parts[rank][q]) - my_off, cnt = dsh_tri_span(n, parts[rank][q], parts[rank][q + 1]);
             float *own = (float *)d_final + my_off + o0;
@@ -621,7 +635,7 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
     for (size_t q = 0; q < maxparts; ++q) {
         // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
         // there while the ctx stream computes part q+1
-        if (q < mine.nparts()) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_part[q], 0));
+        if (q < mine.nparts()) { int rcw = wait_part(c, q); if (rcw) return rcw; }
         if (rank == dst && q < mine.nparts())  // (the destination's own rows: one part, normally in place)
             if ((rc = place_own_rows(c, n, mine, d_local, d_final, c->copy_stream))) return rc;
         if (world == 1) continue;

@@ -270,6 +270,12 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     if (at != T.size()) return E.fail("bands end at %zu of %zu tiles", at, T.size());
     for (uint32_t qd = 0; qd < pp.nparts; ++qd)
         if (part_done[qd] != 1) return E.fail("part %u never completes", qd);
+    if (pp.nparts) {  // the tile counts the signalling k_finalize waits for
+        uint64_t tsum = 0;
+        if (pp.part_tiles.size() != pp.nparts) return E.fail("part_tiles has %zu entries for %u parts", pp.part_tiles.size(), pp.nparts);
+        for (uint32_t c : pp.part_tiles) tsum += c;
+        if (tsum != T.size()) return E.fail("the parts hold %llu tiles of %zu", (unsigned long long)tsum, T.size());
+    }
     if (q.want_parts && pp.nparts + 1 != L.part_w.size()) return E.fail("%u parts planned, layout has %zu", pp.nparts, L.part_w.size() - 1);
     // ---- the two device lists describe the same tiles
     std::vector<U4> dt(T.size()), df(T.size());
@@ -279,8 +285,15 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
             std::vector<uint8_t> used(pp.bands[bi].second - pp.bands[bi].first, 0);
             for (size_t t = sg.b; t < sg.e; ++t) {
                 const U4 &f = df[t];
-                const size_t src = pp.bands[bi].first + f.w;
-                if (f.w >= used.size() || src < sg.b || src >= sg.e || used[f.w]++) return E.fail("finalize list names a C(v) block twice or outside its segment");
+                const uint32_t fw = f.w & 0xFFFFu, fpart = f.w >> 16;  // (C(v) block in the band | the tile's part)
+                const size_t src = pp.bands[bi].first + fw;
+                if (fw >= used.size() || src < sg.b || src >= sg.e || used[fw]++) return E.fail("finalize list names a C(v) block twice or outside its segment");
+                if (pp.nparts) {
+                    if (fpart >= pp.nparts || src < pp.part_first[fpart] || src >= pp.part_first[fpart + 1])
+                        return E.fail("finalize list entry %zu carries part %u, which does not hold tile %zu", t, fpart, src);
+                } else if (fpart) {
+                    return E.fail("finalize list entry %zu carries a part without parts", t);
+                }
                 if (f.x != T[src].x || f.y != T[src].y || (f.z & 0xFFu) != T[src].z || ((f.z >> 8) & 0xFFu) != T[src].w)
                     return E.fail("finalize list entry %zu does not match tile %zu", t, src);
                 if (dt[src].x != T[src].x || dt[src].y != T[src].y || dt[src].z != (T[src].z | (T[src].w << 8)))

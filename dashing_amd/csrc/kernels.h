@@ -83,8 +83,20 @@ struct FinalizeLaunch {
     unsigned long long *phase_cyc = nullptr;  // profiling: per-phase cycle sums of the full kernel (8 x u64, device)
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
+    // part signalling (k_finalize_signal): the call's signal block (layout below), the generation value that marks a part
+    // final, whether completion times are stamped (profiling).  nullptr: completion is marked by events between launches.
+    uint32_t *sig = nullptr;
+    uint32_t sig_gen = 0;
+    int sig_stamp = 0;
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
+// the signal block of a call with parts, in 32-bit words: per part a flag (= the generation of the call that completed
+// it), a count of finished tiles, the tiles it holds in all, a 64-bit wall-clock stamp of its completion; the stamp of the
+// call's start; per tile of the band in flight a count of finished rows
+constexpr uint32_t kSigMaxParts = 256;
+constexpr uint32_t kSigPartFlag = 0, kSigPartCnt = kSigMaxParts, kSigPartTotal = 2 * kSigMaxParts, kSigPartTime = 3 * kSigMaxParts,
+                   kSigT0 = 5 * kSigMaxParts, kSigTileCnt = 5 * kSigMaxParts + 2, kSigWords = kSigTileCnt + 65536;
+hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out);
 // rows [pos0, pos1) of a row-sorted buffer (order[s] = original row, rowoff[s] = its offset) into the packed triangle
 hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,
                             uint64_t pos0, uint64_t pos1, uint64_t n);

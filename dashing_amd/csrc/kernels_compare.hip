@@ -1033,6 +1033,11 @@ struct FinalizeArgs {
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
+    // part signalling (SIGNAL instances only; kernels.h kSig*): counters and flags of the call's parts, the generation
+    // value that marks a part final, whether the signalling thread also leaves a wall-clock stamp (profiling)
+    uint32_t *sig;
+    uint32_t sig_gen;
+    int sig_stamp;
 };
 
 // The two sparse tails of a pair's histogram without walking lists.  The block's 128 lanes share sketch i (one tile
@@ -1060,8 +1065,7 @@ struct FinalizeArgs {
 // relieves the scalar registers (~70 dwords of arguments: the compiler parked the overflow in VGPR lanes -- 67
 // v_writelane + 105 v_readlane VALU instructions in the p <= 12 instance, profiles/r4f).
 template <typename CT, int RK, bool TIMED, bool GENERAL>
-// 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(96))) void k_finalize(FinalizeArgs a)
+__device__ __forceinline__ void finalize_block(const FinalizeArgs &a)
 {
     unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0};
     if constexpr (TIMED) tph[0] = __builtin_readcyclecounter();
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     const int vlo = (int)((tile.z >> 16) & 0xFFu), vhi = (int)(tile.z >> 24);
     // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column.  (32-bit: a
     // band holds at most 2^16 tiles, plan.cpp.)
-    const uint32_t slot = (tile.w * 128u + trow) * 128u + (uint32_t)tid;
+    const uint32_t slot = ((tile.w & 0xFFFFu) * 128u + trow) * 128u + (uint32_t)tid;  // (bits 16.. of w: the tile's part)
     tile.w = (tile.z >> 8) & 0xFFu;
     tile.z &= 0xFFu;
     // (sketch indices and layout positions are 32-bit -- the permutation is -- only the output index is wider)
@@ -1423,6 +1427,58 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
             atomicAdd(&a.phase_cyc[13], (unsigned long long)(mx_it * mx_bins));
         }
     }
+}
+
+// 64 VGPRs (8 waves per SIMD; the compiler settles at 72 / 7 on its own): -7 % on C3, -3 % at p = 10 (profiles/r3f)
+template <typename CT, int RK, bool TIMED, bool GENERAL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(96))) void k_finalize(FinalizeArgs a)
+{
+    finalize_block<CT, RK, TIMED, GENERAL>(a);
+}
+
+// The instance of the plain triangle (rows in original order: full matrix, row ranges, row-sorted parts), and of the
+// pipelined exchange (round 5): ONE launch finalizes a whole band of the tile kernel and the parts announce themselves
+// from inside it (a.sig != nullptr).  (It serves the calls without parts too: with the signalling code behind the body
+// the compiler parks 15 scalar values in VGPR lanes and reads 26 back in the p <= 12 instance, against 27 / 81 without
+// it -- the allocation is that sensitive; configs[3] shape: k_finalize 211 -> see DESIGN.md 3.2.)  One launch per part (an event behind each) cost a source rank of BASELINE
+// configs[2] over 8 ranks 0.49-0.55 ms of k_finalize against 0.43 for one launch -- every launch of ~70 tiles is 2.2
+// waves of blocks with a tail -- and its first part was final 0.3 ms after the tile kernel instead of 0.08.  Here every
+// block, when it is through (fence, barrier), counts itself into its tile; a tile's 128th row counts the tile into its
+// part (bits 16.. of the tile descriptor's w); the part's last tile writes the call's generation value into the part's
+// flag, which the copy stream waits for with hipStreamWaitValue32 (>= generation) in front of the part's transfer
+// (tools/ubench/wait_value.hip: the gate opens 2-3 us after the write).  Two atomics per tile on distinct addresses,
+// one per part: nothing the kernel notices.
+template <typename CT, int RK>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(96))) void k_finalize_signal(FinalizeArgs a)
+{
+    finalize_block<CT, RK, false, false>(a);
+    if (a.sig == nullptr) return;  // (a call without parts: nothing to announce)
+    uint32_t tidx = blockIdx.x >> 7;
+    if (a.xcd_tiles) {
+        tidx = (((blockIdx.x >> 3) >> 7) << 3) + (blockIdx.x & 7u);
+        if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles: no tile, nothing to count)
+    }
+    __threadfence();   // this lane's results are visible device-wide ...
+    __syncthreads();   // ... and so are those of every lane of the block
+    if (threadIdx.x == 0) {
+        uint32_t *sig = a.sig;
+        if (atomicAdd(sig + kSigTileCnt + tidx, 1u) == kTile - 1) {  // the tile's last row
+            const uint32_t q = a.tiles[tidx].w >> 16;
+            if (atomicAdd(sig + kSigPartCnt + q, 1u) + 1u == sig[kSigPartTotal + q]) {  // the part's last tile
+                if (a.sig_stamp) reinterpret_cast<unsigned long long *>(sig + kSigPartTime)[q] = wall_clock64();
+                __threadfence();
+                atomicExch(sig + kSigPartFlag + q, a.sig_gen);
+            }
+        }
+    }
+}
+
+__global__ void k_wall_stamp(unsigned long long *out) { *out = wall_clock64(); }
+
+hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out)
+{
+    hipLaunchKernelGGL(k_wall_stamp, dim3(1), dim3(1), 0, st, out);
+    return hipGetLastError();
 }
 
 // row-sorted parts (plan.h): the rows at the positions [pos0, pos1) of a source rank's key order, lying at rowoff[s] of its
@@ -1905,16 +1961,20 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.stop = f.stop;
     a.phase_cyc = f.phase_cyc;
     a.xcd_tiles = f.xcd_tiles;
+    a.sig = f.sig;
+    a.sig_gen = f.sig_gen;
+    a.sig_stamp = f.sig_stamp;
     a.ntiles = (uint32_t)(f.nslots / ((uint64_t)kTile * kTile));
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
     const bool timed = f.phase_cyc != nullptr;  // profiling only
     const bool general = f.rect || f.square || f.sorted_out || f.knn;
+    if (f.sig && (general || timed)) return hipErrorInvalidValue;  // (the signalling instance is the plain triangle's)
 #define DSH_FIN(CT, RK)                                                                                                  \
     do {                                                                                                                 \
         if (general) hipLaunchKernelGGL((k_finalize<CT, RK, false, true>), dim3(blocks), dim3(128), lds, st, a);        \
         else if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true, false>), dim3(blocks), dim3(128), lds, st, a);      \
-        else hipLaunchKernelGGL((k_finalize<CT, RK, false, false>), dim3(blocks), dim3(128), lds, st, a);                \
+        else hipLaunchKernelGGL((k_finalize_signal<CT, RK>), dim3(blocks), dim3(128), lds, st, a);                       \
     } while (0)
     // (the record width follows the precision like k_build_colindex: colindex_inline)
     if (f.cum_bytes != 2) DSH_FIN(uint32_t, 3);

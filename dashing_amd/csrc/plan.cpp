@@ -662,6 +662,10 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
         pp.nparts = (uint32_t)pstart.size();
     }
     pstart.push_back(T.size());
+    pp.part_first = pstart;
+    pp.part_tiles.clear();
+    if (parts_on)
+        for (size_t q = 0; q + 1 < pstart.size(); ++q) pp.part_tiles.push_back((uint32_t)(pstart[q + 1] - pstart[q]));
     auto part_of_tile = [&](size_t t) -> size_t {
         return (size_t)(std::upper_bound(pstart.begin(), pstart.end() - 1, t) - pstart.begin()) - 1;
     };
@@ -871,7 +875,10 @@ void emit_band_lists(const Layout &L, const PairPlan &pp, size_t bi, U4 *pinT, U
             const uint32_t pl = T[t].z | (T[t].w << 8);
             pinT[t] = U4{T[t].x, T[t].y, pl, (uint32_t)lo | ((uint32_t)hi << 8)};
             const size_t at = pp.finalize_rowmajor ? sg.b + pp.rank[t] : t;
-            pinF[at] = U4{T[t].x, T[t].y, pl | ((uint32_t)lo << 16) | ((uint32_t)hi << 24), (uint32_t)(t - b0)};
+            // (w: the tile's C(v) block in its band -- at most 2^16 tiles per band -- and, above it, the tile's part: the
+            // signalling k_finalize counts a finished tile into that part)
+            const uint32_t part = pp.nparts ? (uint32_t)((std::upper_bound(pp.part_first.begin(), pp.part_first.end() - 1, t) - pp.part_first.begin()) - 1) : 0u;
+            pinF[at] = U4{T[t].x, T[t].y, pl | ((uint32_t)lo << 16) | ((uint32_t)hi << 24), (uint32_t)(t - b0) | (part << 16)};
         }
 }
 

@@ -193,6 +193,8 @@ struct PairPlan {
     uint64_t per_tile_bytes = 0;                         // C(v) scratch per tile
     size_t max_band = 0;                                 // tiles of the largest band
     uint32_t nparts = 0;                                 // parts that get an event (0 without want_parts)
+    std::vector<uint32_t> part_tiles;                    // tiles of every part (all bands): a part is final when they are finalized
+    std::vector<size_t> part_first;                      // first tile of every part in T (+ the end): the part of a tile
     int finalize_rowmajor = 1;
     std::vector<uint32_t> sort_first;                    // scratch of the item sort
     std::vector<U4> sort_tmp;
