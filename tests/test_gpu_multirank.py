@@ -320,6 +320,7 @@ def test_exchange_pair_virtual_ranks_row_sets(ctx):
             ctx.exchange_rows_device_async(local.data_ptr(), rows, r, nparts, dst)
             ctx.synchronize()
             assert ctx.info("parts_done") == k and ctx.info("tiles") == rows.tiles(r), (world, dst, nparts, r)
+            assert ctx.info("parts_signalled") == 1  # (the default on gfx950: flags from inside one launch per band)
             tiles += rows.tiles(r)
             if r != dst:
                 mine = torch.cat([want[dashing_amd.tri_span(n, 0, b):dashing_amd.tri_span(n, 0, e)] for b, e in segs])
@@ -474,9 +475,14 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
 
 @pytest.mark.gpu
 def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
-    """By default the k_finalize launches of the parts alternate between the ctx stream and the second stream (a part's
-    event is recorded on the stream that finished it); finalize_two_streams = 0 keeps them on one.  Bands cut per part
-    (part_band_tiles) put several tile-kernel launches between them.  The exchange sees the same parts either way."""
-    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_two_streams=0")
-    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_two_streams=1,part_band_tiles=200")
-    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_two_streams=0,part_band_tiles=200")
+    """By default (round 5) a band is finalized by ONE launch and the parts announce themselves from inside it (flags the
+    copy stream waits for with hipStreamWaitValue32); finalize_signal = 0 is the older scheme -- one launch and one event
+    per part, the launches alternating between the ctx stream and the second stream (a part's event is recorded on the
+    stream that finished it), finalize_two_streams = 0 keeps them on one.  Bands cut per part (part_band_tiles) put
+    several tile-kernel launches between them.  The exchange sees the same parts either way."""
+    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_signal=0,finalize_two_streams=0")
+    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_signal=0")
+    run_mock_world(tmp_path, 4, 3000, 12, 3, "exchange", dst=2, rowsets=True, expect_topups=True, opts="finalize_signal=0")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=1,part_band_tiles=200")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=0,part_band_tiles=200")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="part_band_tiles=200")  # flags, bands cut per part
