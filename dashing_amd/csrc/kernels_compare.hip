@@ -1391,7 +1391,12 @@ __device__ __forceinline__ void finalize_block(const FinalizeArgs &a)
         }
         return;
     }
-    outp[oidx] = res;
+    // (a signalling call: the result is written THROUGH to memory -- sc0 sc1 -- so that nothing of a part sits dirty in
+    // this XCD's L2 when the part's flag goes up: the eight L2s of the chip are not coherent with each other, and a
+    // release fence per block (buffer_wbl2 + buffer_inv in every wave) made the kernel 7x slower, profiles/rd5m)
+    // (inline assembly: the compiler lowers a relaxed system-scope atomic store of a float to a plain store)
+    if (!GENERAL && a.sig) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(outp + oidx), "v"(res) : "memory");
+    else outp[oidx] = res;
     if constexpr (TIMED) {
         tph[6] = __builtin_readcyclecounter();
         const unsigned long long live = __ballot(1);
@@ -1443,7 +1448,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
 // it -- the allocation is that sensitive; configs[3] shape: k_finalize 211 -> see DESIGN.md 3.2.)  One launch per part (an event behind each) cost a source rank of BASELINE
 // configs[2] over 8 ranks 0.49-0.55 ms of k_finalize against 0.43 for one launch -- every launch of ~70 tiles is 2.2
 // waves of blocks with a tail -- and its first part was final 0.3 ms after the tile kernel instead of 0.08.  Here every
-// block, when it is through (fence, barrier), counts itself into its tile; a tile's 128th row counts the tile into its
+// block, when it is through (its results written through to memory, barrier), counts itself into its tile; a tile's 128th row counts the tile into its
 // part (bits 16.. of the tile descriptor's w); the part's last tile writes the call's generation value into the part's
 // flag, which the copy stream waits for with hipStreamWaitValue32 (>= generation) in front of the part's transfer
 // (tools/ubench/wait_value.hip: the gate opens 2-3 us after the write).  Two atomics per tile on distinct addresses,
@@ -1458,16 +1463,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         tidx = (((blockIdx.x >> 3) >> 7) << 3) + (blockIdx.x & 7u);
         if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles: no tile, nothing to count)
     }
-    __threadfence();   // this lane's results are visible device-wide ...
-    __syncthreads();   // ... and so are those of every lane of the block
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this lane's write-through stores have reached memory ...
+    __syncthreads();                                         // ... and so have those of every lane of the block
     if (threadIdx.x == 0) {
         uint32_t *sig = a.sig;
         if (atomicAdd(sig + kSigTileCnt + tidx, 1u) == kTile - 1) {  // the tile's last row
             const uint32_t q = a.tiles[tidx].w >> 16;
             if (atomicAdd(sig + kSigPartCnt + q, 1u) + 1u == sig[kSigPartTotal + q]) {  // the part's last tile
                 if (a.sig_stamp) reinterpret_cast<unsigned long long *>(sig + kSigPartTime)[q] = wall_clock64();
-                __threadfence();
-                atomicExch(sig + kSigPartFlag + q, a.sig_gen);
+                __hip_atomic_store(sig + kSigPartFlag + q, a.sig_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
