@@ -903,6 +903,10 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->tail_bands = (int)v;
         return DSH_OK;
     }
+    if (!std::strcmp(name, "finalize_shared_instance")) {
+        c->finalize_shared_instance = v != 0;
+        return DSH_OK;
+    }
     if (!std::strcmp(name, "finalize_signal")) {
         if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "finalize_signal is -1 (auto), 0 or 1");
         c->finalize_signal = (int)v;

@@ -123,6 +123,7 @@ struct dsh_ctx {
     bool sig_in_flight = false;
     uint32_t sig_gen = 0;               // generation of the last call with parts: the value its flags take
     bool parts_signalled = false;       // the last call with parts used flags (else events)
+    int finalize_shared_instance = 0;   // option (A/B, profiles/rd5p): calls without parts take k_finalize_signal too
     int finalize_signal = -1;           // option: -1 auto (on where the device supports stream wait-value), 0 events, 1 flags
     int can_wait_value = -1;            // hipDeviceAttributeCanUseStreamWaitValue, queried once
     int wall_clock_khz = 0;

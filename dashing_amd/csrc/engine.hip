@@ -353,11 +353,13 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             HIPCHK(c, hipEventSynchronize(c->ev_sig));
             c->sig_in_flight = false;
         }
-        HIPCHK(c, c->pin_sig.ensure(kSigMaxParts * sizeof(uint32_t)));
+        HIPCHK(c, c->pin_sig.ensure((kSigMaxParts + 2) * sizeof(uint32_t)));
         uint32_t *tot = (uint32_t *)c->pin_sig.ptr;
         for (uint32_t qd = 0; qd < kSigMaxParts; ++qd) tot[qd] = qd < pp.part_tiles.size() ? pp.part_tiles[qd] : 0u;
+        tot[kSigMaxParts] = c->sig_gen;                   // kSigGen
+        tot[kSigMaxParts + 1] = c->profiling ? 1u : 0u;   // kSigStamp
         HIPCHK(c, hipMemsetAsync((uint32_t *)c->sig.ptr + kSigPartCnt, 0, kSigMaxParts * sizeof(uint32_t), c->stream));
-        HIPCHK(c, launch_upload(c->stream, (uint32_t *)c->sig.ptr + kSigPartTotal, tot, kSigMaxParts * sizeof(uint32_t)));
+        HIPCHK(c, launch_upload(c->stream, (uint32_t *)c->sig.ptr + kSigPartTotal, tot, (kSigMaxParts + 2) * sizeof(uint32_t)));
         if (!c->ev_sig) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sig, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(c->ev_sig, c->stream));
         c->sig_in_flight = true;
@@ -473,11 +475,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.col_end = job.col_end;
             f.base_index = job.base_index;
             f.out = job.d_out;
-            if (signal) {
-                f.sig = (uint32_t *)c->sig.ptr;
-                f.sig_gen = c->sig_gen;
-                f.sig_stamp = c->profiling ? 1 : 0;
-            }
+            if (signal) f.sig = (uint32_t *)c->sig.ptr;
+            f.shared_instance = c->finalize_shared_instance;
             if (c->aux_join_pending && !on_aux) {  // (the second stream is behind the index build by stream order)
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
                 c->aux_join_pending = false;

@@ -86,16 +86,17 @@ struct FinalizeLaunch {
     // part signalling (k_finalize_signal): the call's signal block (layout below), the generation value that marks a part
     // final, whether completion times are stamped (profiling).  nullptr: completion is marked by events between launches.
     uint32_t *sig = nullptr;
-    uint32_t sig_gen = 0;
-    int sig_stamp = 0;
+    int shared_instance = 0;  // 1: a call without parts takes k_finalize_signal too (A/B: option finalize_shared_instance)
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
 // the signal block of a call with parts, in 32-bit words: per part a flag (= the generation of the call that completed
 // it), a count of finished tiles, the tiles it holds in all, a 64-bit wall-clock stamp of its completion; the stamp of the
 // call's start; per tile of the band in flight a count of finished rows
 constexpr uint32_t kSigMaxParts = 256;
-constexpr uint32_t kSigPartFlag = 0, kSigPartCnt = kSigMaxParts, kSigPartTotal = 2 * kSigMaxParts, kSigPartTime = 3 * kSigMaxParts,
-                   kSigT0 = 5 * kSigMaxParts, kSigTileCnt = 5 * kSigMaxParts + 2, kSigWords = kSigTileCnt + 65536;
+constexpr uint32_t kSigPartFlag = 0, kSigPartCnt = kSigMaxParts, kSigPartTotal = 2 * kSigMaxParts,
+                   kSigGen = 3 * kSigMaxParts, kSigStamp = kSigGen + 1,  // (uploaded with the totals: kSigMaxParts + 2 words)
+                   kSigPartTime = 3 * kSigMaxParts + 2, kSigT0 = 5 * kSigMaxParts + 2, kSigTileCnt = 5 * kSigMaxParts + 4,
+                   kSigWords = kSigTileCnt + 65536;
 hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out);
 // rows [pos0, pos1) of a row-sorted buffer (order[s] = original row, rowoff[s] = its offset) into the packed triangle
 hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,

@@ -1033,11 +1033,9 @@ struct FinalizeArgs {
     uint64_t row_begin, row_end, col_begin, col_end;
     uint64_t base_index;
     float *out;
-    // part signalling (SIGNAL instances only; kernels.h kSig*): counters and flags of the call's parts, the generation
-    // value that marks a part final, whether the signalling thread also leaves a wall-clock stamp (profiling)
+    // part signalling (k_finalize_signal; kernels.h kSig*): counters and flags of the call's parts; the generation value
+    // that marks a part final and the stamp switch live in the block itself (two kernel arguments fewer)
     uint32_t *sig;
-    uint32_t sig_gen;
-    int sig_stamp;
 };
 
 // The two sparse tails of a pair's histogram without walking lists.  The block's 128 lanes share sketch i (one tile
@@ -1443,9 +1441,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
 
 // The instance of the plain triangle (rows in original order: full matrix, row ranges, row-sorted parts), and of the
 // pipelined exchange (round 5): ONE launch finalizes a whole band of the tile kernel and the parts announce themselves
-// from inside it (a.sig != nullptr).  (It serves the calls without parts too: with the signalling code behind the body
-// the compiler parks 15 scalar values in VGPR lanes and reads 26 back in the p <= 12 instance, against 27 / 81 without
-// it -- the allocation is that sensitive; configs[3] shape: k_finalize 211 -> see DESIGN.md 3.2.)  One launch per part (an event behind each) cost a source rank of BASELINE
+// from inside it (a.sig != nullptr).  (With the signalling code behind the body the compiler parks 15 scalar values in
+// VGPR lanes and reads 26 back in the p <= 12 instance, against 27 / 81 in the plain one -- and is SLOWER all the same
+// when it serves calls without parts: configs[3] shape 215.5-216.7 ms against 211.3-211.6, profiles/rd5p; so those keep
+// k_finalize<.., false, false>; option finalize_shared_instance for the A/B.)  One launch per part (an event behind each) cost a source rank of BASELINE
 // configs[2] over 8 ranks 0.49-0.55 ms of k_finalize against 0.43 for one launch -- every launch of ~70 tiles is 2.2
 // waves of blocks with a tail -- and its first part was final 0.3 ms after the tile kernel instead of 0.08.  Here every
 // block, when it is through (its results written through to memory, barrier), counts itself into its tile; a tile's 128th row counts the tile into its
@@ -1470,8 +1469,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         if (atomicAdd(sig + kSigTileCnt + tidx, 1u) == kTile - 1) {  // the tile's last row
             const uint32_t q = a.tiles[tidx].w >> 16;
             if (atomicAdd(sig + kSigPartCnt + q, 1u) + 1u == sig[kSigPartTotal + q]) {  // the part's last tile
-                if (a.sig_stamp) reinterpret_cast<unsigned long long *>(sig + kSigPartTime)[q] = wall_clock64();
-                __hip_atomic_store(sig + kSigPartFlag + q, a.sig_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sig[kSigStamp]) reinterpret_cast<unsigned long long *>(sig + kSigPartTime)[q] = wall_clock64();
+                __hip_atomic_store(sig + kSigPartFlag + q, sig[kSigGen], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -1966,8 +1965,6 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.phase_cyc = f.phase_cyc;
     a.xcd_tiles = f.xcd_tiles;
     a.sig = f.sig;
-    a.sig_gen = f.sig_gen;
-    a.sig_stamp = f.sig_stamp;
     a.ntiles = (uint32_t)(f.nslots / ((uint64_t)kTile * kTile));
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
     const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
@@ -1978,7 +1975,8 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     do {                                                                                                                 \
         if (general) hipLaunchKernelGGL((k_finalize<CT, RK, false, true>), dim3(blocks), dim3(128), lds, st, a);        \
         else if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true, false>), dim3(blocks), dim3(128), lds, st, a);      \
-        else hipLaunchKernelGGL((k_finalize_signal<CT, RK>), dim3(blocks), dim3(128), lds, st, a);                       \
+        else if (f.sig || f.shared_instance) hipLaunchKernelGGL((k_finalize_signal<CT, RK>), dim3(blocks), dim3(128), lds, st, a); \
+        else hipLaunchKernelGGL((k_finalize<CT, RK, false, false>), dim3(blocks), dim3(128), lds, st, a);                \
     } while (0)
     // (the record width follows the precision like k_build_colindex: colindex_inline)
     if (f.cum_bytes != 2) DSH_FIN(uint32_t, 3);
