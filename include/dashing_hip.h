@@ -287,7 +287,8 @@ int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, ui
  *     order; the destination stages what it receives and puts the rows of every part into place (one contiguous copy
  *     per row) behind the part's transfer;
  *   - longer ranges go in parts of consecutive rows, received in place, as with dsh_collect_parts_async.
- * dsh_exchange_rows_device_async computes rank `rank`'s rows (enqueued; an event per part), dsh_exchange_collect_async
+ * dsh_exchange_rows_device_async computes rank `rank`'s rows (enqueued; every part announces its completion: a flag written from
+ * inside k_finalize, or an event between launches -- option finalize_signal), dsh_exchange_collect_async
  * enqueues the rounds of grouped ncclSend/ncclRecv on the copy stream; every rank calls both with the same arguments;
  * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts) and how
  * many floats d_local must hold.  dsh_exchange_place_device does, for ONE source rank and without a communicator, what
