@@ -126,3 +126,27 @@ def test_bench_gpus_flag_never_falls_back_to_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, timeout=300)
     assert r.returncode != 0 and b"refusing" in r.stderr
+
+
+def test_row_set_helpers_are_pure_host_functions():
+    """dsh_balance_rowsets / dsh_rowsets_rank / dsh_exchange_mode need no device: the partition every rank computes for
+    itself, how a rank's buffer is laid out under the exchange and how many floats it holds"""
+    n, world, nparts = 10000, 8, 8
+    rows = dashing_amd.balance_rowsets(n, world)
+    assert rows.world == world and sum(rows.pairs(r) for r in range(world)) == n * (n - 1) // 2
+    assert sum(rows.tiles(r) for r in range(world)) == 79 * 80 // 2
+    for r in range(world):
+        rs, k, floats = dashing_amd.exchange_mode(n, rows, r, nparts, 0, want_floats=True)
+        segs = rows.rows(r)
+        if r == 0:  # the destination: one part, in final order relative to its first row, up to the end of its last segment
+            assert (rs, k) == (False, 1) and floats == dashing_amd.tri_span(n, segs[0][0], segs[-1][1])
+        else:       # a source: row-sorted (short range and / or top-up segments), exactly its rows
+            assert rs and 2 <= k <= nparts and floats == rows.pairs(r)
+    # contiguous bounds as a table
+    b = dashing_amd.balance_rows(n, world)
+    t = dashing_amd.rowsets_from_bounds(n, b)
+    assert [t.rows(r) for r in range(world)] == [[(b[r], b[r + 1])] for r in range(world)]
+    # a malformed table is refused
+    bad = dashing_amd.RowSets(n, np.array([2, 2, 0, 5000, 9999, 0, 1], np.uint64))  # does not reach n
+    with pytest.raises(dashing_amd.DshError):
+        bad.rows(0)
