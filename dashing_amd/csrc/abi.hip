@@ -786,6 +786,11 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "tiles")) *out = (int64_t)c->pp.T.size();
     else if (!std::strcmp(name, "bands")) *out = (int64_t)c->last_bands;
     else if (!std::strcmp(name, "items")) *out = (int64_t)c->pp.items.size();  // work items of the tile kernel (rounds of 512)
+    else if (!std::strcmp(name, "frag_items")) {  // ... of which overflow fragments (plan.h)
+        uint64_t f = 0;
+        for (uint32_t x : c->pp.band_frags) f += x;
+        *out = (int64_t)f;
+    }
     else if (!std::strcmp(name, "words_per_plane")) *out = c->W;
     else if (!std::strcmp(name, "avg_tile_planes_x100")) {
         uint64_t tot = 0;
@@ -901,6 +906,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "xch_tail_bands")) {
         if (v < 0 || v > 8) return fail(c, DSH_EINVAL, "xch_tail_bands out of range");
         c->tail_bands = (int)v;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "overflow_frag_permille")) {
+        if (v < 0 || v > 1000) return fail(c, DSH_EINVAL, "overflow_frag_permille out of range");
+        c->overflow_frag_permille = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "finalize_shared_instance")) {

@@ -151,6 +151,7 @@ struct dsh_ctx {
     int emax_opt = -1;  // cap of the listed upper tail; -1: auto_list_cap(p, true)
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
     int part_band_tiles = 2048;       // a part of at least this many tiles gets its own launch of the tile kernel (plan.cpp)
+    int overflow_frag_permille = 500;  // overflow fragments of the tile kernel (plan.h, Tuning): 0 = never
     int tail_bands = 2, tail_permille = 100, tail_permille2 = 350, tail_head_min_rounds = 7;  // small jobs with parts: the tile kernel cut at whole rounds (plan.h, Tuning)
     std::vector<double> part_ready_ms;  // (profiling) when each part of the last call with parts was final, from the call's start
     std::vector<uint64_t> part_floats;  // and the floats of the rank's buffer it holds

@@ -297,6 +297,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     tu.xcd_swizzle = c->xcd_swizzle;
     tu.finalize_rowmajor = c->finalize_rowmajor;
     tu.part_band_tiles = (uint32_t)c->part_band_tiles;
+    tu.overflow_frag_max_permille = (uint32_t)c->overflow_frag_permille;
     tu.tail_bands = (uint32_t)c->tail_bands;
     tu.tail_permille = (uint32_t)c->tail_permille;
     tu.tail_permille2 = (uint32_t)c->tail_permille2;
@@ -404,7 +405,8 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                                               L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
         else if (use_lockstep(c))
             HIPCHK(c, launch_pair_counts_lockstep(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
-                                                  L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
+                                                  L.Npad, c->Kpad, c->W, L.P, dt, di, ni, bi < pp.band_frags.size() ? pp.band_frags[bi] : 0u,
+                                                  c->cum.ptr, nslots));
         else
             HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                          L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));

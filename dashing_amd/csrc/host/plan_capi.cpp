@@ -36,7 +36,7 @@ struct Err {
 // layout), 2 sorted_rows (whole sorted layout, rows [rb,re) index plane columns: shards / band-wise kNN), 3 triangle
 // rows in ROW-SORTED parts (the wanted rows one key-ordered run, parts = runs of whole tile rows of that order).
 // stats out: [0] tiles, [1] bands, [2] items, [3] parts with an event, [4] planes per tile x 100, [5] Npad, [6] P,
-// [7] rounds of 512 items summed over the bands.
+// [7] rounds of 512 items summed over the bands (a round of fragments counted as one), [8] overflow fragments.
 // extra: further wanted segments {b0, e0, ...} (plan.h, row sets; modes 0 and 3 with a sorted layout only)
 static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorted, uint64_t rb, uint64_t re, uint64_t cb,
                       uint64_t ce, uint32_t nparts, int want_parts, int p, uint64_t cum_budget, int lockstep, int nsplit,
@@ -148,7 +148,7 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     q.col_end = ce;
     PairPlan pp;
     const bool any = build_pairs(L, q, tu, pp);
-    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    for (int i = 0; i < 9; ++i) stats[i] = 0;
     stats[5] = L.Npad;
     stats[6] = L.P;
     // ---- every wanted pair is owned by exactly one (tile, lane) -- the `active` predicate of k_finalize
@@ -250,18 +250,34 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
         std::vector<uint32_t> next(bd.second - bd.first);
         for (size_t t = bd.first; t < bd.second; ++t) next[t - bd.first] = pp.chunks[t].x;
         std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per(bd.second - bd.first);
+        const uint32_t cpp_ = tu.W >= (uint32_t)tu.kc ? tu.W / tu.kc : 1;
+        // overflow fragments (plan.h): the band's LAST band_frags items, each inside one plane, equal in length, at most one
+        // round of them; the whole items in front of them a whole number of rounds
+        const uint32_t nfr = bi < pp.band_frags.size() ? pp.band_frags[bi] : 0u;
+        if (nfr > bi_.second - bi_.first || nfr > tu.round_items) return E.fail("band %zu: %u fragments", bi, nfr);
+        if (nfr && (!tu.lockstep || (bi_.second - bi_.first - nfr) % tu.round_items)) return E.fail("band %zu: fragments behind %zu whole items", bi, bi_.second - bi_.first - nfr);
+        stats[8] += nfr;
         for (size_t it = bi_.first; it < bi_.second; ++it) {
             const U4 &I = pp.items[it];
             if (I.x >= per.size() || I.y >= I.z) return E.fail("item %zu is malformed", it);
-            per[I.x].emplace_back(I.y, I.z);
+            const bool frag = it >= bi_.second - nfr;
+            if ((I.w != 0) != frag) return E.fail("item %zu: fragment flag %u at the wrong place", it, I.w);
+            if (frag && (I.y / cpp_ != (I.z - 1) / cpp_ || I.z - I.y != pp.items[bi_.second - 1].z - pp.items[bi_.second - 1].y))
+                return E.fail("fragment %zu spans two planes or differs in length", it);
+            per[I.x].emplace_back(I.y, I.z | (frag ? 0x80000000u : 0u));
         }
-        const uint32_t cpp_ = tu.W >= (uint32_t)tu.kc ? tu.W / tu.kc : 1;
         for (size_t t = 0; t < per.size(); ++t) {
             std::sort(per[t].begin(), per[t].end());
             uint32_t x = pp.chunks[bd.first + t].x;
-            for (auto &pr : per[t]) {
+            for (size_t k = 0; k < per[t].size(); ++k) {
+                auto &pr = per[t][k];
+                const bool frag = (pr.second & 0x80000000u) != 0;
+                pr.second &= 0x7FFFFFFFu;
                 if (pr.first != x) return E.fail("items of tile %zu leave a gap or overlap at chunk %u", t, x);
-                if (tu.W >= (uint32_t)tu.kc && ((pr.first % cpp_) || (pr.second % cpp_))) return E.fail("an item of tile %zu is not whole planes", t);
+                // whole items are stored, fragments added: a plane is covered by ONE whole item or by fragments only
+                if (!frag && tu.W >= (uint32_t)tu.kc && ((pr.first % cpp_) || (pr.second % cpp_))) return E.fail("an item of tile %zu is not whole planes", t);
+                if (frag && (pr.first % cpp_) && !(k > 0 && (per[t][k - 1].second & 0x7FFFFFFFu) == pr.first))
+                    return E.fail("a fragment of tile %zu starts inside a plane that fragments do not cover from its start", t);
                 x = pr.second;
             }
             if (x != pp.chunks[bd.first + t].y) return E.fail("items of tile %zu end at chunk %u, not %u", t, x, pp.chunks[bd.first + t].y);
@@ -322,7 +338,10 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     stats[4] = T.empty() ? 0 : planes_sum * 100 / T.size();
     // rounds of the lockstep tile kernel over all bands (a band of k items takes ceil(k / round_items) rounds)
     stats[7] = 0;
-    for (auto &bi_ : pp.band_items) stats[7] += (bi_.second - bi_.first + tu.round_items - 1) / tu.round_items;
+    for (size_t b = 0; b < pp.band_items.size(); ++b) {
+        const uint32_t nfr = b < pp.band_frags.size() ? pp.band_frags[b] : 0u;
+        stats[7] += (pp.band_items[b].second - pp.band_items[b].first - nfr + tu.round_items - 1) / tu.round_items + (nfr ? 1 : 0);
+    }
     return 0;
 }
 
@@ -348,7 +367,7 @@ int dshh_plan_check_rowset(uint64_t n, const uint32_t *keys, const uint64_t *tab
     uint64_t rb, re;
     std::vector<uint64_t> extra;
     rs.rank_rows(rank, rb, re, extra);
-    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    for (int i = 0; i < 9; ++i) stats[i] = 0;
     if (rb >= re) return 0;
     return plan_check(n, keys, rowsorted ? 3 : 0, 1, rb, re, 0, 0, rowsorted ? nparts : 1, 1, p, cum_budget, 1, 0, 64, extra, stats, err, cap);
 }

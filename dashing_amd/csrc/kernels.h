@@ -47,7 +47,7 @@ hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint3
 // the same arithmetic with the waves of a SIMD kept in one instruction class (512-thread workgroups, two items each)
 hipError_t launch_pair_counts_lockstep(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes, uint32_t Npad,
                                        uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
-                                       uint32_t nitems, void *cum, uint64_t nslots);
+                                       uint32_t nitems, uint32_t nfrag, void *cum, uint64_t nslots);
 hipError_t launch_pair_counts_mfma(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes,
                                    uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
                                    const uint4 *tiles, const uint4 *items, uint32_t nitems, void *cum,

@@ -556,6 +556,31 @@ __device__ __forceinline__ void store8(uint32_t *dst, const uint32_t *a)
     reinterpret_cast<uint4 *>(dst)[1] = make_uint4(a[4], a[5], a[6], a[7]);
 }
 
+// a fragment's partial counts (overflow fragments, plan.h): 32-bit atomics -- two uint16 counts per word never carry into
+// each other: a plane's total is at most 2^p < 65536 whenever CT is uint16_t
+__device__ __forceinline__ void add8(uint16_t *dst, const uint32_t *a)
+{
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(d + i, a[2 * i] | (a[2 * i + 1] << 16));
+}
+__device__ __forceinline__ void add8(uint32_t *dst, const uint32_t *a)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(dst + i, a[i]);
+}
+
+// the C(v) blocks the fragments add to, cleared: one workgroup per fragment item, the one holding its plane's first chunk
+template <typename CT>
+__global__ __launch_bounds__(256) void k_zero_frag_blocks(const uint4 *__restrict__ frags, uint32_t cpp, CT *__restrict__ cum, uint64_t nslots)
+{
+    const uint4 it = frags[blockIdx.x];
+    if (it.y % cpp) return;
+    uint4 *dst = reinterpret_cast<uint4 *>(cum + (uint64_t)(it.y / cpp) * nslots + (uint64_t)it.x * (kTile * kTile));
+    constexpr uint32_t n16 = kTile * kTile * sizeof(CT) / 16;
+    for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = make_uint4(0, 0, 0, 0);
+}
+
 template <int KC, int U, typename CT>
 __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict__ planes,
                                                       uint32_t Npad, uint32_t Kpad, uint32_t W,
@@ -667,7 +692,10 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint32_t *__restrict_
 // transition into the last row of a chunk (no extra barrier, no exposed LDS latency) was slower (14.7 vs 14.4 ms).
 // A half whose item is shorter (or missing) keeps executing the same instruction stream on stale LDS data -- the
 // barriers need every wave -- and simply stores nothing.
-template <int KC, typename CT>
+// FRAG: the instance for overflow fragments (plan.h) -- items that are pieces of ONE plane; their partial counts are
+// added to the plane's C(v) block (cleared by k_zero_frag_blocks) instead of stored.  A launch of its own behind the
+// whole items', so that the kernel of every other call stays exactly as it was.
+template <int KC, typename CT, bool FRAG = false>
 __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restrict__ planes, uint32_t Npad,
                                                          uint32_t Kpad, uint32_t W, uint32_t P,
                                                          const uint4 *__restrict__ tiles,
@@ -723,8 +751,13 @@ __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restri
     auto flush = [&]() {
         if (flush_pl < P) {
             CT *dst = cum_tile + (uint64_t)flush_pl * nslots;
+            if constexpr (FRAG) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) store8(dst + r * kTile, acc[r]);
+                for (int r = 0; r < 8; ++r) add8(dst + r * kTile, acc[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) store8(dst + r * kTile, acc[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r)
@@ -774,8 +807,13 @@ __global__ __launch_bounds__(512) void k_pair_counts_ls(const uint32_t *__restri
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
-        flush_due = active && ((ch + 1) & (cpp - 1)) == 0;  // the same chunk in both halves (items are whole planes)
-        flush_pl = (ch + 1) / cpp - 1;
+        if constexpr (FRAG) {  // a fragment lies inside one plane: its counts go out behind its last chunk
+            flush_due = active && it + 1 == my_len;
+            flush_pl = ch / cpp;
+        } else {
+            flush_due = active && ((ch + 1) & (cpp - 1)) == 0;  // the same chunk in both halves (items are whole planes)
+            flush_pl = (ch + 1) / cpp - 1;
+        }
     }
     if (flush_due) flush();
 }
@@ -1927,11 +1965,39 @@ static hipError_t launch_pcl(hipStream_t st, const uint32_t *planes, uint32_t Np
     return hipGetLastError();
 }
 
+template <int KC, typename CT>
+static hipError_t launch_pcl_frag(hipStream_t st, const uint32_t *planes, uint32_t Npad, uint32_t Kpad, uint32_t W, uint32_t P,
+                                  const uint4 *tiles, const uint4 *frags, uint32_t nfrag, void *cum, uint64_t nslots)
+{
+    const size_t lds = (size_t)KC * 4096;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_pair_counts_ls<KC, CT, true>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_pair_counts_ls<KC, CT, true>), dim3((nfrag + 1) / 2), dim3(512), lds, st, planes, Npad, Kpad, W, P, tiles, frags,
+                       nfrag, reinterpret_cast<CT *>(cum), nslots);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_counts_lockstep(hipStream_t st, int kc, int cum_bytes, const uint32_t *planes, uint32_t Npad,
                                        uint32_t Kpad, uint32_t W, uint32_t P, const uint4 *tiles, const uint4 *items,
-                                       uint32_t nitems, void *cum, uint64_t nslots)
+                                       uint32_t nitems, uint32_t nfrag, void *cum, uint64_t nslots)
 {
     if (nitems == 0 || Kpad == 0) return hipSuccess;
+    if (nfrag) {  // the band's last nfrag items are overflow fragments: the whole items first, then the fragments' launch
+        if (nfrag > nitems || W < (uint32_t)kc || (kc != 16 && kc != 32)) return hipErrorInvalidValue;
+        const uint4 *fr = items + (nitems - nfrag);
+        // (the blocks the fragments add to are cleared in front of the whole items' kernel: nothing waits for it later)
+        if (cum_bytes == 2) hipLaunchKernelGGL((k_zero_frag_blocks<uint16_t>), dim3(nfrag), dim3(256), 0, st, fr, W / (uint32_t)kc, (uint16_t *)cum, nslots);
+        else hipLaunchKernelGGL((k_zero_frag_blocks<uint32_t>), dim3(nfrag), dim3(256), 0, st, fr, W / (uint32_t)kc, (uint32_t *)cum, nslots);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_pair_counts_lockstep(st, kc, cum_bytes, planes, Npad, Kpad, W, P, tiles, items, nitems - nfrag, 0, cum, nslots);
+        if (e != hipSuccess) return e;
+        if (cum_bytes == 2)
+            return kc == 16 ? launch_pcl_frag<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, fr, nfrag, cum, nslots)
+                 : kc == 32 ? launch_pcl_frag<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, fr, nfrag, cum, nslots) : hipErrorInvalidValue;
+        return kc == 16 ? launch_pcl_frag<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, fr, nfrag, cum, nslots)
+             : kc == 32 ? launch_pcl_frag<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, fr, nfrag, cum, nslots) : hipErrorInvalidValue;
+    }
     if (W < (uint32_t)kc)  // plane boundaries inside a chunk (p < 9): the kernel with the in-loop flush
         return launch_pair_counts(st, kc, cum_bytes, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     if (cum_bytes == 2) {

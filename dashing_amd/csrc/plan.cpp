@@ -586,6 +586,7 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     pp.band_items.clear();
     pp.segs.clear();
     pp.items.clear();
+    pp.band_frags.clear();
     pp.nparts = 0;
     pp.max_band = 0;
     pp.finalize_rowmajor = tu.finalize_rowmajor;
@@ -778,7 +779,24 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     return true;
 }
 
-// work items of band bi, appended to pp.items (bands in order): {tile index in band, chunk begin, chunk end}
+// overflow fragments (plan.h, Tuning): of `ni` one-plane items, how many are cut (the last `over`) and into how many
+// fragments each (`f`); over = 0: none
+static void overflow_fragments(const Tuning &tu, uint32_t cpp, uint64_t piece, uint64_t ni, uint64_t &over, uint32_t &f)
+{
+    over = 0;
+    f = 1;
+    const uint64_t RI = tu.round_items;
+    if (!tu.lockstep || tu.nsplit != 0 || RI == 0 || tu.overflow_frag_max_permille == 0 || piece != cpp || cpp < 2 || ni <= RI) return;
+    const uint64_t o = ni % RI;
+    if (o == 0 || o * 1000 > RI * tu.overflow_frag_max_permille) return;
+    uint32_t ff = 1;
+    while (ff * 2 <= cpp && o * (ff * 2) <= RI) ff *= 2;
+    if (ff < 2) return;
+    over = o;
+    f = ff;
+}
+
+// work items of band bi, appended to pp.items (bands in order): {tile index in band, chunk begin, chunk end, fragment?}
 void build_band_items(const Tuning &tu, PairPlan &pp, size_t bi)
 {
     const auto &bd = pp.bands[bi];
@@ -838,6 +856,21 @@ void build_band_items(const Tuning &tu, PairPlan &pp, size_t bi)
         }
         if (!by_length && tu.lockstep && tu.ls_sort_items && lmin != lmax)
             std::stable_sort(I.begin() + g0, I.end(), [](const U4 &x, const U4 &y) { return x.z - x.y > y.z - y.y; });
+    }
+    // overflow fragments: the band's last `over` items (whole planes all of them: piece = one plane) in f pieces each
+    uint64_t over = 0;
+    uint32_t f = 1;
+    overflow_fragments(tu, cpp, piece, I.size() - i0, over, f);
+    if (pp.band_frags.size() <= bi) pp.band_frags.resize(bi + 1, 0);
+    pp.band_frags[bi] = 0;
+    if (over) {
+        std::vector<U4> &tail = pp.sort_tmp;
+        tail.assign(I.end() - (ptrdiff_t)over, I.end());
+        I.resize(I.size() - over);
+        const uint32_t fr = cpp / f;
+        for (const U4 &it : tail)
+            for (uint32_t b0 = it.y; b0 < it.z; b0 += fr) I.push_back(U4{it.x, b0, std::min<uint32_t>(it.z, b0 + fr), 1});
+        pp.band_frags[bi] = (uint32_t)(over * f);
     }
     if (pp.band_items.size() <= bi) pp.band_items.resize(bi + 1);
     pp.band_items[bi] = std::make_pair(i0, I.size());
@@ -902,7 +935,10 @@ uint64_t band_item_count(const Tuning &tu, const PairPlan &pp, size_t bi)
         const uint64_t len = CR[t].y - CR[t].x;
         cnt += len <= piece ? (len ? 1 : 0) : (len + piece - 1) / piece;
     }
-    return cnt;
+    uint64_t over = 0;
+    uint32_t f = 1;
+    overflow_fragments(tu, cpp, piece, cnt, over, f);
+    return cnt - over + over * f;
 }
 
 }  // namespace plan

@@ -170,6 +170,12 @@ struct Tuning {
     // (a cut elsewhere rounds every band up: +1 round, profiles/r4i): the head's parts travel while the tails compute.
     // Each tail takes tail_permille of the rounds left; no cut is made if it would add a round.
     uint32_t round_items = 512;
+    // Overflow fragments: a band of one-plane items whose count is a little above a multiple of a round would spend a
+    // whole round on the few items left over (3 614 items = 7 rounds + 30 items: 1.56 ms instead of 1.37).  When the
+    // overflow is at most overflow_frag_max_permille of a round, those items are cut into f equal fragments of a plane
+    // (f a power of two, overflow x f <= one round): the extra round then lasts 1/f of a round.  A fragment ADDS its
+    // partial counts to the plane's C(v) block with atomics (cleared first); whole items keep their plain stores.
+    uint32_t overflow_frag_max_permille = 500;  // 0: never
     uint32_t tail_bands = 2;
     uint32_t tail_permille = 100;
     uint32_t tail_permille2 = 350;  // share of the rounds left for the tails in front of the last one (0: tail_permille)
@@ -187,7 +193,8 @@ struct PairPlan {
     std::vector<std::pair<size_t, size_t>> bands;        // tile ranges, one tile-kernel launch each
     std::vector<std::pair<size_t, size_t>> band_items;   // item ranges of the bands
     std::vector<std::vector<Seg>> segs;                  // per band
-    std::vector<U4> items;                               // {tile index in band, chunk begin, chunk end, 0}
+    std::vector<U4> items;                               // {tile index in band, chunk begin, chunk end, 1 for a fragment of a plane}
+    std::vector<uint32_t> band_frags;                    // per band: its LAST band_frags[b] items are fragments
     std::vector<uint32_t> rank;                          // position of tile t in the row-major order of its segment
     std::vector<U2> chunks;                              // chunk range of every tile
     uint64_t per_tile_bytes = 0;                         // C(v) scratch per tile

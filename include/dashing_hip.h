@@ -369,7 +369,9 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * "xch_tail_permille" (default 100: one round of the tile kernel of a rank of BASELINE configs[2] over 8) / "xch_tail_permille2" (the
  * share of the tails in front of the last one, default 350; 0 = the same) / "xch_tail_head_min_rounds" (such a tail must leave the head
  * at least this many rounds, default 7): a job with parts of at most 64 rounds of 512 one-plane work items has its tile kernel cut
- * at whole rounds into head and tail launches of at most 16 rounds, so that the head's parts travel while the tails compute, "finalize_shared_instance" (0 | 1, A/B only: calls without parts take the signalling instance of k_finalize too), "finalize_signal" (-1 auto | 0 | 1: a call with parts finalizes a band in ONE launch and the parts announce themselves from inside it --
+ * at whole rounds into head and tail launches of at most 16 rounds, so that the head's parts travel while the tails compute, "overflow_frag_permille" (0..1000, default 500: a band of one-plane work items whose count lies at most that share of a round above a
+ * multiple of 512 has the items left over cut into fragments of a plane that ADD their counts, so that the extra round is a fraction of one; 0 = never),
+ * "finalize_shared_instance" (0 | 1, A/B only: calls without parts take the signalling instance of k_finalize too), "finalize_signal" (-1 auto | 0 | 1: a call with parts finalizes a band in ONE launch and the parts announce themselves from inside it --
  * the copy stream waits for a part's flag with hipStreamWaitValue32 -- instead of one launch and one event per part; auto = where the
  * device supports it), "finalize_two_streams" (0|1: with events, the
  * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4

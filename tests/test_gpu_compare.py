@@ -784,6 +784,32 @@ def test_mle_division_against_the_oracle_over_the_operand_range(ctx, oracle, p):
     assert np.allclose(got_c[fin], want_c[fin], rtol=1e-12)
 
 
+@pytest.mark.parametrize("p", [12, 14, 16])
+def test_overflow_fragments_do_not_change_results(ctx, p):
+    """overflow fragments of the tile kernel (plan.h): when a band's one-plane items lie a little above a multiple of 512,
+    the items left over run as fragments of a plane that ADD their counts (32-bit atomics, two uint16 counts per word below
+    p = 16) to a cleared C(v) block.  Byte-identical to the run without them, for row ranges too."""
+    sizes = {12: range(3000, 4400, 200), 14: range(1500, 2700, 150), 16: range(900, 1500, 100)}[p]
+    hit = 0
+    try:
+        for n in sizes:
+            regs = synth.survey_sketches(n, p, seed=500 + n)[0]
+            ctx.set_sketches(regs)
+            ctx.set_option("overflow_frag_permille", 0)
+            base = ctx.dist_rows()
+            assert ctx.info("frag_items") == 0
+            part0 = ctx.dist_rows(128, n // 2 // 128 * 128 + 256)
+            for pm in (500, 1000):
+                ctx.set_option("overflow_frag_permille", pm)
+                got = ctx.dist_rows()
+                hit += ctx.info("frag_items") > 0
+                assert got.tobytes() == base.tobytes(), (p, n, pm, ctx.info("frag_items"))
+                assert ctx.dist_rows(128, n // 2 // 128 * 128 + 256).tobytes() == part0.tobytes(), (p, n, pm)
+    finally:
+        ctx.set_option("overflow_frag_permille", 500)
+    assert hit >= 3, "these sizes are meant to produce overflow fragments"
+
+
 def test_out_of_range_registers_are_refused(ctx):
     """uploaded registers above 64 - p + 1 (corrupt / foreign sketches) make the compare entry points fail loudly
     instead of aliasing into wrong histogram bins"""
