@@ -786,7 +786,8 @@ static void overflow_fragments(const Tuning &tu, uint32_t cpp, uint64_t piece, u
     over = 0;
     f = 1;
     const uint64_t RI = tu.round_items;
-    if (!tu.lockstep || tu.nsplit != 0 || RI == 0 || tu.overflow_frag_max_permille == 0 || piece != cpp || cpp < 2 || ni <= RI) return;
+    if (!tu.lockstep || tu.nsplit != 0 || RI == 0 || tu.overflow_frag_max_permille == 0 || piece != cpp || cpp < 2 || ni == 0) return;
+    // (a band of less than a round -- the tail band of an exchange call can hold a few dozen items -- is all overflow)
     const uint64_t o = ni % RI;
     if (o == 0 || o * 1000 > RI * tu.overflow_frag_max_permille) return;
     uint32_t ff = 1;

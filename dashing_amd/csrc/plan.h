@@ -173,7 +173,8 @@ struct Tuning {
     // Overflow fragments: a band of one-plane items whose count is a little above a multiple of a round would spend a
     // whole round on the few items left over (3 614 items = 7 rounds + 30 items: 1.56 ms instead of 1.37).  When the
     // overflow is at most overflow_frag_max_permille of a round, those items are cut into f equal fragments of a plane
-    // (f a power of two, overflow x f <= one round): the extra round then lasts 1/f of a round.  A fragment ADDS its
+    // (f a power of two, overflow x f <= one round): the extra round then lasts 1/f of a round.  A band of less than a
+    // round (a small job; the tail band of an exchange call, which can hold a few dozen items) is all overflow.  A fragment ADDS its
     // partial counts to the plane's C(v) block with atomics (cleared first); whole items keep their plain stores.
     uint32_t overflow_frag_max_permille = 500;  // 0: never
     uint32_t tail_bands = 2;
