@@ -706,11 +706,12 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
                 const uint64_t nb = (tails[b] + kBandRounds - 1) / kBandRounds;
                 for (uint64_t x = 0; x < nb; ++x) quota.push_back(tails[b] / nb + (x < tails[b] % nb ? 1 : 0));
             }
-            uint64_t target = 0, acc = 0, rounds = 0, band_items = 0;
+            // (the quota is the band's own: what a band leaves of its last round must not slide into the next band and
+            // push that one over a round boundary)
+            uint64_t acc = 0, rounds = 0, band_items = 0;
             size_t t = 0;
             for (size_t b = 0; b + 1 < quota.size(); ++b) {
-                target += quota[b] * RI;
-                while (t < T.size() && acc + (T[t].w - T[t].z) <= target) {
+                while (t < T.size() && band_items + (T[t].w - T[t].z) <= quota[b] * RI) {
                     acc += T[t].w - T[t].z;
                     band_items += T[t].w - T[t].z;
                     ++t;

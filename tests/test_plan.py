@@ -332,6 +332,25 @@ def test_tail_bands_cut_the_tile_kernel_at_whole_rounds(host):
     assert cut >= 2
 
 
+def test_a_second_tail_band_keeps_its_own_quota_of_rounds(host):
+    """14 rounds = 8 + 5 + 1: what the head leaves of its last round must not slide into the middle band and push it over a
+    round (the plan then fell back to 13 + 1 and the rank's first part left a millisecond later: 4 ranks of BASELINE
+    configs[2], profiles/rd5t)"""
+    rng = np.random.default_rng(33)
+    seen = 0
+    for n in (7000, 8000, 9000, 10000):
+        for spread in (2, 3, 4):
+            keys = make_keys(rng, n, 14, spread=spread)
+            tab = balance_rowsets(host, n, 4, dst=0)
+            for r in range(1, 4):
+                st = check_rowset(host, keys, tab, r, 1, 8, p=14)
+                rounds = -(-round(st["tiles"] * st["planes_x100"] / 100) // 512)
+                if 13 <= rounds <= 16:
+                    assert st["bands"] == 3, (n, spread, r, st)
+                    seen += 1
+    assert seen >= 5
+
+
 def test_the_destination_of_an_exchange_takes_a_bonus(host):
     """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~12 % (or the share asked for) more tiles
     than the mean and the others correspondingly fewer -- still every row with one owner, every boundary aligned"""
