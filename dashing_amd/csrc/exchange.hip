@@ -438,7 +438,7 @@ int parse_table(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, int dst, plan::
 }
 
 // the key order and the row offsets of a rank's row-sorted buffer (wanted rows: the extra segments, then the main range, each
-// key-ordered as one run), from THIS context's host copy of the keys (every rank holds every sketch, the per-sketch pass
+// key-ordered as one run -- the main range as two where plan::rowsorted_split cuts it), from THIS context's host copy of the keys (every rank holds every sketch, the per-sketch pass
 // is deterministic: the destination derives what the source used)
 int rowsorted_tables(dsh_ctx *c, uint64_t n, const XMode &m, std::vector<uint32_t> &order, std::vector<uint64_t> &rowoff,
                      std::vector<uint32_t> &scratch)
@@ -449,7 +449,7 @@ int rowsorted_tables(dsh_ctx *c, uint64_t n, const XMode &m, std::vector<uint32_
     const uint64_t cnt = plan::rowset_rows(m.rb, m.re, m.extra);
     order.resize(cnt);
     std::vector<std::pair<uint64_t, uint64_t>> segs;  // the wanted order: extra segments first, then the main range
-    plan::wanted_order(n, m.rb, m.re, &m.extra, segs);
+    plan::wanted_order(n, m.rb, m.re, &m.extra, segs, true);
     uint64_t at = 0;
     for (auto &sg : segs) {
         plan::sort_rows_by_key(c->hk32, sg.first, sg.second, order.data() + at, scratch);

@@ -57,7 +57,7 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
     build_layout(keys, n, want_sorted, lrb, lre, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0, extra.empty() ? nullptr : &extra);
     // the wanted segments, main range first
     std::vector<std::pair<uint64_t, uint64_t>> wsegs;  // (the wanted order: extra segments first, then the main range)
-    wanted_order(n, lrb, lre, &extra, wsegs);
+    wanted_order(n, lrb, lre, &extra, wsegs, rowsorted);
     auto in_rows = [&](uint64_t i) {
         for (auto &w : wsegs)
             if (i >= w.first && i < w.second) return true;
@@ -371,5 +371,8 @@ int dshh_plan_check_rowset(uint64_t n, const uint32_t *keys, const uint64_t *tab
     if (rb >= re) return 0;
     return plan_check(n, keys, rowsorted ? 3 : 0, 1, rb, re, 0, 0, rowsorted ? nparts : 1, 1, p, cum_budget, 1, 0, 64, extra, stats, err, cap);
 }
+
+// first row of the second run of a row-sorted range (plan::rowsorted_split), re when the range stays one run
+uint64_t dshh_rowsorted_split(uint64_t n, uint64_t rb, uint64_t re) { return rowsorted_split(n, rb, re); }
 
 }  // extern "C"

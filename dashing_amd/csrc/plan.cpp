@@ -116,14 +116,38 @@ bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts)
 
 // tiles of every wanted tile row of a row set, in layout order: the block at layout block index b meets the NTc - b
 // blocks from itself to the right (the runs of the layout lie in row order, plan.h)
-void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs)
+uint64_t rowsorted_split(uint64_t n, uint64_t rb, uint64_t re)
+{
+    if (re > n) re = n;
+    if (rb >= re) return re;
+    const uint64_t TR = (re - rb + kTile - 1) / kTile, NTc = (n - rb + kTile - 1) / kTile;
+    if (TR < 16) return re;
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < TR; ++t) total += NTc - t;
+    uint64_t K = 0, acc = 0;
+    while (K < TR && acc * 100 < total * 15) acc += NTc - (TR - 1 - K), ++K;
+    if (K < 2 || TR - K < 8) return re;
+    const uint64_t x = rb + (TR - K) * kTile;
+    // mean output length of a row: n - 1 - row
+    const long double len_all = (long double)n - 1 - 0.5L * (long double)(rb + re - 1), len_tail = (long double)n - 1 - 0.5L * (long double)(x + re - 1);
+    return len_tail <= 0.65L * len_all ? x : re;
+}
+
+void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs,
+                  bool rowsorted)
 {
     segs.clear();
     if (re > n) re = n;
     if (rb >= re) return;
     if (extra)
         for (size_t x = 0; x + 1 < extra->size(); x += 2) segs.emplace_back((*extra)[x], std::min<uint64_t>((*extra)[x + 1], n));
-    segs.emplace_back(rb, re);
+    const uint64_t x = rowsorted ? rowsorted_split(n, rb, re) : re;
+    if (x > rb && x < re) {
+        segs.emplace_back(rb, x);
+        segs.emplace_back(x, re);
+    } else {
+        segs.emplace_back(rb, re);
+    }
 }
 
 static void wanted_tile_rows(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<uint64_t> &cnt)
@@ -445,8 +469,15 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
     L.re = re;
     L.rowsorted = want_sorted && rowsorted_nparts > 0;
     L.extra = extra;
-    if (L.rowsorted || !extra.empty()) L.parts = {rb, re};  // ONE key-ordered run
-    else L.parts = want_sorted ? parts : std::vector<uint64_t>();
+    if (L.rowsorted) {  // ONE key-ordered run, or two (rowsorted_split)
+        const uint64_t x = rowsorted_split(n, rb, re);
+        if (x > rb && x < re) L.parts = {rb, x, re};
+        else L.parts = {rb, re};
+    } else if (!extra.empty()) {
+        L.parts = {rb, re};
+    } else {
+        L.parts = want_sorted ? parts : std::vector<uint64_t>();
+    }
     L.n = n;
     L.vlo = vr[0];
     L.vhi = vr[1];
@@ -481,7 +512,7 @@ void build_layout(const uint32_t *k32, uint64_t n, int want_sorted, uint64_t rb,
         // tile rows that hold wanted rows, in the WANTED ORDER (extra segments first, then the main range: the order of the
         // tile list, of the parts and of a row-sorted buffer), and the wanted rows in front of each of these ranges
         std::vector<std::pair<uint64_t, uint64_t>> wsegs;
-        wanted_order(n, rb, re, &extra, wsegs);
+        wanted_order(n, rb, re, &extra, wsegs, L.rowsorted);
         uint64_t wrows = 0;
         for (auto &sg : wsegs) {
             L.wtr.emplace_back((uint32_t)((sg.first - rb) / kTile), (uint32_t)((sg.second - rb + kTile - 1) / kTile));

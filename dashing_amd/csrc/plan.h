@@ -74,8 +74,17 @@ constexpr uint64_t kTopupMaxRows = 32768;
 // (~0u: the default: 120 where a rank holds at least 16 tile rows, else 0) thousandths of a rank's mean tile count more than
 // the others.
 void balance_rowsets(uint64_t n, uint32_t world, RowSets &rs, uint32_t prep_permille = ~0u, int dst = -1, uint32_t dst_bonus_permille = ~0u);
-// the wanted segments in the WANTED ORDER: the extra segments (row order) first, then the main range
-void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs);
+// the wanted segments in the WANTED ORDER: the extra segments (row order) first, then the main range.  Every segment is
+// key-ordered as one run in a row-sorted layout; `rowsorted`: the main range comes as TWO runs where rowsorted_split() cuts it.
+void wanted_order(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> *extra, std::vector<std::pair<uint64_t, uint64_t>> &segs,
+                  bool rowsorted = false);
+// A row-sorted range that reaches far down the triangle (2-4 ranks) ends in a run of its own: in ONE key-ordered run the
+// last tile rows of the layout -- few tiles each, computed by the rank's last launch -- hold rows from anywhere in the
+// range, i.e. as much output per row as any (2 ranks of BASELINE configs[2]: 31 MB final only behind the last kernel);
+// as a run of their own they hold the range's LAST rows, the short ones of the triangle (10 MB).  Returns the first row
+// of that run (rb + a multiple of 128), or re: no cut -- unless the last ~15 % of the range's tiles are tile rows whose
+// rows are on average at most 0.65 as long as the range's, the cut only costs planes per tile.
+uint64_t rowsorted_split(uint64_t n, uint64_t rb, uint64_t re);
 // tiles a rank with these rows computes, and the rows it holds
 uint64_t rowset_tiles(uint64_t n, uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);
 uint64_t rowset_rows(uint64_t rb, uint64_t re, const std::vector<uint64_t> &extra);

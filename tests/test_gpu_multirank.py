@@ -410,6 +410,7 @@ def test_exchange_protocol_other_destination_and_ragged_ranges(tmp_path):
     (8, 4000, 10, 8, 0),   # the shape of the driver's 8-rank run, scaled: ranges of 2-6 tile rows + top-ups
     (4, 3000, 12, 3, 2),   # the destination itself holds top-up segments (computed in place, in final order)
     (3, 1400, 12, 8, 1),   # more parts asked for than a rank has tile rows
+    (3, 6000, 10, 8, 1),   # a row-sorted range that ends in a run of its last rows (plan::rowsorted_split)
 ])
 def test_exchange_protocol_row_sets_between_processes(tmp_path, world, n, p, nparts, dst):
     """the balanced partition -- a rank's rows are a range plus top-up tile rows from the bottom of the
@@ -426,6 +427,14 @@ def test_exchange_protocol_row_sets_edge_shapes(tmp_path):
     run_mock_world(tmp_path, 4, 2600, 12, 1, "exchange", dst=0, rowsets=True, expect_topups=True)  # one part each
     run_mock_world(tmp_path, 3, 1100, 16, 3, "exchange", dst=2, rowsets=True, expect_topups=True)  # p = 16
     run_mock_world(tmp_path, 2, 33000, 8, 4, "exchange", dst=1, rowsets=True)          # n > 32 768: contiguous ranges
+
+
+@pytest.mark.gpu
+def test_exchange_protocol_row_sorted_range_in_two_runs(tmp_path):
+    """2 ranks: the source's range reaches to the bottom of the triangle and is key-ordered as two runs (its last rows on
+    their own, plan::rowsorted_split); the destination derives the same order from its own keys"""
+    run_mock_world(tmp_path, 2, 5200, 10, 8, "exchange", dst=0, rowsets=True)
+    run_mock_world(tmp_path, 2, 5200, 12, 5, "exchange", dst=1, rowsets=True)
 
 
 @pytest.mark.gpu

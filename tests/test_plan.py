@@ -351,6 +351,32 @@ def test_a_second_tail_band_keeps_its_own_quota_of_rounds(host):
     assert seen >= 5
 
 
+def test_a_long_row_sorted_range_ends_in_a_run_of_its_last_rows(host):
+    """2-4 ranks: a row-sorted range that reaches far down the triangle is key-ordered as TWO runs, so that the tile rows the
+    rank's last launch computes hold its shortest rows (little output behind the last kernel).  Short ranges (8 ranks)
+    stay one run.  The plans still cover every pair exactly once (the checker), at a few hundredths of a plane per tile."""
+    host.dshh_rowsorted_split.restype = C.c_uint64
+    host.dshh_rowsorted_split.argtypes = [C.c_uint64] * 3
+    n = 10000
+    for world, split_ranks in ((2, {1}), (3, {2}), (4, {3}), (8, set())):
+        tab = balance_rowsets(host, n, world, dst=0)
+        for r in range(1, world):
+            (rb, re), *_ = rank_rows(host, n, tab, r)[0]
+            x = host.dshh_rowsorted_split(n, rb, re)
+            assert (x < re) == (r in split_ranks), (world, r, rb, re, x)
+            if x < re:
+                assert rb < x and (x - rb) % 128 == 0
+                # the rows behind the cut are short: at most 0.65 of the range's mean output per row
+                assert (n - 1 - (x + re - 1) / 2) <= 0.65 * (n - 1 - (rb + re - 1) / 2)
+    rng = np.random.default_rng(8)
+    for n, world in ((6000, 2), (9000, 3)):
+        keys = make_keys(rng, n, 12)
+        tab = balance_rowsets(host, n, world, dst=0)
+        for r in range(1, world):
+            st = check_rowset(host, keys, tab, r, 1, 8)
+            assert st["parts"] >= 2
+
+
 def test_the_destination_of_an_exchange_takes_a_bonus(host):
     """dsh_balance_rowsets(dst): the rank that receives sends nothing, so it holds ~12 % (or the share asked for) more tiles
     than the mean and the others correspondingly fewer -- still every row with one owner, every boundary aligned"""
