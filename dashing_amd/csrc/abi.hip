@@ -39,7 +39,7 @@ int dsh_device_count(void)
 static void release_ctx(dsh_ctx *c)
 {
     (void)hipSetDevice(c->device);
-    for (hipStream_t s : {c->stream, c->copy_stream, c->aux_stream})
+    for (hipStream_t s : {c->stream, c->copy_stream, c->aux_stream, c->place_stream})
         if (s) (void)hipStreamSynchronize(s);
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
@@ -55,7 +55,7 @@ static void release_ctx(dsh_ctx *c)
     c->pin_xch.release();
     c->pin_sig.release();
     for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_sig, &c->ev_band_tiles,
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_sig, &c->ev_band_tiles,
                           &c->ev_band_aux}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
@@ -63,10 +63,12 @@ static void release_ctx(dsh_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->tickets) (void)hipEventDestroy(e);
     for (auto e : c->ev_part) (void)hipEventDestroy(e);
+    for (auto e : c->ev_round) (void)hipEventDestroy(e);
+    c->ev_round.clear();
     c->ev_pool.clear();
     c->tickets.clear();
     c->ev_part.clear();
-    for (hipStream_t *s : {&c->stream, &c->copy_stream, &c->aux_stream}) {
+    for (hipStream_t *s : {&c->stream, &c->copy_stream, &c->aux_stream, &c->place_stream}) {
         if (*s) (void)hipStreamDestroy(*s);
         *s = nullptr;
     }
@@ -89,6 +91,7 @@ int dsh_create(int device, dsh_ctx **out)
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         create_copy_stream(&c->copy_stream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        create_copy_stream(&c->place_stream) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_band_tiles, hipEventDisableTiming) != hipSuccess ||
@@ -117,6 +120,7 @@ int dsh_synchronize(dsh_ctx *c)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->place_stream));
     return DSH_OK;
 }
 
@@ -770,6 +774,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "parts_done")) *out = c->parts_done;
     else if (!std::strcmp(name, "parts_signalled")) *out = c->parts_signalled ? 1 : 0;
     else if (!std::strcmp(name, "sketch_kernel_us")) *out = (int64_t)(c->sketch_ms * 1000.0);
+    else if (!std::strcmp(name, "place_kernel_us")) *out = (int64_t)(c->place_ms * 1000.0);
     else if (!std::strcmp(name, "whatif_mfma")) {
 #ifdef DSH_WHATIF_MFMA
         *out = 1;

@@ -83,6 +83,7 @@ struct dsh_ctx {
     // host runs on its own stream while the kernels of call b+1 fill the other buffer
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // prepare(): the column index is built next to the bit-plane transform
+    hipStream_t place_stream = nullptr; // destination of an exchange: received rows are put into place beside the next round's transfer
     hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
     hipEvent_t ev_band_tiles = nullptr, ev_band_aux = nullptr;  // a band's C(v) ready / its k_finalize launches on the second stream done
     bool aux_join_pending = false;
@@ -102,6 +103,8 @@ struct dsh_ctx {
     DevBuf place_tab;                   // dsh_exchange_place_device's own tables (ctx stream; xch_tab belongs to the copy stream)
     PinBuf pin_xch;
     hipEvent_t ev_xch_tab = nullptr;
+    hipEvent_t ev_place_done = nullptr;        // the last placement of a collect (the copy stream joins it)
+    std::vector<hipEvent_t> ev_round;          // round q of a collect has arrived (place_stream waits for it)
     bool xch_tab_in_flight = false;
     bool pass_from_zero = false;        // the next per-sketch pass covers every sketch (the destination of an exchange)
     DevBuf hist;                        // [n][64] per-sketch register histograms (k_selfhist_card -> k_card_from_hist)
@@ -180,6 +183,7 @@ struct dsh_ctx {
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
     // profiling
     bool profiling = false;
+    double place_ms = 0;  // (profiling) device time of the last dsh_exchange_place_device's placement kernel
     double pair_ms = 0, fin_ms = 0, prep_ms = 0, sketch_ms = 0;
     uint32_t pair_launches = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -243,6 +247,22 @@ inline void invalidate(dsh_ctx *c)
     c->card_estim = -1;
     c->hk32_valid = false;
 }
+
+// hipStreamWaitValue32 on this device (asked once): what lets the parts of a call announce themselves from inside k_finalize
+inline bool device_can_wait_value(dsh_ctx *c)
+{
+    if (c->can_wait_value < 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) v = 0;
+        c->can_wait_value = v;
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess) khz = 0;
+        c->wall_clock_khz = khz;
+    }
+    return c->can_wait_value == 1;
+}
+// a call with parts will signal them (engine.hip: run_pairs)
+inline bool parts_will_signal(dsh_ctx *c) { return !c->finalize_timing && !c->finalize_stop && c->finalize_signal != 0 && device_can_wait_value(c); }
 
 inline void reset_prof(dsh_ctx *c)
 {

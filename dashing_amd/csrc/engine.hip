@@ -334,15 +334,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     // stamped / general instances (profiling aids, rectangles) and not where the device lacks stream wait-value.
     bool signal = false;
     if (with_parts && pp.nparts >= 1 && pp.nparts <= kSigMaxParts && !c->finalize_timing && !c->finalize_stop && c->finalize_signal != 0) {
-        if (c->can_wait_value < 0) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) v = 0;
-            c->can_wait_value = v;
-            int khz = 0;
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess) khz = 0;
-            c->wall_clock_khz = khz;
-        }
-        signal = c->can_wait_value == 1;
+        signal = device_can_wait_value(c);
         if (!signal && c->finalize_signal == 1) return fail(c, DSH_ENODEV, "option finalize_signal = 1, but the device does not support hipStreamWaitValue32");
     }
     c->parts_signalled = signal;

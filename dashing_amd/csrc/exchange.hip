@@ -409,26 +409,40 @@ struct XMode {
     bool rowsorted = false;
     uint64_t rb = 0, re = 0;      // the rank's main range
     std::vector<uint64_t> extra;  // its extra segments {b0, e0, ...}
-    std::vector<uint64_t> cut;    // rowsorted: counts of wanted rows (layout order); else row boundaries (range_parts)
+    std::vector<uint64_t> cut;    // rowsorted: counts of wanted rows (wanted order); else row boundaries (range_parts)
+    uint32_t kreq = 1;            // the number of parts asked of the part functions (what the compute call passes on)
     size_t nparts() const { return cut.empty() ? 0 : cut.size() - 1; }
     uint64_t span(uint64_t n) const { return plan::rowset_span(n, rb, re, extra); }
 };
 
-XMode xmode(uint64_t n, const plan::RowSets &rs, int r, uint32_t nparts, int dst)
+// Every rank's mode.  The parts are units of COMPLETION (a part's rows are final when k_finalize has passed them); what
+// travels are MESSAGES: the q-th of `nparts` equal pieces of a source's buffer, sent as soon as the parts it overlaps are
+// final (dsh_exchange_collect_async) -- the destination receives message q of every source in one round, and a round lasts
+// as long as its largest message, so the messages of all sources are the same share of (about equal) spans.
+// `fine_rank` >= 0: that rank (the caller, when its parts announce themselves from inside k_finalize: a part then costs a
+// flag, not a launch) cuts its row-sorted rows as finely as they complete -- every tile row a part: a message waits for
+// the part that holds its last value, and a coarse part that ends just short of a message's end would hold it back by a
+// whole part.  Nobody else needs to know: the destination deals in messages and rows only.
+std::vector<XMode> xmodes(uint64_t n, const plan::RowSets &rs, uint32_t nparts, int dst, int fine_rank = -1)
 {
-    XMode m;
-    rs.rank_rows((uint32_t)r, m.rb, m.re, m.extra);
-    if (m.rb >= m.re) return m;
-    if (r == dst) {
-        m.cut = {m.rb, m.re};
-    } else if (!m.extra.empty() || plan::rowsorted_rule(n, m.rb, m.re, nparts)) {
-        m.rowsorted = true;
-        plan::rowsorted_part_positions(n, m.rb, m.re, nparts, m.cut, &m.extra);
-    } else {
-        plan::range_parts(n, m.rb, m.re, nparts, m.cut);
+    std::vector<XMode> modes(rs.world);
+    for (uint32_t r = 0; r < rs.world; ++r) {
+        XMode &m = modes[r];
+        rs.rank_rows(r, m.rb, m.re, m.extra);
+        if (m.rb >= m.re) continue;
+        if ((int)r == dst) {
+            m.cut = {m.rb, m.re};
+            continue;
+        }
+        m.rowsorted = !m.extra.empty() || plan::rowsorted_rule(n, m.rb, m.re, nparts);
+        m.kreq = (m.rowsorted && (int)r == fine_rank) ? std::max<uint32_t>(nparts, kSigMaxParts) : nparts;
+        if (m.rowsorted) plan::rowsorted_part_positions(n, m.rb, m.re, m.kreq, m.cut, &m.extra);
+        else plan::range_parts(n, m.rb, m.re, nparts, m.cut);
     }
-    return m;
+    return modes;
 }
+
+XMode xmode(uint64_t n, const plan::RowSets &rs, int r, uint32_t nparts, int dst) { return xmodes(n, rs, nparts, dst)[(size_t)r]; }
 
 int parse_table(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, int dst, plan::RowSets &rs)
 {
@@ -512,7 +526,8 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
     reset_prof(c);
     c->parts_done = 0;
     if (c->n < 2) return DSH_OK;
-    const XMode m = xmode(c->n, rs, rank, nparts, dst);
+    const std::vector<XMode> modes = xmodes(c->n, rs, nparts, dst, parts_will_signal(c) ? rank : -1);
+    const XMode &m = modes[(size_t)rank];
     // the destination places the row-sorted spans of the others: its per-sketch pass must cover their rows too -- also
     // when it holds no rows itself (it used to return before any pass and fail later in the collect, with the
     // peers' sends already posted)
@@ -521,7 +536,7 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
     if (rank == dst)
         for (uint32_t r = 0; r < rs.world; ++r) {
             if ((int)r == dst) continue;
-            const XMode o = xmode(c->n, rs, (int)r, nparts, dst);
+            const XMode &o = modes[r];
             if (o.rowsorted && o.rb < first_needed) from_zero = true;
         }
     if (m.rb >= m.re) {
@@ -543,7 +558,7 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
     j.result_type = result_type;
     j.k = k;
     j.rect = 0;
-    j.nparts = rank == dst ? 1 : nparts;
+    j.nparts = rank == dst ? 1 : m.kreq;
     j.rowsorted = m.rowsorted ? 1 : 0;
     j.row_begin = m.rb;
     j.row_end = m.re;
@@ -556,20 +571,11 @@ int dsh_exchange_rows_device_async(dsh_ctx *c, int estim, int result_type, int k
     return rc;
 }
 
-// rank `src`'s parts, as they lie in its buffer: offset and length of part q (floats), and where a part of consecutive
-// rows lands in the final matrix
-static void part_span(uint64_t n, const XMode &m, const std::vector<uint64_t> &rowoff, size_t q, uint64_t &off, uint64_t &cnt,
-                      uint64_t &final_off)
+// message q of M of a buffer of `total` floats: [first, first + cnt)
+static void message_span(uint64_t total, size_t q, size_t M, uint64_t &first, uint64_t &cnt)
 {
-    if (m.rowsorted) {
-        off = rowoff[m.cut[q]];
-        cnt = rowoff[m.cut[q + 1]] - off;
-        final_off = 0;
-    } else {
-        off = dsh_tri_span(n, m.rb, m.cut[q]);
-        cnt = dsh_tri_span(n, m.cut[q], m.cut[q + 1]);
-        final_off = dsh_tri_span(n, 0, m.cut[q]);
-    }
+    first = (uint64_t)((unsigned __int128)total * q / M);
+    cnt = (uint64_t)((unsigned __int128)total * (q + 1) / M) - first;
 }
 
 int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, uint32_t nparts, const void *d_local, void *d_final,
@@ -584,29 +590,40 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
     if (!c->comm && rs.world != 1) return fail(c, DSH_ESTATE, "dsh_comm_init first");
     if ((int)rs.world != world) return fail(c, DSH_EINVAL, "the row-set table is for %u ranks, the communicator has %d", rs.world, world);
     if (rank == dst && !d_final) return DSH_EINVAL;
-    std::vector<XMode> modes((size_t)world);
-    size_t maxparts = 0;
-    for (int r = 0; r < world; ++r) {
-        modes[r] = xmode(n, rs, r, nparts, dst);
-        maxparts = std::max(maxparts, modes[r].nparts());
-    }
+    const std::vector<XMode> modes = xmodes(n, rs, nparts, dst, c->parts_signalled ? rank : -1);  // (as this rank's compute call cut them)
     const XMode &mine = modes[rank];
     if (c->parts_done != mine.nparts())
         return fail(c, DSH_ESTATE, "dsh_exchange_rows_device_async of this rank's rows must come first (%u parts computed, %zu expected)",
                     c->parts_done, mine.nparts());
     Rccl *rc_ = world > 1 ? rccl() : nullptr;
+    // The exchange runs in M = nparts ROUNDS: message q of every source -- the q-th M-th of its buffer, whatever rows that
+    // is -- in one grouped ncclSend/ncclRecv.  A round lasts as long as its largest message, and the ranks' spans are
+    // about equal (dsh_balance_rowsets), so no link waits for another's longer message.  A source sends message q once
+    // the part that holds its last value is final (parts = units of completion, final in order); the destination's own rows
+    // are one part, computed in place, and gate nothing but the end of the call.
+    const size_t M = nparts;
     // row-sorted sources: their key order and row offsets.  A source knows its own (the layout); the destination derives
-    // them from its keys, stages what it receives and puts the rows into place behind every round.
+    // them from its keys, stages what it receives and puts the rows that are complete into place behind every round.
     std::vector<std::vector<uint64_t>> rowoff((size_t)world);
     std::vector<std::vector<uint32_t>> order((size_t)world);
-    std::vector<uint64_t> stage_off((size_t)world, 0), tab_off((size_t)world, 0);
+    std::vector<uint64_t> stage_off((size_t)world, 0), tab_off((size_t)world, 0), total((size_t)world, 0);
     uint64_t stage_total = 0, tab_bytes = 0;
+    std::vector<PlaceEnt> ents;  // the placement launches of the rounds (destination)
+    std::vector<int> ent_src;
+    std::vector<uint32_t> round_ent(M + 1, 0), round_rows(M, 0);
+    uint64_t ent_off = 0;
+    for (int r = 0; r < world; ++r)
+        if (r != dst && !modes[r].rowsorted) total[r] = dsh_tri_span(n, modes[r].rb, modes[r].re);
     if (rank != dst) {
-        if (mine.rowsorted) rowoff[rank] = c->lay.rowoff_w;
+        if (mine.rowsorted) {
+            rowoff[rank] = c->lay.rowoff_w;
+            total[rank] = rowoff[rank].empty() ? 0 : rowoff[rank].back();
+        }
     } else {
         for (int r = 0; r < world; ++r) {
             if (r == dst || !modes[r].rowsorted) continue;
             if ((rc = rowsorted_tables(c, n, modes[r], order[r], rowoff[r], c->lay.sort_a))) return rc;
+            total[r] = rowoff[r].back();
             stage_off[r] = stage_total;
             stage_total += rowoff[r].back();
             tab_off[r] = tab_bytes;
@@ -618,6 +635,35 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
                 HIPCHK(c, hipEventSynchronize(c->ev_xch_tab));
                 c->xch_tab_in_flight = false;
             }
+            // behind the sources' tables: the entries of every round's placement launch (k_rows_place) -- the rows of a
+            // source that lie completely inside its first q + 1 messages and did not inside its first q
+            ent_off = tab_bytes;
+            std::vector<uint64_t> rows_in((size_t)world, 0);
+            for (size_t q = 0; q < M; ++q) {
+                round_ent[q] = (uint32_t)ents.size();
+                uint32_t row0 = 0;
+                for (int src = 0; src < world; ++src) {
+                    if (src == dst || !modes[src].rowsorted) continue;
+                    uint64_t first, cnt;
+                    message_span(total[src], q, M, first, cnt);
+                    const std::vector<uint64_t> &ro = rowoff[src];  // ro[s] = start of the row at position s, ro.back() = total
+                    const uint64_t p1 = (uint64_t)(std::upper_bound(ro.begin(), ro.end(), first + cnt) - ro.begin()) - 1;
+                    const uint64_t p0 = rows_in[src];
+                    rows_in[src] = std::max(p0, p1);
+                    if (p1 <= p0) continue;
+                    PlaceEnt e;
+                    e.src = nullptr, e.order = nullptr, e.rowoff = nullptr;  // (device addresses: below, once the buffers exist)
+                    e.pos0 = p0;
+                    e.row0 = row0;
+                    e.nrows = (uint32_t)(p1 - p0);
+                    row0 += e.nrows;
+                    ents.push_back(e);
+                    ent_src.push_back(src);
+                }
+                round_rows[q] = row0;
+            }
+            round_ent[M] = (uint32_t)ents.size();
+            tab_bytes += ents.size() * sizeof(PlaceEnt);
             HIPCHK(c, c->pin_xch.ensure(tab_bytes));
             HIPCHK(c, c->xch_tab.ensure(tab_bytes));
             for (int r = 0; r < world; ++r) {
@@ -626,50 +672,99 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
                 std::memcpy(h, rowoff[r].data(), rowoff[r].size() * sizeof(uint64_t));
                 std::memcpy(h + rowoff[r].size() * sizeof(uint64_t), order[r].data(), order[r].size() * sizeof(uint32_t));
             }
+            for (size_t x = 0; x < ents.size(); ++x) {
+                const int src = ent_src[x];
+                const uint8_t *t = (const uint8_t *)c->xch_tab.ptr + tab_off[src];
+                ents[x].src = (const float *)c->xch_stage.ptr + stage_off[src];
+                ents[x].rowoff = (const uint64_t *)t;
+                ents[x].order = (const uint32_t *)(t + rowoff[src].size() * sizeof(uint64_t));
+            }
+            if (!ents.empty()) std::memcpy((uint8_t *)c->pin_xch.ptr + ent_off, ents.data(), ents.size() * sizeof(PlaceEnt));
             HIPCHK(c, hipMemcpyAsync(c->xch_tab.ptr, c->pin_xch.ptr, tab_bytes, hipMemcpyHostToDevice, c->copy_stream));
             if (!c->ev_xch_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xch_tab, hipEventDisableTiming));
             HIPCHK(c, hipEventRecord(c->ev_xch_tab, c->copy_stream));
             c->xch_tab_in_flight = true;
+            while (c->ev_round.size() < M) {
+                hipEvent_t e = nullptr;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->ev_round.push_back(e);
+            }
         }
     }
-    for (size_t q = 0; q < maxparts; ++q) {
-        // round q: part q of every rank.  The copy stream joins this rank's "part q done" event; the transfer then runs
-        // there while the ctx stream computes part q+1
-        if (q < mine.nparts()) { int rcw = wait_part(c, q); if (rcw) return rcw; }
-        if (rank == dst && q < mine.nparts())  // (the destination's own rows: one part, normally in place)
-            if ((rc = place_own_rows(c, n, mine, d_local, d_final, c->copy_stream))) return rc;
-        if (world == 1) continue;
+    // (source) where this rank's parts end in its buffer: message q waits for the part that holds its last value
+    std::vector<uint64_t> part_end;
+    if (rank != dst)
+        for (size_t i = 0; i < mine.nparts(); ++i)
+            part_end.push_back(mine.rowsorted ? rowoff[rank][mine.cut[i + 1]] : dsh_tri_span(n, mine.rb, mine.cut[i + 1]));
+    bool placed = false;
+    size_t next_wait = 0;  // (source) the first part the copy stream has not joined yet
+    for (size_t q = 0; q < M && world > 1; ++q) {
+        uint64_t my_first = 0, my_cnt = 0;
+        if (rank != dst && mine.nparts()) {
+            message_span(total[rank], q, M, my_first, my_cnt);
+            if (my_cnt) {
+                // the copy stream joins the completion (a flag k_finalize sets, or an event) of every part up to the one that
+                // holds the message's last value: the parts of a band are final in ALMOST the order of the list
+                const size_t i = std::min((size_t)(std::lower_bound(part_end.begin(), part_end.end(), my_first + my_cnt) - part_end.begin()),
+                                          mine.nparts() - 1);
+                for (; next_wait <= i; ++next_wait) {
+                    int rcw = wait_part(c, next_wait);
+                    if (rcw) return rcw;
+                }
+            }
+        }
+        bool any = my_cnt != 0;
+        if (rank == dst)
+            for (int src = 0; src < world && !any; ++src) {
+                uint64_t f, k;
+                message_span(src == dst ? 0 : total[src], q, M, f, k);
+                any = k != 0;
+            }
+        if (!any) continue;
         NCCLCHK(c, rc_->GroupStart());
         ncclResult_t e = ncclSuccess;
         if (rank == dst) {
             for (int src = 0; src < world && e == ncclSuccess; ++src) {
-                if (src == dst || q >= modes[src].nparts()) continue;
-                uint64_t off, cnt, foff;
-                part_span(n, modes[src], rowoff[src], q, off, cnt, foff);
-                float *to = modes[src].rowsorted ? (float *)c->xch_stage.ptr + stage_off[src] + off : (float *)d_final + foff;
-                if (cnt) e = rc_->Recv(to, cnt, ncclFloat32, src, c->comm, c->copy_stream);
+                if (src == dst) continue;
+                uint64_t first, cnt;
+                message_span(total[src], q, M, first, cnt);
+                if (!cnt) continue;
+                float *to = modes[src].rowsorted ? (float *)c->xch_stage.ptr + stage_off[src] + first
+                                                 : (float *)d_final + dsh_tri_span(n, 0, modes[src].rb) + first;
+                e = rc_->Recv(to, cnt, ncclFloat32, src, c->comm, c->copy_stream);
             }
-        } else if (q < mine.nparts()) {
-            uint64_t off, cnt, foff;
-            part_span(n, mine, rowoff[rank], q, off, cnt, foff);
-            if (cnt) {
-                if (!d_local) e = ncclInvalidArgument;
-                else e = rc_->Send((const float *)d_local + off, cnt, ncclFloat32, dst, c->comm, c->copy_stream);
-            }
+        } else {
+            if (!d_local) e = ncclInvalidArgument;
+            else e = rc_->Send((const float *)d_local + my_first, my_cnt, ncclFloat32, dst, c->comm, c->copy_stream);
         }
         if (e != ncclSuccess) {
             (void)rc_->GroupEnd();
             return fail(c, DSH_EIO, "ncclSend/ncclRecv: %s", rc_->GetErrorString(e));
         }
         NCCLCHK(c, rc_->GroupEnd());
-        if (rank == dst)  // the rows of the row-sorted parts that just arrived go to their places
-            for (int src = 0; src < world; ++src) {
-                if (src == dst || !modes[src].rowsorted || q >= modes[src].nparts()) continue;
-                const uint8_t *t = (const uint8_t *)c->xch_tab.ptr + tab_off[src];
-                HIPCHK(c, launch_row_place(c->copy_stream, (const float *)c->xch_stage.ptr + stage_off[src], (float *)d_final,
-                                           (const uint32_t *)(t + rowoff[src].size() * sizeof(uint64_t)), (const uint64_t *)t,
-                                           modes[src].cut[q], modes[src].cut[q + 1], n));
-            }
+        // the rows that are now complete go to their places: ONE launch per round, on a stream of its own behind the
+        // round's event, so that the next round's transfer does not wait for it
+        if (rank == dst && stage_total && round_rows[q]) {
+            HIPCHK(c, hipEventRecord(c->ev_round[q], c->copy_stream));
+            HIPCHK(c, hipStreamWaitEvent(c->place_stream, c->ev_round[q], 0));
+            HIPCHK(c, launch_rows_place(c->place_stream, (const PlaceEnt *)((const uint8_t *)c->xch_tab.ptr + ent_off) + round_ent[q],
+                                        round_ent[q + 1] - round_ent[q], round_rows[q], (float *)d_final, n));
+            placed = true;
+        }
+    }
+    if (rank == dst) {
+        // the destination's own rows (one part, normally computed in place) and the placements: the copy stream, which
+        // dsh_comm_wait waits for, ends behind both
+        if (mine.nparts()) {
+            int rcw = wait_part(c, 0);
+            if (rcw) return rcw;
+            if ((rc = place_own_rows(c, n, mine, d_local, d_final, c->copy_stream))) return rc;
+        }
+        if (placed) {
+            if (!c->ev_place_done) HIPCHK(c, hipEventCreateWithFlags(&c->ev_place_done, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_place_done, c->place_stream));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_place_done, 0));
+        }
     }
     return DSH_OK;
 }
@@ -701,11 +796,23 @@ int dsh_exchange_place_device(dsh_ctx *c, const uint64_t *rowsets, int src, uint
     HIPCHK(c, c->place_tab.ensure(bytes));
     HIPCHK(c, hipMemcpyAsync(c->place_tab.ptr, rowoff.data(), ro_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync((uint8_t *)c->place_tab.ptr + ro_bytes, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    for (size_t q = 0; q + 1 < m.cut.size(); ++q)
-        HIPCHK(c, launch_row_place(c->stream, (const float *)d_src_local, (float *)d_final,
-                                   (const uint32_t *)((const uint8_t *)c->place_tab.ptr + ro_bytes), (const uint64_t *)c->place_tab.ptr,
-                                   m.cut[q], m.cut[q + 1], n));
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // (profiling: the device time of the placement itself, dsh_get_info "place_kernel_us")
+    if (c->profiling) {
+        HIPCHK(c, hipEventCreate(&e0));
+        HIPCHK(c, hipEventCreate(&e1));
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+    }
+    HIPCHK(c, launch_row_place(c->stream, (const float *)d_src_local, (float *)d_final,
+                               (const uint32_t *)((const uint8_t *)c->place_tab.ptr + ro_bytes), (const uint64_t *)c->place_tab.ptr,
+                               0, order.size(), n));
+    if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (the pageable tables must outlive their copies)
+    if (e1) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->place_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     return DSH_OK;
 }
 

@@ -98,6 +98,15 @@ constexpr uint32_t kSigPartFlag = 0, kSigPartCnt = kSigMaxParts, kSigPartTotal =
                    kSigPartTime = 3 * kSigMaxParts + 2, kSigT0 = 5 * kSigMaxParts + 2, kSigTileCnt = 5 * kSigMaxParts + 4,
                    kSigWords = kSigTileCnt + 65536;
 hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out);
+// (k_rows_place) the rows of one source's part in a round of the exchange: positions [pos0, pos0 + nrows) of its key order
+struct PlaceEnt {
+    const float *src;         // the source's staged buffer
+    const uint32_t *order;    // its key order (original row of every position)
+    const uint64_t *rowoff;   // where the row at a position starts in the buffer
+    uint64_t pos0;
+    uint32_t row0, nrows;     // the blocks [row0, row0 + nrows) of the launch
+};
+hipError_t launch_rows_place(hipStream_t st, const PlaceEnt *ent, uint32_t nent, uint32_t total_rows, float *out, uint64_t n);
 // rows [pos0, pos1) of a row-sorted buffer (order[s] = original row, rowoff[s] = its offset) into the packed triangle
 hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,
                             uint64_t pos0, uint64_t pos1, uint64_t n);

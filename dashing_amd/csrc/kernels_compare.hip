@@ -1524,23 +1524,52 @@ hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out)
 
 // row-sorted parts (plan.h): the rows at the positions [pos0, pos1) of a source rank's key order, lying at rowoff[s] of its
 // buffer, go to their places in dashing's packed triangle (row r starts at r (2n - r - 1) / 2 and holds n - 1 - r values).
-// One block per row; a row is contiguous on both sides.
+// A row is contiguous on both sides; a block copies kPlaceChunk values of it (blockIdx.y = the chunk: the longest rows
+// of a part -- 40 KB at n = 10 000 -- would otherwise keep 128 blocks busy while 128 CUs idle).
+constexpr uint32_t kPlaceChunk = 4096;
+__device__ __forceinline__ void place_row_chunk(const float *__restrict__ src, float *__restrict__ out, const uint32_t *__restrict__ order,
+                                                const uint64_t *__restrict__ rowoff, uint64_t s, uint64_t n)
+{
+    const uint64_t r = order[s], len = n - 1 - r;
+    const uint64_t x0 = (uint64_t)blockIdx.y * kPlaceChunk;
+    if (x0 >= len) return;
+    const uint64_t x1 = x0 + kPlaceChunk < len ? x0 + kPlaceChunk : len;
+    const float *from = src + rowoff[s];
+    float *to = out + r * (2 * n - r - 1) / 2;
+    for (uint64_t x = x0 + threadIdx.x; x < x1; x += 256) to[x] = from[x];
+}
+
 __global__ __launch_bounds__(256) void k_row_place(const float *__restrict__ src, float *__restrict__ out,
                                                     const uint32_t *__restrict__ order, const uint64_t *__restrict__ rowoff,
                                                     uint64_t pos0, uint64_t n)
 {
-    const uint64_t s = pos0 + blockIdx.x;
-    const uint64_t r = order[s], len = n - 1 - r;
-    const float *from = src + rowoff[s];
-    float *to = out + r * (2 * n - r - 1) / 2;
-    for (uint64_t x = threadIdx.x; x < len; x += 256) to[x] = from[x];
+    place_row_chunk(src, out, order, rowoff, pos0 + blockIdx.x, n);
 }
 
 hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const uint32_t *order, const uint64_t *rowoff,
                             uint64_t pos0, uint64_t pos1, uint64_t n)
 {
-    if (pos1 <= pos0) return hipSuccess;
-    hipLaunchKernelGGL(k_row_place, dim3((uint32_t)(pos1 - pos0)), dim3(256), 0, st, src, out, order, rowoff, pos0, n);
+    if (pos1 <= pos0 || n < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_row_place, dim3((uint32_t)(pos1 - pos0), (uint32_t)((n - 1 + kPlaceChunk - 1) / kPlaceChunk)), dim3(256), 0, st,
+                       src, out, order, rowoff, pos0, n);
+    return hipGetLastError();
+}
+
+// one round of the exchange at the destination: the parts of ALL row-sorted sources that arrived in it, in ONE launch
+// (a launch per source left seven small kernels in a row behind the last transfer of an 8-rank step).  Entry e covers
+// the blocks [row0, row0 + nrows) of the grid's x.
+__global__ __launch_bounds__(256) void k_rows_place(const PlaceEnt *__restrict__ ent, uint32_t nent, float *__restrict__ out, uint64_t n)
+{
+    uint32_t e = 0;
+    while (e + 1 < nent && ent[e + 1].row0 <= blockIdx.x) ++e;
+    const PlaceEnt E = ent[e];
+    place_row_chunk(E.src, out, E.order, E.rowoff, E.pos0 + (blockIdx.x - E.row0), n);
+}
+
+hipError_t launch_rows_place(hipStream_t st, const PlaceEnt *ent, uint32_t nent, uint32_t total_rows, float *out, uint64_t n)
+{
+    if (!nent || !total_rows || n < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_rows_place, dim3(total_rows, (uint32_t)((n - 1 + kPlaceChunk - 1) / kPlaceChunk)), dim3(256), 0, st, ent, nent, out, n);
     return hipGetLastError();
 }
 

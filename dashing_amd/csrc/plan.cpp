@@ -191,41 +191,47 @@ void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t npa
     pos.assign(1, 0);
     if (re > n) re = n;
     if (rb >= re) return;
-    const uint64_t R = rowset_rows(rb, re, extra ? *extra : std::vector<uint64_t>());
-    // cut after the wanted tile row (in the wanted order) that reaches q / nparts of the tiles.  The extra segments come
-    // FIRST: their tile rows are short (the bottom of the triangle), and several of them share a part -- a part is a
-    // message of its own in the exchange and a launch of k_finalize, a row of 3 tiles is worth neither; the rank's last
-    // part is then ONE tile row of its main range, which is what stays exposed behind its last kernel.  (Only the last
-    // tile row of a segment that ends at n can hold fewer than 128 rows: a rank with extra segments has all its
-    // boundaries on multiples of 128 or at n; its positions count whole tile rows of 128 all the same, see below.)
-    std::vector<uint64_t> cnt;
-    wanted_tile_rows(n, rb, re, extra, cnt);
-    const uint64_t TR = cnt.size();
-    uint64_t total = 0;
-    for (uint64_t c : cnt) total += c;
-    // rows in front of the wanted tile row t of the wanted order
+    // Parts of about equal OUTPUT (bytes), cut between tile rows of the wanted order.  A part is a message of the exchange:
+    // the destination receives part q of every source in one round, and a round lasts as long as its largest message --
+    // sources whose parts differ in size (or in number) leave links idle.  The rows of a key-ordered run come from anywhere
+    // in its row range, so a tile row of the run holds 128 x the run's MEAN row length (n - 1 - row) -- known without the
+    // keys, which is what lets every rank compute every rank's cuts.  The extra segments come FIRST in the wanted order:
+    // their tile rows are short (the bottom of the triangle), several of them share a part; a rank's last part is then
+    // the end of its main range, which is what stays exposed behind its last kernel.
     std::vector<std::pair<uint64_t, uint64_t>> segs;
-    wanted_order(n, rb, re, extra, segs);
-    std::vector<uint64_t> rows_before(TR + 1, 0);
-    {
-        size_t t = 0;
-        uint64_t acc_rows = 0;
-        for (auto &sg : segs)
-            for (uint64_t b = sg.first; b < sg.second; b += kTile) {
-                rows_before[t++] = acc_rows;
-                acc_rows += std::min<uint64_t>(kTile, sg.second - b);
-            }
-        rows_before[TR] = acc_rows;
+    wanted_order(n, rb, re, extra, segs, true);
+    std::vector<uint64_t> rows_after;   // wanted rows up to and including tile row t of the wanted order
+    std::vector<long double> w_after;   // output up to and including it
+    uint64_t acc_rows = 0;
+    long double acc_w = 0;
+    for (auto &sg : segs) {
+        const long double mean_len = (long double)n - 1 - 0.5L * (long double)(sg.first + sg.second - 1);
+        for (uint64_t b = sg.first; b < sg.second; b += kTile) {
+            const uint64_t rows = std::min<uint64_t>(kTile, sg.second - b);
+            const long double w = (long double)rows * std::max<long double>(mean_len, 1.0L);
+            acc_rows += rows;
+            acc_w += w;
+            rows_after.push_back(acc_rows);
+            w_after.push_back(acc_w);
+        }
     }
-    uint64_t acc = 0, t = 0;
-    for (uint32_t q = 1; q < nparts && t < TR;) {
-        const uint64_t t0 = t;
-        while (t < TR && (acc * nparts < total * q || t == t0)) acc += cnt[t++];
-        if (t >= TR) break;
-        pos.push_back(rows_before[t]);
-        q = std::max<uint32_t>(q + 1, (uint32_t)(acc * nparts / std::max<uint64_t>(total, 1)) + 1);  // (no part of a few tiles)
+    const size_t TR = rows_after.size();
+    const size_t K = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(nparts, TR));
+    size_t t = 0;  // tile rows in front of the next part
+    for (size_t q = 1; q < K; ++q) {
+        // the boundary nearest to q / K of the output, behind at least one more tile row and with one left for every later part
+        const long double target = acc_w * (long double)q / (long double)K;
+        size_t best = t + 1;
+        for (size_t c = t + 1; c + (K - q) <= TR; ++c) {
+            const long double dc = w_after[c - 1] > target ? w_after[c - 1] - target : target - w_after[c - 1];
+            const long double db = w_after[best - 1] > target ? w_after[best - 1] - target : target - w_after[best - 1];
+            if (dc < db) best = c;
+            if (w_after[c - 1] >= target) break;
+        }
+        pos.push_back(rows_after[best - 1]);
+        t = best;
     }
-    pos.push_back(R);
+    pos.push_back(acc_rows);
 }
 
 // ---- row sets --------------------------------------------------------------------------------------------------------

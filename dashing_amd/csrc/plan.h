@@ -102,8 +102,8 @@ int auto_list_cap(int p, bool upper);
 // rowsorted_rule: a range of fewer than 1024 rows per part whose span is at most 1 GiB (the destination stages it).
 bool rowsorted_rule(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts);
 // cut positions (multiples of 128 rows of the key order, front() = 0, back() = number of wanted rows) of about equal
-// tile counts.  With extra segments the positions count WANTED rows only (main range first, then the extra segments
-// in row order): the compact order the rank's buffer and the destination's tables use.
+// OUTPUT, at most nparts of them (nparts >= the tile rows: every tile row a part).  The positions count WANTED rows in the wanted order
+// (extra segments first, then the main range): the compact order the rank's buffer and the destination's tables use.
 void rowsorted_part_positions(uint64_t n, uint64_t rb, uint64_t re, uint32_t nparts, std::vector<uint64_t> &pos,
                               const std::vector<uint64_t> *extra = nullptr);
 // the key order of the rows [lo, hi): dst[0 .. hi - lo) = their indices, stable by (T, L, hi) of the per-sketch keys

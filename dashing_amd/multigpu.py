@@ -208,17 +208,23 @@ class PipelinedShards:
         return (self.stage, self.block_off) if self.rank == self.dst else None
 
 
-def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02):
+def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.005, nmsg=8):
     """The N-rank step predicted from per-rank compute times (tools/shard_model.py measures them on one GPU, bench.py
-    --gpus N on the ranks themselves): every source's parts go to rank 0 over that source's own xGMI link at `link_gbs`
-    + `round_ms` per round; a link carries one part at a time; rank 0 places a row-sorted part behind its arrival at
-    `place_rate` bytes/s.  rows[r]: rank, wall_ms, rowsorted, and either part_info = [(ready_ms, bytes)] -- when every
-    part was final, measured with events (dsh_last_part_info; shifted so that the last part ends with the rank's wall) --
-    or the older estimate from prepare_ms, pair_ms, finalize_ms, parts, bands, span_bytes: part q ready after prepare, the
-    tile kernel and (q+1)/parts of k_finalize.  rows[0] is the destination.
-    Returns (step ms, the rank that bounds it; 0: compute)."""
-    step_ms, worst = max(x["wall_ms"] for x in rows), 0
+    --gpus N on the ranks themselves), following what dsh_exchange_collect_async does: the destination (rows[0]) receives
+    in `nmsg` ROUNDS -- one grouped ncclSend/ncclRecv per round: message q of every source, the q-th nmsg-th of its
+    buffer, every source over its own xGMI link at `link_gbs`.  A source's message is ready when the part that holds its
+    last value is final; a round starts when the previous one has arrived and every message in it is ready, and lasts as
+    long as its largest message + `round_ms`.  What a round completes of the row-sorted sources' rows is put into place
+    by ONE launch on a stream of its own (`place_rate` bytes/s + `place_launch_ms`), beside the next round's transfer.
+    rows[r]: rank, wall_ms, rowsorted, and either part_info = [(ready_ms, bytes)] -- when every part was final, measured
+    on the device (dsh_last_part_info; shifted so that the last part ends with the rank's wall) -- or the older estimate
+    from prepare_ms, pair_ms, finalize_ms, parts, bands, span_bytes: part q ready after prepare, the tile kernel and
+    (q+1)/parts of k_finalize.
+    Returns (step ms, the rank that bounds it; 0: the destination's own compute)."""
+    step_ms, worst = rows[0]["wall_ms"] if rows else 0.0, 0
+    srcs = []
     for x in rows[1:]:
+        step_ms = max(step_ms, x["wall_ms"])
         parts = x.get("part_info")
         if parts:
             shift = max(0.0, x["wall_ms"] - parts[-1][0])  # (host time of the call: counted in front of the kernels)
@@ -232,11 +238,32 @@ def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02):
                 else:
                     ready = x["prepare_ms"] + x["pair_ms"] + x["finalize_ms"] * (q + 1) / k
                 parts.append((max(ready, x["wall_ms"]) if q == k - 1 else ready, x["span_bytes"] / k))
-        done = 0.0
-        for ready, by in parts:
-            done = max(ready, done) + by / (link_gbs * 1e9) * 1e3 + round_ms
-        if x["rowsorted"] and place_rate and parts:
-            done += parts[-1][1] / place_rate * 1e3  # the last part's rows put into place
-        if done > step_ms:
-            step_ms, worst = done, x["rank"]
+        total = sum(b for _, b in parts)
+        if not total:
+            continue
+        ends, acc, latest = [], 0.0, 0.0
+        for r, b in parts:
+            acc += b
+            latest = max(latest, r)  # (a message waits for every part up to the one that holds its last value)
+            ends.append((acc, latest))
+        msgs = []
+        for q in range(nmsg):
+            end = total * (q + 1) / nmsg
+            ready = next((r for e, r in ends if e >= end - 0.5), ends[-1][1])
+            msgs.append((ready, total / nmsg))
+        srcs.append((x["rank"], bool(x["rowsorted"]), msgs))
+    if not srcs:
+        return step_ms, worst
+    arrived = placed = 0.0
+    gate = 0
+    for q in range(nmsg):
+        ready_rank, ready = max(((rk, m[q][0]) for rk, _, m in srcs), key=lambda t: t[1])
+        big_rank, big = max(((rk, m[q][1]) for rk, _, m in srcs), key=lambda t: t[1])
+        gate = ready_rank if ready > arrived else big_rank
+        arrived = max(arrived, ready) + big / (link_gbs * 1e9) * 1e3 + round_ms
+        staged = sum(m[q][1] for _, rs, m in srcs if rs)
+        placed = max(placed, arrived) + (staged / place_rate * 1e3 + place_launch_ms if staged and place_rate else 0.0)
+    done = max(arrived, placed)
+    if done > step_ms:
+        step_ms, worst = done, gate
     return step_ms, worst

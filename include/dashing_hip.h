@@ -283,14 +283,19 @@ int dsh_collect_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *bounds, ui
  * The layout of every rank's buffer follows from (table, nparts, dst) alone:
  *   - the destination computes its own rows in place (d_local = d_final + the offset of its first row) as ONE part;
  *   - a rank with extra segments, or with a range of fewer than 1024 rows per part (span <= 1 GiB), goes ROW-SORTED: every
- *     segment key-ordered as one run, its parts are runs of whole tile rows of that order, d_local holds the rows in that
- *     order; the destination stages what it receives and puts the rows of every part into place (one contiguous copy
- *     per row) behind the part's transfer;
- *   - longer ranges go in parts of consecutive rows, received in place, as with dsh_collect_parts_async.
+ *     segment key-ordered as one run (a range that reaches far down the triangle as two: its last rows on their own),
+ *     d_local holds the rows in that order; the destination stages what it receives and puts the rows that are complete
+ *     into place (one contiguous copy per row) behind every round, on a stream of its own;
+ *   - longer ranges hold consecutive rows, received in place.
+ * PARTS are units of completion (runs of whole tile rows, final in order; at most nparts -- a row-sorted rank whose parts
+ * announce themselves from inside k_finalize cuts every tile row a part); what travels are MESSAGES: the exchange runs in
+ * nparts ROUNDS, round q = one grouped ncclSend/ncclRecv of message q of every source, the q-th nparts-th of its buffer,
+ * sent as soon as the part that holds its last value is final.  A round lasts as long as its largest message; with the
+ * spans of dsh_balance_rowsets about equal no link waits for another's.
  * dsh_exchange_rows_device_async computes rank `rank`'s rows (enqueued; every part announces its completion: a flag written from
  * inside k_finalize, or an event between launches -- option finalize_signal), dsh_exchange_collect_async
- * enqueues the rounds of grouped ncclSend/ncclRecv on the copy stream; every rank calls both with the same arguments;
- * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts) and how
+ * enqueues the rounds on the copy stream; every rank calls both with the same arguments;
+ * dsh_comm_wait completes them.  dsh_exchange_mode tells how a rank's buffer is laid out (rowsorted 0/1, parts at nparts) and how
  * many floats d_local must hold.  dsh_exchange_place_device does, for ONE source rank and without a communicator, what
  * the destination does with that rank's buffer (tests and single-GPU timing of an N-rank plan).
  * dsh_dist_collect(bounds = NULL) runs this pair over dsh_balance_rowsets' table. */
@@ -383,7 +388,8 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
  * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands", "items" (work items of the tile kernel),
- * "words_per_plane", "avg_tile_planes_x100" (of the last dist call). */
+ * "words_per_plane", "avg_tile_planes_x100" (of the last dist call), "frag_items", "parts_done", "parts_signalled",
+ * "place_kernel_us" (with profiling on: device time of the last dsh_exchange_place_device's placement kernel). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.
  * Every *_device entry point runs on THIS stream and (except the *_async forms) returns after its work has

@@ -260,7 +260,9 @@ def test_exchange_pair_virtual_ranks_row_sorted_parts(ctx):
             ctx.attach_device(regs.data_ptr(), n, p)  # a rank starts from the registers alone
             ctx.exchange_rows_device_async(local.data_ptr(), bounds, r, nparts, dst)
             ctx.synchronize()
-            assert ctx.info("parts_done") == k, (world, dst, nparts, r)
+            # (a row-sorted source whose parts announce themselves from inside k_finalize cuts as finely as its rows complete:
+            # every tile row a part -- the messages of the exchange are shares of its buffer, not parts)
+            assert ctx.info("parts_done") >= k if rs else ctx.info("parts_done") == k, (world, dst, nparts, r)
             if rs and span:  # key order, not the final span
                 off = dashing_amd.tri_span(n, 0, bounds[r])
                 assert not torch.equal(local[:span], want[off:off + span])
@@ -319,7 +321,7 @@ def test_exchange_pair_virtual_ranks_row_sets(ctx):
             ctx.attach_device(regs.data_ptr(), n, p)
             ctx.exchange_rows_device_async(local.data_ptr(), rows, r, nparts, dst)
             ctx.synchronize()
-            assert ctx.info("parts_done") == k and ctx.info("tiles") == rows.tiles(r), (world, dst, nparts, r)
+            assert (ctx.info("parts_done") >= k if rs else ctx.info("parts_done") == k) and ctx.info("tiles") == rows.tiles(r), (world, dst, nparts, r)
             assert ctx.info("parts_signalled") == 1  # (the default on gfx950: flags from inside one launch per band)
             tiles += rows.tiles(r)
             if r != dst:
@@ -341,7 +343,7 @@ def test_exchange_pair_virtual_ranks_row_sets(ctx):
     ctx.synchronize()
     info = ctx.last_part_info()
     ctx.set_profiling(False)
-    assert len(info) == k >= 2 and sum(b for _, b in info) == 4 * floats
+    assert len(info) >= k >= 2 and sum(b for _, b in info) == 4 * floats
     assert all(ms > 0 for ms, _ in info) and info[-1][0] == max(ms for ms, _ in info)
 
 
@@ -473,7 +475,7 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
     for r_ in mg["per_rank"]:
         assert {"prepare_ms", "pair_ms", "finalize_ms", "wall_ms", "exposed_exchange_ms", "tiles", "items", "rounds_of_512", "part_info"} <= set(r_)
         assert r_["wall_ms"] > 0 and r_["pair_ms"] > 0
-    assert len(mg["per_rank"][1]["part_info"]) == mg["per_rank"][1]["parts"] >= 1
+    assert len(mg["per_rank"][1]["part_info"]) >= mg["per_rank"][1]["parts"] >= 1  # (a signalling row-sorted rank: a part per tile row)
     ping = mg["link_gbs_measured"]
     assert ping["payload_intact"] is True and ping["single_GBs_min"] > 0 and ping["concurrent_per_link_GBs"] > 0, ping
     model = mg["model"]
