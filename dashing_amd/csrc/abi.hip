@@ -55,7 +55,7 @@ static void release_ctx(dsh_ctx *c)
     c->pin_xch.release();
     c->pin_sig.release();
     for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_sig, &c->ev_band_tiles,
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_first_tiles, &c->ev_sig, &c->ev_band_tiles,
                           &c->ev_band_aux}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
@@ -774,6 +774,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "parts_done")) *out = c->parts_done;
     else if (!std::strcmp(name, "parts_signalled")) *out = c->parts_signalled ? 1 : 0;
     else if (!std::strcmp(name, "sketch_kernel_us")) *out = (int64_t)(c->sketch_ms * 1000.0);
+    else if (!std::strcmp(name, "xch_recv_gated")) *out = c->xch_recv_gated ? 1 : 0;
     else if (!std::strcmp(name, "place_kernel_us")) *out = (int64_t)(c->place_ms * 1000.0);
     else if (!std::strcmp(name, "whatif_mfma")) {
 #ifdef DSH_WHATIF_MFMA
@@ -920,6 +921,11 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     }
     if (!std::strcmp(name, "finalize_shared_instance")) {
         c->finalize_shared_instance = v != 0;
+        return DSH_OK;
+    }
+    if (!std::strcmp(name, "xch_recv_gate")) {
+        if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "xch_recv_gate is -1 (auto), 0 or 1");
+        c->xch_recv_gate = (int)v;
         return DSH_OK;
     }
     if (!std::strcmp(name, "finalize_signal")) {

@@ -103,6 +103,9 @@ struct dsh_ctx {
     DevBuf place_tab;                   // dsh_exchange_place_device's own tables (ctx stream; xch_tab belongs to the copy stream)
     PinBuf pin_xch;
     hipEvent_t ev_xch_tab = nullptr;
+    hipEvent_t ev_first_tiles = nullptr;       // the tile kernel of the last call's first band has run
+    bool xch_recv_gated = false;               // (info) the last collect of a destination waited for its tile kernel
+    int xch_recv_gate = -1;                    // option: -1 auto | 0 | 1 (exchange.hip, the destination's receives)
     hipEvent_t ev_place_done = nullptr;        // the last placement of a collect (the copy stream joins it)
     std::vector<hipEvent_t> ev_round;          // round q of a collect has arrived (place_stream waits for it)
     bool xch_tab_in_flight = false;

@@ -403,6 +403,10 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             HIPCHK(c, launch_pair_counts(c->stream, c->kc, c->cum_bytes, (const uint32_t *)c->planes.ptr,
                                          L.Npad, c->Kpad, c->W, L.P, dt, di, ni, c->cum.ptr, nslots));
         if (b) (void)hipEventRecord(b, c->stream);
+        if (bi == 0) {  // (the destination of an exchange may post its receives behind its first tile kernel, exchange.hip)
+            if (!c->ev_first_tiles) HIPCHK(c, hipEventCreateWithFlags(&c->ev_first_tiles, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_first_tiles, c->stream));
+        }
         // (option finalize_two_streams) the k_finalize launches of a band with several segments alternate between the ctx
         // stream and the second stream: the tail of one launch runs beside the head of the next.  The second stream starts
         // behind the band's tile kernel and the ctx stream joins it again before the band's C(v) scratch is overwritten.

@@ -696,6 +696,17 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
     if (rank != dst)
         for (size_t i = 0; i < mine.nparts(); ++i)
             part_end.push_back(mine.rowsorted ? rowoff[rank][mine.cut[i + 1]] : dsh_tri_span(n, mine.rb, mine.cut[i + 1]));
+    // The destination's receives: an RCCL kernel that waits for its peers spins on the GPU; beside the phase-locked tile
+    // kernel it would slow every round down to the CU it shares.  A SHORT job of the destination (one launch of at most 8
+    // rounds: its peers then run 6 + 1 rounds and have nothing to send before about the same moment) therefore posts its
+    // receives behind its tile kernel; longer jobs post at once -- their peers' first messages come much earlier (option
+    // xch_recv_gate: -1 auto | 0 at once | 1 behind the first tile kernel).
+    if (rank == dst && world > 1 && mine.nparts() && c->ev_first_tiles) {
+        const uint64_t rounds = (c->pp.items.size() + 511) / 512;
+        const bool gate = c->xch_recv_gate == 1 || (c->xch_recv_gate < 0 && c->last_bands == 1 && rounds <= 8);
+        if (gate) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_first_tiles, 0));
+        c->xch_recv_gated = gate;
+    }
     bool placed = false;
     size_t next_wait = 0;  // (source) the first part the copy stream has not joined yet
     for (size_t q = 0; q < M && world > 1; ++q) {

@@ -208,7 +208,7 @@ class PipelinedShards:
         return (self.stage, self.block_off) if self.rank == self.dst else None
 
 
-def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.005, nmsg=8):
+def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.005, nmsg=8, dst_gate=None):
     """The N-rank step predicted from per-rank compute times (tools/shard_model.py measures them on one GPU, bench.py
     --gpus N on the ranks themselves), following what dsh_exchange_collect_async does: the destination (rows[0]) receives
     in `nmsg` ROUNDS -- one grouped ncclSend/ncclRecv per round: message q of every source, the q-th nmsg-th of its
@@ -220,8 +220,15 @@ def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.
     on the device (dsh_last_part_info; shifted so that the last part ends with the rank's wall) -- or the older estimate
     from prepare_ms, pair_ms, finalize_ms, parts, bands, span_bytes: part q ready after prepare, the tile kernel and
     (q+1)/parts of k_finalize.
+    dst_gate: None = as the library decides (a destination whose job is one launch of at most 8 rounds posts its receives
+    behind its tile kernel, so that no RCCL kernel spins beside it; option xch_recv_gate), True / False to force.
     Returns (step ms, the rank that bounds it; 0: the destination's own compute)."""
     step_ms, worst = rows[0]["wall_ms"] if rows else 0.0, 0
+    gate_ms = 0.0
+    if rows and "finalize_ms" in rows[0]:
+        short = rows[0].get("bands", 1) == 1 and rows[0].get("rounds_of_512", 99) <= 8
+        if dst_gate or (dst_gate is None and short):
+            gate_ms = max(0.0, rows[0]["wall_ms"] - rows[0]["finalize_ms"])  # (the end of its tile kernel)
     srcs = []
     for x in rows[1:]:
         step_ms = max(step_ms, x["wall_ms"])
@@ -254,7 +261,7 @@ def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.
         srcs.append((x["rank"], bool(x["rowsorted"]), msgs))
     if not srcs:
         return step_ms, worst
-    arrived = placed = 0.0
+    arrived, placed = gate_ms, 0.0
     gate = 0
     for q in range(nmsg):
         ready_rank, ready = max(((rk, m[q][0]) for rk, _, m in srcs), key=lambda t: t[1])

@@ -376,6 +376,8 @@ int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
  * at least this many rounds, default 7): a job with parts of at most 64 rounds of 512 one-plane work items has its tile kernel cut
  * at whole rounds into head and tail launches of at most 16 rounds, so that the head's parts travel while the tails compute, "overflow_frag_permille" (0..1000, default 500: a band of one-plane work items whose count lies at most that share of a round above a
  * multiple of 512 has the items left over cut into fragments of a plane that ADD their counts, so that the extra round is a fraction of one; 0 = never),
+ * "xch_recv_gate" (-1 auto | 0 | 1: the destination of an exchange posts its receives behind its first tile kernel instead of at once -- an RCCL
+ * kernel waiting for its peers spins beside the tile kernel; auto = for a job of one launch of at most 8 rounds, whose peers have nothing to send earlier),
  * "finalize_shared_instance" (0 | 1, A/B only: calls without parts take the signalling instance of k_finalize too), "finalize_signal" (-1 auto | 0 | 1: a call with parts finalizes a band in ONE launch and the parts announce themselves from inside it --
  * the copy stream waits for a part's flag with hipStreamWaitValue32 -- instead of one launch and one event per part; auto = where the
  * device supports it), "finalize_two_streams" (0|1: with events, the

@@ -497,3 +497,6 @@ def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
     run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=1,part_band_tiles=200")
     run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=0,part_band_tiles=200")
     run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="part_band_tiles=200")  # flags, bands cut per part
+    # the destination posts its receives at once, or behind its first tile kernel (auto: short jobs only)
+    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", rowsets=True, opts="xch_recv_gate=1")
+    run_mock_world(tmp_path, 3, 1400, 12, 8, "exchange", dst=1, rowsets=True, opts="xch_recv_gate=0")
