@@ -835,7 +835,6 @@ def multi_gpu_diagnostics(ctx, torch, dist, dashing_amd, multigpu, dev, regs_d, 
         my_rows = rows_of.rows(rank)
     else:
         rs, k, my_rows = False, 1, [(bounds[rank], bounds[rank + 1])]
-    items = ctx.info("items")
     ctx.set_profiling(True)  # one more pass for the parts' completion times (events; outside the timed loop)
     ctx.attach_device(regs_d.data_ptr(), n, p)
     if rows_of is not None:
@@ -843,6 +842,7 @@ def multi_gpu_diagnostics(ctx, torch, dist, dashing_amd, multigpu, dev, regs_d, 
         ctx.synchronize()
     pinfo = ctx.last_part_info() if rows_of is not None else []
     ctx.set_profiling(False)
+    items = ctx.info("items")  # (of the rank's own job: rank 0 has run the single-GPU reference pass in between)
     mine = {"rank": rank, "part_info": [(round(a, 4), b) for a, b in pinfo], "rows": my_rows, "pairs": my_pairs, "span_bytes": 4 * my_pairs, "tiles": ctx.info("tiles"), "items": items,
             "rounds_of_512": -(-items // 512), "planes_per_tile": ctx.info("avg_tile_planes_x100") / 100.0, "parts": k, "rowsorted": rs,
             "bands": ctx.info("bands"), "prepare_ms": round(km["prepare_ms"] / reps, 4), "pair_ms": round(km["pair_ms"] / reps, 4),
