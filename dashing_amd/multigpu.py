@@ -234,7 +234,7 @@ def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.
         step_ms = max(step_ms, x["wall_ms"])
         parts = x.get("part_info")
         if parts:
-            shift = max(0.0, x["wall_ms"] - parts[-1][0])  # (host time of the call: counted in front of the kernels)
+            shift = max(0.0, x["wall_ms"] - max(r for r, _ in parts))  # (host time of the call: counted in front of the kernels)
             parts = [(r + shift, b) for r, b in parts]
         else:
             k = max(x["parts"], 1)
