@@ -8,11 +8,13 @@ row-sorted parts timed on the same GPU, and a pipeline model of the transfers (N
                                                   rowsets[:prep_permille[:dst_bonus_permille]] = dsh_balance_rowsets (range + top-up
                                                   tile rows; rank 0 receives and takes the bonus)
 
-Exchange model: every source's parts go to rank 0 over that source's own xGMI link at LINK_GBS + 20 us per round; part q
-of a rank is ready after its prepare, its tile kernel and (q+1)/parts of its finalize (small parts share one launch of
-the tile kernel); a link carries one part at a time; rank 0 places a row-sorted part behind its arrival (measured copy
-rate).  The link rate is an ASSUMPTION (45 GB/s = about what RCCL point-to-point reaches on one link): the step is
-printed for 30 / 45 / 60 GB/s so that a measured rate (bench.py --gpus N: multi_gpu.link_gbs_measured) can be placed."""
+Exchange model (dashing_amd.multigpu.pipeline_model, following dsh_exchange_collect_async): NPARTS rounds; round q carries
+message q of every source -- the q-th NPARTS-th of its buffer, ready when every part (measured: dsh_last_part_info) up to the
+one that holds its last value is final -- over that source's own xGMI link at LINK_GBS; a round starts when the previous
+one has arrived, lasts as long as its largest message + 20 us; rank 0 puts the rows a round completed into place on a
+stream of its own (measured kernel rate).  The link rate is an ASSUMPTION (45 GB/s = about what RCCL point-to-point reaches
+on one link): the step is printed for 30 / 45 / 60 GB/s so that a measured rate (bench.py --gpus N:
+multi_gpu.link_gbs_measured) can be placed."""
 import json
 import os
 import sys
