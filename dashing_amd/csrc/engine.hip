@@ -255,7 +255,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     if (with_parts) {  // the signal block of the parts (kernels.h kSig*; used when the call turns out to signal, below)
         HIPCHK(c, c->sig.ensure((size_t)kSigWords * sizeof(uint32_t)));
         if (c->sig_gen == 0) {  // (first use: the flags must not hold garbage that passes for a generation)
-            HIPCHK(c, hipMemsetAsync(c->sig.ptr, 0, (size_t)kSigTileCnt * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->sig.ptr, 0, (size_t)kSigWords * sizeof(uint32_t), c->stream));  // (and the tile counters, which clear themselves from then on)
             c->sig_gen = 1;
         }
     }
@@ -332,7 +332,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     // Part signalling (kernels.h, k_finalize_signal): with parts, ONE k_finalize launch per band; the parts' flags are
     // written from inside it and the copy stream waits for them with hipStreamWaitValue32 (exchange.hip).  Not with the
     // stamped / general instances (profiling aids, rectangles) and not where the device lacks stream wait-value.
-    bool signal = false;
+    bool signal = false, sig_upload = false;
     if (with_parts && pp.nparts >= 1 && pp.nparts <= kSigMaxParts && !c->finalize_timing && !c->finalize_stop && c->finalize_signal != 0) {
         signal = device_can_wait_value(c);
         if (!signal && c->finalize_signal == 1) return fail(c, DSH_ENODEV, "option finalize_signal = 1, but the device does not support hipStreamWaitValue32");
@@ -346,16 +346,17 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             HIPCHK(c, hipEventSynchronize(c->ev_sig));
             c->sig_in_flight = false;
         }
-        HIPCHK(c, c->pin_sig.ensure((kSigMaxParts + 2) * sizeof(uint32_t)));
-        uint32_t *tot = (uint32_t *)c->pin_sig.ptr;
+        // the words kSigPartCnt .. kSigStamp of the block lie one behind the other: the parts' counters (zero), their totals,
+        // the call's generation, the stamp switch -- uploaded with the first band's lists, in one launch (the tile counters
+        // clear themselves: k_finalize_signal)
+        static_assert(kSigPartTotal == kSigPartCnt + kSigMaxParts && kSigGen == kSigPartTotal + kSigMaxParts && kSigStamp == kSigGen + 1, "signal block layout");
+        HIPCHK(c, c->pin_sig.ensure((2 * kSigMaxParts + 2) * sizeof(uint32_t)));
+        uint32_t *blk = (uint32_t *)c->pin_sig.ptr, *tot = blk + kSigMaxParts;
+        for (uint32_t qd = 0; qd < kSigMaxParts; ++qd) blk[qd] = 0u;
         for (uint32_t qd = 0; qd < kSigMaxParts; ++qd) tot[qd] = qd < pp.part_tiles.size() ? pp.part_tiles[qd] : 0u;
         tot[kSigMaxParts] = c->sig_gen;                   // kSigGen
         tot[kSigMaxParts + 1] = c->profiling ? 1u : 0u;   // kSigStamp
-        HIPCHK(c, hipMemsetAsync((uint32_t *)c->sig.ptr + kSigPartCnt, 0, kSigMaxParts * sizeof(uint32_t), c->stream));
-        HIPCHK(c, launch_upload(c->stream, (uint32_t *)c->sig.ptr + kSigPartTotal, tot, (kSigMaxParts + 2) * sizeof(uint32_t)));
-        if (!c->ev_sig) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sig, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->ev_sig, c->stream));
-        c->sig_in_flight = true;
+        sig_upload = true;
     }
     const float ksinv_f = (float)(1. / (double)job.k);
     if (c->finalize_timing) {
@@ -378,9 +379,21 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         const uint32_t ni = (uint32_t)(item_off[bi + 1] - item_off[bi]);
         if (ni) std::memcpy(pinI + item_off[bi], I.data() + item_off[bi], (size_t)ni * sizeof(uint4));
         c->host_lists_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_b0).count();
-        HIPCHK(c, launch_upload(c->stream, (uint4 *)c->tiles.ptr + bd.first, pinT + bd.first, (size_t)nt * sizeof(uint4)));
-        HIPCHK(c, launch_upload(c->stream, (uint4 *)c->tiles.ptr + T.size() + bd.first, pinF + bd.first, (size_t)nt * sizeof(uint4)));
-        if (ni) HIPCHK(c, launch_upload(c->stream, (uint4 *)c->items.ptr + item_off[bi], pinI + item_off[bi], (size_t)ni * sizeof(uint4)));
+        {
+            UploadSegs up;
+            uint32_t nseg = 0;
+            if (sig_upload) up.add(nseg, (uint32_t *)c->sig.ptr + kSigPartCnt, c->pin_sig.ptr, (2 * kSigMaxParts + 2) * sizeof(uint32_t));
+            up.add(nseg, (uint4 *)c->tiles.ptr + bd.first, pinT + bd.first, (size_t)nt * sizeof(uint4));
+            up.add(nseg, (uint4 *)c->tiles.ptr + T.size() + bd.first, pinF + bd.first, (size_t)nt * sizeof(uint4));
+            up.add(nseg, (uint4 *)c->items.ptr + item_off[bi], pinI + item_off[bi], (size_t)ni * sizeof(uint4));
+            HIPCHK(c, launch_upload_segs(c->stream, up, nseg));
+            if (sig_upload) {
+                if (!c->ev_sig) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sig, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->ev_sig, c->stream));
+                c->sig_in_flight = true;
+                sig_upload = false;
+            }
+        }
         HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));
         c->lists_in_flight = true;
         const uint4 *dt = (const uint4 *)c->tiles.ptr + bd.first;
@@ -418,7 +431,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             plan::Seg all{bd.first, bd.second, -1, 1};
             for (const plan::Seg &sg : pp.segs[bi]) all.hist_bins = std::max(all.hist_bins, sg.hist_bins);
             one_seg.push_back(all);
-            HIPCHK(c, hipMemsetAsync((uint32_t *)c->sig.ptr + kSigTileCnt, 0, (size_t)nt * sizeof(uint32_t), c->stream));
         }
         if (two) {
             HIPCHK(c, hipEventRecord(c->ev_band_tiles, c->stream));

@@ -97,6 +97,22 @@ constexpr uint32_t kSigPartFlag = 0, kSigPartCnt = kSigMaxParts, kSigPartTotal =
                    kSigGen = 3 * kSigMaxParts, kSigStamp = kSigGen + 1,  // (uploaded with the totals: kSigMaxParts + 2 words)
                    kSigPartTime = 3 * kSigMaxParts + 2, kSigT0 = 5 * kSigMaxParts + 2, kSigTileCnt = 5 * kSigMaxParts + 4,
                    kSigWords = kSigTileCnt + 65536;
+// (k_upload_segs) up to four uploads from page-locked staging in one launch
+struct UploadSeg {
+    uint32_t *dst;
+    const uint32_t *src;
+    uint64_t nwords;
+};
+struct UploadSegs {
+    UploadSeg s[4];
+    void add(uint32_t &n, void *dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return;
+        s[n].dst = (uint32_t *)dst, s[n].src = (const uint32_t *)src, s[n].nwords = (bytes + 3) / 4;
+        ++n;
+    }
+};
+hipError_t launch_upload_segs(hipStream_t st, const UploadSegs &u, uint32_t nseg);
 hipError_t launch_wall_stamp(hipStream_t st, unsigned long long *out);
 // (k_rows_place) the rows of one source's part in a round of the exchange: positions [pos0, pos0 + nrows) of its key order
 struct PlaceEnt {

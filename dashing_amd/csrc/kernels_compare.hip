@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
     if (threadIdx.x == 0) {
         uint32_t *sig = a.sig;
         if (atomicAdd(sig + kSigTileCnt + tidx, 1u) == kTile - 1) {  // the tile's last row
+            atomicExch(sig + kSigTileCnt + tidx, 0u);  // (ready for the next launch: no clearing between the bands of a call)
             const uint32_t q = a.tiles[tidx].w >> 16;
             if (atomicAdd(sig + kSigPartCnt + q, 1u) + 1u == sig[kSigPartTotal + q]) {  // the part's last tile
                 if (sig[kSigStamp]) reinterpret_cast<unsigned long long *>(sig + kSigPartTime)[q] = wall_clock64();
@@ -1852,6 +1853,25 @@ __global__ __launch_bounds__(256) void k_upload(uint32_t *__restrict__ dst, cons
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += stride) dst[w] = src[w];
+}
+
+// up to four uploads in ONE launch (blockIdx.y = the segment): a band's lists and, in front of the first band, the parts'
+// signal block -- four launches of 4 us and as many gaps in front of a tile kernel otherwise (profiles/rd5tr)
+__global__ __launch_bounds__(256) void k_upload_segs(UploadSegs u)
+{
+    const UploadSeg g = u.s[blockIdx.y];
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < g.nwords; w += stride) g.dst[w] = g.src[w];
+}
+
+hipError_t launch_upload_segs(hipStream_t st, const UploadSegs &u, uint32_t nseg)
+{
+    uint64_t most = 0;
+    for (uint32_t i = 0; i < nseg; ++i) most = std::max(most, u.s[i].nwords);
+    if (!nseg || !most) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(256, (most + 255) / 256);
+    hipLaunchKernelGGL(k_upload_segs, dim3(blocks, nseg), dim3(256), 0, st, u);
+    return hipGetLastError();
 }
 
 hipError_t launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes)
