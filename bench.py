@@ -460,7 +460,13 @@ def run(args, backend, world, rank, line, dist_on):
     if multi:
         exchange = "torch.distributed" if backend == "nccl" else "gloo (host staged)"
         path, ver = dashing_amd.comm_library()
-        rccl_info = {"library": path, "nccl_version_code": ver, "available_on_rank0": dashing_amd.comm_available(),
+        # every RCCL image mapped into this process (torch bundles one with the soname librccl.so.1, so the library's
+        # dlopen("librccl.so.1") resolves to THAT image when torch was imported first: one copy, shared) and the one
+        # whose ncclSend/ncclRecv the C-ABI exchange calls
+        copies = sorted({l.split()[-1] for l in open("/proc/self/maps") if "rccl" in l.rsplit("/", 1)[-1] and l.split()[-1].startswith("/")})
+        rccl_info = {"library": path, "carried_the_exchange": None, "rccl_copies_mapped": copies,
+                     "torch_bundled_rccl": next((c_ for c_ in copies if "/torch/lib/" in c_), None),
+                     "nccl_version_code": ver, "available_on_rank0": dashing_amd.comm_available(),
                      "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"),
                      "torch_nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None}
         # (DSH_BENCH_EXCHANGE=cabi-mock with the gloo dry run: the C-ABI exchange between the ranks sharing cuda:0 over the
@@ -489,6 +495,8 @@ def run(args, backend, world, rank, line, dist_on):
                 sys.stderr.write("bench.py: rank %d: C-ABI communicator not used (%s): torch.distributed exchange\n" % (rank, why))
                 rccl_info["cabi_fallback_reason"] = why
     use_cabi = exchange.startswith("c-abi")
+    if rccl_info is not None:
+        rccl_info["carried_the_exchange"] = path if use_cabi else ("torch.distributed (%s)" % rccl_info["torch_bundled_rccl"] if backend == "nccl" else "gloo")
     NPARTS = int(os.environ.get("DSH_BENCH_PARTS", "8"))
     if use_cabi:
         exchange = "c-abi rccl, pipelined in <= %d parts per rank (dsh_exchange_rows_device_async + dsh_exchange_collect_async)" % NPARTS
@@ -719,9 +727,12 @@ def run(args, backend, world, rank, line, dist_on):
             del ref
         else:
             parity = {"assembled_equals_single_gpu": None, "note": "spans kept on their ranks (not gathered): rank 0's own span is checked against the CPU oracle"}
-    if rank == 0 and not args.no_cpu_baseline and (not multi or not gather):
+    if rank == 0 and not args.no_cpu_baseline:
+        # every line carries the CPU leg -- with N ranks a bounded 4-s sample on rank 0, outside the
+        # timed loop, while the other ranks wait in the next collective.  A gathered run holds the whole assembled matrix
+        # on rank 0; otherwise only the rows rank 0 computed can be compared.
         cpu, par2 = cpu_baseline(regs_h, full, n, p, args.cpu_seconds if not multi else min(args.cpu_seconds, 4.0),
-                                 max_rows=rows_of.rows(0)[0][1] if rows_of is not None else bounds[1])
+                                 max_rows=None if (not multi or gather) else (rows_of.rows(0)[0][1] if rows_of is not None else bounds[1]))
         parity = par2 if parity is None else {**parity, "rank0_span_vs_cpu": par2}
 
     line.update({

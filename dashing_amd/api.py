@@ -26,7 +26,7 @@ SYMBOLS = [
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
     "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_exchange_mode", "dsh_exchange_rows_device_async",
-    "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
+    "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_exchange_probe_parts_async", "dsh_diag_spin_start", "dsh_diag_spin_stop", "dsh_abi_version", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_balance_rowsets", "dsh_rowsets_from_bounds", "dsh_rowsets_rank", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_last_part_info", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",
@@ -80,6 +80,8 @@ def load_library():
             "or `make -C dashing_amd/csrc` (there is no CPU fallback)" % path)
     _preload_torch_hip_runtime()
     lib = C.CDLL(path)
+    if int(lib.dsh_abi_version()) != ABI_VERSION:  # (a stale in-tree .so: shifted arguments, not link errors)
+        raise ImportError("%s has ABI version %d, this binding was written against %d: rebuild (make -C dashing_amd/csrc)" % (path, lib.dsh_abi_version(), ABI_VERSION))
     u64, i32, vp = C.c_uint64, C.c_int, C.c_void_p
     lib.dsh_backend_name.restype = C.c_char_p
     lib.dsh_device_count.restype = i32
@@ -116,6 +118,11 @@ def load_library():
     lib.dsh_exchange_rows_device_async.argtypes = [vp, i32, i32, i32, vp, i32, C.c_uint32, i32, vp]
     lib.dsh_exchange_collect_async.argtypes = [vp, u64, vp, C.c_uint32, vp, vp, i32]
     lib.dsh_exchange_place_device.argtypes = [vp, vp, i32, C.c_uint32, i32, vp, vp]
+    lib.dsh_exchange_probe_parts_async.argtypes = [vp, u64, vp, i32, C.c_uint32, i32, vp, vp]
+    lib.dsh_diag_spin_start.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.dsh_diag_spin_stop.argtypes = [vp]
+    lib.dsh_abi_version.argtypes = []
+    lib.dsh_abi_version.restype = C.c_int
     lib.dsh_balance_rowsets.argtypes = [u64, C.c_uint32, i32, i32, i32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.dsh_rowsets_from_bounds.argtypes = [vp, C.c_uint32, vp]
     lib.dsh_rowsets_rank.argtypes = [u64, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), C.POINTER(u64)]
@@ -160,6 +167,13 @@ def load_library():
 
 def backend_name():
     return load_library().dsh_backend_name().decode()
+
+
+ABI_VERSION = 6  # include/dashing_hip.h DSH_ABI_VERSION this binding was written against
+
+
+def abi_version():
+    return int(load_library().dsh_abi_version())
 
 
 def device_count():
@@ -520,6 +534,17 @@ class Context:
     def exchange_place_device(self, rows, src, nparts, src_local_ptr, final_ptr, dst=0):
         t = _table(self.n, rows)
         self._ck(self._lib.dsh_exchange_place_device(self._h, t.ctypes.data, src, nparts, dst, C.c_void_p(src_local_ptr), C.c_void_p(final_ptr)))
+
+    def exchange_probe_parts_async(self, n, rows, rank, nparts, local_ptr, probe_ptr, dst=0):
+        """behind every part's gate a copy KERNEL of the part's share of the rank's buffer into `probe` (diagnostic)"""
+        t = _table(n, rows)
+        self._ck(self._lib.dsh_exchange_probe_parts_async(self._h, n, t.ctypes.data, rank, nparts, dst, C.c_void_p(local_ptr), C.c_void_p(probe_ptr)))
+
+    def diag_spin_start(self, nblocks, threads=256, lds_bytes=16384, max_ms=2000):
+        self._ck(self._lib.dsh_diag_spin_start(self._h, nblocks, threads, lds_bytes, max_ms))
+
+    def diag_spin_stop(self):
+        self._ck(self._lib.dsh_diag_spin_stop(self._h))
 
     def comm_wait(self):
         """dsh_wait with a deadline on the RCCL traffic (DSH_COMM_TIMEOUT_S): an error instead of a hang"""

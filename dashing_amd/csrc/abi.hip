@@ -27,6 +27,8 @@ extern "C" {
 
 const char *dsh_backend_name(void) { return "hip:gfx950"; }
 
+int dsh_abi_version(void) { return DSH_ABI_VERSION; }
+
 int dsh_device_count(void)
 {
     int n = 0;
@@ -41,6 +43,15 @@ static void release_ctx(dsh_ctx *c)
     (void)hipSetDevice(c->device);
     for (hipStream_t s : {c->stream, c->copy_stream, c->aux_stream, c->place_stream})
         if (s) (void)hipStreamSynchronize(s);
+    if (c->spin_running && c->spin_flag) *(volatile uint32_t *)c->spin_flag = 1;
+    if (c->spin_stream) {
+        (void)hipStreamSynchronize(c->spin_stream);
+        (void)hipStreamDestroy(c->spin_stream);
+        c->spin_stream = nullptr;
+    }
+    c->spin_running = false;
+    if (c->spin_flag) (void)hipHostFree(c->spin_flag);
+    c->spin_flag = nullptr;
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
                       &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->place_tab, &c->sig, &c->perm, &c->items, &c->cum, &c->tiles,

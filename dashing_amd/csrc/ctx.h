@@ -184,6 +184,10 @@ struct dsh_ctx {
     int finalize_timing = 0;  // profiling only: the s_memtime-stamped instance of k_finalize (same results, per-phase cycles)
     DevBuf phase_cyc;       // 8 x u64 of the last call with finalize_timing
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
+    // diagnostics (dsh_diag_spin_*): a kernel that waits like an RCCL receive kernel, on a stream of its own
+    uint32_t *spin_flag = nullptr;      // page-locked, mapped
+    hipStream_t spin_stream = nullptr;
+    bool spin_running = false;
     // profiling
     bool profiling = false;
     double place_ms = 0;  // (profiling) device time of the last dsh_exchange_place_device's placement kernel

@@ -592,6 +592,7 @@ int dsh_exchange_collect_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, 
     if (rank == dst && !d_final) return DSH_EINVAL;
     const std::vector<XMode> modes = xmodes(n, rs, nparts, dst, c->parts_signalled ? rank : -1);  // (as this rank's compute call cut them)
     const XMode &mine = modes[rank];
+    if (n < 2) return DSH_OK;  // (dsh_exchange_rows_device_async computed nothing either: no pairs, no messages)
     if (c->parts_done != mine.nparts())
         return fail(c, DSH_ESTATE, "dsh_exchange_rows_device_async of this rank's rows must come first (%u parts computed, %zu expected)",
                     c->parts_done, mine.nparts());
@@ -827,6 +828,104 @@ int dsh_exchange_place_device(dsh_ctx *c, const uint64_t *rowsets, int src, uint
     return DSH_OK;
 }
 
+/* ---- diagnostics of the exchange on ONE GPU (no communicator needed) ------------------------------------------------ */
+namespace {
+
+// what an RCCL send kernel does with a part: plain loads of the rank's buffer through the L2 of whatever XCD the
+// workgroup runs on (NOT the copy engine, which reads memory), stores into another buffer
+__global__ __launch_bounds__(256) void k_probe_copy(const float *__restrict__ src, float *__restrict__ dst, uint64_t cnt)
+{
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < cnt; x += (uint64_t)gridDim.x * 256) dst[x] = src[x];
+}
+
+// a kernel that waits like an RCCL receive kernel whose peers have nothing to send yet: `threads` lanes per workgroup,
+// `lds` bytes of LDS held, lane 0 polling a word of page-locked host memory; leaves when the word is set or after
+// max_ticks of the device's wall clock (so that a host that never comes back cannot hang the GPU)
+__global__ void k_diag_spin(const uint32_t *flag, unsigned long long max_ticks, uint32_t *touched)
+{
+    extern __shared__ uint32_t spin_lds[];
+    if (threadIdx.x == 0) spin_lds[0] = blockIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        uint32_t v = 0;
+        if (threadIdx.x == 0) v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = __shfl(v, 0);
+        if (__syncthreads_or(v != 0 || wall_clock64() - t0 > max_ticks)) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (threadIdx.x == 0 && touched) atomicAdd(touched, spin_lds[0] + 1 - blockIdx.x);
+}
+
+}  // namespace
+
+int dsh_exchange_probe_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *rowsets, int rank, uint32_t nparts, int dst,
+                                   const void *d_local, void *d_probe)
+{
+    if (!c || !rowsets || nparts == 0 || rank < 0 || !d_local || !d_probe) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    plan::RowSets rs;
+    if ((rc = parse_table(c, n, rowsets, dst, rs))) return rc;
+    if ((uint32_t)rank >= rs.world) return fail(c, DSH_EINVAL, "bad rank %d (world %u)", rank, rs.world);
+    const std::vector<XMode> modes = xmodes(n, rs, nparts, dst, c->parts_signalled ? rank : -1);  // (as the compute call cut them)
+    const XMode &mine = modes[(size_t)rank];
+    if (c->parts_done != mine.nparts())
+        return fail(c, DSH_ESTATE, "dsh_exchange_rows_device_async of this rank's rows must come first (%u parts computed, %zu expected)",
+                    c->parts_done, mine.nparts());
+    // where the parts end in the rank's buffer (the destination computes relative to its first row, as one part)
+    uint64_t at = 0;
+    for (size_t i = 0; i < mine.nparts(); ++i) {
+        uint64_t end;
+        if (rank == dst) end = dsh_tri_span(n, mine.rb, mine.extra.empty() ? mine.re : mine.extra.back());
+        else if (mine.rowsorted) end = c->lay.rowoff_w[mine.cut[i + 1]];
+        else end = dsh_tri_span(n, mine.rb, mine.cut[i + 1]);
+        if ((rc = wait_part(c, i))) return rc;
+        if (end > at) {
+            const uint64_t cnt = end - at;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((cnt + 255) / 256, 2048);
+            hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(256), 0, c->copy_stream, (const float *)d_local + at, (float *)d_probe + at, cnt);
+            HIPCHK(c, hipGetLastError());
+        }
+        at = std::max(at, end);
+    }
+    return DSH_OK;
+}
+
+int dsh_diag_spin_start(dsh_ctx *c, uint32_t nblocks, uint32_t threads, uint32_t lds_bytes, uint32_t max_ms)
+{
+    if (!c || nblocks == 0 || nblocks > 4096 || threads < 64 || threads > 1024 || (threads & 63) || lds_bytes > 160 * 1024 || max_ms == 0 || max_ms > 10000)
+        return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (c->spin_running) return fail(c, DSH_ESTATE, "dsh_diag_spin_stop first");
+    (void)device_can_wait_value(c);  // (also asks for the wall clock's rate)
+    if (c->wall_clock_khz <= 0) return fail(c, DSH_ENODEV, "the device reports no wall clock rate");
+    if (!c->spin_flag) HIPCHK(c, hipHostMalloc((void **)&c->spin_flag, 64, hipHostMallocMapped));
+    if (!c->spin_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->spin_stream, hipStreamNonBlocking));
+    *(volatile uint32_t *)c->spin_flag = 0;
+    uint32_t *dflag = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer((void **)&dflag, c->spin_flag, 0));
+    if (lds_bytes > 64 * 1024) HIPCHK(c, ensure_dynamic_lds((const void *)k_diag_spin, lds_bytes));
+    hipLaunchKernelGGL(k_diag_spin, dim3(nblocks), dim3(threads), std::max<uint32_t>(lds_bytes, 16), c->spin_stream, dflag,
+                       (unsigned long long)max_ms * (unsigned long long)c->wall_clock_khz, (uint32_t *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    c->spin_running = true;
+    return DSH_OK;
+}
+
+int dsh_diag_spin_stop(dsh_ctx *c)
+{
+    if (!c) return DSH_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->spin_running) return DSH_OK;
+    *(volatile uint32_t *)c->spin_flag = 1;
+    c->spin_running = false;
+    HIPCHK(c, hipStreamSynchronize(c->spin_stream));
+    return DSH_OK;
+}
+
 int dsh_allgather_device(dsh_ctx *c, const void *d_send, uint64_t bytes_per_rank, void *d_recv)
 {
     if (!c || (bytes_per_rank && (!d_send || !d_recv))) return DSH_EINVAL;
@@ -849,6 +948,7 @@ int dsh_dist_collect(dsh_ctx *c, int estim, int result_type, int k, const uint64
         // the library's own partition: balanced row sets (range + top-up tile rows, dsh_balance_rowsets) through the
         // pipelined exchange pair -- what bench.py --gpus N times, for a host without device pointers
         if (dst < 0 || dst >= world) return fail(c, DSH_EINVAL, "bad destination rank %d (world %d)", dst, world);
+        if (n < 2) return DSH_OK;  // no pairs: an empty matrix on every rank, nothing to exchange
         plan::RowSets rs;
         plan::balance_rowsets(n, (uint32_t)world, rs, ~0u, dst);
         std::vector<uint64_t> tab(rs.words());

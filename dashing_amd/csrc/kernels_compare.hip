@@ -1500,8 +1500,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
         tidx = (((blockIdx.x >> 3) >> 7) << 3) + (blockIdx.x & 7u);
         if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles: no tile, nothing to count)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this lane's write-through stores have reached memory ...
-    __syncthreads();                                         // ... and so have those of every lane of the block
+    // every WAVE waits for its own write-through stores (gfx9 counts stores in vmcnt; a workgroup-scope release fence
+    // compiles to lgkmcnt(0) only, which would let wave 1's stores still be in flight when wave 0 counts the block:
+    // ADVICE r5) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // ... so behind the barrier the stores of every lane of the block have been acknowledged
     if (threadIdx.x == 0) {
         uint32_t *sig = a.sig;
         if (atomicAdd(sig + kSigTileCnt + tidx, 1u) == kTile - 1) {  // the tile's last row

@@ -54,6 +54,13 @@ extern "C" {
 
 typedef struct dsh_ctx dsh_ctx;
 
+/* ABI version: bumped whenever an entry point changes its signature or a table its layout (6: dsh_exchange_* take a
+ * row-set table instead of bounds + world).  A host compiled against another DSH_ABI_VERSION links fine but would pass
+ * shifted arguments: compare with dsh_abi_version() once at start-up.  (A bounds array handed to a function that now
+ * parses a row-set table is refused, not over-read: its first word, 0, is not a valid world.) */
+#define DSH_ABI_VERSION 6
+int dsh_abi_version(void);
+
 /* ---- context ---------------------------------------------------------------------------- */
 const char *dsh_backend_name(void);       /* "hip:gfx950" */
 int dsh_device_count(void);               /* number of visible HIP devices (0 if none) */
@@ -312,6 +319,21 @@ int dsh_exchange_collect_async(dsh_ctx *ctx, uint64_t n, const uint64_t *rowsets
                                void *d_final, int dst);
 int dsh_exchange_place_device(dsh_ctx *ctx, const uint64_t *rowsets, int src, uint32_t nparts, int dst,
                               const void *d_src_local, void *d_final);
+/* Diagnostics of the exchange on ONE GPU (tests/test_gpu_multirank.py, tools/interference_probe.py; no communicator):
+ *   dsh_exchange_probe_parts_async  after dsh_exchange_rows_device_async with the same (table, rank, nparts, dst): enqueues
+ *                        on the copy stream, for every part of the rank's call, the part's gate (the flag k_finalize
+ *                        sets / the event) and behind it a copy KERNEL of the part's share of d_local into d_probe at the
+ *                        same offsets -- plain loads through the L2s while k_finalize is still running, exactly what an
+ *                        RCCL send kernel does with the part (the copy engine of a hipMemcpy reads memory instead).
+ *                        dsh_wait / dsh_comm_wait completes it.  d_probe: as many floats as d_local.
+ *   dsh_diag_spin_start  occupies `nblocks` workgroups of `threads` lanes and `lds_bytes` of LDS each with a kernel that
+ *                        polls a word of host memory -- what an RCCL receive kernel does while its peers have nothing to
+ *                        send -- on a stream of its own, until dsh_diag_spin_stop or max_ms (<= 10 000) have passed:
+ *                        measures what such a kernel costs the tile kernel beside it (option xch_recv_gate). */
+int dsh_exchange_probe_parts_async(dsh_ctx *ctx, uint64_t n, const uint64_t *rowsets, int rank, uint32_t nparts, int dst,
+                                   const void *d_local, void *d_probe);
+int dsh_diag_spin_start(dsh_ctx *ctx, uint32_t nblocks, uint32_t threads, uint32_t lds_bytes, uint32_t max_ms);
+int dsh_diag_spin_stop(dsh_ctx *ctx);
 int dsh_comm_available(void);
 int dsh_comm_library(char *path_out, size_t cap, int *version_out);
 int dsh_comm_unique_id(void *id_out);

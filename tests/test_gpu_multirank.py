@@ -467,6 +467,14 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
     assert mg["ranks"] == 2 and mg["exchange"].startswith("c-abi rccl"), mg
     assert "mock_rccl" in mg["exchange_library"]["library"]
     assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+    # an N > 1 line carries the CPU leg too, checked against the ASSEMBLED matrix
+    cpu = line["cpu_baseline"]
+    assert cpu is not None and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port", cpu
+    assert line["parity_vs_cpu"]["rank0_span_vs_cpu"]["max_rel_diff"] <= 1e-6
+    # both RCCL copies a process may hold are named, and which one carried the exchange
+    xl = mg["exchange_library"]
+    assert xl["carried_the_exchange"] == xl["library"] and isinstance(xl["rccl_copies_mapped"], list)
+    assert any("mock_rccl" in p_ for p_ in xl["rccl_copies_mapped"])
     # the line is self-diagnosing: the row sets, every rank's phases, the link rate measured through
     # the library's communicator, and the pipeline model's prediction for these times at that rate beside the measurement
     assert [d["rank"] for d in mg["row_sets"]] == [0, 1] and sum(d["pairs"] for d in mg["row_sets"]) == 3000 * 2999 // 2
@@ -500,3 +508,85 @@ def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
     # the destination posts its receives at once, or behind its first tile kernel (auto: short jobs only)
     run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", rowsets=True, opts="xch_recv_gate=1")
     run_mock_world(tmp_path, 3, 1400, 12, 8, "exchange", dst=1, rowsets=True, opts="xch_recv_gate=0")
+
+
+@pytest.mark.parametrize("signal", [1, 0])
+def test_signalled_parts_are_visible_to_a_kernel_reader_with_inputs_changing_every_step(signal):
+    """VERDICT r5 item 2 / ADVICE r5: the parts of a source rank announce themselves from INSIDE the running k_finalize
+    (write-through stores, a flag, hipStreamWaitValue32 on the copy stream) and the next thing on the copy stream of a real
+    run is an RCCL send KERNEL that reads the part through some XCD's L2.  The stand-in transport reads by copy engine and
+    every other test recomputes identical values, so a flag raised before the data, or a stale L2 line of the previous
+    step, would pass unseen.  Here: behind every part's gate a copy kernel (dsh_exchange_probe_parts_async: plain loads
+    from workgroups on all XCDs, while k_finalize is still running) copies the part into a side buffer, and the register
+    matrix CHANGES every step (two collections taken in turn), so that anything left over from the previous step is a
+    wrong value.  40 steps, several virtual ranks of an 8-rank plan (row-sorted with top-ups, consecutive rows, the
+    destination), both completion schemes (flags from inside one launch / an event per part)."""
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    n, p, world, nparts, dst = 5200, 12, 8, 8, 0
+    mats = [torch.from_numpy(synth.survey_sketches(n, p, seed=s)[0]).cuda() for s in (31, 32)]
+    with dashing_amd.Context(0) as ctx:
+        ctx.set_option("finalize_signal", signal)
+        rows = dashing_amd.balance_rowsets(n, world, -1, dst)
+        # what every step must produce: the rank's buffer after a full synchronisation, per collection
+        for rank in (1, 4, 7, dst):
+            rs, k, floats = dashing_amd.exchange_mode(n, rows, rank, nparts, dst, want_floats=True)
+            assert floats > 0
+            local = torch.empty(floats, dtype=torch.float32, device="cuda")
+            probe = torch.empty(floats, dtype=torch.float32, device="cuda")
+            want = []
+            for m in mats:
+                ctx.attach_device(m.data_ptr(), n, p)
+                ctx.exchange_rows_device_async(local.data_ptr(), rows, rank, nparts, dst)
+                ctx.synchronize()
+                want.append(local.clone())
+            assert not torch.equal(want[0], want[1])
+            assert ctx.info("parts_signalled") == signal
+            for step in range(40):
+                which = step & 1
+                probe.fill_(-5.0)
+                torch.cuda.synchronize()
+                ctx.attach_device(mats[which].data_ptr(), n, p)
+                ctx.exchange_rows_device_async(local.data_ptr(), rows, rank, nparts, dst)
+                ctx.exchange_probe_parts_async(n, rows, rank, nparts, local.data_ptr(), probe.data_ptr(), dst)
+                ctx.synchronize()
+                bad = int((probe != want[which]).sum().item())
+                assert bad == 0, "rank %d step %d (finalize_signal=%d): %d of %d values read behind a part's gate differ from the step's result (stale: %d equal the previous step's)" % (
+                    rank, step, signal, bad, floats, int(((probe != want[which]) & (probe == want[1 - which])).sum().item()))
+                assert torch.equal(local, want[which])
+
+
+def test_diag_spin_leaves_by_itself_and_results_do_not_change(ctx):
+    """dsh_diag_spin_start: workgroups that wait like an RCCL receive kernel beside the library's kernels -- they leave on
+    dsh_diag_spin_stop or when max_ms have passed (a host that never comes back cannot hang the GPU), a second start
+    without a stop is refused, and a compare call beside them gives the same bytes."""
+    import time
+
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    n, p = 1500, 12
+    regs = torch.from_numpy(synth.survey_sketches(n, p, seed=5)[0]).cuda()
+    ctx.attach_device(regs.data_ptr(), n, p)
+    want = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device="cuda")
+    ctx.dist_rows_device(want.data_ptr(), 0, n)
+    ctx.synchronize()
+    got = torch.zeros_like(want)
+    ctx.diag_spin_start(16, 256, 32768, 3000)
+    with pytest.raises(dashing_amd.DshError):
+        ctx.diag_spin_start(16, 256, 32768, 3000)
+    ctx.attach_device(regs.data_ptr(), n, p)
+    ctx.dist_rows_device(got.data_ptr(), 0, n)
+    ctx.synchronize()
+    ctx.diag_spin_stop()
+    assert torch.equal(got, want)
+    t0 = time.perf_counter()
+    ctx.diag_spin_start(8, 512, 65536, 200)  # nobody stops it: it leaves after 200 ms
+    time.sleep(0.5)
+    ctx.diag_spin_stop()
+    assert time.perf_counter() - t0 < 5.0
