@@ -887,13 +887,17 @@ def multi_gpu_diagnostics(ctx, torch, dist, dashing_amd, multigpu, dev, regs_d, 
             place_rate = 4 * fl1 / best
             del tmp
     if rank == 0 and world > 1:
-        def predict(g):
-            ms, worst = multigpu.pipeline_model(allr, place_rate, g, nmsg=nparts)
+        def predict(g, interference=None):
+            ms, worst = multigpu.pipeline_model(allr, place_rate, g, nmsg=nparts, dst_interference=interference)
             return {"step_model_ms": round(ms, 4), "bound_by": "link/placement of rank %d" % worst if worst else "compute (slowest rank)"}
 
         model = {"what": "dashing_amd.multigpu.pipeline_model (the model of tools/shard_model.py) over the per-rank times above, following dsh_exchange_collect_async: %d rounds, message q of every source (the q-th share of its buffer, ready when the part that holds its last value is final) over its own link into rank 0, a round as long as its largest message + 20 us, the completed rows of a round placed by one launch at place_rate beside the next round" % nparts,
                  "place_rate_GBs": round(place_rate / 1e9, 2) if place_rate else None,
                  "sensitivity_by_assumed_link_GBs": {"%g" % g: predict(g) for g in (30.0, 45.0, 60.0)},
+                 "with_measured_recv_interference_at_45_GBs": {k_: predict(45.0, v_) for k_, v_ in multigpu.MEASURED_RECV_INTERFERENCE.items()},
+                 # the three things the model ASSUMES: the first real run names the wrong one
+                 "model_assumptions": {"link_gbs": [30.0, 45.0, 60.0], "round_overhead_us": 20.0,
+                                       "interference": "none in step_model_ms; with_measured_recv_interference_* applies what a waiting kernel of 7-28 workgroups cost the destination's kernels on one GPU (profiles/rd6a/interference_probe.jsonl): x1.13 tile kernel (not when the receives are gated behind it) and x1.17 k_finalize if it holds > 32 KB of LDS, x1.02 / x1.17 at 4 KB"},
                  "measured_ms_per_step": round(ms_per_step, 4)}
         if ping and "concurrent_per_link_GBs" in ping and ping["concurrent_per_link_GBs"] > 0:
             model["at_measured_link_rate"] = {"link_GBs": ping["concurrent_per_link_GBs"], **predict(ping["concurrent_per_link_GBs"])}

@@ -21,7 +21,7 @@ _LIB = None
 SYMBOLS = [
     "dsh_backend_name", "dsh_device_count", "dsh_create", "dsh_destroy", "dsh_last_error",
     "dsh_synchronize", "dsh_sketches_alloc", "dsh_upload_sketches", "dsh_download_sketches", "dsh_copy_sketches_device",
-    "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_async", "dsh_sketch_batch_device",
+    "dsh_attach_device_sketches", "dsh_sketch_batch", "dsh_sketch_batch_async", "dsh_sketch_batch_device", "dsh_sketch_fastx_batch_async",
     "dsh_clear_sketches", "dsh_cardinalities", "dsh_dist_rows", "dsh_dist_rows_device",
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
@@ -98,6 +98,7 @@ def load_library():
     lib.dsh_attach_device_sketches.argtypes = [vp, vp, u64, i32]
     lib.dsh_sketch_batch.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32, vp]
     lib.dsh_sketch_batch_async.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
+    lib.dsh_sketch_fastx_batch_async.argtypes = [vp, vp, vp, vp, C.c_uint32, u64, i32, i32, vp]
     lib.dsh_sketch_batch_device.argtypes = [vp, vp, vp, C.c_uint32, u64, i32, i32]
     lib.dsh_clear_sketches.argtypes = [vp, u64, u64]
     lib.dsh_cardinalities.argtypes = [vp, i32, vp]
@@ -410,6 +411,24 @@ class Context:
         off = np.ascontiguousarray(genome_off, np.uint64)
         self._ck(self._lib.dsh_sketch_batch_async(
             self._h, seq_pinned.ctypes.data, off.ctypes.data, off.size - 1, first_slot, k, int(bool(canon))))
+
+    def sketch_fastx_batch(self, files, first_slot=0, k=31, canon=True):
+        """files: one bytes object per genome, the raw text of a plain FASTA file (dsh_sketch_fastx_batch_async: the
+        parse runs on the device).  Returns the per-genome status words (0 = decoded and sketched; != 0 = refused, nothing
+        sketched: not plain FASTA) after waiting."""
+        ng = len(files)
+        off = np.zeros(ng + 1, np.uint64)
+        lens = np.array([len(f) for f in files], np.uint64)
+        for g in range(ng):
+            off[g + 1] = off[g] + ((int(lens[g]) + 1 + 31) & ~31)
+        raw = np.full(max(int(off[-1]), 1), 0x4E, np.uint8)
+        for g, f in enumerate(files):
+            raw[int(off[g]): int(off[g]) + len(f)] = np.frombuffer(f, np.uint8)
+        status = np.zeros(max(ng, 1), np.uint32)
+        self._ck(self._lib.dsh_sketch_fastx_batch_async(
+            self._h, raw.ctypes.data, off.ctypes.data, lens.ctypes.data, ng, first_slot, k, int(bool(canon)), status.ctypes.data))
+        self.wait()
+        return status[:ng]
 
     def sketch_batch_device(self, seq_ptr, genome_off, first_slot=0, k=31, canon=True):
         off = np.ascontiguousarray(genome_off, np.uint64)

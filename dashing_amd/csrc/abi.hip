@@ -55,7 +55,8 @@ static void release_ctx(dsh_ctx *c)
     (void)comm_release(c);
     for (DevBuf *b : {&c->gather_full, &c->gather_local, &c->regs_own, &c->card, &c->planes, &c->exc, &c->exc_n, &c->excv,
                       &c->keys, &c->tailhist, &c->hist, &c->cidx_rec, &c->cidx_ent, &c->colS_n, &c->colS_key, &c->colS_card, &c->colS_th, &c->colS_rl, &c->rowoff, &c->xch_stage, &c->xch_tab, &c->place_tab, &c->sig, &c->perm, &c->items, &c->cum, &c->tiles,
-                      &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc})
+                      &c->outbuf, &c->outbuf2[0], &c->outbuf2[1], &c->seqbuf, &c->workbuf, &c->phase_cyc, &c->rawbuf, &c->fx_tab,
+                      &c->fx_summ, &c->fx_state, &c->fx_declen, &c->fx_status})
         b->release();
     if (c->pin_perm) (void)hipHostFree(c->pin_perm);
     c->pin_perm = nullptr;
@@ -65,7 +66,8 @@ static void release_ctx(dsh_ctx *c)
     c->pin_rowoff.release();
     c->pin_xch.release();
     c->pin_sig.release();
-    for (hipEvent_t *e : {&c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
+    c->pin_fx.release();
+    for (hipEvent_t *e : {&c->ev_fx, &c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
                           &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_first_tiles, &c->ev_sig, &c->ev_band_tiles,
                           &c->ev_band_aux}) {
         if (*e) (void)hipEventDestroy(*e);
@@ -341,6 +343,72 @@ int dsh_sketch_batch_device(dsh_ctx *c, const void *d_seq, const uint64_t *genom
     if (rc) return rc;
     invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSH_OK;
+}
+
+int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t *genome_off, const uint64_t *raw_len,
+                                 uint32_t n_genomes, uint64_t first_slot, int k, int canon, uint32_t *status_out)
+{
+    int rc = sketch_check(c, genome_off, n_genomes, first_slot, k);
+    if (rc) return rc;
+    if ((rc = bind(c))) return rc;
+    if (n_genomes == 0) return DSH_OK;
+    if (!raw_len) return DSH_EINVAL;
+    const uint64_t lo = genome_off[0], hi = genome_off[n_genomes];
+    if (hi < lo) return fail(c, DSH_EINVAL, "genome_off not monotone");
+    if (lo & 31) return fail(c, DSH_EINVAL, "genome_off[0] must be a multiple of 32");
+    // the decoder's tables: genomes, then the 16 KB chunks of their raw bytes (one workgroup each)
+    std::vector<FastxGenome> gen(n_genomes);
+    std::vector<FastxChunk> chunks;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        const uint64_t b = genome_off[g], e = genome_off[g + 1];
+        if (e < b || (b & 31) || raw_len[g] > e - b)
+            return fail(c, DSH_EINVAL, "genome %u: its region must start on a multiple of 32 and hold its %llu raw bytes", g, (unsigned long long)raw_len[g]);
+        gen[g].off = b - lo;
+        gen[g].rawlen = raw_len[g];
+        gen[g].region_end = e - lo;
+        gen[g].chunk0 = (uint32_t)chunks.size();
+        for (uint64_t x = 0; x < raw_len[g]; x += kFastxChunk)
+            chunks.push_back(FastxChunk{b - lo + x, (uint32_t)std::min<uint64_t>(kFastxChunk, raw_len[g] - x), g});
+        gen[g].nchunks = (uint32_t)chunks.size() - gen[g].chunk0;
+        if (chunks.size() > 0x7FFFFFFFull) return fail(c, DSH_EINVAL, "batch too large");
+    }
+    const size_t bytes = (size_t)(hi - lo);
+    HIPCHK(c, c->rawbuf.ensure(bytes + 256));
+    HIPCHK(c, c->seqbuf.ensure(bytes + 256));
+    if (bytes) {
+        if (!raw) return DSH_EINVAL;
+        HIPCHK(c, hipMemcpyAsync(c->rawbuf.ptr, raw + lo, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    const size_t gbytes = gen.size() * sizeof(FastxGenome), cbytes = chunks.size() * sizeof(FastxChunk);
+    if (c->fx_in_flight) {  // (the previous batch's tables have long been uploaded unless calls come back to back)
+        HIPCHK(c, hipEventSynchronize(c->ev_fx));
+        c->fx_in_flight = false;
+    }
+    HIPCHK(c, c->pin_fx.ensure(gbytes + cbytes));
+    std::memcpy(c->pin_fx.ptr, gen.data(), gbytes);
+    if (cbytes) std::memcpy((uint8_t *)c->pin_fx.ptr + gbytes, chunks.data(), cbytes);
+    HIPCHK(c, c->fx_tab.ensure(gbytes + cbytes));
+    HIPCHK(c, launch_upload(c->stream, c->fx_tab.ptr, c->pin_fx.ptr, gbytes + cbytes));
+    if (!c->ev_fx) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fx, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_fx, c->stream));
+    c->fx_in_flight = true;
+    HIPCHK(c, c->fx_summ.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint4)));
+    HIPCHK(c, c->fx_state.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint2)));
+    HIPCHK(c, c->fx_declen.ensure(gen.size() * sizeof(uint64_t)));
+    HIPCHK(c, c->fx_status.ensure(gen.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(c->fx_status.ptr, 0, gen.size() * sizeof(uint32_t), c->stream));
+    HIPCHK(c, launch_fastx_decode(c->stream, (const uint8_t *)c->rawbuf.ptr, (const FastxChunk *)((const uint8_t *)c->fx_tab.ptr + gbytes),
+                                  (uint32_t)chunks.size(), (const FastxGenome *)c->fx_tab.ptr, n_genomes, (uint4 *)c->fx_summ.ptr,
+                                  (uint2 *)c->fx_state.ptr, (uint64_t *)c->fx_declen.ptr, (uint32_t *)c->fx_status.ptr,
+                                  (uint8_t *)c->seqbuf.ptr));
+    if (status_out)
+        HIPCHK(c, hipMemcpyAsync(status_out, c->fx_status.ptr, gen.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> off(n_genomes + 1);
+    for (uint32_t g = 0; g <= n_genomes; ++g) off[g] = genome_off[g] - lo;
+    rc = sketch_common(c, (const uint8_t *)c->seqbuf.ptr, off.data(), n_genomes, first_slot, k, canon);
+    if (rc) return rc;
+    invalidate(c);
     return DSH_OK;
 }
 

@@ -184,6 +184,11 @@ struct dsh_ctx {
     int finalize_timing = 0;  // profiling only: the s_memtime-stamped instance of k_finalize (same results, per-phase cycles)
     DevBuf phase_cyc;       // 8 x u64 of the last call with finalize_timing
     int nsplit = 0;  // plane-range splits per tile; 0 = auto (aim at >= 16 items per workgroup slot)
+    // dsh_sketch_fastx_batch_async: raw FASTA bytes of a batch, the decoder's tables and scratch (kernels_fastx.hip)
+    DevBuf rawbuf, fx_tab, fx_summ, fx_state, fx_declen, fx_status;
+    PinBuf pin_fx;
+    hipEvent_t ev_fx = nullptr;         // the upload of pin_fx has run
+    bool fx_in_flight = false;
     // diagnostics (dsh_diag_spin_*): a kernel that waits like an RCCL receive kernel, on a stream of its own
     uint32_t *spin_flag = nullptr;      // page-locked, mapped
     hipStream_t spin_stream = nullptr;

@@ -203,6 +203,9 @@ static double now_s()
 static const bool g_timing = std::getenv("DSH_TIMING") != nullptr;  // phase times on stderr
 
 static const size_t kSketchBatchBytes = (size_t)128 << 20;  // file bytes per sketching batch
+// plain FASTA is decoded on the device (dsh_sketch_fastx_batch_async: the host only read()s the file bytes into the
+// staging); DSH_HOST_PARSE=1 keeps the host parser for everything (A/B, and the path compressed inputs and pipes take anyway)
+static const bool g_device_parse = std::getenv("DSH_HOST_PARSE") == nullptr;
 
 // page-locked staging is only worth allocating (0.06-0.08 s for the two buffers) when the input does not fit one
 // batch: the first batch is parsed into pageable memory anyway
@@ -301,6 +304,9 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         pending.slots.clear();
         pending.fnames.clear();
     };
+    uint32_t *status[2] = {nullptr, nullptr};  // per batch buffer: the device decoder's verdict per staged genome (page-locked)
+    size_t status_cap[2] = {0, 0};
+    std::vector<size_t> refused_check;         // the slots the status words of the batch in flight belong to
     size_t g = 0, bi = 0;
     while (g < n) {
         const double t_b0 = now_s();
@@ -309,6 +315,8 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         while (e < n && (e == g || bytes + genome_file_size(o.inpaths[e]) <= batch_bytes)) bytes += genome_file_size(o.inpaths[e++]);
         const size_t nb = e - g;
         std::vector<int> cached(nb, 0), gz(nb, 0);
+        std::vector<int> rawkind(nb, 0);        // plain FASTA whose raw bytes are staged: decoded on the device
+        std::vector<uint64_t> rawlen_of(nb, 0);
         std::vector<std::string> fnames(nb);
         std::vector<std::vector<std::string>> files(nb);
         std::vector<std::vector<uint8_t>> zseq(nb);  // genomes whose sequence length the file size does not bound: compressed
@@ -369,6 +377,28 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             uint8_t *dst = buf + off[t];
             const size_t cap = (size_t)(off[t + 1] - off[t]);
             size_t len = 0;
+            bool raw_ok = !gz[i] && g_device_parse;
+            if (raw_ok) {
+                // the raw bytes of the genome's files, a '\n' between two files; every file must begin with '>' (what is
+                // not plain FASTA is the host parser's: below -- and the device refuses what it meets later, FASTQ-like
+                // '+' lines: status != 0, re-parsed after the batch)
+                for (const auto &f : files[i]) {
+                    if (len) dst[len++] = '\n';
+                    const size_t at = len;
+                    const long rc = read_raw_into(f, dst, cap, len);
+                    if (rc == -1) die("Could not open %s", f.c_str());
+                    if (rc == -2 || (len > at && dst[at] != '>')) {
+                        raw_ok = false;
+                        break;
+                    }
+                }
+                if (raw_ok) {
+                    rawkind[i] = 1;
+                    rawlen_of[i] = len;
+                    continue;  // (no fill: the device pads the DECODED region; raw bytes behind rawlen are never looked at)
+                }
+                len = 0;
+            }
             if (gz[i]) {
                 if (!zseq[i].empty()) std::memcpy(dst, zseq[i].data(), zseq[i].size());
                 len = zseq[i].size();
@@ -404,13 +434,39 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
             DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
         }
+        // what the device refused of the PREVIOUS batch (its status words are final since the dsh_wait above): the host
+        // parses those genomes itself
+        for (size_t t = 0; t < refused_check.size(); ++t) {
+            if (!status[(bi + 1) & 1][t]) continue;
+            std::vector<uint8_t> whole;
+            for (const auto &f2 : split_genome_paths(o.inpaths[refused_check[t]])) {
+                if (!whole.empty()) whole.push_back('N');
+                if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
+            }
+            late.emplace_back(refused_check[t], std::move(whole));
+        }
+        refused_check.clear();
+        if (slot_of.size() > status_cap[bi & 1]) {
+            if (status[bi & 1]) dsh_free_host(status[bi & 1]);
+            status_cap[bi & 1] = slot_of.size() + slot_of.size() / 2 + 64;
+            if (!(status[bi & 1] = (uint32_t *)dsh_alloc_host(status_cap[bi & 1] * sizeof(uint32_t)))) die("could not allocate pinned host memory");
+        }
+        if (!slot_of.empty()) std::memset(status[bi & 1], 0, slot_of.size() * sizeof(uint32_t));
+        std::vector<uint64_t> rlen(slot_of.size(), 0);
+        for (size_t t = 0; t < slot_of.size(); ++t) rlen[t] = rawlen_of[src_of[t]];
         size_t r0 = 0;
-        while (r0 < slot_of.size()) {  // consecutive runs of slots go in one call each
+        while (r0 < slot_of.size()) {  // consecutive runs of slots of one kind (raw FASTA / parsed sequence) go in one call each
+            const int kind = rawkind[src_of[r0]];
             size_t r1 = r0 + 1;
-            while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1) ++r1;
-            DSH(ctx, dsh_sketch_batch_async(ctx, buf, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon));
+            while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1 && rawkind[src_of[r1]] == kind) ++r1;
+            if (kind)
+                DSH(ctx, dsh_sketch_fastx_batch_async(ctx, buf, off.data() + r0, rlen.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon,
+                                                      status[bi & 1] + r0));
+            else
+                DSH(ctx, dsh_sketch_batch_async(ctx, buf, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon));
             r0 = r1;
         }
+        refused_check.assign(slot_of.begin(), slot_of.end());  // (status word t of this batch belongs to slot_of[t]; host-parsed ones stay 0)
         for (auto &lg : late) {  // (max-merged into their slots: a genome may be fed in several calls)
             lg.second.push_back('N');
             const uint64_t loff[2] = {0, lg.second.size()};
@@ -428,9 +484,22 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
     }
     dsh_ctx *ctx = cf.get();
     DSH(ctx, dsh_wait(ctx));
+    for (size_t t = 0; t < refused_check.size(); ++t) {  // what the device refused of the last batch
+        if (!status[(bi + 1) & 1][t]) continue;
+        std::vector<uint8_t> whole;
+        for (const auto &f2 : split_genome_paths(o.inpaths[refused_check[t]])) {
+            if (!whole.empty()) whole.push_back('N');
+            if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
+        }
+        whole.push_back('N');
+        const uint64_t loff[2] = {0, whole.size()};
+        DSH(ctx, dsh_sketch_batch(ctx, whole.data(), loff, 1, refused_check[t], o.k, o.canon, nullptr));
+    }
     finish(ctx);
     for (auto &b : pin)
         if (b) dsh_free_host(b);  // (buffers never adopted are freed by the CtxFuture)
+    for (auto &s : status)
+        if (s) dsh_free_host(s);
 }
 
 static int sketch_main(int argc, char **argv)

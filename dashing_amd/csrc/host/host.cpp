@@ -428,6 +428,31 @@ long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t
     return nrec;
 }
 
+long read_raw_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    long rc = 0;
+    for (;;) {
+        if (len == cap) {  // full: fine if the file ends here
+            char extra;
+            const ssize_t r = ::read(fd, &extra, 1);
+            rc = r == 0 ? 0 : (r < 0 ? -1 : -2);
+            break;
+        }
+        const ssize_t r = ::read(fd, dst + len, std::min<size_t>(cap - len, (size_t)1 << 26));
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            rc = -1;
+            break;
+        }
+        if (r == 0) break;
+        len += (size_t)r;
+    }
+    ::close(fd);
+    return rc;
+}
+
 bool is_gzip_file(const std::string &path)
 {
     // "its sequence length cannot be bounded by its size": compressed (gzip / zstd magic), or not a regular file at

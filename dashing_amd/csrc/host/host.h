@@ -35,6 +35,10 @@ long append_fastx(const std::string &path, std::vector<uint8_t> &out);
 // Same into caller-owned memory (e.g. page-locked staging): appends at dst[len...] and advances len; -2 if the
 // `cap` bytes would not hold it.  An uncompressed file never yields more sequence bytes than its size.
 long append_fastx_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len);
+// The raw bytes of a plain file, as they lie on disk, appended at dst[len...] (the parse happens on the device:
+// dsh_sketch_fastx_batch_async).  Returns 0, -1 if the file cannot be opened or read, -2 if `cap` would not hold it (the
+// file grew since it was sized).
+long read_raw_into(const std::string &path, uint8_t *dst, size_t cap, size_t &len);
 bool is_gzip_file(const std::string &path);  // compressed input: gzip (1f 8b) or zstd (28 b5 2f fd) magic
 
 // ---- .hll files (header layout is a best-effort restatement) --------

@@ -156,6 +156,24 @@ struct SketchWork {
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs);
 
+// FASTA text -> clean base stream on the device (kernels_fastx.hip).  A genome's raw file bytes lie at [off, off + rawlen)
+// of the raw buffer (off 32-aligned) and are decoded to the same offset of the output buffer, the rest of the region up to
+// region_end filled with 'N'; a chunk is what one workgroup takes (begin 32-aligned, len <= kFastxChunk).
+constexpr uint32_t kFastxChunk = 16384;
+struct FastxChunk {
+    uint64_t begin;
+    uint32_t len, genome;
+};
+struct FastxGenome {
+    uint64_t off, rawlen, region_end;
+    uint32_t chunk0, nchunks;
+};
+// summ [nchunks] uint4, state [nchunks] uint2, declen [ngenomes], status [ngenomes] (zeroed by the caller; != 0 afterwards:
+// not plain FASTA, nothing emitted)
+hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
+                               const FastxGenome *genomes, uint32_t ngenomes, uint4 *summ, uint2 *state, uint64_t *declen,
+                               uint32_t *status, uint8_t *out);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (kernel, device) instead of on every launch
 // (ADVICE r4): remembers the largest size granted so far and only calls the runtime for a larger one.
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);

@@ -208,7 +208,14 @@ class PipelinedShards:
         return (self.stage, self.block_off) if self.rank == self.dst else None
 
 
-def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.005, nmsg=8, dst_gate=None):
+# What a kernel that WAITS like an RCCL receive kernel costs the destination's own kernels (tools/interference_probe.py,
+# profiles/rd6a/interference_probe.jsonl: BASELINE configs[2] over 8 ranks, the destination's job, 7 ... 28 waiting
+# workgroups): holding more LDS than the tile kernel leaves free on a CU (> 32 KB: it then owns a CU) the tile kernel
+# takes 1.12-1.14x and k_finalize 1.14-1.30x as long; holding 4 KB (co-resident) 0.98-1.05x and 1.17-1.30x.
+MEASURED_RECV_INTERFERENCE = {"lds_over_32k": {"pair": 1.13, "finalize": 1.17}, "lds_4k": {"pair": 1.02, "finalize": 1.17}}
+
+
+def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.005, nmsg=8, dst_gate=None, dst_interference=None):
     """The N-rank step predicted from per-rank compute times (tools/shard_model.py measures them on one GPU, bench.py
     --gpus N on the ranks themselves), following what dsh_exchange_collect_async does: the destination (rows[0]) receives
     in `nmsg` ROUNDS -- one grouped ncclSend/ncclRecv per round: message q of every source, the q-th nmsg-th of its
@@ -222,12 +229,21 @@ def pipeline_model(rows, place_rate, link_gbs, round_ms=0.02, place_launch_ms=0.
     (q+1)/parts of k_finalize.
     dst_gate: None = as the library decides (a destination whose job is one launch of at most 8 rounds posts its receives
     behind its tile kernel, so that no RCCL kernel spins beside it; option xch_recv_gate), True / False to force.
+    dst_interference: None (the assumption of rounds 3-5: receive kernels waiting beside the destination's kernels cost
+    them nothing) or {"pair": f, "finalize": f} (e.g. MEASURED_RECV_INTERFERENCE[...]): the destination's tile kernel --
+    unless its receives are gated behind it -- and its k_finalize take f times as long.
     Returns (step ms, the rank that bounds it; 0: the destination's own compute)."""
     step_ms, worst = rows[0]["wall_ms"] if rows else 0.0, 0
     gate_ms = 0.0
     if rows and "finalize_ms" in rows[0]:
         short = rows[0].get("bands", 1) == 1 and rows[0].get("rounds_of_512", 99) <= 8
-        if dst_gate or (dst_gate is None and short):
+        gated = bool(dst_gate or (dst_gate is None and short))
+        if dst_interference and len(rows) > 1:
+            extra = rows[0]["finalize_ms"] * (dst_interference.get("finalize", 1.0) - 1.0)
+            if not gated:
+                extra += rows[0].get("pair_ms", 0.0) * (dst_interference.get("pair", 1.0) - 1.0)
+            step_ms += extra
+        if gated:
             gate_ms = max(0.0, rows[0]["wall_ms"] - rows[0]["finalize_ms"])  # (the end of its tile kernel)
     srcs = []
     for x in rows[1:]:

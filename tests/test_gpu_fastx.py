@@ -1,0 +1,159 @@
+"""GPU parity of the device-side FASTA decode (dsh_sketch_fastx_batch_async, kernels_fastx.hip): the registers of raw file
+bytes decoded ON THE DEVICE equal, bit for bit, the CPU oracle's registers of the sequence the HOST parser
+(host/host.cpp FastxParser, through libdashing_host.so) extracts from the same file -- the reference's
+Encoder::for_each(func, path) includes the parse (src/sketch_and_cmp.h:338-342).  What is not plain FASTA is refused per
+genome (status != 0, nothing sketched), never guessed at."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import dashing_amd
+from dashing_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host():
+    lib = C.CDLL(os.path.join(ROOT, "dashing_amd", "libdashing_host.so"))
+    lib.dshh_append_fastx.restype = C.c_long
+    lib.dshh_append_fastx.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    return lib
+
+
+def host_parse(host, tmp_path, name, data):
+    """the sequence the host parser hands the sketch kernel for this file ('N' between records)"""
+    pth = tmp_path / name
+    pth.write_bytes(data)
+    buf = np.zeros(len(data) + 64, np.uint8)
+    n = C.c_size_t(0)
+    rc = host.dshh_append_fastx(str(pth).encode(), buf.ctypes.data, buf.size, C.byref(n))
+    assert rc >= 0
+    return buf[: n.value].copy()
+
+
+def fasta(rng, records, width, eol=b"\n", final_eol=True, blank_every=0):
+    out = []
+    for i, (name, seq) in enumerate(records):
+        out.append(b">" + name + eol)
+        s = bytes(seq)
+        if width <= 0:
+            out.append(s + eol)
+        else:
+            for x in range(0, len(s), width):
+                out.append(s[x : x + width] + eol)
+                if blank_every and (x // width) % blank_every == blank_every - 1:
+                    out.append(eol)
+    data = b"".join(out)
+    if not final_eol and data.endswith(eol):
+        data = data[: -len(eol)]
+    return data
+
+
+def check(ctx, oracle, host, tmp_path, files, k=31, p=10, canon=True, expect_status=None):
+    ctx.alloc(len(files), p)
+    status = ctx.sketch_fastx_batch(files, 0, k, canon)
+    got = ctx.download(0, len(files)) if hasattr(ctx, "download") else None
+    if got is None:
+        got = np.zeros((len(files), 1 << p), np.uint8)
+        ctx._ck(ctx._lib.dsh_download_sketches(ctx._h, 0, len(files), got.ctypes.data))
+    seqs = [host_parse(host, tmp_path, "f%d.fa" % i, f) for i, f in enumerate(files)]
+    for g, (f, s) in enumerate(zip(files, seqs)):
+        refused = expect_status is not None and expect_status[g]
+        assert bool(status[g]) == bool(refused), "genome %d: status %d" % (g, status[g])
+        if refused:
+            assert not got[g].any(), "a refused genome must contribute nothing"
+            continue
+        seq, off = synth.concat_for_device([s])
+        want = oracle.sketch_batch(seq, off, k, p, canon)[0]
+        assert (got[g] == want).all(), "genome %d: %d registers differ" % (g, int((got[g] != want).sum()))
+    return got
+
+
+def genomes(n, L, seed, decorate=True):
+    return [bytes(g) for g in synth.synthetic_genomes(n, L, seed=seed, decorate=decorate)]
+
+
+def test_line_widths_record_shapes_and_line_ends(ctx, oracle, host, tmp_path):
+    rng = np.random.default_rng(1)
+    gs = genomes(8, 30011, 3)
+    files = [
+        fasta(rng, [(b"g0 plain 80 columns", gs[0])], 80),
+        fasta(rng, [(b"g1 60 columns, no newline at the end", gs[1])], 60, final_eol=False),
+        fasta(rng, [(b"g2 one line", gs[2])], 0),
+        fasta(rng, [(b"g3 CRLF", gs[3])], 70, eol=b"\r\n"),
+        fasta(rng, [(b"r%d >inner @signs + plus" % i, gs[4][i * 3000 : (i + 1) * 3000]) for i in range(10)], 61),
+        fasta(rng, [(b"g5 63", gs[5])], 63) + fasta(rng, [(b"second 64", gs[6])], 64) + fasta(rng, [(b"third 65", gs[7])], 65),
+        fasta(rng, [(b"blank lines", gs[6])], 50, blank_every=7),
+        fasta(rng, [(b"width 1", gs[7][:4000])], 1),
+    ]
+    check(ctx, oracle, host, tmp_path, files)
+
+
+def test_headers_of_every_length_and_position(ctx, oracle, host, tmp_path):
+    """header lines from 1 byte to several 16 KB chunks long (the carry must survive whole workgroups), records shorter than
+    k, empty records, '@' first on a later line (the host parser takes it for a header too), lowercase and N runs"""
+    rng = np.random.default_rng(2)
+    gs = genomes(6, 50021, 5)
+    long_name = bytes(rng.integers(33, 126, 40000, dtype=np.uint8)).replace(b"\n", b"x")
+    files = [
+        fasta(rng, [(b"", gs[0])], 80),
+        fasta(rng, [(long_name, gs[1]), (long_name[:17000], gs[2][:30000]), (b"x", gs[2][30000:])], 80),
+        fasta(rng, [(b"short", b"ACGT"), (b"empty", b""), (b"real", gs[3]), (b"tail", b"ACGTACGTAC")], 80),
+        b">a\n" + gs[4][:20000] + b"\n@b also a header\n" + gs[4][20000:] + b"\n",
+        fasta(rng, [(b"only a header", b"")], 80),
+        b">no sequence, no newline",
+        b">",
+        fasta(rng, [(b"g5", gs[5])], 16384 - 3),  # lines as long as a chunk
+        fasta(rng, [(b"g5b", gs[5])], 64),        # a newline at the same byte of every lane
+        fasta(rng, [(b"g5c", gs[5])], 63),
+    ]
+    check(ctx, oracle, host, tmp_path, files, k=21)
+    check(ctx, oracle, host, tmp_path, files, k=32, p=12, canon=False)
+
+
+def test_what_is_not_plain_fasta_is_refused_not_guessed(ctx, oracle, host, tmp_path):
+    rng = np.random.default_rng(3)
+    gs = genomes(4, 20011, 7, decorate=False)
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, gs[0][i * 100 : (i + 1) * 100], b"I" * 100) for i in range(150))
+    files = [
+        fasta(rng, [(b"ok", gs[1])], 80),
+        fq,                                              # FASTQ: begins with '@'
+        b"\n" + fasta(rng, [(b"blank first", gs[2])], 80),  # does not begin with '>'
+        fasta(rng, [(b"plus line", gs[3])], 80) + b"+\nIIII\n",  # a '+' line inside a '>' file
+        b"",                                             # an empty file: nothing to refuse, nothing to sketch
+        fasta(rng, [(b"ok too", gs[2])], 77),
+    ]
+    # a '+' that starts a line exactly at a lane / chunk boundary
+    body = gs[3][: 16384 - 4]
+    files.append(b">x\n" + body + b"\n+\nII\n")
+    files.append(b">y\n" + gs[3][: 64 - 4] + b"\n+\n")
+    check(ctx, oracle, host, tmp_path, files, expect_status=[0, 1, 1, 1, 0, 0, 1, 1])
+
+
+def test_many_genomes_random_shapes(ctx, oracle, host, tmp_path):
+    rng = np.random.default_rng(4)
+    files = []
+    for i in range(40):
+        L = int(rng.integers(1, 120000))
+        g = genomes(1, max(L, 64), 100 + i, decorate=bool(i & 1))[0][:L]
+        nrec = int(rng.integers(1, 6))
+        cuts = sorted(set([0, L] + [int(x) for x in rng.integers(0, L + 1, nrec - 1)]))
+        recs = [(bytes(rng.integers(48, 123, int(rng.integers(0, 200)), dtype=np.uint8)), g[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        files.append(fasta(rng, recs, int(rng.choice([0, 1, 13, 60, 64, 70, 80, 127, 128, 1000])), eol=b"\r\n" if i % 5 == 4 else b"\n",
+                           final_eol=bool(i % 3)))
+    check(ctx, oracle, host, tmp_path, files)
+    check(ctx, oracle, host, tmp_path, files[:10], k=5, p=14)
+
+
+def test_a_genome_of_many_chunks_and_precision_above_lds(ctx, oracle, host, tmp_path):
+    """5 Mbp on 80-column lines = 310 chunks (the per-genome scan walks more than one chunk per lane); p = 18 takes the
+    variant of k_sketch that keeps its registers in HBM"""
+    rng = np.random.default_rng(5)
+    g = genomes(1, 5_000_000, 11, decorate=True)[0]
+    files = [fasta(rng, [(b"big", g)], 80), fasta(rng, [(b"big one line", g[:3_000_000])], 0)]
+    check(ctx, oracle, host, tmp_path, files)
+    check(ctx, oracle, host, tmp_path, [files[0][:400000]], p=18)
