@@ -68,8 +68,7 @@ static void release_ctx(dsh_ctx *c)
     c->pin_sig.release();
     c->pin_fx.release();
     for (hipEvent_t *e : {&c->ev_fx, &c->ev_work, &c->ev_lists, &c->ev_perm, &c->ev_keys, &c->ev_filled[0], &c->ev_filled[1],
-                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_first_tiles, &c->ev_sig, &c->ev_band_tiles,
-                          &c->ev_band_aux}) {
+                          &c->ev_drained[0], &c->ev_drained[1], &c->ev_aux_fork, &c->ev_aux_join, &c->ev_xch_tab, &c->ev_place_done, &c->ev_first_tiles, &c->ev_sig}) {
         if (*e) (void)hipEventDestroy(*e);
         *e = nullptr;
     }
@@ -106,9 +105,7 @@ int dsh_create(int device, dsh_ctx **out)
         hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         create_copy_stream(&c->place_stream) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_band_tiles, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_band_aux, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming) != hipSuccess) {
         release_ctx(c);
         delete c;
         return DSH_EIO;
@@ -646,6 +643,8 @@ int dsh_dist_rect(dsh_ctx *c, int estim, int result_type, int k, uint64_t qb, ui
 
 // cost model for balancing shards: a tile costs its dense planes plus ~5 plane-equivalents of
 // finalize work (6.6 ms finalize vs 1.4 ms per plane on the C3 workload, profiles/r1f)
+constexpr double kShardC0 = 5.0;           // finalize work of a tile in plane-equivalents
+constexpr double kAssemblerPermille = 21;  // the un-permute (0.42 ms) on rank 0 of a 19.9 ms pass (profiles/r1k)
 static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb)
 {
     const uint32_t NT = c->lay.Npad / kTile;
@@ -655,14 +654,14 @@ static void shard_bounds(dsh_ctx *c, uint32_t nshards, std::vector<uint32_t> &tb
         for (uint32_t tj = ti; tj < NT; ++tj) {
             int pb, pe;
             plan::tile_planes(c->lay, ti, tj, pb, pe);
-            rowcost[ti] += (pe - pb) + c->shard_c0;
+            rowcost[ti] += (pe - pb) + kShardC0;
         }
         total += rowcost[ti];
     }
     // Contiguous tile-row ranges that minimise the largest shard (linear partition by bisection on the
     // limit + greedy fill).  Shard 0 belongs to the rank that also assembles the result (the un-permute,
     // about assembler_permille/1000 of a single-GPU pass): it carries that as extra cost.
-    const double extra0 = nshards > 1 ? total * c->assembler_permille / 1000.0 : 0.0;
+    const double extra0 = nshards > 1 ? total * kAssemblerPermille / 1000.0 : 0.0;
     auto fill = [&](double limit, std::vector<uint32_t> *out) -> bool {
         uint32_t ti = 0;
         for (uint32_t r = 0; r < nshards; ++r) {
@@ -735,8 +734,7 @@ int dsh_unpermute_device(dsh_ctx *c, const void *d_sorted_tri, void *d_out_tri)
     if (!whole_sorted(c)) return fail(c, DSH_ESTATE, "no sorted plan (call dsh_shard_plan / dsh_dist_shard_device first)");
     if (c->n < 2) return DSH_OK;
     if (!d_sorted_tri || !d_out_tri) return DSH_EINVAL;
-    HIPCHK(c, launch_unpermute(c->stream, (const float *)d_sorted_tri, (const uint32_t *)c->perm.ptr,
-                               c->unperm_gather ? (const uint32_t *)c->perm.ptr + c->n : nullptr, c->n, (float *)d_out_tri));
+    HIPCHK(c, launch_unpermute(c->stream, (const float *)d_sorted_tri, (const uint32_t *)c->perm.ptr + c->n, c->n, (float *)d_out_tri));
     return DSH_OK;
 }
 
@@ -890,7 +888,7 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
 {
     if (!c || !name) return DSH_EINVAL;
     if (!std::strcmp(name, "kc")) {
-        if (v != 0 && v != 16 && v != 32 && v != 64) return fail(c, DSH_EINVAL, "kc must be 0 (auto), 16, 32 or 64");
+        if (v != 0 && v != 16 && v != 32) return fail(c, DSH_EINVAL, "kc must be 0 (auto), 16 or 32");
         c->kc_opt = (int)v;
         c->planes_valid = false;  // Kpad depends on kc
         return DSH_OK;
@@ -900,23 +898,9 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->cum_budget = (uint64_t)v;
         return DSH_OK;
     }
-    if (!std::strcmp(name, "unpermute_gather")) {
-        c->unperm_gather = v != 0;
-        return DSH_OK;
-    }
     if (!std::strcmp(name, "knn_square_budget_bytes")) {
         if (v < 0) return fail(c, DSH_EINVAL, "knn_square_budget_bytes must be >= 0");
         c->knn_square_budget = (uint64_t)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "assembler_permille")) {
-        if (v < 0 || v > 500) return fail(c, DSH_EINVAL, "assembler_permille out of range");
-        c->assembler_permille = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "shard_c0_x10")) {
-        if (v < 0 || v > 10000) return fail(c, DSH_EINVAL, "shard_c0_x10 out of range");
-        c->shard_c0 = (double)v / 10.0;
         return DSH_OK;
     }
     if (!std::strcmp(name, "sort")) {
@@ -929,39 +913,12 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->range_sort_min_rows = (int)std::min<int64_t>(v, 1 << 30);
         return DSH_OK;
     }
-    if (!std::strcmp(name, "ls_sort_items")) {
-        c->ls_sort_items = v != 0;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "finalize_two_streams")) {
-        c->finalize_two_streams = v != 0;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "colindex_split")) {
-        if (v != 0 && v != 1 && v != 2 && v != 4) return fail(c, DSH_EINVAL, "colindex_split must be 0 (automatic), 1, 2 or 4");
-        c->colindex_split = (int)v;
-        c->planes_valid = false;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "ls_item_chunks")) {
-        if (v < 1 || v > (1 << 20)) return fail(c, DSH_EINVAL, "ls_item_chunks out of range");
-        c->ls_item_chunks = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "pair_lockstep")) {
-        if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "pair_lockstep must be -1, 0 or 1");
-        c->pair_lockstep = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "pair_mfma")) {  // what-if only: the north star keeps the matrix cores off this path
 #ifdef DSH_WHATIF_MFMA
+    if (!std::strcmp(name, "pair_mfma")) {  // what-if builds only (make WHATIF=1): the north star keeps the matrix cores off this path
         c->pair_mfma = v != 0;
         return DSH_OK;
-#else
-        if (v == 0) return DSH_OK;
-        return fail(c, DSH_EINVAL, "pair_mfma: this library was built without the matrix-core what-if (make WHATIF=1)");
-#endif
     }
+#endif
     if (!std::strcmp(name, "finalize_stop")) {  // profiling only: results are meaningless while it is set
         if (v < 0 || v > 4) return fail(c, DSH_EINVAL, "finalize_stop must be in [0,4]");
         if (v && !c->profiling) return fail(c, DSH_ESTATE, "finalize_stop needs dsh_set_profiling(ctx, 1)");
@@ -998,10 +955,6 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
         c->overflow_frag_permille = (int)v;
         return DSH_OK;
     }
-    if (!std::strcmp(name, "finalize_shared_instance")) {
-        c->finalize_shared_instance = v != 0;
-        return DSH_OK;
-    }
     if (!std::strcmp(name, "xch_recv_gate")) {
         if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "xch_recv_gate is -1 (auto), 0 or 1");
         c->xch_recv_gate = (int)v;
@@ -1010,33 +963,6 @@ int dsh_set_option(dsh_ctx *c, const char *name, int64_t v)
     if (!std::strcmp(name, "finalize_signal")) {
         if (v < -1 || v > 1) return fail(c, DSH_EINVAL, "finalize_signal is -1 (auto), 0 or 1");
         c->finalize_signal = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "xch_tail_head_min_rounds")) {
-        if (v < 2 || v > 64) return fail(c, DSH_EINVAL, "xch_tail_head_min_rounds out of range");
-        c->tail_head_min_rounds = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "xch_tail_permille2")) {
-        if (v < 0 || v > 900) return fail(c, DSH_EINVAL, "xch_tail_permille2 out of range");
-        c->tail_permille2 = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "xch_tail_permille")) {
-        if (v < 1 || v > 900) return fail(c, DSH_EINVAL, "xch_tail_permille out of range");
-        c->tail_permille = (int)v;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "finalize_xcd_tiles")) {
-        c->finalize_xcd_tiles = v != 0;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "finalize_rowmajor")) {
-        c->finalize_rowmajor = v != 0;
-        return DSH_OK;
-    }
-    if (!std::strcmp(name, "xcd_swizzle")) {
-        c->xcd_swizzle = v != 0;
         return DSH_OK;
     }
     return fail(c, DSH_EINVAL, "unknown option %s", name);

@@ -85,7 +85,6 @@ struct dsh_ctx {
     hipStream_t aux_stream = nullptr;   // prepare(): the column index is built next to the bit-plane transform
     hipStream_t place_stream = nullptr; // destination of an exchange: received rows are put into place beside the next round's transfer
     hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
-    hipEvent_t ev_band_tiles = nullptr, ev_band_aux = nullptr;  // a band's C(v) ready / its k_finalize launches on the second stream done
     bool aux_join_pending = false;
     DevBuf outbuf2[2];
     hipEvent_t ev_filled[2] = {nullptr, nullptr};  // kernels of the call that filled outbuf2[b] done (recorded on stream)
@@ -129,7 +128,6 @@ struct dsh_ctx {
     bool sig_in_flight = false;
     uint32_t sig_gen = 0;               // generation of the last call with parts: the value its flags take
     bool parts_signalled = false;       // the last call with parts used flags (else events)
-    int finalize_shared_instance = 0;   // option (A/B, profiles/rd5p): calls without parts take k_finalize_signal too
     int finalize_signal = -1;           // option: -1 auto (on where the device supports stream wait-value), 0 events, 1 flags
     int can_wait_value = -1;            // hipDeviceAttributeCanUseStreamWaitValue, queried once
     int wall_clock_khz = 0;
@@ -158,27 +156,14 @@ struct dsh_ctx {
     int elow_opt = -1;  // cap of the listed lower tail; -1: auto_list_cap(p, false)
     int part_band_tiles = 2048;       // a part of at least this many tiles gets its own launch of the tile kernel (plan.cpp)
     int overflow_frag_permille = 500;  // overflow fragments of the tile kernel (plan.h, Tuning): 0 = never
-    int tail_bands = 2, tail_permille = 100, tail_permille2 = 350, tail_head_min_rounds = 7;  // small jobs with parts: the tile kernel cut at whole rounds (plan.h, Tuning)
+    int tail_bands = 2;  // option xch_tail_bands: small jobs with parts have their tile kernel cut at whole rounds (plan.h, Tuning)
     std::vector<double> part_ready_ms;  // (profiling) when each part of the last call with parts was final, from the call's start
     std::vector<uint64_t> part_floats;  // and the floats of the rank's buffer it holds
-    int finalize_xcd_tiles = 1;       // k_finalize: block -> tile mapping that keeps a tile's 128 rows on one XCD (option, A/B)
-    int finalize_rowmajor = 1;        // k_finalize walks every segment's tiles in row-major order (option, A/B only)
     size_t last_bands = 0;            // tile-kernel launches groups (bands) of the last dist call
     uint64_t cum_budget = 8ull << 30;  // scratch for C(v) per pair slot: larger jobs run in bands (2 -> 8 GiB: -1.5 % at 100 000 x p=10)
-    int xcd_swizzle = 1;
     int sort_mode = -1;  // -1 auto (key-ordered columns for triangle calls of >= range_sort_min_rows rows), 0 never
     int range_sort_min_rows = 1024;  // smaller row ranges keep the cached identity layout (a rebuild costs more than it saves)
-    int assembler_permille = 21;  // the un-permute (0.42 ms) on rank 0 of a 19.9 ms pass (profiles/r1k)
-    int unperm_gather = 1;  // un-permute driven from the destination (coalesced writes) instead of the source
     uint64_t knn_square_budget = (uint64_t)96 << 30;  // all-vs-all kNN keeps an n x n float matrix in HBM up to this size
-    double shard_c0 = 5.0;  // finalize work of a tile in plane-equivalents (shard balancing)
-    int ls_sort_items = 1;
-    int finalize_two_streams = 1;  // the k_finalize launches of a call with parts alternate between the two streams (profiles/r5f)
-    int colindex_split = 0;  // workgroups per column block of k_build_colindex (0: automatic)
-    int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes)
-    // k_pair_counts_ls (512-thread workgroups, AND and BCNT batches phase-locked across the waves of a SIMD): -1 auto
-    // = 1 = wherever a plane is at least one chunk (W >= kc), 0 never (the free-running k_pair_counts)
-    int pair_lockstep = -1;
     int pair_mfma = 0;  // WHAT-IF only (built with `make WHATIF=1`): 1 = the AND+popcount tile kernel on the matrix cores
     int finalize_stop = 0;  // profiling only: k_finalize leaves after phase 1..4 (results are then meaningless)
     int finalize_timing = 0;  // profiling only: the s_memtime-stamped instance of k_finalize (same results, per-phase cycles)
@@ -248,7 +233,7 @@ inline bool use_lockstep(const dsh_ctx *c)
 {
     // wherever a plane is at least one chunk (p >= 9): since the kernel needs one barrier per k-row it beats the
     // free-running one at every precision (profiles/r3f/lockstep_ab.jsonl: -5 % at p = 10 ... -17 % at p = 16)
-    return !(c->pair_mfma || c->kc > 32 || c->W < (uint32_t)c->kc || c->pair_lockstep == 0);
+    return !(c->pair_mfma || c->W < (uint32_t)c->kc);
 }
 
 inline bool whole_sorted(const dsh_ctx *c) { return c->planes_valid && c->lay.whole; }

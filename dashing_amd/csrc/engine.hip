@@ -196,7 +196,6 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
             ci.cardS = (double *)c->colS_card.ptr;
             ci.thS = (uint8_t *)c->colS_th.ptr;
             ci.rl = (uint32_t *)c->colS_rl.ptr;
-            ci.split = c->colindex_split;
             HIPCHK(c, launch_build_colindex(c->aux_stream, ci));
         }
         HIPCHK(c, hipEventRecord(c->ev_aux_join, c->aux_stream));
@@ -292,16 +291,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
     tu.cum_budget = c->cum_budget;
     tu.nsplit = c->nsplit;
     tu.lockstep = use_lockstep(c);
-    tu.ls_item_chunks = c->ls_item_chunks;
-    tu.ls_sort_items = c->ls_sort_items;
-    tu.xcd_swizzle = c->xcd_swizzle;
-    tu.finalize_rowmajor = c->finalize_rowmajor;
     tu.part_band_tiles = (uint32_t)c->part_band_tiles;
     tu.overflow_frag_max_permille = (uint32_t)c->overflow_frag_permille;
     tu.tail_bands = (uint32_t)c->tail_bands;
-    tu.tail_permille = (uint32_t)c->tail_permille;
-    tu.tail_permille2 = (uint32_t)c->tail_permille2;
-    tu.tail_head_min_rounds = (uint32_t)c->tail_head_min_rounds;
     // Tiles, bands and segments of the whole job first; the work items and the two device lists are made, uploaded and
     // launched BAND BY BAND: the host plans band b + 1 while the GPU runs band b (at 100 000 x p=10 the plan of 306 000
     // tiles took the host 8 ms that nothing hid, round 4 / profiles/r4y).
@@ -420,11 +412,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             if (!c->ev_first_tiles) HIPCHK(c, hipEventCreateWithFlags(&c->ev_first_tiles, hipEventDisableTiming));
             HIPCHK(c, hipEventRecord(c->ev_first_tiles, c->stream));
         }
-        // (option finalize_two_streams) the k_finalize launches of a band with several segments alternate between the ctx
-        // stream and the second stream: the tail of one launch runs beside the head of the next.  The second stream starts
-        // behind the band's tile kernel and the ctx stream joins it again before the band's C(v) scratch is overwritten.
-        const bool two = !signal && c->finalize_two_streams && pp.segs[bi].size() > 1;
-        bool aux_used = false;
         // signal mode: ONE launch over the band's tiles; the parts announce themselves (k_finalize_signal)
         std::vector<plan::Seg> one_seg;
         if (signal) {
@@ -432,15 +419,9 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             for (const plan::Seg &sg : pp.segs[bi]) all.hist_bins = std::max(all.hist_bins, sg.hist_bins);
             one_seg.push_back(all);
         }
-        if (two) {
-            HIPCHK(c, hipEventRecord(c->ev_band_tiles, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_band_tiles, 0));
-        }
-        size_t seg_no = 0;
+        // (without flags -- finalize_signal = 0, or a device without stream wait-value -- one launch and one event per part)
         for (const plan::Seg &sg : signal ? one_seg : pp.segs[bi]) {
-            const bool on_aux = two && (seg_no++ & 1);
-            hipStream_t fst = on_aux ? c->aux_stream : c->stream;
-            aux_used = aux_used || on_aux;
+            hipStream_t fst = c->stream;
             FinalizeLaunch f;
             f.cum = c->cum.ptr;  // the band's C(v); a tile's block is named by its descriptor
             f.cum_bytes = c->cum_bytes;
@@ -468,7 +449,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.n = c->n;
             f.ncols = L.ncols;
             f.stop = c->finalize_stop;
-            f.xcd_tiles = c->finalize_xcd_tiles;
             f.phase_cyc = c->finalize_timing ? (unsigned long long *)c->phase_cyc.ptr : nullptr;
             f.rect = job.rect;
             f.sorted_out = job.sorted_rows;
@@ -486,8 +466,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
             f.base_index = job.base_index;
             f.out = job.d_out;
             if (signal) f.sig = (uint32_t *)c->sig.ptr;
-            f.shared_instance = c->finalize_shared_instance;
-            if (c->aux_join_pending && !on_aux) {  // (the second stream is behind the index build by stream order)
+            if (c->aux_join_pending) {  // (the position index is built on the second stream)
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
                 c->aux_join_pending = false;
             }
@@ -509,10 +488,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                     }
                 }
             }
-        }
-        if (aux_used) {  // the ctx stream goes on (next band's tile kernel, the end of the call) behind the second stream
-            HIPCHK(c, hipEventRecord(c->ev_band_aux, c->aux_stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_band_aux, 0));
         }
         if (d) (void)hipEventRecord(d, c->stream);
         if (a && b && d) {
@@ -551,7 +526,6 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                 else if (!L.rowsorted) c->part_floats[q] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
             }
         } else if (e_call0 && !ev_part_t.empty()) {
-            if (c->aux_stream) HIPCHK(c, hipStreamSynchronize(c->aux_stream));
             c->part_ready_ms.assign(c->parts_done, 0.0);
             c->part_floats.assign(c->parts_done, 0);
             for (auto &pe : ev_part_t) {

@@ -317,8 +317,8 @@ static int plan_check(uint64_t n, const uint32_t *keys, int mode, int want_sorte
                 const int lo = (int)((f.z >> 16) & 0xFFu), hi = (int)(f.z >> 24);
                 if (hi - lo + 1 > sg.hist_bins) return E.fail("segment hist_bins %d too small for tile %zu", sg.hist_bins, src);
             }
-            if (pp.finalize_rowmajor) {  // tile row by tile row inside the segment, columns ascending (the tile rows come in the
-                                          // wanted order: the extra segments' first)
+            {  // tile row by tile row inside the segment, columns ascending (the tile rows come in the wanted order: the
+               // extra segments' first)
                 std::vector<uint32_t> rows_seen;
                 for (size_t t = sg.b + 1; t < sg.e; ++t) {
                     if (df[t - 1].x == df[t].x) {

@@ -32,7 +32,6 @@ struct ColIndexLaunch {
     double *cardS;            // [Npad]
     uint8_t *thS;             // [Npad][64]
     uint32_t *rl;             // [Npad][E]
-    int split = 0;            // workgroups per column block (1, 2, 4); 0: chosen from the number of blocks
 };
 hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c);
 hipError_t launch_transform(hipStream_t st, const uint8_t *regs, uint64_t n, int p, int vlo,
@@ -79,14 +78,12 @@ struct FinalizeLaunch {
     float *out2 = nullptr;
     uint64_t knn_ld = 0, knn_rows = 0;
     int stop = 0;  // profiling: k_finalize leaves after phase `stop`
-    int xcd_tiles = 0;    // k_finalize: the rows of a tile on one XCD
     unsigned long long *phase_cyc = nullptr;  // profiling: per-phase cycle sums of the full kernel (8 x u64, device)
     uint64_t row_begin, row_end, col_begin, col_end, base_index;
     float *out;
     // part signalling (k_finalize_signal): the call's signal block (layout below), the generation value that marks a part
     // final, whether completion times are stamped (profiling).  nullptr: completion is marked by events between launches.
     uint32_t *sig = nullptr;
-    int shared_instance = 0;  // 1: a call without parts takes k_finalize_signal too (A/B: option finalize_shared_instance)
 };
 hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f);
 // the signal block of a call with parts, in 32-bit words: per part a flag (= the generation of the call that completed
@@ -128,9 +125,8 @@ hipError_t launch_row_place(hipStream_t st, const float *src, float *out, const 
                             uint64_t pos0, uint64_t pos1, uint64_t n);
 hipError_t launch_unpermute_staged(hipStream_t st, const float *in, const uint32_t *inv,
                                    const int64_t *rowdelta, uint64_t n, float *out);
-// inv != nullptr: destination-driven variant (coalesced writes, gathered reads); else scatter via perm
-hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
-                            uint64_t n, float *out);
+// destination-driven (coalesced writes, gathered reads through inv, the inverse of perm)
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *inv, uint64_t n, float *out);
 
 hipError_t launch_topk(hipStream_t st, const float *vals, uint64_t rows, uint64_t ncols,
                        uint64_t row0, uint64_t col0, int descending, uint32_t nn,

@@ -1065,7 +1065,6 @@ struct FinalizeArgs {
     float *out2;
     uint64_t knn_ld, knn_rows;
     int stop;             // profiling only (option "finalize_stop"): leave after phase 1..4 with a dummy store
-    int xcd_tiles;        // block -> tile mapping that keeps a tile on one XCD (see the kernel)
     uint32_t ntiles;      // tiles of this launch
     unsigned long long *phase_cyc;  // profiling only (TIMED instances): shader-clock cycles per phase, summed over waves
     uint64_t row_begin, row_end, col_begin, col_end;
@@ -1120,17 +1119,13 @@ __device__ __forceinline__ void finalize_block(const FinalizeArgs &a)
     // k_finalize's tile descriptor (its own list, row-major per segment -- run_pairs): {row block, column block, plane
     // begin | plane end << 8 | smallest << 16 | largest << 24 register value of the two blocks' sketches, index of the
     // tile's C(v) block in the band}: the histogram columns of a block only span the values its own sketches can hold
-    // block -> (tile, row of the tile).  Plain: 128 consecutive blocks share a tile.  xcd_tiles: consecutive blocks go to
-    // consecutive XCDs (block b runs on XCD b % 8: observed dispatch behaviour, speed only), so block b takes row (b / 8) %
-    // 128 of tile (b / 1024) * 8 + b % 8: the 128 rows of a tile run on ONE XCD and its column block's position index,
-    // tail histograms and keys are fetched into that XCD's L2 once instead of into all eight.
-    uint32_t tidx = blockIdx.x >> 7, trow = blockIdx.x & 127u;
-    if (a.xcd_tiles) {
-        const uint32_t kq = blockIdx.x >> 3;
-        tidx = ((kq >> 7) << 3) + (blockIdx.x & 7u);
-        trow = kq & 127u;
-        if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles)
-    }
+    // block -> (tile, row of the tile): consecutive blocks go to consecutive XCDs (block b runs on XCD b % 8: observed
+    // dispatch behaviour, speed only), so block b takes row (b / 8) % 128 of tile (b / 1024) * 8 + b % 8: the 128 rows of a
+    // tile run on ONE XCD and its column block's position index, tail histograms and keys are fetched into that XCD's L2
+    // once instead of into all eight.
+    const uint32_t kq = blockIdx.x >> 3;
+    const uint32_t tidx = ((kq >> 7) << 3) + (blockIdx.x & 7u), trow = kq & 127u;
+    if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles)
     uint4 tile = a.tiles[tidx];
     const int vlo = (int)((tile.z >> 16) & 0xFFu), vhi = (int)(tile.z >> 24);
     // pair slot in the band's C(v): the tile's block (tile.w), this block's row of it, this lane's column.  (32-bit: a
@@ -1482,7 +1477,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
 // from inside it (a.sig != nullptr).  (With the signalling code behind the body the compiler parks 15 scalar values in
 // VGPR lanes and reads 26 back in the p <= 12 instance, against 27 / 81 in the plain one -- and is SLOWER all the same
 // when it serves calls without parts: configs[3] shape 215.5-216.7 ms against 211.3-211.6, profiles/rd5p; so those keep
-// k_finalize<.., false, false>; option finalize_shared_instance for the A/B.)  One launch per part (an event behind each) cost a source rank of BASELINE
+// k_finalize<.., false, false>.)  One launch per part (an event behind each) cost a source rank of BASELINE
 // configs[2] over 8 ranks 0.49-0.55 ms of k_finalize against 0.43 for one launch -- every launch of ~70 tiles is 2.2
 // waves of blocks with a tail -- and its first part was final 0.3 ms after the tile kernel instead of 0.08.  Here every
 // block, when it is through (its results written through to memory, barrier), counts itself into its tile; a tile's 128th row counts the tile into its
@@ -1495,11 +1490,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8), amdg
 {
     finalize_block<CT, RK, false, false>(a);
     if (a.sig == nullptr) return;  // (a call without parts: nothing to announce)
-    uint32_t tidx = blockIdx.x >> 7;
-    if (a.xcd_tiles) {
-        tidx = (((blockIdx.x >> 3) >> 7) << 3) + (blockIdx.x & 7u);
-        if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles: no tile, nothing to count)
-    }
+    const uint32_t tidx = (((blockIdx.x >> 3) >> 7) << 3) + (blockIdx.x & 7u);
+    if (tidx >= a.ntiles) return;  // (the grid is rounded up to whole groups of 8 tiles: no tile, nothing to count)
     // every WAVE waits for its own write-through stores (gfx9 counts stores in vmcnt; a workgroup-scope release fence
     // compiles to lgkmcnt(0) only, which would let wave 1's stores still be in flight when wave 0 counts the block:
     // ADVICE r5) ...
@@ -1578,20 +1570,6 @@ hipError_t launch_rows_place(hipStream_t st, const PlaceEnt *ent, uint32_t nent,
     return hipGetLastError();
 }
 
-// sorted packed triangle -> packed triangle in original sketch order (one block per sorted row)
-__global__ __launch_bounds__(256) void k_unpermute(const float *__restrict__ in,
-                                                    const uint32_t *__restrict__ perm, uint64_t n,
-                                                    float *__restrict__ out)
-{
-    const uint64_t si = blockIdx.x;
-    const uint64_t i = perm[si];
-    const float *row = in + si * (2 * n - si - 1) / 2 - (si + 1);
-    for (uint64_t sj = si + 1 + threadIdx.x; sj < n; sj += 256) {
-        const uint64_t j = perm[sj];
-        const uint64_t a = i < j ? i : j, b = i < j ? j : i;
-        out[a * (2 * n - a - 1) / 2 + b - (a + 1)] = row[sj];
-    }
-}
 
 // same mapping driven from the destination: one block per ORIGINAL row a, coalesced writes of
 // row a of the output, gathered reads (inv = inverse of perm)
@@ -1634,12 +1612,10 @@ hipError_t launch_unpermute_staged(hipStream_t st, const float *in, const uint32
     return hipGetLastError();
 }
 
-hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *perm, const uint32_t *inv,
-                            uint64_t n, float *out)
+hipError_t launch_unpermute(hipStream_t st, const float *in, const uint32_t *inv, uint64_t n, float *out)
 {
     if (n < 2) return hipSuccess;
-    if (inv) hipLaunchKernelGGL(k_unpermute_gather, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, inv, n, out);
-    else hipLaunchKernelGGL(k_unpermute, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, perm, n, out);
+    hipLaunchKernelGGL(k_unpermute_gather, dim3((uint32_t)(n - 1)), dim3(256), 0, st, in, inv, n, out);
     return hipGetLastError();
 }
 
@@ -1924,7 +1900,6 @@ hipError_t launch_build_colindex(hipStream_t st, const ColIndexLaunch &c)
     // few column blocks (C3: 79; a rank of 8: 28-79): up to 4 workgroups per block, each a quarter of the buckets
     uint32_t G = 1;
     while (G < 4 && c.nblocks * G < 256 && c.nbuckets / (2 * G) >= 4096) G *= 2;
-    if (c.split == 1 || c.split == 2 || c.split == 4) G = std::min<uint32_t>((uint32_t)c.split, std::max<uint32_t>(1, c.nbuckets / 1024));
     const size_t lds = (size_t)(c.nbuckets / G) * sizeof(uint32_t);
 #define DSH_COLINDEX(PT, RK)                                                                                                  \
     do {                                                                                                                      \
@@ -1993,14 +1968,12 @@ hipError_t launch_pair_counts(hipStream_t st, int kc, int cum_bytes, const uint3
         switch (kc) {
         case 16: return launch_pc_u<16, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
         case 32: return launch_pc_u<32, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
-        case 64: return launch_pc_u<64, uint16_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
         default: return hipErrorInvalidValue;
         }
     }
     switch (kc) {
     case 16: return launch_pc_u<16, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     case 32: return launch_pc_u<32, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
-    case 64: return launch_pc_u<64, uint32_t>(st, planes, Npad, Kpad, W, P, tiles, items, nitems, cum, nslots);
     default: return hipErrorInvalidValue;
     }
 }
@@ -2082,11 +2055,10 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     a.col_end = f.col_end; a.base_index = f.base_index; a.out = f.out;
     a.stop = f.stop;
     a.phase_cyc = f.phase_cyc;
-    a.xcd_tiles = f.xcd_tiles;
     a.sig = f.sig;
     a.ntiles = (uint32_t)(f.nslots / ((uint64_t)kTile * kTile));
     const size_t lds = (64 + 128 + 8) * sizeof(uint32_t) + (size_t)f.hist_bins * 128 * (f.cum_bytes == 2 ? 2 : 4);
-    const uint32_t blocks = f.xcd_tiles ? (a.ntiles + 7u) / 8u * 8u * 128u : (uint32_t)((f.nslots + 127) / 128);
+    const uint32_t blocks = (a.ntiles + 7u) / 8u * 8u * 128u;  // (whole groups of 8 tiles: a tile's 128 rows on one XCD)
     const bool timed = f.phase_cyc != nullptr;  // profiling only
     const bool general = f.rect || f.square || f.sorted_out || f.knn;
     if (f.sig && (general || timed)) return hipErrorInvalidValue;  // (the signalling instance is the plain triangle's)
@@ -2094,7 +2066,7 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeLaunch &f)
     do {                                                                                                                 \
         if (general) hipLaunchKernelGGL((k_finalize<CT, RK, false, true>), dim3(blocks), dim3(128), lds, st, a);        \
         else if (timed) hipLaunchKernelGGL((k_finalize<CT, RK, true, false>), dim3(blocks), dim3(128), lds, st, a);      \
-        else if (f.sig || f.shared_instance) hipLaunchKernelGGL((k_finalize_signal<CT, RK>), dim3(blocks), dim3(128), lds, st, a); \
+        else if (f.sig) hipLaunchKernelGGL((k_finalize_signal<CT, RK>), dim3(blocks), dim3(128), lds, st, a); \
         else hipLaunchKernelGGL((k_finalize<CT, RK, false, false>), dim3(blocks), dim3(128), lds, st, a);                \
     } while (0)
     // (the record width follows the precision like k_build_colindex: colindex_inline)

@@ -626,7 +626,6 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     pp.band_frags.clear();
     pp.nparts = 0;
     pp.max_band = 0;
-    pp.finalize_rowmajor = tu.finalize_rowmajor;
     const uint32_t NT = L.Npad / kTile;
     // tile list: {row block, col block, plane begin, plane end}; a tile only needs the planes
     // v in (max(min lo of its two blocks), max threshold of its two blocks]
@@ -724,7 +723,7 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
             std::vector<uint64_t> tails;  // rounds of the tail bands, last band first
             uint64_t left = R;
             for (uint32_t b = 0; b < ntails; ++b) {
-                const uint64_t pm = b == 0 || tu.tail_permille2 == 0 ? tu.tail_permille : tu.tail_permille2;
+                const uint64_t pm = b == 0 ? tu.tail_permille : tu.tail_permille2;
                 const uint64_t r = std::max<uint64_t>(1, (left * pm + 500) / 1000);
                 // (a tail in front of the last one only pays where the head keeps enough rounds for its parts' transfer to
                 // hide behind it: 14 rounds -> 8 + 5 + 1, but 7 rounds -> 6 + 1, profiles/rd5d)
@@ -799,9 +798,8 @@ bool build_tiles(const Layout &L, const PairQuery &job, const Tuning &tu, PairPl
     for (auto &sv : pp.segs)
         for (auto &sg : sv)
             for (size_t t = sg.b; t < sg.e; ++t) rank[t] = (uint32_t)(t - sg.b);
-    if (tu.xcd_swizzle)
-        for (auto &sv : pp.segs)
-            for (auto &sg : sv) xcd_order(T, rank, sg.b, sg.e, tu.lockstep ? 2 : 1);
+    for (auto &sv : pp.segs)
+        for (auto &sg : sv) xcd_order(T, rank, sg.b, sg.e, tu.lockstep ? 2 : 1);
     // chunk range of every tile (the work items of a band are cut from these: build_band_items)
     const uint32_t KC = (uint32_t)tu.kc;
     const uint32_t cpp = tu.W >= KC ? tu.W / KC : 1;  // chunks per plane when a plane spans chunks
@@ -863,7 +861,7 @@ void build_band_items(const Tuning &tu, PairPlan &pp, size_t bi)
     // a group of pieces equal lengths are kept together, longest first, tiles in order (only a tile's last piece can be
     // shorter; with whole-plane pieces every item of the group has the same length and nothing moves).  One counting
     // pass, one placing pass: at 100 000 sketches the host plans 306 000 tiles and nothing hides it (profiles/r4y).
-    const bool by_length = tu.lockstep && tu.ls_sort_items && piece <= 65536;
+    const bool by_length = tu.lockstep && piece <= 65536;
     std::vector<uint32_t> &first = pp.sort_first;
     for (uint32_t s = 0; s < maxpieces; ++s) {
         const size_t g0 = I.size();
@@ -893,7 +891,7 @@ void build_band_items(const Tuning &tu, PairPlan &pp, size_t bi)
             if (place) out[first[piece - len]++] = it;
             else *out++ = it;
         }
-        if (!by_length && tu.lockstep && tu.ls_sort_items && lmin != lmax)
+        if (!by_length && tu.lockstep && lmin != lmax)
             std::stable_sort(I.begin() + g0, I.end(), [](const U4 &x, const U4 &y) { return x.z - x.y > y.z - y.y; });
     }
     // overflow fragments: the band's last `over` items (whole planes all of them: piece = one plane) in f pieces each
@@ -946,7 +944,7 @@ void emit_band_lists(const Layout &L, const PairPlan &pp, size_t bi, U4 *pinT, U
             tile_vrange(L, T[t], lo, hi);
             const uint32_t pl = T[t].z | (T[t].w << 8);
             pinT[t] = U4{T[t].x, T[t].y, pl, (uint32_t)lo | ((uint32_t)hi << 8)};
-            const size_t at = pp.finalize_rowmajor ? sg.b + pp.rank[t] : t;
+            const size_t at = sg.b + pp.rank[t];
             // (w: the tile's C(v) block in its band -- at most 2^16 tiles per band -- and, above it, the tile's part: the
             // signalling k_finalize counts a finished tile into that part)
             const uint32_t part = pp.nparts ? (uint32_t)((std::upper_bound(pp.part_first.begin(), pp.part_first.end() - 1, t) - pp.part_first.begin()) - 1) : 0u;

@@ -167,10 +167,7 @@ struct Tuning {
     uint64_t cum_budget = 8ull << 30;
     int nsplit = 0;
     bool lockstep = true;
-    int ls_item_chunks = 64;
-    int ls_sort_items = 1;
-    int xcd_swizzle = 1;
-    int finalize_rowmajor = 1;
+    int ls_item_chunks = 64;  // lockstep kernel: work items of at most about this many K-chunks (whole planes; 16/32/64 within noise, profiles/rd5j)
     uint32_t part_band_tiles = 2048;  // a part of at least this many tiles also ends the band of the tile kernel
     // Tail bands (jobs with parts = the exchange; jobs of at most 64 rounds of one-plane items, in bands of at most 16).  The lockstep
     // tile kernel runs in ROUNDS of round_items work items (2 per workgroup, one workgroup per CU); a rank's parts only
@@ -187,8 +184,8 @@ struct Tuning {
     // partial counts to the plane's C(v) block with atomics (cleared first); whole items keep their plain stores.
     uint32_t overflow_frag_max_permille = 500;  // 0: never
     uint32_t tail_bands = 2;
-    uint32_t tail_permille = 100;
-    uint32_t tail_permille2 = 350;  // share of the rounds left for the tails in front of the last one (0: tail_permille)
+    uint32_t tail_permille = 100;   // the last tail: one round of the tile kernel of a rank of BASELINE configs[2] over 8
+    uint32_t tail_permille2 = 350;  // share of the rounds left for the tails in front of the last one
     uint32_t tail_head_min_rounds = 7;  // a tail in front of the last one must leave the head at least this many rounds
 };
 
@@ -212,7 +209,6 @@ struct PairPlan {
     uint32_t nparts = 0;                                 // parts that get an event (0 without want_parts)
     std::vector<uint32_t> part_tiles;                    // tiles of every part (all bands): a part is final when they are finalized
     std::vector<size_t> part_first;                      // first tile of every part in T (+ the end): the part of a tile
-    int finalize_rowmajor = 1;
     std::vector<uint32_t> sort_first;                    // scratch of the item sort
     std::vector<U4> sort_tmp;
 };

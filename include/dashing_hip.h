@@ -402,28 +402,36 @@ int dsh_last_part_info(dsh_ctx *ctx, double *ready_ms /* [cap] or NULL */, uint6
  * [6] such waves; [7] their lanes; sums over lanes of [8] MLE iterations, [9] live bins, [10] iterations x bins; sums over
  * waves of the per-wave maxima [11] iterations, [12] bins, [13] their product (what a wave pays); [14..15] zero. */
 int dsh_finalize_phase_cycles(dsh_ctx *ctx, uint64_t *out16);
-/* Tunables; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
- * byte-identical output over their ranges): "kc" (0 auto | 16 | 32 | 64 k-rows per LDS stage), "emax" / "elow" (caps of the listed upper / lower register tail, 0..255, -1 auto),
- * "sort" (-1 auto|0|1 key-ordered columns), "range_sort_min_rows", "nsplit" (pieces per tile, 0 auto),
- * "pair_lockstep" (-1 auto|0|1: the phase-locked tile kernel k_pair_counts_ls vs the free-running k_pair_counts),
- * "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles" (0|1: a tile's 128 rows on one XCD),
- * "part_band_tiles" (a part of at least this many tiles also ends a launch of the tile kernel), "xch_tail_bands" (0..8, default 2: the second only where the head keeps at least 7 rounds) /
- * "xch_tail_permille" (default 100: one round of the tile kernel of a rank of BASELINE configs[2] over 8) / "xch_tail_permille2" (the
- * share of the tails in front of the last one, default 350; 0 = the same) / "xch_tail_head_min_rounds" (such a tail must leave the head
- * at least this many rounds, default 7): a job with parts of at most 64 rounds of 512 one-plane work items has its tile kernel cut
- * at whole rounds into head and tail launches of at most 16 rounds, so that the head's parts travel while the tails compute, "overflow_frag_permille" (0..1000, default 500: a band of one-plane work items whose count lies at most that share of a round above a
- * multiple of 512 has the items left over cut into fragments of a plane that ADD their counts, so that the extra round is a fraction of one; 0 = never),
- * "xch_recv_gate" (-1 auto | 0 | 1: the destination of an exchange posts its receives behind its first tile kernel instead of at once -- an RCCL
- * kernel waiting for its peers spins beside the tile kernel; auto = for a job of one launch of at most 8 rounds, whose peers have nothing to send earlier),
- * "finalize_shared_instance" (0 | 1, A/B only: calls without parts take the signalling instance of k_finalize too), "finalize_signal" (-1 auto | 0 | 1: a call with parts finalizes a band in ONE launch and the parts announce themselves from inside it --
- * the copy stream waits for a part's flag with hipStreamWaitValue32 -- instead of one launch and one event per part; auto = where the
- * device supports it), "finalize_two_streams" (0|1: with events, the
- * k_finalize launches of a call with parts alternate between two streams), "colindex_split" (0 auto | 1 | 2 | 4
- * workgroups per column block of the position index), "cum_budget_bytes", "knn_square_budget_bytes", "unpermute_gather",
- * "assembler_permille", "shard_c0_x10"; profiling only: "finalize_timing" (the stamped instance of k_finalize, same results);
- * what-if only: "pair_mfma" (refused unless the library was built with `make WHATIF=1`).
- * "finalize_stop" (1..4) is a profiling aid that DOES change results (k_finalize leaves after a phase and stores a dummy):
- * it is accepted only while dsh_set_profiling is on and is cleared when profiling is switched off. */
+/* Options; returns DSH_EINVAL for unknown names or values.  None changes a result (tests/test_gpu_compare.py asserts
+ * byte-identical output over their ranges).  The tuning knobs of rounds 2-5 whose A/B was decided are gone together with
+ * their losing arms (profiles/HISTORY.md has the measurements); what is left is what a caller or a first run on other
+ * hardware needs:
+ *   resources     "cum_budget_bytes"        scratch for the pair counts C(v) (default 8 GiB): larger jobs run in bands
+ *                 "knn_square_budget_bytes" all-vs-all dsh_knn keeps an n x n float matrix in HBM up to this size (96 GiB)
+ *   layout        "sort"                    -1 auto | 0 | 1: key-ordered plane columns (0 = identity: the slow, simple layout)
+ *                 "range_sort_min_rows"     row ranges shorter than this keep the cached identity layout (default 1024)
+ *                 "emax" / "elow"           caps of the listed upper / lower register tail, 0..255, -1 auto (per precision);
+ *                                           0 / 0 = bit-planes over the whole value range (adversarial register laws)
+ *   tile kernel   "kc"                      0 auto | 16 | 32 k-rows per LDS stage
+ *                 "nsplit"                  pieces per tile, 0 auto (work items of at most 64 chunks)
+ *                 "overflow_frag_permille"  0..1000 (default 500): a band whose one-plane work items number at most that
+ *                                           share of a round above a multiple of 512 has the items left over cut into
+ *                                           fragments that ADD their counts; 0 = never
+ *   exchange      "part_band_tiles"         a part of at least this many tiles also ends a launch of the tile kernel (2048)
+ *                 "xch_tail_bands"          0..8 (default 2): a job with parts of at most 64 rounds has its tile kernel cut
+ *                                           at whole rounds into a head and this many tails, so that the head's parts
+ *                                           travel while the tails compute
+ *                 "xch_recv_gate"           -1 auto | 0 | 1: the destination posts its receives behind its first tile
+ *                                           kernel instead of at once (a waiting receive kernel beside the tile kernel
+ *                                           costs it 2-14 %, profiles/rd6a/interference_probe.jsonl); auto = for a job
+ *                                           of one launch of at most 8 rounds, whose peers have nothing to send earlier
+ *                 "finalize_signal"         -1 auto | 0 | 1: parts announce themselves from inside ONE k_finalize launch
+ *                                           per band (flags + hipStreamWaitValue32) instead of one launch and one event
+ *                                           per part; auto = where the device supports stream wait-value
+ *   profiling     "finalize_timing"         the s_memtime-stamped instance of k_finalize (same results)
+ *                 "finalize_stop"           1..4: k_finalize leaves after a phase and stores a dummy -- CHANGES results;
+ *                                           accepted only while dsh_set_profiling is on, cleared when it is switched off
+ * ("pair_mfma" exists only in a library built with `make WHATIF=1`: the matrix-core what-if the north star excludes.) */
 int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
  * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands", "items" (work items of the tile kernel),

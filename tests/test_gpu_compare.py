@@ -187,8 +187,7 @@ def test_row_range_in_parts_and_pipelined_collect(ctx, n, p):
 
 def test_finalize_tile_order_does_not_change_results(ctx):
     """k_finalize walks its own row-major tile list while the tile kernel's launch order is XCD-interleaved (run_pairs):
-    with hundreds of tiles per segment, every combination of the two orders, a row range, parts and several bands gives
-    the same bytes"""
+    with hundreds of tiles per segment, a row range, parts and several bands give the same bytes"""
     import torch
 
     n, p = 3300, 10
@@ -197,12 +196,9 @@ def test_finalize_tile_order_does_not_change_results(ctx):
     base = ctx.dist_rows()
     dev = torch.device("cuda", 0)
     try:
-        for rm, xs in ((0, 1), (1, 0), (0, 0), (1, 1)):
-            ctx.set_option("finalize_rowmajor", rm)
-            ctx.set_option("xcd_swizzle", xs)
-            assert ctx.dist_rows().tobytes() == base.tobytes(), (rm, xs)
-            lo, span = dashing_amd.tri_span(n, 0, 640), dashing_amd.tri_span(n, 640, 2100)
-            assert ctx.dist_rows(640, 2100).tobytes() == base[lo : lo + span].tobytes(), (rm, xs)
+        assert ctx.dist_rows().tobytes() == base.tobytes()
+        lo, span = dashing_amd.tri_span(n, 0, 640), dashing_amd.tri_span(n, 640, 2100)
+        assert ctx.dist_rows(640, 2100).tobytes() == base[lo : lo + span].tobytes()
         out = torch.full((base.size,), -1.0, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         ctx.dist_rows_parts_device_async(out.data_ptr(), 0, n, 3)
@@ -216,8 +212,6 @@ def test_finalize_tile_order_does_not_change_results(ctx):
         ctx.wait()
         assert out.cpu().numpy().tobytes() == base.tobytes()
     finally:
-        ctx.set_option("finalize_rowmajor", 1)
-        ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
@@ -360,9 +354,11 @@ def test_options_do_not_change_results(ctx):
     ctx.set_sketches(regs)
     base = ctx.dist_rows()
     try:
-        for kc in (16, 64, 32):
+        for kc in (16, 32):
             ctx.set_option("kc", kc)
             assert ctx.dist_rows().tobytes() == base.tobytes()
+        with pytest.raises(dashing_amd.DshError):
+            ctx.set_option("kc", 64)
         for emax in (0, 1, 8, 64, 200, 255, -1):   # dense-only .. full exception lists: same exact histogram
             ctx.set_option("emax", emax)
             assert ctx.dist_rows().tobytes() == base.tobytes()
@@ -371,8 +367,6 @@ def test_options_do_not_change_results(ctx):
             ctx.set_option("emax", emax)
             assert ctx.dist_rows().tobytes() == base.tobytes()
             assert ctx.dist_rect(3, 133, 0, 140).tobytes() == ctx.dist_rect(3, 133, 0, 140).tobytes()
-        ctx.set_option("xcd_swizzle", 0)
-        assert ctx.dist_rows().tobytes() == base.tobytes()
         for sm in (0, 1, -1):   # identity vs (threshold,min)-sorted plane columns
             ctx.set_option("sort", sm)
             assert ctx.dist_rows().tobytes() == base.tobytes()
@@ -383,19 +377,17 @@ def test_options_do_not_change_results(ctx):
         ctx.set_option("cum_budget_bytes", 1 << 21)  # force many bands
         assert ctx.dist_rows().tobytes() == base.tobytes()
         ctx.set_option("cum_budget_bytes", 8 << 30)
-        # the r1 tile kernel (256-thread workgroups, no phase-locking) vs the default lockstep kernel: same integers
-        ctx.set_option("pair_lockstep", 0)
         for kc, ns in ((16, 0), (32, 0), (16, 3), (16, 64)):
             ctx.set_option("kc", kc)
             ctx.set_option("nsplit", ns)
             assert ctx.dist_rows().tobytes() == base.tobytes()
-        ctx.set_option("pair_lockstep", 1)
         ctx.set_option("nsplit", 0)
-        for chunks in (1, 16, 64, 100000):  # item size of the lockstep kernel
-            ctx.set_option("ls_item_chunks", chunks)
-            assert ctx.dist_rows().tobytes() == base.tobytes()
-        ctx.set_option("ls_item_chunks", 64)
-        ctx.set_option("pair_lockstep", -1)
+        # the tuning knobs whose A/B was decided in rounds 2-5 are gone, with their losing arms
+        for gone in ("pair_lockstep", "ls_item_chunks", "ls_sort_items", "xcd_swizzle", "finalize_rowmajor", "finalize_xcd_tiles",
+                     "finalize_two_streams", "finalize_shared_instance", "colindex_split", "unpermute_gather", "xch_tail_permille",
+                     "xch_tail_permille2", "xch_tail_head_min_rounds", "assembler_permille", "shard_c0_x10"):
+            with pytest.raises(dashing_amd.DshError):
+                ctx.set_option(gone, 1)
         # the what-if variant of the tile kernel on the matrix cores is not in the product library (`make WHATIF=1`
         # builds it): the default build refuses the option; a what-if build must give the same integers
         if ctx.info("whatif_mfma"):
@@ -407,54 +399,45 @@ def test_options_do_not_change_results(ctx):
             with pytest.raises(dashing_amd.DshError):
                 ctx.set_option("pair_mfma", 1)
     finally:
-        ctx.set_option("pair_mfma", 0)
-        ctx.set_option("pair_lockstep", -1)
-        ctx.set_option("ls_item_chunks", 64)
+        if ctx.info("whatif_mfma"):
+            ctx.set_option("pair_mfma", 0)
         ctx.set_option("kc", 0)
         ctx.set_option("emax", -1)
         ctx.set_option("elow", -1)
         ctx.set_option("sort", -1)
         ctx.set_option("nsplit", 0)
-        ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("cum_budget_bytes", 8 << 30)
 
 
 @pytest.mark.parametrize("p,n", [(8, 300), (9, 300), (10, 700), (11, 300), (12, 260), (13, 300), (15, 200), (16, 150), (18, 40)])
-def test_lockstep_and_free_running_tile_kernels_agree(ctx, p, n):
-    """k_pair_counts_ls (two work items per 512-thread workgroup, AND/BCNT batches phase-locked, deferred plane flush,
-    a shorter or missing partner item idling at the barriers) vs k_pair_counts, forced on at every precision where a
-    plane spans whole chunks (p >= 9; below, the option falls back); odd item counts and unequal item lengths included."""
+def test_tile_kernel_item_shapes_agree_with_the_oracle(ctx, oracle, p, n):
+    """k_pair_counts_ls (two work items per 512-thread workgroup, AND/BCNT batches phase-locked, deferred plane flush, a
+    shorter or missing partner item idling at the barriers) at every precision where a plane spans whole chunks (p >= 9;
+    below, the free-running k_pair_counts of the small precisions), k-rows per stage 16 / 32, tiles cut into 1 .. 5 pieces
+    (odd item counts, unequal item lengths): the same bytes every way, and those within 1e-6 of the CPU oracle."""
     regs = synth.synthetic_sketches(n, p, seed=900 + p)
     ctx.set_sketches(regs)
     try:
-        ctx.set_option("pair_lockstep", 0)
-        free = ctx.dist_rows()
-        assert ctx.info("lockstep") == 0
-        ctx.set_option("pair_lockstep", 1)
-        for kc, ns, chunks, srt in ((16, 0, 16, 1), (32, 0, 16, 1), (16, 3, 16, 1), (16, 0, 1, 0), (16, 0, 100000, 1), (16, 5, 7, 0), (16, 0, 16, 0)):
+        base = ctx.dist_rows()
+        want = oracle.dist_tri(regs)
+        close(base, want)
+        for kc, ns in ((16, 0), (32, 0), (16, 3), (16, 1), (32, 5), (16, 64)):
             ctx.set_option("kc", kc)
             ctx.set_option("nsplit", ns)
-            ctx.set_option("ls_item_chunks", chunks)
-            ctx.set_option("ls_sort_items", srt)  # equal-length items next to each other (the kernel pairs neighbours)
             got = ctx.dist_rows()
             assert ctx.info("lockstep") == (1 if (1 << p) // 32 >= kc else 0)
-            assert got.tobytes() == free.tobytes(), (kc, ns, chunks, srt)
-        ctx.set_option("ls_sort_items", 1)
+            assert got.tobytes() == base.tobytes(), (kc, ns)
         # a row range (odd tile counts) and a rectangle through the same kernel
         ctx.set_option("kc", 0)
         ctx.set_option("nsplit", 0)
-        ctx.set_option("ls_item_chunks", 16)
         part = ctx.dist_rows(5, n - 3)
+        lo = dashing_amd.tri_span(n, 0, 5)
+        assert part.tobytes() == base[lo : lo + part.size].tobytes()
         rect = ctx.dist_rect(0, n // 2, n // 3, n)
-        ctx.set_option("pair_lockstep", 0)
-        assert ctx.dist_rows(5, n - 3).tobytes() == part.tobytes()
-        assert ctx.dist_rect(0, n // 2, n // 3, n).tobytes() == rect.tobytes()
+        close(rect, oracle.dist_rect(regs[: n // 2], regs[n // 3 :]))
     finally:
-        ctx.set_option("pair_lockstep", -1)
         ctx.set_option("kc", 0)
         ctx.set_option("nsplit", 0)
-        ctx.set_option("ls_item_chunks", 16)
-        ctx.set_option("ls_sort_items", 1)
 
 
 def test_properties_at_scale(ctx, oracle):
@@ -528,14 +511,10 @@ def test_virtual_shards_assemble(ctx, nshards):
         sorted_full[off[r] : off[r + 1]] = span[: off[r + 1] - off[r]]
     torch.cuda.synchronize()
     final = torch.full((off[-1],), -3.0, dtype=torch.float32, device=dev)
-    for mode in (1, 0):  # destination-driven (default) and source-driven un-permute
-        ctx.set_option("unpermute_gather", mode)
-        final.fill_(-3.0)
-        torch.cuda.synchronize()
-        ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
-        ctx.synchronize()
-        assert final.cpu().numpy().tobytes() == want.tobytes()
-    ctx.set_option("unpermute_gather", 1)
+    torch.cuda.synchronize()
+    ctx.unpermute_device(sorted_full.data_ptr(), final.data_ptr())
+    ctx.synchronize()
+    assert final.cpu().numpy().tobytes() == want.tobytes()
     # the same from the padded blocks a gather delivers (shard r at r * stride)
     stride = max(max(off[r + 1] - off[r] for r in range(nshards)), 1) + 5
     stage = torch.full((nshards * stride,), -4.0, dtype=torch.float32, device=dev)
@@ -567,11 +546,10 @@ def test_set_triple_measures(ctx, oracle, rt):
 
 
 @pytest.mark.parametrize("p", [9, 10, 12, 13, 14])
-def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
+def test_record_width_does_not_change_results(ctx, oracle, p):
     """round 4: the position index keeps a bucket's first 7 (p <= 12, lists of <= 256 entries) or 3 entries inside its
-    record; list caps beyond 256 entries switch a small-p collection to the narrow records and four look-up rounds; the
-    blocks of k_finalize map to tiles XCD-wise or plainly.  Same exact histograms whatever the combination -- and equal
-    to the oracle's."""
+    record; list caps beyond 256 entries switch a small-p collection to the narrow records and four look-up rounds.
+    Same exact histograms whatever the combination -- and equal to the oracle's."""
     n = 300
     regs = synth.synthetic_sketches(n, p, seed=70 + p)
     ctx.set_sketches(regs)
@@ -582,13 +560,8 @@ def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
         for emax, elow in ((255, 255), (200, 17), (128, 128), (0, 0), (64, 255), (3, 250), (-1, -1)):
             ctx.set_option("emax", emax)
             ctx.set_option("elow", elow)
-            for xcd in (1, 0):
-                ctx.set_option("finalize_xcd_tiles", xcd)
-                assert ctx.dist_rows().tobytes() == base.tobytes(), (p, emax, elow, xcd)
+            assert ctx.dist_rows().tobytes() == base.tobytes(), (p, emax, elow)
             assert ctx.dist_rows(estim=dashing_amd.ESTIM_ORIGINAL).tobytes() != b""  # (runs; checked against the oracle below)
-        for split in (1, 2, 4, 0):  # workgroups per column block of the index build (each owns a range of the buckets)
-            ctx.set_option("colindex_split", split)
-            assert ctx.dist_rows().tobytes() == base.tobytes(), (p, "colindex_split", split)
         ctx.set_option("emax", 255)
         ctx.set_option("elow", 255)
         for estim in (0, 1, 2):  # every estimator on the narrow-record path of a small p
@@ -597,8 +570,6 @@ def test_record_width_and_block_mapping_do_not_change_results(ctx, oracle, p):
     finally:
         ctx.set_option("emax", -1)
         ctx.set_option("elow", -1)
-        ctx.set_option("finalize_xcd_tiles", 1)
-        ctx.set_option("colindex_split", 0)
 
 
 @pytest.mark.parametrize("p", [16, 22, 23])

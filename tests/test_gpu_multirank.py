@@ -495,15 +495,12 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
 @pytest.mark.gpu
 def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
     """By default (round 5) a band is finalized by ONE launch and the parts announce themselves from inside it (flags the
-    copy stream waits for with hipStreamWaitValue32); finalize_signal = 0 is the older scheme -- one launch and one event
-    per part, the launches alternating between the ctx stream and the second stream (a part's event is recorded on the
-    stream that finished it), finalize_two_streams = 0 keeps them on one.  Bands cut per part (part_band_tiles) put
-    several tile-kernel launches between them.  The exchange sees the same parts either way."""
-    run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_signal=0,finalize_two_streams=0")
+    copy stream waits for with hipStreamWaitValue32); finalize_signal = 0 is the scheme for devices without stream
+    wait-value -- one launch and one event per part.  Bands cut per part (part_band_tiles) put several tile-kernel
+    launches between them.  The exchange sees the same parts either way."""
     run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", opts="finalize_signal=0")
     run_mock_world(tmp_path, 4, 3000, 12, 3, "exchange", dst=2, rowsets=True, expect_topups=True, opts="finalize_signal=0")
-    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=1,part_band_tiles=200")
-    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,finalize_two_streams=0,part_band_tiles=200")
+    run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="finalize_signal=0,part_band_tiles=200")
     run_mock_world(tmp_path, 2, 9000, 10, 4, "parts", opts="part_band_tiles=200")  # flags, bands cut per part
     # the destination posts its receives at once, or behind its first tile kernel (auto: short jobs only)
     run_mock_world(tmp_path, 3, 3000, 12, 4, "exchange", rowsets=True, opts="xch_recv_gate=1")
