@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -117,7 +118,12 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
     return acc;
 }
 
-template <bool GLOBAL, bool CANON>
+// REG32 (p <= kMaxPReg32, round 6): the workgroup's registers are ONE 32-bit word each, so the register rule is a single
+// native LDS atomic -- ds_max_u32, nothing returned, nothing to wait for -- instead of a byte read that filters, a branch
+// and a compare-and-swap loop on the containing word: a wave walked that 13-instruction path whenever ONE of its 64
+// lanes raised a register (~5 of 57 VALU per k-mer at p = 10, profiles/rd5g/sketch_instr.json).  4 KiB of LDS at p = 10,
+// 32 KiB at p = 13; above that the packed bytes keep two workgroups' worth of waves per CU.
+template <bool GLOBAL, bool CANON, bool REG32>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, uint8_t *__restrict__ regs)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     // [0, 2^p/4): registers as packed bytes; then the packed words of the current sub-chunk, one
     // slot per lane plus one for the 32 bases that follow it (each lane needs its right neighbour)
     const int tid = threadIdx.x;
-    const uint32_t mwords = GLOBAL ? 0u : (1u << p) >> 2;
+    const uint32_t mwords = GLOBAL ? 0u : (REG32 ? (1u << p) : (1u << p) >> 2);
     const SketchWork wk = work[blockIdx.x];
     uint32_t *lregs = GLOBAL ? reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p)) : lds;
     uint64_t *xF = reinterpret_cast<uint64_t *>(lds + ((mwords + 3) & ~3u));
@@ -199,6 +205,10 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             uint32_t lz = zh < zl + 32u ? zh : zl + 32u;
             asm("" : "+v"(lz));  // keep the comparison below in 32 bits (hipcc otherwise widens it to u64)
             const uint32_t val = lz + 1u;
+            if constexpr (REG32) {
+                atomicMax(&lregs[idx], val);  // ds_max_u32
+                return;
+            }
             // filter with a plain byte read: almost no k-mer can raise its register
             if (reinterpret_cast<const uint8_t *>(lregs)[idx] > lz) return;
             uint32_t *wp = &lregs[idx >> 2];
@@ -226,8 +236,15 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     if (GLOBAL) return;
     __syncthreads();
     uint32_t *g = reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p));
-    for (uint32_t w = tid; w < mwords; w += 256) {
-        const uint32_t mine = lregs[w];
+    const uint32_t gwords = (1u << p) >> 2;
+    for (uint32_t w = tid; w < gwords; w += 256) {
+        uint32_t mine;
+        if constexpr (REG32) {
+            const uint4 q = reinterpret_cast<const uint4 *>(lregs)[w];  // four registers -> their packed bytes
+            mine = q.x | (q.y << 8) | (q.z << 16) | (q.w << 24);
+        } else {
+            mine = lregs[w];
+        }
         if (!mine) continue;
         uint32_t old = g[w];
         for (;;) {
@@ -238,6 +255,13 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             old = prev;
         }
     }
+}
+
+// A/B of round 6 only (tools/bench_sketch.py, profiles/rd6*): DSH_SKETCH_BYTES=1 keeps the packed-byte registers at every p
+static bool sketch_force_bytes()
+{
+    static const bool v = std::getenv("DSH_SKETCH_BYTES") != nullptr;
+    return v;
 }
 
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
@@ -263,17 +287,17 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
     return e;
 }
 
-template <bool GLOBAL>
+template <bool GLOBAL, bool REG32>
 static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
                                   uint8_t *regs, size_t lds)
 {
     if (lds > (48u << 10)) {
-        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true>)
-                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false>), lds);
+        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, REG32>)
+                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, REG32>), lds);
         if (e != hipSuccess) return e;
     }
-    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
-    else hipLaunchKernelGGL((k_sketch<GLOBAL, false>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, REG32>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, REG32>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
 }
 
@@ -282,10 +306,12 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
 {
     if (nwork == 0) return hipSuccess;
     const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
-    if (p > kMaxPLds) return launch_sketch_v<true>(st, seq, work, nwork, k, p, canon, regs, xch);
-    // registers (2^p bytes, 16-byte aligned) + the exchange slots
-    const size_t lds = ((((size_t)1 << p) + 15) & ~(size_t)15) + xch;
-    return launch_sketch_v<false>(st, seq, work, nwork, k, p, canon, regs, lds);
+    if (p > kMaxPLds) return launch_sketch_v<true, false>(st, seq, work, nwork, k, p, canon, regs, xch);
+    // registers (a word each up to p = kMaxPReg32, packed bytes above; 16-byte aligned) + the exchange slots
+    const bool reg32 = p <= kMaxPReg32 && !sketch_force_bytes();
+    const size_t lds = ((((size_t)(reg32 ? 4 : 1) << p) + 15) & ~(size_t)15) + xch;
+    if (reg32) return launch_sketch_v<false, true>(st, seq, work, nwork, k, p, canon, regs, lds);
+    return launch_sketch_v<false, false>(st, seq, work, nwork, k, p, canon, regs, lds);
 }
 
 }  // namespace dsh

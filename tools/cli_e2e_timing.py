@@ -41,7 +41,10 @@ def main():
         cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
         out = os.path.join(d, "dist.bin")
         ref = None
-        for env_extra, threads in (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({}, 16), ({}, 8), ({}, 32), ({"DSH_HOST_PARSE": "1"}, 16)) + tuple(
+        runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
+        for th in (1, 2, 4, 8):
+            runs += (({}, th), ({"DSH_HOST_PARSE": "1"}, th))
+        for env_extra, threads in runs + tuple(
                 (dict(kv.split("=") for kv in e.split(",")), 16) for e in filter(None, os.environ.get("EXTRA", "").split(";"))):
             time.sleep(0.5)
             env = dict(os.environ, DSH_TIMING="1", **env_extra)
@@ -53,7 +56,7 @@ def main():
             if ref is None:
                 ref = data
             print(json.dumps({"env": env_extra, "threads": threads, "rc": r.returncode, "wall_s": round(wall, 4), "same_matrix_as_first_run": data == ref,
-                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:60]}), flush=True)
+                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:4] + [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][-3:]}), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
