@@ -6,6 +6,8 @@
 // rejected.  There is no CPU compute path: without a gfx950 device the program exits non-zero.
 #include <getopt.h>
 #include <omp.h>
+
+#include <atomic>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -202,13 +204,20 @@ static double now_s()
 }
 static const bool g_timing = std::getenv("DSH_TIMING") != nullptr;  // phase times on stderr
 
-static const size_t kSketchBatchBytes = (size_t)128 << 20;  // file bytes per sketching batch
+// File bytes per sketching batch, and the page-locked staging buffers the batches cycle through.  The batches of a large
+// input travel back to back: batch b is parsed (or, for plain FASTA, just read: the device decodes it) into buffer b % 3
+// and enqueued at once -- host-to-device copy + kernels behind the previous batch on the context's stream -- while the
+// host already fills the next buffer; a buffer is only waited for when its turn comes again (a ticket per batch).
+// Round 5 waited for batch b - 1 before enqueueing batch b (two buffers): 4.9 ms per 128 MB = 27 GB/s where the copy
+// alone takes 2.6 ms (profiles/rd6c/cli_e2e_timing.jsonl).
+static const size_t kSketchBatchBytes = (size_t)48 << 20;
+constexpr int kStageBufs = 3;
 // plain FASTA is decoded on the device (dsh_sketch_fastx_batch_async: the host only read()s the file bytes into the
 // staging); DSH_HOST_PARSE=1 keeps the host parser for everything (A/B, and the path compressed inputs and pipes take anyway)
 static const bool g_device_parse = std::getenv("DSH_HOST_PARSE") == nullptr;
 
-// page-locked staging is only worth allocating (0.06-0.08 s for the two buffers) when the input does not fit one
-// batch: the first batch is parsed into pageable memory anyway
+// page-locked staging is only worth allocating (pinning runs at ~3 GB/s) when the input does not fit one batch: the
+// first batch is parsed into pageable memory anyway
 static size_t staging_bytes_for(const std::vector<std::string> &paths)
 {
     uint64_t total = 0;
@@ -220,17 +229,20 @@ static size_t staging_bytes_for(const std::vector<std::string> &paths)
 }
 
 // The GPU context is created on its own thread while the host already parses the first batch: bringing the HIP
-// runtime up costs ~0.2 s, as much as reading a gigabase of FASTA on 16 threads.
+// runtime up costs ~0.1-0.2 s, as much as reading gigabases of FASTA on 16 threads.  The same thread then page-locks the
+// staging buffers ONE BY ONE (stage_ready counts them): the main thread takes each as soon as it exists.
 struct CtxFuture {
     std::promise<dsh_ctx *> ready;
     std::future<dsh_ctx *> fut;
-    std::future<void> done;  // the context thread itself (it goes on to allocate the staging buffers)
+    std::future<void> done;  // the context thread itself
     dsh_ctx *ctx = nullptr;
-    uint8_t *stage[2] = {nullptr, nullptr};  // page-locked staging for fill_sketches, allocated on the ctx thread too
+    uint8_t *stage[kStageBufs] = {};  // page-locked staging for fill_sketches, allocated on the ctx thread too
+    std::atomic<int> stage_ready{0};
     size_t stage_cap = 0;
     CtxFuture(int device, size_t n, int S, size_t staging_bytes = 0)
     {
         fut = ready.get_future();
+        stage_cap = staging_bytes;
         done = std::async(std::launch::async, [this, device, n, S, staging_bytes]() {
             const double t0 = now_s();
             dsh_ctx *c = nullptr;
@@ -239,9 +251,10 @@ struct CtxFuture {
             ready.set_value(c);  // the main thread may use the context from here on
             const double t1 = now_s();
             if (staging_bytes) {
-                for (auto &b : stage)
-                    if (!(b = (uint8_t *)dsh_alloc_host(staging_bytes))) die("could not allocate %zu bytes of pinned host memory", staging_bytes);
-                stage_cap = staging_bytes;
+                for (int b = 0; b < kStageBufs; ++b) {
+                    if (!(stage[b] = (uint8_t *)dsh_alloc_host(staging_bytes))) die("could not allocate %zu bytes of pinned host memory", staging_bytes);
+                    stage_ready.store(b + 1, std::memory_order_release);
+                }
             }
             if (g_timing) std::fprintf(stderr, "[timing] on the context thread: dsh_create + alloc %.3f s, pinned staging %.3f s\n", t1 - t0, now_s() - t1);
         });
@@ -251,65 +264,86 @@ struct CtxFuture {
         if (!ctx) ctx = fut.get();
         return ctx;
     }
-    void wait_staging()
+    // staging buffer b, once the context thread has page-locked it (nullptr: none were asked for)
+    uint8_t *take_stage(int b)
     {
-        if (done.valid()) done.get();
+        if (!stage_cap) return nullptr;
+        while (stage_ready.load(std::memory_order_acquire) <= b) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        uint8_t *p = stage[b];
+        stage[b] = nullptr;
+        return p;
     }
     ~CtxFuture()
     {
-        wait_staging();
+        if (done.valid()) done.get();
         for (auto &b : stage)
             if (b) dsh_free_host(b);
     }
 };
 
-// Hot loop 1 (src/sketch_and_cmp.h:314-360, 484-528) as a stream: genomes are taken in batches of <= ~128 MB of
-// file bytes; a batch is parsed on the host threads STRAIGHT INTO page-locked staging (every genome has its
-// region reserved from the file sizes; what the headers and newlines leave over is filled with 'N'), then
-// copied and sketched asynchronously (dsh_sketch_batch_async) while the next batch is parsed into the other
-// staging buffer.  Cache hits (-W / sketch -c) read the .hll instead; .hll files of a batch are written after its
-// kernel has run, again overlapped with the next batch.
+// Hot loop 1 (src/sketch_and_cmp.h:314-360, 484-528) as a stream: genomes are taken in batches of <= ~48 MB of
+// file bytes; a batch is staged by the host threads STRAIGHT INTO page-locked memory (every genome has its region
+// reserved from the file sizes) -- the raw bytes of plain FASTA files, which the device decodes
+// (dsh_sketch_fastx_batch_async), or the sequence the host parser extracts (compressed inputs, pipes, FASTQ; what is
+// left of the region filled with 'N') -- and enqueued at once; the staging buffers take turns (see kStageBufs).  Cache
+// hits (-W / sketch -c) read the .hll instead; .hll files of a batch are written when its buffer's turn comes again.
 static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool skip_cached, bool load_cached = false)
 {
     const size_t n = o.inpaths.size();
     const size_t m = (size_t)1 << o.S;
     const size_t batch_bytes = kSketchBatchBytes;
-    // staging: the FIRST batch is parsed into pageable memory (the HIP runtime is still coming up on the context
-    // thread, and page-locking memory needs it); later batches alternate between the two page-locked buffers
-    // that thread allocated meanwhile
-    uint8_t *pin[2] = {nullptr, nullptr};
-    size_t pin_cap[2] = {0, 0};
+    // staging: the FIRST batch goes to pageable memory (the HIP runtime is still coming up on the context thread, and
+    // page-locking memory needs it); later batches cycle through the page-locked buffers that thread allocates meanwhile
+    uint8_t *pin[kStageBufs] = {};
+    size_t pin_cap[kStageBufs] = {};
+    bool pin_taken[kStageBufs] = {};
     std::unique_ptr<uint8_t[]> first_stage;  // uninitialised: the parsing threads touch its pages first
-    struct Done {  // a batch whose kernel is in flight / finished: what is left to do on the host
-        std::vector<size_t> slots;
+    struct Flight {  // a batch whose copy + kernels are enqueued: what is left to do on the host when its buffer is reused
+        bool valid = false;
+        uint64_t ticket = 0;
+        std::vector<size_t> slots;       // staged genome t -> its slot (= index into o.inpaths)
         std::vector<std::string> fnames;
-    } pending;
-    auto finish = [&](dsh_ctx *ctx) {  // after dsh_wait: write the .hll files of the previous batch
-        if (!write_files || pending.slots.empty()) {
-            pending.slots.clear();
-            pending.fnames.clear();
-            return;
+        std::vector<char> raw;           // decoded on the device: its status word says whether the device took it
+    } fl[kStageBufs];
+    uint32_t *status[kStageBufs] = {};   // per buffer: the device decoder's verdict per staged genome (page-locked)
+    size_t status_cap[kStageBufs] = {};
+    auto sketch_on_host = [&](dsh_ctx *ctx, size_t slot) {  // a genome the staged path could not take: parsed growably, sketched on its own
+        std::vector<uint8_t> whole;
+        for (const auto &f2 : split_genome_paths(o.inpaths[slot])) {
+            if (!whole.empty()) whole.push_back('N');
+            if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
         }
-        std::vector<uint8_t> rows(pending.slots.size() * m);
-        size_t r0 = 0;
-        while (r0 < pending.slots.size()) {  // consecutive slots in one download
-            size_t r1 = r0 + 1;
-            while (r1 < pending.slots.size() && pending.slots[r1] == pending.slots[r1 - 1] + 1) ++r1;
-            DSH(ctx, dsh_download_sketches(ctx, pending.slots[r0], r1 - r0, rows.data() + r0 * m));
-            r0 = r1;
-        }
-#pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
-        for (long t = 0; t < (long)pending.slots.size(); ++t)
-            if (write_hll(pending.fnames[t], rows.data() + (size_t)t * m, o.S, o.estim, o.estim, false, 0.0)) die("Could not write %s", pending.fnames[t].c_str());
-        pending.slots.clear();
-        pending.fnames.clear();
+        whole.push_back('N');
+        const uint64_t loff[2] = {0, whole.size()};
+        DSH(ctx, dsh_sketch_batch(ctx, whole.data(), loff, 1, slot, o.k, o.canon, nullptr));  // (max-merged into its slot)
     };
-    uint32_t *status[2] = {nullptr, nullptr};  // per batch buffer: the device decoder's verdict per staged genome (page-locked)
-    size_t status_cap[2] = {0, 0};
-    std::vector<size_t> refused_check;         // the slots the status words of the batch in flight belong to
+    auto retire = [&](int x) {  // the batch that last used buffer x has been sketched: refusals, .hll files
+        Flight &f = fl[x];
+        if (!f.valid) return;
+        dsh_ctx *ctx = cf.get();
+        DSH(ctx, dsh_event_wait(ctx, f.ticket));
+        for (size_t t = 0; t < f.slots.size(); ++t)
+            if (f.raw[t] && status[x][t]) sketch_on_host(ctx, f.slots[t]);  // not plain FASTA after all (a '+' line: FASTQ-like)
+        if (write_files && !f.slots.empty()) {
+            std::vector<uint8_t> rows(f.slots.size() * m);
+            size_t r0 = 0;
+            while (r0 < f.slots.size()) {  // consecutive slots in one download
+                size_t r1 = r0 + 1;
+                while (r1 < f.slots.size() && f.slots[r1] == f.slots[r1 - 1] + 1) ++r1;
+                DSH(ctx, dsh_download_sketches(ctx, f.slots[r0], r1 - r0, rows.data() + r0 * m));
+                r0 = r1;
+            }
+#pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
+            for (long t = 0; t < (long)f.slots.size(); ++t)
+                if (write_hll(f.fnames[t], rows.data() + (size_t)t * m, o.S, o.estim, o.estim, false, 0.0)) die("Could not write %s", f.fnames[t].c_str());
+        }
+        f.valid = false;
+    };
     size_t g = 0, bi = 0;
     while (g < n) {
         const double t_b0 = now_s();
+        const int x = (int)(bi % kStageBufs);
+        retire(x);
         // the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
         size_t e = g, bytes = 0;
         while (e < n && (e == g || bytes + genome_file_size(o.inpaths[e]) <= batch_bytes)) bytes += genome_file_size(o.inpaths[e++]);
@@ -321,7 +355,7 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         std::vector<std::vector<std::string>> files(nb);
         std::vector<std::vector<uint8_t>> zseq(nb);  // genomes whose sequence length the file size does not bound: compressed
                                                      // files, FIFOs, /dev/stdin, process substitutions (parsed growably)
-        std::vector<std::pair<size_t, std::vector<uint8_t>>> late;  // (slot, sequence): a plain file that outgrew its region
+        std::vector<size_t> late;  // slots of plain files that outgrew their region: sketched on their own after the batch
 #pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
         for (long i = 0; i < (long)nb; ++i) {
             const std::string &entry = o.inpaths[g + i];
@@ -357,18 +391,18 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             first_stage.reset(new uint8_t[std::max<uint64_t>(tot, 1)]);
             buf = first_stage.get();
         } else {
-            if (bi <= 2 && !pin[bi & 1]) {  // adopt the buffers the context thread prepared
-                cf.wait_staging();
-                pin[bi & 1] = cf.stage[bi & 1];
-                cf.stage[bi & 1] = nullptr;
-                pin_cap[bi & 1] = pin[bi & 1] ? cf.stage_cap : 0;
+            if (!pin_taken[x]) {  // adopt the buffer the context thread prepared
+                pin[x] = cf.take_stage(x);
+                pin_cap[x] = pin[x] ? cf.stage_cap : 0;
+                pin_taken[x] = true;
             }
-            if (tot > pin_cap[bi & 1]) {  // (this buffer's previous batch completed at the dsh_wait of the last iteration)
-                if (pin[bi & 1]) dsh_free_host(pin[bi & 1]);
-                pin_cap[bi & 1] = tot + (tot >> 4);
-                if (!(pin[bi & 1] = (uint8_t *)dsh_alloc_host(pin_cap[bi & 1]))) die("could not allocate %zu bytes of pinned host memory", pin_cap[bi & 1]);
+            if (tot > pin_cap[x]) {  // (this buffer's previous batch was retired above)
+                if (pin[x]) dsh_free_host(pin[x]);
+                pin_cap[x] = tot + (tot >> 4);
+                (void)cf.get();
+                if (!(pin[x] = (uint8_t *)dsh_alloc_host(pin_cap[x]))) die("could not allocate %zu bytes of pinned host memory", pin_cap[x]);
             }
-            buf = pin[bi & 1];
+            buf = pin[x];
         }
         const double t_alloc = now_s();
 #pragma omp parallel for schedule(dynamic) num_threads(o.nthreads)
@@ -381,7 +415,7 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             if (raw_ok) {
                 // the raw bytes of the genome's files, a '\n' between two files; every file must begin with '>' (what is
                 // not plain FASTA is the host parser's: below -- and the device refuses what it meets later, FASTQ-like
-                // '+' lines: status != 0, re-parsed after the batch)
+                // '+' lines: status != 0, re-parsed when the batch is retired)
                 for (const auto &f : files[i]) {
                     if (len) dst[len++] = '\n';
                     const size_t at = len;
@@ -408,15 +442,10 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
                     if (len) dst[len++] = 'N';
                     const long rc = append_fastx_into(f, dst, cap, len);
                     if (rc == -1) die("Could not open %s", f.c_str());
-                    if (rc == -2) {  // the file grew after its region was sized: read the whole genome growably instead and
-                                     // sketch it on its own after the batch (what is staged is a prefix of it: harmless)
-                        std::vector<uint8_t> whole;
-                        for (const auto &f2 : files[i]) {
-                            if (!whole.empty()) whole.push_back('N');
-                            if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
-                        }
+                    if (rc == -2) {  // the file grew after its region was sized: the whole genome is read growably and sketched
+                                     // on its own after the batch (what is staged is a prefix of it: harmless)
 #pragma omp critical
-                        late.emplace_back(slot_of[t], std::move(whole));
+                        late.push_back(slot_of[t]);
                         break;
                     }
                 }
@@ -425,8 +454,6 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         }
         const double t_parsed = now_s();
         dsh_ctx *ctx = cf.get();
-        DSH(ctx, dsh_wait(ctx));  // the previous batch has been sketched: its staging buffer is free, its rows are final
-        finish(ctx);
         for (size_t i = 0; i < nb; ++i) {
             if (!cached[i] || (skip_cached && !load_cached)) continue;  // `sketch -c`: nothing to do for a cached genome
             int p = 0;
@@ -434,24 +461,12 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             if (read_hll(fnames[i], r, p) || p != o.S) die("Bad cached sketch %s (expected p=%d)", fnames[i].c_str(), o.S);
             DSH(ctx, dsh_upload_sketches(ctx, r.data(), g + i, 1));
         }
-        // what the device refused of the PREVIOUS batch (its status words are final since the dsh_wait above): the host
-        // parses those genomes itself
-        for (size_t t = 0; t < refused_check.size(); ++t) {
-            if (!status[(bi + 1) & 1][t]) continue;
-            std::vector<uint8_t> whole;
-            for (const auto &f2 : split_genome_paths(o.inpaths[refused_check[t]])) {
-                if (!whole.empty()) whole.push_back('N');
-                if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
-            }
-            late.emplace_back(refused_check[t], std::move(whole));
+        if (slot_of.size() > status_cap[x]) {
+            if (status[x]) dsh_free_host(status[x]);
+            status_cap[x] = slot_of.size() + slot_of.size() / 2 + 64;
+            if (!(status[x] = (uint32_t *)dsh_alloc_host(status_cap[x] * sizeof(uint32_t)))) die("could not allocate pinned host memory");
         }
-        refused_check.clear();
-        if (slot_of.size() > status_cap[bi & 1]) {
-            if (status[bi & 1]) dsh_free_host(status[bi & 1]);
-            status_cap[bi & 1] = slot_of.size() + slot_of.size() / 2 + 64;
-            if (!(status[bi & 1] = (uint32_t *)dsh_alloc_host(status_cap[bi & 1] * sizeof(uint32_t)))) die("could not allocate pinned host memory");
-        }
-        if (!slot_of.empty()) std::memset(status[bi & 1], 0, slot_of.size() * sizeof(uint32_t));
+        if (!slot_of.empty()) std::memset(status[x], 0, slot_of.size() * sizeof(uint32_t));
         std::vector<uint64_t> rlen(slot_of.size(), 0);
         for (size_t t = 0; t < slot_of.size(); ++t) rlen[t] = rawlen_of[src_of[t]];
         size_t r0 = 0;
@@ -461,45 +476,36 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             while (r1 < slot_of.size() && slot_of[r1] == slot_of[r1 - 1] + 1 && rawkind[src_of[r1]] == kind) ++r1;
             if (kind)
                 DSH(ctx, dsh_sketch_fastx_batch_async(ctx, buf, off.data() + r0, rlen.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon,
-                                                      status[bi & 1] + r0));
+                                                      status[x] + r0));
             else
                 DSH(ctx, dsh_sketch_batch_async(ctx, buf, off.data() + r0, (uint32_t)(r1 - r0), slot_of[r0], o.k, o.canon));
             r0 = r1;
         }
-        refused_check.assign(slot_of.begin(), slot_of.end());  // (status word t of this batch belongs to slot_of[t]; host-parsed ones stay 0)
-        for (auto &lg : late) {  // (max-merged into their slots: a genome may be fed in several calls)
-            lg.second.push_back('N');
-            const uint64_t loff[2] = {0, lg.second.size()};
-            DSH(ctx, dsh_sketch_batch(ctx, lg.second.data(), loff, 1, lg.first, o.k, o.canon, nullptr));
-        }
+        for (size_t slot : late) sketch_on_host(ctx, slot);
+        Flight &f = fl[x];
+        f.slots = slot_of;
+        f.fnames.clear();
+        f.raw.clear();
         for (size_t t = 0; t < slot_of.size(); ++t) {
-            pending.slots.push_back(slot_of[t]);
-            pending.fnames.push_back(fnames[src_of[t]]);
+            f.fnames.push_back(fnames[src_of[t]]);
+            f.raw.push_back((char)rawkind[src_of[t]]);
         }
+        DSH(ctx, dsh_event_record(ctx, &f.ticket));
+        f.valid = true;
+        if (bi == 0) retire(x);  // (the pageable first buffer is not kept: its copy was synchronous anyway)
         if (g_timing)
-            std::fprintf(stderr, "[timing] batch %zu: %zu genomes, %.1f MB staged: pinned alloc %.3f s, parse into staging %.3f s, wait+enqueue %.3f s\n",
+            std::fprintf(stderr, "[timing] batch %zu: %zu genomes, %.1f MB staged: retire + pinned alloc %.3f s, stage %.3f s, enqueue %.3f s\n",
                          bi, nb, tot / 1e6, t_alloc - t_b0, t_parsed - t_alloc, now_s() - t_parsed);
         g = e;
         ++bi;
     }
+    for (size_t b = bi >= (size_t)kStageBufs ? bi - kStageBufs : 0; b < bi; ++b) retire((int)(b % kStageBufs));  // oldest first
     dsh_ctx *ctx = cf.get();
     DSH(ctx, dsh_wait(ctx));
-    for (size_t t = 0; t < refused_check.size(); ++t) {  // what the device refused of the last batch
-        if (!status[(bi + 1) & 1][t]) continue;
-        std::vector<uint8_t> whole;
-        for (const auto &f2 : split_genome_paths(o.inpaths[refused_check[t]])) {
-            if (!whole.empty()) whole.push_back('N');
-            if (append_fastx(f2, whole) < 0) die("Could not open %s", f2.c_str());
-        }
-        whole.push_back('N');
-        const uint64_t loff[2] = {0, whole.size()};
-        DSH(ctx, dsh_sketch_batch(ctx, whole.data(), loff, 1, refused_check[t], o.k, o.canon, nullptr));
-    }
-    finish(ctx);
     for (auto &b : pin)
         if (b) dsh_free_host(b);  // (buffers never adopted are freed by the CtxFuture)
-    for (auto &s : status)
-        if (s) dsh_free_host(s);
+    for (auto &s2 : status)
+        if (s2) dsh_free_host(s2);
 }
 
 static int sketch_main(int argc, char **argv)

@@ -264,6 +264,16 @@ static bool sketch_force_bytes()
     return v;
 }
 
+static int sketch_reg32_maxp()  // (A/B: DSH_SKETCH_REG32_MAXP=14..15 tries the word-per-register layout above kMaxPReg32)
+{
+    static const int v = [] {
+        const char *e = std::getenv("DSH_SKETCH_REG32_MAXP");
+        const int x = e ? std::atoi(e) : kMaxPReg32;
+        return x < 4 ? 4 : (x > 15 ? 15 : x);
+    }();
+    return v;
+}
+
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
 {
     // (a handful of kernels x devices: a small table under a mutex; the CLI's one-thread-per-device path gets here from
@@ -308,7 +318,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
     const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
     if (p > kMaxPLds) return launch_sketch_v<true, false>(st, seq, work, nwork, k, p, canon, regs, xch);
     // registers (a word each up to p = kMaxPReg32, packed bytes above; 16-byte aligned) + the exchange slots
-    const bool reg32 = p <= kMaxPReg32 && !sketch_force_bytes();
+    const bool reg32 = p <= sketch_reg32_maxp() && !sketch_force_bytes();
     const size_t lds = ((((size_t)(reg32 ? 4 : 1) << p) + 15) & ~(size_t)15) + xch;
     if (reg32) return launch_sketch_v<false, true>(st, seq, work, nwork, k, p, canon, regs, lds);
     return launch_sketch_v<false, false>(st, seq, work, nwork, k, p, canon, regs, lds);

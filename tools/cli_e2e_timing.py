@@ -41,9 +41,14 @@ def main():
         cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
         out = os.path.join(d, "dist.bin")
         ref = None
+        for _ in range(3):  # what a process that does nothing costs: exec + dynamic loading of the HIP runtime + exit
+            t0 = time.perf_counter()
+            subprocess.run([cli, "--help"], capture_output=True)
+            print(json.dumps({"what": "dashing-amd --help (exec + ld.so + exit)", "wall_s": round(time.perf_counter() - t0, 4)}), flush=True)
         runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
-        for th in (1, 2, 4, 8):
+        for th in (2, 4, 8):
             runs += (({}, th), ({"DSH_HOST_PARSE": "1"}, th))
+        runs += (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
         for env_extra, threads in runs + tuple(
                 (dict(kv.split("=") for kv in e.split(",")), 16) for e in filter(None, os.environ.get("EXTRA", "").split(";"))):
             time.sleep(0.5)

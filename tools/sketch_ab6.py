@@ -7,12 +7,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p, G in ((10, 1000), (12, 300), (13, 300), (8, 300)):
+CASES = ((10, 1000), (12, 300), (13, 300), (8, 300)) if not os.environ.get("HIGH_P") else ((14, 300), (15, 200))
+for p, G in CASES:
     for rep in range(2):
         for mode in ("bytes", "reg32"):
             env = dict(os.environ)
             if mode == "bytes":
                 env["DSH_SKETCH_BYTES"] = "1"
+            elif os.environ.get("HIGH_P"):
+                env["DSH_SKETCH_REG32_MAXP"] = "15"
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_sketch.py"), "--genomes", str(G), "--p", str(p), "--cpu-genomes", "2"],
                                capture_output=True, env=env, timeout=900)
             line = next((l for l in r.stdout.decode().splitlines() if l.startswith("{")), None)
