@@ -122,7 +122,7 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
 // native LDS atomic -- ds_max_u32, nothing returned, nothing to wait for -- instead of a byte read that filters, a branch
 // and a compare-and-swap loop on the containing word: a wave walked that 13-instruction path whenever ONE of its 64
 // lanes raised a register (~5 of 57 VALU per k-mer at p = 10, profiles/rd5g/sketch_instr.json).  4 KiB of LDS at p = 10,
-// 32 KiB at p = 13; above that the packed bytes keep two workgroups' worth of waves per CU.
+// 64 KiB at p = 14; above that the packed bytes keep more than one workgroup per CU.
 template <bool GLOBAL, bool CANON, bool REG32>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
@@ -269,7 +269,7 @@ static int sketch_reg32_maxp()  // (A/B: DSH_SKETCH_REG32_MAXP=14..15 tries the 
     static const int v = [] {
         const char *e = std::getenv("DSH_SKETCH_REG32_MAXP");
         const int x = e ? std::atoi(e) : kMaxPReg32;
-        return x < 4 ? 4 : (x > 15 ? 15 : x);
+        return x < 4 ? 4 : (x > 15 ? 15 : x);  // (p = 15: 128 KiB of LDS, the most a workgroup can be given beside the exchange slots)
     }();
     return v;
 }

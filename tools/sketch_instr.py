@@ -111,8 +111,41 @@ def analyse(lines, var):
     return out
 
 
+def analyse_reg32(lines):
+    """round 6: the instance with one 32-bit word per LDS register (p <= 13): a k-mer's straight-line code ends in ONE
+    ds_max_u32 -- no filter read, no branch, no CAS path.  VALU between consecutive ds_max_u32 (median over the start positions
+    of the all-valid copy and of the per-position-test copy of the unrolled loop), by phase where the anchors allow."""
+    body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb1EEE")
+    anchors = [i for i, l in enumerate(body) if l.startswith("ds_max_u32")]
+    blocks = [body[anchors[k] + 1: anchors[k + 1] + 1] for k in range(len(anchors) - 1)]
+    per = []
+    for b in blocks:
+        names = [l.split()[0] for l in b if l.startswith("v_")]
+        cmp64 = next((k for k, o in enumerate(names) if o.startswith("v_cmp_lt_u64")), None)
+        last_mad = max((k for k, o in enumerate(names) if o.startswith("v_mad_u64_u32")), default=None)
+        if cmp64 is None or last_mad is None:
+            continue
+        per.append({"window_and_validity": cmp64, "canonical": 3, "hash": last_mad + 1 - (cmp64 + 3), "register_rule": len(names) - (last_mad + 1), "total": len(names)})
+    med = lambda key: statistics.median([p[key] for p in per]) if per else 0
+    cnt = collections.Counter(l.split()[0] for b in blocks for l in b if l.startswith("v_"))
+    full = sum(c for k, c in cnt.items() if FULL.match(k))
+    tot = sum(cnt.values())
+    return {"instance": "REG32 (p <= 13): ds_max_u32", "static_valu_total": sum(1 for l in body if l.startswith("v_")), "ds_max_u32": len(anchors),
+            "ds_cmpst": sum(1 for l in body if l.startswith("ds_cmpst")), "per_kmer_median": {k: med(k) for k in ("window_and_validity", "canonical", "hash", "register_rule", "total")},
+            "pack_and_prologue_valu_before_first_kmer": sum(1 for l in body[:anchors[0]] if l.startswith("v_")) if anchors else None,
+            "issue_classes_of_the_unrolled_loop": {"full_rate_share": round(full / max(tot, 1), 4), "nominal_cycles_per_inst": round((2.0 * full + 4.0 * (tot - full)) / max(tot, 1), 3)}}
+
+
 def main():
     lines = listing()
+    if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELb1EEE") for l in lines):  # round 6: <GLOBAL, CANON, REG32>
+        byte_body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb0EEE")
+        print(json.dumps({"kernel": "k_sketch<GLOBAL=false, CANON=true, REG32>", "reg32": analyse_reg32(lines),
+                          "bytes_instance_static": {"static_valu_total": sum(1 for l in byte_body if l.startswith("v_")),
+                                                    "ds_read_u8": sum(1 for l in byte_body if l.startswith("ds_read_u8")),
+                                                    "ds_cmpst": sum(1 for l in byte_body if l.startswith("ds_cmpst"))},
+                          "note": "static counts of the unrolled body (median over start positions, both copies of the loop); the measured total per k-mer is SQ_INSTS_VALU x 64 / bases of bench.py's PMC pass (configs[1] entry)"}, indent=1))
+        return
     both = any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELi") for l in lines)
     res = {"kernel": "k_sketch<GLOBAL=false, CANON=true>", "variants": [analyse(lines, 0), analyse(lines, 1)] if both else [analyse(lines, 1)],
            "note": "static counts of the unrolled body (median over start positions); per 32 bases the pack + window test add pack_and_prologue/32 per k-mer for every lane and once more for the 64 lanes that pack the sub-chunk's right neighbour"}
