@@ -26,7 +26,7 @@ SYMBOLS = [
     "dsh_dist_rows_async", "dsh_dist_rows_device_async", "dsh_wait", "dsh_wait_event",
     "dsh_event_record", "dsh_event_wait", "dsh_event_query",
     "dsh_comm_available", "dsh_comm_library", "dsh_comm_wait", "dsh_exchange_mode", "dsh_exchange_rows_device_async",
-    "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_exchange_probe_parts_async", "dsh_diag_spin_start", "dsh_diag_spin_stop", "dsh_abi_version", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
+    "dsh_exchange_collect_async", "dsh_exchange_place_device", "dsh_exchange_probe_parts_async", "dsh_diag_spin_start", "dsh_diag_spin_stop", "dsh_abi_version", "dsh_preload", "dsh_comm_unique_id", "dsh_comm_init", "dsh_comm_destroy", "dsh_comm_rank", "dsh_collect_spans", "dsh_collect_spans_async",
     "dsh_allgather_device", "dsh_dist_collect", "dsh_range_parts", "dsh_dist_rows_parts_device_async", "dsh_collect_parts_async",
     "dsh_dist_rect", "dsh_knn", "dsh_shard_plan", "dsh_dist_shard_device", "dsh_unpermute_device", "dsh_unpermute_staged_device", "dsh_unpermute_blocks_device", "dsh_tri_span", "dsh_tri_index", "dsh_partition_rows", "dsh_balance_rows", "dsh_balance_rowsets", "dsh_rowsets_from_bounds", "dsh_rowsets_rank", "dsh_alloc_host", "dsh_free_host",
     "dsh_set_profiling", "dsh_last_kernel_ms", "dsh_last_part_info", "dsh_finalize_phase_cycles", "dsh_set_option", "dsh_get_info", "dsh_stream",

@@ -121,6 +121,16 @@ void dsh_destroy(dsh_ctx *c)
     delete c;
 }
 
+int dsh_preload(int device, unsigned what)
+{
+    if (hipSetDevice(device) != hipSuccess) return DSH_ENODEV;
+    hipError_t e = hipSuccess;
+    if ((what & DSH_PRELOAD_SKETCH) && e == hipSuccess) e = preload_sketch_kernels();
+    if ((what & DSH_PRELOAD_SKETCH) && e == hipSuccess) e = preload_fastx_kernels();
+    if ((what & DSH_PRELOAD_COMPARE) && e == hipSuccess) e = preload_compare_kernels();
+    return e == hipSuccess ? DSH_OK : DSH_EIO;
+}
+
 const char *dsh_last_error(const dsh_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 
 int dsh_synchronize(dsh_ctx *c)

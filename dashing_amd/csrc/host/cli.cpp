@@ -248,6 +248,7 @@ struct CtxFuture {
             dsh_ctx *c = nullptr;
             if (int rc = dsh_create(device, &c)) die("[dashing-amd] no usable gfx950 device (dsh_create = %d); there is no CPU fallback", rc);
             DSH(c, dsh_sketches_alloc(c, n, S));
+            (void)dsh_preload(device, DSH_PRELOAD_SKETCH);  // (the main thread is still staging its first batch)
             ready.set_value(c);  // the main thread may use the context from here on
             const double t1 = now_s();
             if (staging_bytes) {
@@ -256,6 +257,7 @@ struct CtxFuture {
                     stage_ready.store(b + 1, std::memory_order_release);
                 }
             }
+            (void)dsh_preload(device, DSH_PRELOAD_COMPARE);  // (beside the main thread's sketching: dist finds its kernels loaded)
             if (g_timing) std::fprintf(stderr, "[timing] on the context thread: dsh_create + alloc %.3f s, pinned staging %.3f s\n", t1 - t0, now_s() - t1);
         });
     }
@@ -457,6 +459,7 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         }
         const double t_parsed = now_s();
         dsh_ctx *ctx = cf.get();
+        const double t_ctx = now_s();
         for (size_t i = 0; i < nb; ++i) {
             if (!cached[i] || (skip_cached && !load_cached)) continue;  // `sketch -c`: nothing to do for a cached genome
             int p = 0;
@@ -495,10 +498,11 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         }
         DSH(ctx, dsh_event_record(ctx, &f.ticket));
         f.valid = true;
+        const double t_enq = now_s();
         if (bi == 0) retire(x);  // (the pageable first buffer is not kept: its copy was synchronous anyway)
-        if (g_timing)
-            std::fprintf(stderr, "[timing] batch %zu: %zu genomes, %.1f MB staged: retire + pinned alloc %.3f s, stage %.3f s, enqueue %.3f s\n",
-                         bi, nb, tot / 1e6, t_alloc - t_b0, t_parsed - t_alloc, now_s() - t_parsed);
+        if (g_timing && (bi < 4 || bi % 32 == 0))
+            std::fprintf(stderr, "[timing] batch %zu: %zu genomes, %.1f MB staged: retire + pinned alloc %.3f s, stage %.3f s, wait for the context %.3f s, enqueue %.3f s, first-batch retire %.3f s\n",
+                         bi, nb, tot / 1e6, t_alloc - t_b0, t_parsed - t_alloc, t_ctx - t_parsed, t_enq - t_ctx, now_s() - t_enq);
         g = e;
         ++bi;
     }

@@ -170,6 +170,11 @@ hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxCh
                                const FastxGenome *genomes, uint32_t ngenomes, uint4 *summ, uint2 *state, uint64_t *declen,
                                uint32_t *status, uint8_t *out);
 
+// dsh_preload: load the code objects of the kernel translation units now (else: at the first launch from each)
+hipError_t preload_compare_kernels();
+hipError_t preload_fastx_kernels();
+hipError_t preload_sketch_kernels();
+
 // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (kernel, device) instead of on every launch
 // (ADVICE r4): remembers the largest size granted so far and only calls the runtime for a larger one.
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);

@@ -309,6 +309,12 @@ __global__ __launch_bounds__(256) void k_fastx_pad(const FastxGenome *__restrict
     for (uint64_t x = e16 + tid; x < e; x += nthr) out[x] = 'N';
 }
 
+hipError_t preload_fastx_kernels()
+{
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_fastx_pad));
+}
+
 hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
                                const FastxGenome *genomes, uint32_t ngenomes, uint4 *summ, uint2 *state, uint64_t *declen,
                                uint32_t *status, uint8_t *out)

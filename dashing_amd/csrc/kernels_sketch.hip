@@ -311,6 +311,12 @@ static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const Sket
     return hipGetLastError();
 }
 
+hipError_t preload_sketch_kernels()
+{
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sketch<false, true, true>));
+}
+
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs)
 {

@@ -67,6 +67,13 @@ int dsh_device_count(void);               /* number of visible HIP devices (0 if
 int dsh_create(int device, dsh_ctx **out);
 void dsh_destroy(dsh_ctx *ctx);
 const char *dsh_last_error(const dsh_ctx *ctx);
+/* Load the kernels' code objects NOW (the HIP runtime otherwise loads each when one of its kernels is first launched:
+ * 10-40 ms in the middle of the first sketch batch / the first dist call).  No context needed and safe to call from any
+ * thread, also beside a thread that uses a context: a host that has something else to do while the runtime comes up (the
+ * CLI stages its first batch) calls it there.  what: DSH_PRELOAD_SKETCH | DSH_PRELOAD_COMPARE. */
+#define DSH_PRELOAD_SKETCH 1u
+#define DSH_PRELOAD_COMPARE 2u
+int dsh_preload(int device, unsigned what);
 int dsh_synchronize(dsh_ctx *ctx);
 
 /* ---- the resident sketch matrix ----------------------------------------------------------

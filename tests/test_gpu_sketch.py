@@ -157,3 +157,11 @@ def test_async_batches_from_pinned_staging(ctx, oracle):
     ctx.sketch_batch_async(stage[0].array, oa, 0, k, True)
     ctx.wait()
     assert (ctx.download() == want).all()
+
+
+def test_preload_loads_the_code_objects_without_a_context():
+    """dsh_preload: no context, any thread; unknown bits are ignored, a device that does not exist is refused"""
+    lib = dashing_amd.load_library()
+    assert lib.dsh_preload(0, 3) == 0
+    assert lib.dsh_preload(0, 0) == 0
+    assert lib.dsh_preload(99, 1) != 0

@@ -46,9 +46,12 @@ def main():
             subprocess.run([cli, "--help"], capture_output=True)
             print(json.dumps({"what": "dashing-amd --help (exec + ld.so + exit)", "wall_s": round(time.perf_counter() - t0, 4)}), flush=True)
         runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
-        for th in (2, 4, 8):
+        if os.environ.get("SHORT"):
+            runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16)) * 3
+        for th in (2, 4, 8) if not os.environ.get("SHORT") else ():
             runs += (({}, th), ({"DSH_HOST_PARSE": "1"}, th))
-        runs += (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
+        if not os.environ.get("SHORT"):
+            runs += (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
         for env_extra, threads in runs + tuple(
                 (dict(kv.split("=") for kv in e.split(",")), 16) for e in filter(None, os.environ.get("EXTRA", "").split(";"))):
             time.sleep(0.5)
@@ -61,7 +64,7 @@ def main():
             if ref is None:
                 ref = data
             print(json.dumps({"env": env_extra, "threads": threads, "rc": r.returncode, "wall_s": round(wall, 4), "same_matrix_as_first_run": data == ref,
-                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:4] + [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][-3:]}), flush=True)
+                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:6] + [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][-3:]}), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
