@@ -203,6 +203,14 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static const bool g_timing = std::getenv("DSH_TIMING") != nullptr;  // phase times on stderr
+// (DSH_TIMING with DSH_T0 = the launcher's wall clock in seconds since the epoch: where the process is, seen from outside)
+static void since_launch(const char *what)
+{
+    const char *t0 = std::getenv("DSH_T0");
+    if (!g_timing || !t0) return;
+    const double now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[timing] %s: %.3f s after the launch\n", what, now - std::atof(t0));
+}
 
 // File bytes per sketching batch, and the page-locked staging buffers the batches cycle through.  The batches of a large
 // input travel back to back: batch b is parsed (or, for plain FASTA, just read: the device decodes it) into buffer b % 3
@@ -521,12 +529,15 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
 // without the destructors.  DSH_FULL_TEARDOWN=1 runs them (leak checkers).
 [[maybe_unused]] static void leave(dsh_ctx *ctx)
 {
+    since_launch("outputs closed");
     std::fflush(nullptr);
     if (std::getenv("DSH_FULL_TEARDOWN")) {
         dsh_destroy(ctx);
         return;
     }
     if (ctx) (void)dsh_synchronize(ctx);
+    since_launch("leaving");
+    std::fflush(nullptr);
     std::_Exit(EXIT_SUCCESS);
 }
 
@@ -781,6 +792,7 @@ static int dist_main(int argc, char **argv)
     for (auto &q : o.querypaths) o.inpaths.push_back(q);  // queries follow the references (src/distmain.cpp:130-133)
     const size_t n = o.inpaths.size();
     const double t_start = now_s();
+    since_launch("dist: options parsed, context thread about to start");
     CtxFuture cf(o.device, n, o.S, o.presketched ? 0 : staging_bytes_for(o.inpaths));  // the HIP runtime comes up while the first batch is read
     dsh_ctx *ctx = nullptr;
     const double t_fill0 = now_s();
@@ -1052,6 +1064,7 @@ int main(int argc, char **argv)
     // before main(), so that never took effect -- ADVICE r2 -- and a re-exec with the variable set costs more process
     // start-up than the few milliseconds idle workers spin by default.  Set OMP_WAIT_POLICY=passive in the environment
     // if the host threads are needed elsewhere between the parallel regions.)
+    since_launch("main() entered");
     if (argc < 2 || !std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) {
         std::fprintf(stderr, "%s\nUsage: dashing-amd <subcommand> [options...]\nSubcommands:\n  sketch\n  dist (also: cmp, setdist)\n  union | fold | view   (utilities on .hll files)\n  printmat              (binary distance matrix -> text)\n  hll                   (cardinality of the k-mers of a set of files)\n", kVersion);
         return EXIT_FAILURE;

@@ -55,7 +55,7 @@ def main():
         for env_extra, threads in runs + tuple(
                 (dict(kv.split("=") for kv in e.split(",")), 16) for e in filter(None, os.environ.get("EXTRA", "").split(";"))):
             time.sleep(0.5)
-            env = dict(os.environ, DSH_TIMING="1", **env_extra)
+            env = dict(os.environ, DSH_TIMING="1", DSH_T0=repr(time.time()), **env_extra)
             t0 = time.perf_counter()
             r = subprocess.run([cli, "dist", "-k", "31", "-S", "10", "-p", str(threads), "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst],
                                capture_output=True, env=env, timeout=600)
@@ -64,7 +64,7 @@ def main():
             if ref is None:
                 ref = data
             print(json.dumps({"env": env_extra, "threads": threads, "rc": r.returncode, "wall_s": round(wall, 4), "same_matrix_as_first_run": data == ref,
-                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:6] + [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][-3:]}), flush=True)
+                              "timing": [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][:8] + [l for l in r.stderr.decode(errors="replace").splitlines() if "[timing]" in l][-3:]}), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
