@@ -47,7 +47,7 @@ def main():
             print(json.dumps({"what": "dashing-amd --help (exec + ld.so + exit)", "wall_s": round(time.perf_counter() - t0, 4)}), flush=True)
         runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({}, 16), ({"DSH_HOST_PARSE": "1"}, 16))
         if os.environ.get("SHORT"):
-            runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16)) * 3
+            runs = (({}, 16), ({"DSH_HOST_PARSE": "1"}, 16), ({"DSH_FULL_TEARDOWN": "1"}, 16), ({"DSH_HOST_PARSE": "1", "DSH_FULL_TEARDOWN": "1"}, 16)) * 3
         for th in (2, 4, 8) if not os.environ.get("SHORT") else ():
             runs += (({}, th), ({"DSH_HOST_PARSE": "1"}, th))
         if not os.environ.get("SHORT"):
