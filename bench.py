@@ -1063,8 +1063,8 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, args, G=1000, L=5_000_000, p
             e2e = cli_end_to_end(torch, dev, seq, G, L, p, tri, cores)
             if e2e and "wall_s" in e2e:
                 e2e["gpu_idle_fraction"] = round(1.0 - step_s / e2e["wall_s"], 4)
-                e2e["gpu_idle_note"] = ("1 - (the in-process sketch+dist step, %.1f ms) / wall.  Where the wall goes (DSH_TIMING=1, profiles/rd6e-f/cli_e2e_timing.jsonl): ~0.10 s bringing the HIP runtime up (the first batch is staged meanwhile), "
-                                        "~0.12 s streaming the 5.06 GB of file bytes through page-locked staging and PCIe at ~43 GB/s (host memory copies of 16 threads; the device decodes the FASTA text and sketches each 48 MB batch in 0.2 ms), ~0.03 s first-use code loading + dist + output; the host parser was never the bound (it runs at the same 45 GB/s on 16 threads), it is at 2-4 threads" % (step_s * 1e3))
+                e2e["gpu_idle_note"] = ("1 - (the in-process sketch+dist step, %.1f ms) / wall.  Where the wall goes (DSH_TIMING=1, profiles/rd6e ... rd6i/cli_e2e_timing.jsonl): ~0.10 s bringing the HIP runtime up (the first batch is staged meanwhile), "
+                                        "~0.12 s streaming the 5.06 GB of file bytes through page-locked staging and PCIe at ~43 GB/s (host memory copies of 16 threads; the device decodes the FASTA text and sketches each 48 MB batch in 0.2 ms), ~0.07 s first batch + dist + output, and in most runs ~0.10 s between the program's _Exit and the parent seeing it end (the driver releasing the process's GPU state); the host parser was never the bound (it runs at the same 45 GB/s on 16 threads), it is at 2-4 threads" % (step_s * 1e3))
         except Exception as e:  # noqa: BLE001
             e2e = {"error": "%s: %s" % (type(e).__name__, e)}
     del seq, out

@@ -81,6 +81,15 @@ long dshh_append_fastx_into(const char *path, uint8_t *dst, size_t cap, size_t *
     return n;
 }
 
+// the raw bytes of a plain file behind dst[*len ..) (the device parses them: dsh_sketch_fastx_batch_async)
+long dshh_read_raw_into(const char *path, uint8_t *dst, size_t cap, size_t *len)
+{
+    size_t l = *len;
+    const long rc = read_raw_into(path, dst, cap, l);
+    if (rc == 0) *len = l;
+    return rc;
+}
+
 int dshh_sort_paths(const char *joined, char *out, size_t cap)
 {
     auto v = unpack(joined);

@@ -134,6 +134,30 @@ def test_fastx_into_caller_memory(host, tmp_path):
     assert n.value == len(seq) and out[: n.value].tobytes() == seq
 
 
+def test_raw_file_bytes_into_caller_memory(host, tmp_path):
+    """read_raw_into (the CLI stages plain FASTA as it lies on disk; the device decodes it): appends behind what is there,
+    an exact fit is fine, a file that outgrew its region is reported (-2), a missing one too (-1)"""
+    host.dshh_read_raw_into.restype = C.c_long
+    host.dshh_read_raw_into.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    data = b">r1 some header\nACGT\nAC\n>r2\nGG"
+    fa = tmp_path / "raw.fa"
+    fa.write_bytes(data)
+    buf = np.full(len(data) + 5, ord("x"), np.uint8)
+    n = C.c_size_t(2)
+    assert host.dshh_read_raw_into(str(fa).encode(), buf.ctypes.data, buf.size, C.byref(n)) == 0
+    assert n.value == 2 + len(data) and buf[2 : n.value].tobytes() == data and buf[:2].tobytes() == b"xx" and buf[n.value] == ord("x")
+    exact = np.zeros(len(data), np.uint8)
+    n = C.c_size_t(0)
+    assert host.dshh_read_raw_into(str(fa).encode(), exact.ctypes.data, exact.size, C.byref(n)) == 0 and exact.tobytes() == data
+    small = np.zeros(len(data) - 1, np.uint8)
+    n = C.c_size_t(0)
+    assert host.dshh_read_raw_into(str(fa).encode(), small.ctypes.data, small.size, C.byref(n)) == -2 and n.value == 0
+    assert host.dshh_read_raw_into(b"/nonexistent.fa", small.ctypes.data, small.size, C.byref(n)) == -1
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert host.dshh_read_raw_into(str(empty).encode(), small.ctypes.data, small.size, C.byref(n)) == 0 and n.value == 0
+
+
 def test_sort_and_split(host, tmp_path):
     sizes = {"a": 10, "b": 300, "c": 300, "d": 5}
     paths = []
