@@ -357,3 +357,58 @@ def test_hll_subcommand(genomes, oracle, tmp_path, S):
     one = oracle.sketch_batch(joined, np.array([0, joined.size], np.uint64), 31, S)
     want = oracle.cardinalities(one)[0]
     assert abs(got - want) <= 1e-6 * want + 1e-6   # printed with %lf: 6 decimals
+
+
+def test_device_parse_and_host_parse_give_the_same_files(genomes, oracle, tmp_path):
+    """Round 6: plain FASTA is staged as raw file bytes and decoded on the device (dsh_sketch_fastx_batch_async);
+    DSH_HOST_PARSE=1 keeps the host parser.  Inputs the device path must hand back to the host parser -- a FASTQ file (begins
+    with '@'), a '>' file with a FASTQ-like '+' line in it (REFUSED by the device after the batch: re-parsed), a file with a
+    blank first line, a genome made of two files (a newline between them), CRLF -- next to gzip'ed and plain ones, enough
+    bytes for several batches and all three staging buffers: same binary matrix, same sizes file, same .hll cache files;
+    registers equal to the oracle's for the plain genomes."""
+    d, paths, seqs = genomes
+    big = synth.synthetic_genomes(14, 9_000_000, seed=0xB16, decorate=True)   # 14 x 9 MB: batches of <= 48 MB
+    extra = []
+    for i, g in enumerate(big):
+        p = tmp_path / ("big%02d.fna" % i)
+        p.write_bytes(synth.to_fasta(g, "big%d" % i, width=80 if i % 3 else 61))
+        extra.append(str(p))
+    s0, s1 = seqs[0], seqs[1]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s0[i * 150 : (i + 1) * 150].tobytes(), b"I" * 150) for i in range(300)))
+    plus = tmp_path / "plus.fa"
+    plus.write_bytes(synth.to_fasta(s1[:20000], "a") + b"+\n" + b"I" * 10 + b"\n")
+    blank = tmp_path / "blank.fa"
+    blank.write_bytes(b"\n" + synth.to_fasta(s1[:30000], "b"))
+    part1, part2 = tmp_path / "part1.fa", tmp_path / "part2.fa"
+    part1.write_bytes(synth.to_fasta(s0[:25000], "p1")[:-1])  # no newline at the end of the first file
+    part2.write_bytes(synth.to_fasta(s0[25000:50000], "p2"))
+    crlf = tmp_path / "crlf.fa"
+    crlf.write_bytes(synth.to_fasta(s1[:40000], "c").replace(b"\n", b"\r\n"))
+    inputs = extra[:5] + [str(fq), str(plus)] + extra[5:9] + [str(blank), "%s %s" % (part1, part2), str(crlf)] + paths[:7] + extra[9:]
+    lst = tmp_path / "in.txt"
+    lst.write_text("\n".join(inputs) + "\n")
+    outs = {}
+    for mode, env in (("device", {}), ("host", {"DSH_HOST_PARSE": "1"})):
+        pre = tmp_path / ("cache_" + mode)
+        pre.mkdir()
+        o, sz = tmp_path / (mode + ".bin"), tmp_path / (mode + ".sizes")
+        r = subprocess.run([CLI, "dist", "-k", "31", "-S", "11", "-p", "4", "-b", "--avoid-sorting", "-W", "-P", str(pre), "-O", str(o), "-o", str(sz), "-F", str(lst)],
+                           capture_output=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[mode] = (o.read_bytes(), sz.read_bytes(), {f: (pre / f).read_bytes() for f in sorted(os.listdir(pre))})
+    assert outs["device"][0] == outs["host"][0] and outs["device"][1] == outs["host"][1]
+    assert list(outs["device"][2]) == list(outs["host"][2]) and len(outs["device"][2]) == len(inputs)
+    import ctypes as C
+
+    hostlib = C.CDLL(os.path.join(ROOT, "dashing_amd", "libdashing_host.so"))
+    def regs_of(blob_path):
+        buf = np.zeros(1 << 11, np.uint8)
+        p_ = C.c_int(0)
+        assert hostlib.dshh_read_hll(blob_path.encode(), buf.ctypes.data, C.c_size_t(buf.size), C.byref(p_)) == 0 and p_.value == 11
+        return buf
+    want = oracle_regs(oracle, [big[0], big[13]], 31, 11)
+    names = sorted(os.listdir(tmp_path / "cache_device"))
+    for g, w in ((0, want[0]), (13, want[1])):
+        f = next(n for n in names if n.startswith("big%02d.fna" % g))
+        assert (regs_of(str(tmp_path / "cache_device" / f)) == w).all()
