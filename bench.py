@@ -592,6 +592,70 @@ def run(args, backend, world, rank, line, dist_on):
             dt_, ph = float(t[0].item()), [float(t[1].item()), float(t[2].item())]
         return dt_, ph, res
 
+    # ---- probe (N > 1, gathered, C-ABI exchange).  The library's exchange has only ever run over a stand-in transport on
+    # one GPU; the driver's multi-GPU run may be the only real one.  ONE untimed step must therefore reproduce the
+    # single-GPU matrix bit for bit before anything is timed; if it does not (or fails, or misses its deadline), the
+    # parts are announced by events instead of flags (finalize_signal = 0) and the probe repeated; if that fails too,
+    # torch.distributed carries contiguous spans (the fallback of a library that cannot load RCCL).  Every rank takes
+    # the same turn (all-reduce); the line says which path was timed and why.
+    probe = None
+    if multi and gather and use_cabi:
+        ref_p = None
+        if rank == 0:
+            ref_p = torch.empty(total_pairs, dtype=torch.float32, device=dev)
+            ctx.attach_device(regs_d.data_ptr(), n, p)
+            ctx.dist_rows_device(ref_p.data_ptr(), 0, n, dashing_amd.ESTIM_ERTL_MLE, dashing_amd.JI, K)
+            ctx.synchronize()
+        inject = int(os.environ.get("DSH_BENCH_INJECT_PROBE_FAIL", "0"))  # (tests: the first k probes "fail")
+        attempts = []
+
+        def probe_once(label):
+            ok, why = 1, None
+            old_to = os.environ.get("DSH_COMM_TIMEOUT_S")
+            os.environ["DSH_COMM_TIMEOUT_S"] = os.environ.get("DSH_BENCH_PROBE_TIMEOUT_S", "45")
+            try:
+                res = step(False, True)
+                if rank == 0 and not torch.equal(ref_p, res[:total_pairs]):
+                    ok, why = 0, "the assembled matrix differs from the single-GPU one in %d values" % int((ref_p != res[:total_pairs]).sum().item())
+                if len(attempts) < inject:
+                    ok, why = 0, "injected (DSH_BENCH_INJECT_PROBE_FAIL)"
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, "%s: %s" % (type(e).__name__, e)
+            finally:
+                if old_to is None:
+                    os.environ.pop("DSH_COMM_TIMEOUT_S", None)
+                else:
+                    os.environ["DSH_COMM_TIMEOUT_S"] = old_to
+            flag = torch.tensor([ok], device=cpu_or_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            attempts.append({"path": label, "ok_on_this_rank": bool(ok), "ok_on_every_rank": int(flag.item()) == 1, "why": why})
+            return int(flag.item()) == 1
+
+        if probe_once("c-abi exchange, parts announced as configured (flags where the device has stream wait-value)"):
+            probe = {"timed_path": "c-abi exchange", "attempts": attempts}
+        else:
+            try:
+                ctx.set_option("finalize_signal", 0)
+            except Exception:  # noqa: BLE001
+                pass
+            if probe_once("c-abi exchange, finalize_signal = 0 (one k_finalize launch and one event per part)"):
+                probe = {"timed_path": "c-abi exchange with finalize_signal = 0", "attempts": attempts}
+                exchange += " [finalize_signal = 0 after a failed probe]"
+            else:
+                try:
+                    ctx.comm_destroy()
+                except Exception:  # noqa: BLE001
+                    pass
+                use_cabi, rows_of, my_floats = False, None, None
+                exchange = ("torch.distributed" if backend == "nccl" else "gloo (host staged)") + " [fallback: the c-abi exchange failed its probe twice]"
+                sizes = multigpu.span_sizes(n, bounds)
+                my_pairs = sizes[rank]
+                alloc_buffers(gather)
+                probe = {"timed_path": exchange, "attempts": attempts}
+                if rccl_info is not None:
+                    rccl_info["carried_the_exchange"] = "torch.distributed (%s)" % rccl_info["torch_bundled_rccl"] if backend == "nccl" else "gloo"
+                sys.stderr.write("bench.py: rank %d: C-ABI exchange failed its probe (%s): torch.distributed exchange\n" % (rank, attempts[-1]["why"]))
+        del ref_p
     dt, phases, full = timed_loop(gather)
     ms_per_step = dt / args.steps * 1e3
     value = total_pairs * args.steps / dt
@@ -752,7 +816,7 @@ def run(args, backend, world, rank, line, dist_on):
             **diag,
             "ranks": world, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "backend": backend,
             "exchange": exchange if gather else "none: every rank keeps its span (output %.1f GB > %.1f GB; --exchange gather collects it)" % (4 * total_pairs / 1e9, GATHER_LIMIT_BYTES / 1e9),
-            "exchange_library": rccl_info, "row_bounds": bounds if rows_of is None else None,
+            "exchange_library": rccl_info, "probe": probe, "row_bounds": bounds if rows_of is None else None,
             "row_sets": rows_of.describe() if rows_of is not None else None, "pairs_per_rank": sizes,
             "phase_ms_max_over_ranks": {"compute_incl_prepare": round(phases[0], 4), "exchange" if not use_cabi else "exchange_exposed_after_last_kernel": round(phases[1], 4),
                                         "k_pair_counts": round(kphase[0], 4), "k_finalize": round(kphase[1], 4), "prepare": round(kphase[2], 4)},

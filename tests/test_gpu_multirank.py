@@ -493,6 +493,33 @@ def test_bench_two_ranks_run_the_cabi_exchange_over_the_stand_in(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_probe_falls_back_when_the_exchange_does_not_reproduce_the_matrix(tmp_path):
+    """The N-rank bench line is only worth something if its exchange is right, and the driver's multi-GPU run may be the
+    first time RCCL carries it: before anything is timed ONE step must reproduce the single-GPU matrix.  A failed probe
+    (injected here) first switches the parts' announcement from flags to events and probes again; a second failure hands
+    the exchange to torch.distributed with contiguous spans.  Either way every rank takes the same turn, the line says
+    what was timed and why, and the assembled matrix equals the single-GPU one."""
+    import json
+
+    if not os.path.exists(MOCK):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(MOCK)])
+    for inject, want_path in ((1, "finalize_signal = 0"), (2, "fallback")):
+        r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                   {"DSH_BENCH_BACKEND": "gloo", "DSH_BENCH_EXCHANGE": "cabi-mock", "DSH_RCCL_LIB": MOCK, "DSH_BENCH_N": "2000",
+                    "MOCK_RCCL_TIMEOUT_S": "240", "DSH_BENCH_NO_PING": "1", "DSH_BENCH_INJECT_PROBE_FAIL": str(inject)}, timeout=600)
+        out = r.stdout.decode()
+        assert r.returncode == 0, (out + r.stderr.decode())[-3000:]
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+        pr = line["multi_gpu"]["probe"]
+        assert want_path in pr["timed_path"], pr
+        assert len(pr["attempts"]) == inject + (1 if inject == 1 else 0) and not pr["attempts"][0]["ok_on_every_rank"], pr
+        assert line["parity_vs_cpu"]["assembled_equals_single_gpu"] is True
+        assert line["value"] > 0
+        if inject == 2:
+            assert line["multi_gpu"]["exchange"].startswith("gloo") and line["multi_gpu"]["row_sets"] is None
+
+
+@pytest.mark.gpu
 def test_exchange_protocol_with_finalize_on_one_stream_and_cut_bands(tmp_path):
     """By default (round 5) a band is finalized by ONE launch and the parts announce themselves from inside it (flags the
     copy stream waits for with hipStreamWaitValue32); finalize_signal = 0 is the scheme for devices without stream
