@@ -402,13 +402,53 @@ def test_device_parse_and_host_parse_give_the_same_files(genomes, oracle, tmp_pa
     import ctypes as C
 
     hostlib = C.CDLL(os.path.join(ROOT, "dashing_amd", "libdashing_host.so"))
+    hostlib.dshh_read_hll.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+
     def regs_of(blob_path):
         buf = np.zeros(1 << 11, np.uint8)
         p_ = C.c_int(0)
-        assert hostlib.dshh_read_hll(blob_path.encode(), buf.ctypes.data, C.c_size_t(buf.size), C.byref(p_)) == 0 and p_.value == 11
+        assert hostlib.dshh_read_hll(blob_path.encode(), buf.ctypes.data, buf.size, C.byref(p_)) == 0 and p_.value == 11
         return buf
     want = oracle_regs(oracle, [big[0], big[13]], 31, 11)
     names = sorted(os.listdir(tmp_path / "cache_device"))
     for g, w in ((0, want[0]), (13, want[1])):
         f = next(n for n in names if n.startswith("big%02d.fna" % g))
         assert (regs_of(str(tmp_path / "cache_device" / f)) == w).all()
+
+
+def test_device_parse_many_tiny_genomes_and_one_larger_than_a_batch(tmp_path):
+    """the staging of the streaming loader at its edges: 2 500 genomes of 40 .. 3 000 bases (thousands of regions and decode
+    chunks per batch, genomes shorter than k, empty files) and one genome of 70 MB (larger than a batch and than the
+    page-locked buffers the context thread prepared: the buffer is re-allocated in the middle of the stream) -- the
+    device parse and the host parse write the same matrix and the same sizes"""
+    rng = np.random.default_rng(6)
+    base = synth.synthetic_genomes(1, 3000, seed=0xAB, decorate=False)[0]
+    inputs = []
+    for i in range(2500):
+        L = int(rng.integers(40, 3000)) if i % 97 else 0
+        g = base[:L].copy()
+        if L:
+            pos = rng.integers(0, L, max(1, L // 20))
+            g[pos] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, pos.size)]
+        p = tmp_path / ("t%04d.fa" % i)
+        p.write_bytes(synth.to_fasta(g, "t%d" % i, width=int(rng.choice([60, 70, 80]))) if L else b"")
+        inputs.append(str(p))
+    huge = synth.synthetic_genomes(1, 70_000_000, seed=0xCD, decorate=True)[0]
+    hp = tmp_path / "huge.fa"
+    with open(hp, "wb") as f:
+        f.write(b">huge, 16 MB lines\n")
+        for x in range(0, huge.size, 1 << 24):  # 16 MB lines: newlines are rare, the carry runs across a thousand chunks
+            f.write(huge[x : x + (1 << 24)].tobytes() + b"\n")
+    inputs.insert(1200, str(hp))
+    lst = tmp_path / "in.txt"
+    lst.write_text("\n".join(inputs) + "\n")
+    outs = {}
+    for mode, env in (("device", {}), ("host", {"DSH_HOST_PARSE": "1"})):
+        o, sz = tmp_path / (mode + ".bin"), tmp_path / (mode + ".sizes")
+        r = subprocess.run([CLI, "dist", "-k", "21", "-S", "10", "-p", "6", "-b", "--avoid-sorting", "-O", str(o), "-o", str(sz), "-F", str(lst)],
+                           capture_output=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[mode] = (o.read_bytes(), sz.read_bytes())
+    assert outs["device"] == outs["host"]
+    n = len(inputs)
+    assert len(outs["device"][0]) == 9 + 4 * (n * (n - 1) // 2)
