@@ -373,6 +373,8 @@ int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t 
             return fail(c, DSH_EINVAL, "genome %u: its region must start on a multiple of 32 and hold its %llu raw bytes", g, (unsigned long long)raw_len[g]);
         gen[g].off = b - lo;
         gen[g].rawlen = raw_len[g];
+        gen[g].fmt = (raw_len[g] && raw && raw[b] == '@') ? 1u : 0u;  // (the device checks that the rest keeps the promise)
+        gen[g].pad_ = 0;
         gen[g].region_end = e - lo;
         gen[g].chunk0 = (uint32_t)chunks.size();
         for (uint64_t x = 0; x < raw_len[g]; x += kFastxChunk)
@@ -400,13 +402,13 @@ int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t 
     if (!c->ev_fx) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fx, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_fx, c->stream));
     c->fx_in_flight = true;
-    HIPCHK(c, c->fx_summ.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint4)));
+    HIPCHK(c, c->fx_summ.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(FastxSumm)));
     HIPCHK(c, c->fx_state.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint2)));
     HIPCHK(c, c->fx_declen.ensure(gen.size() * sizeof(uint64_t)));
     HIPCHK(c, c->fx_status.ensure(gen.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(c->fx_status.ptr, 0, gen.size() * sizeof(uint32_t), c->stream));
     HIPCHK(c, launch_fastx_decode(c->stream, (const uint8_t *)c->rawbuf.ptr, (const FastxChunk *)((const uint8_t *)c->fx_tab.ptr + gbytes),
-                                  (uint32_t)chunks.size(), (const FastxGenome *)c->fx_tab.ptr, n_genomes, (uint4 *)c->fx_summ.ptr,
+                                  (uint32_t)chunks.size(), (const FastxGenome *)c->fx_tab.ptr, n_genomes, (FastxSumm *)c->fx_summ.ptr,
                                   (uint2 *)c->fx_state.ptr, (uint64_t *)c->fx_declen.ptr, (uint32_t *)c->fx_status.ptr,
                                   (uint8_t *)c->seqbuf.ptr));
     if (status_out)

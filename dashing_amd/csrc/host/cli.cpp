@@ -357,7 +357,7 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         // the batch: genomes [g, e) whose files total <= batch_bytes (at least one)
         // (the FIRST batch is small: it travels from pageable memory, a synchronous staged copy, while the page-locked buffers
         // are still being allocated)
-        const size_t limit = bi == 0 ? std::min<size_t>(batch_bytes, (size_t)8 << 20) : batch_bytes;
+        const size_t limit = (bi == 0 && cf.stage_cap) ? std::min<size_t>(batch_bytes, (size_t)8 << 20) : batch_bytes;  // (an input of one batch stays one)
         size_t e = g, bytes = 0;
         while (e < n && (e == g || bytes + genome_file_size(o.inpaths[e]) <= limit)) bytes += genome_file_size(o.inpaths[e++]);
         const size_t nb = e - g;
@@ -426,15 +426,19 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
             size_t len = 0;
             bool raw_ok = !gz[i] && g_device_parse;
             if (raw_ok) {
-                // the raw bytes of the genome's files, a '\n' between two files; every file must begin with '>' (what is
-                // not plain FASTA is the host parser's: below -- and the device refuses what it meets later, FASTQ-like
-                // '+' lines: status != 0, re-parsed when the batch is retired)
+                // the raw bytes of the genome's files, a '\n' between two files unless the first ends with one (FASTQ counts
+                // lines); every file must begin with '>' -- FASTA -- or every file with '@' -- FASTQ in four-line records.
+                // What is neither is the host parser's (below), and so is what the device refuses later: a '+' line in a
+                // FASTA file, a FASTQ file that does not keep to four lines per record (status != 0: re-parsed when the
+                // batch is retired).
+                uint8_t kind = 0;
                 for (const auto &f : files[i]) {
-                    if (len) dst[len++] = '\n';
+                    if (len && dst[len - 1] != '\n') dst[len++] = '\n';
                     const size_t at = len;
                     const long rc = read_raw_into(f, dst, cap, len);
                     if (rc == -1) die("Could not open %s", f.c_str());
-                    if (rc == -2 || (len > at && dst[at] != '>')) {
+                    if (len > at && !kind) kind = dst[at];
+                    if (rc == -2 || (len > at && (dst[at] != kind || (kind != '>' && kind != '@')))) {
                         raw_ok = false;
                         break;
                     }

@@ -163,11 +163,16 @@ struct FastxChunk {
 struct FastxGenome {
     uint64_t off, rawlen, region_end;
     uint32_t chunk0, nchunks;
+    uint32_t fmt, pad_;  // 0: FASTA (begins with '>'), 1: FASTQ in strict four-line records (begins with '@')
 };
-// summ [nchunks] uint4, state [nchunks] uint2, declen [ngenomes], status [ngenomes] (zeroed by the caller; != 0 afterwards:
-// not plain FASTA, nothing emitted)
+struct FastxSumm {  // what a chunk tells the per-genome scan (kernels_fastx.hip, k_fastx_scan)
+    uint32_t fn, bad8;
+    uint32_t a[4], b[4];
+};
+// summ [nchunks], state [nchunks] uint2, declen [ngenomes], status [ngenomes] (zeroed by the caller; != 0 afterwards: not
+// what its format promises, nothing emitted)
 hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
-                               const FastxGenome *genomes, uint32_t ngenomes, uint4 *summ, uint2 *state, uint64_t *declen,
+                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint2 *state, uint64_t *declen,
                                uint32_t *status, uint8_t *out);
 
 // dsh_preload: load the code objects of the kernel translation units now (else: at the first launch from each)

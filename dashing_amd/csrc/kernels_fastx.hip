@@ -16,9 +16,14 @@
 //                     header's first byte to its newline); the lane's transfer function in 6 bits
 //   workgroup (16 KB) prefix composition over its 256 lanes                                       k_fastx_scan / _compact
 //   genome            prefix composition + prefix sum of the kept bytes over its chunks           k_fastx_offsets
-// What is NOT plain FASTA -- a genome that does not begin with '>', a line that begins with '+' (FASTQ: the quality
-// lines may hold any character and need record state) -- raises the genome's status word: nothing of it is emitted
-// (its region becomes all 'N': no k-mer) and the host parses that file itself.  HBM-bound byte work: no MFMA.
+// FASTQ (a genome that begins with '@') in strict four-line records takes the same three kernels with a simpler carry --
+// the line index modulo 4, i.e. the newlines so far: additive -- and per-lane bit planes of that count; sequence lines
+// are kept, a header's newline becomes the record's invalid byte.
+// What does not keep its format's promise -- a first byte that is neither '>' nor '@', a FASTA line that begins with '+',
+// FASTQ lines 4r that are not '@' headers or 4r + 2 that are not '+' lines, quality bytes that do not number the
+// sequence bytes (multi-line or cut-off records: kseq's record state decides those) -- raises the genome's status word:
+// nothing of it is emitted (its region becomes all 'N': no k-mer) and the host parses that file itself.  HBM-bound
+// byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,16 +33,22 @@ namespace dsh {
 
 namespace {
 
+// carries.  FASTA: the line that runs into a position is a HEADER line / a SEQUENCE line / a FRESH line starts here.
+// FASTQ: the index of the line, modulo 4 (0 header, 1 sequence, 2 '+', 3 quality).  Transfer functions on (at most) four
+// states, two bits per entry.
 constexpr uint32_t FX_HDR = 0, FX_SEQ = 1, FX_FRESH = 2;
-constexpr uint32_t kFnIdentity = FX_HDR | (FX_SEQ << 2) | (FX_FRESH << 4);
+constexpr uint32_t kFnIdentity = 0u | (1u << 2) | (2u << 4) | (3u << 6);
 
-__device__ __forceinline__ uint32_t fn_const(uint32_t c) { return c | (c << 2) | (c << 4); }
+__device__ __forceinline__ uint32_t fn_const(uint32_t c) { return c | (c << 2) | (c << 4) | (3u << 6); }
 __device__ __forceinline__ uint32_t fn_apply(uint32_t f, uint32_t x) { return (f >> (2 * x)) & 3u; }
 // first a, then b
 __device__ __forceinline__ uint32_t fn_then(uint32_t a, uint32_t b)
 {
-    return fn_apply(b, fn_apply(a, 0)) | (fn_apply(b, fn_apply(a, 1)) << 2) | (fn_apply(b, fn_apply(a, 2)) << 4);
+    return fn_apply(b, fn_apply(a, 0)) | (fn_apply(b, fn_apply(a, 1)) << 2) | (fn_apply(b, fn_apply(a, 2)) << 4) |
+           (fn_apply(b, fn_apply(a, 3)) << 6);
 }
+// x -> (x + k) mod 4
+__device__ __forceinline__ uint32_t fn_add(uint32_t k) { return (k & 3u) | (((k + 1) & 3u) << 2) | (((k + 2) & 3u) << 4) | (((k + 3) & 3u) << 6); }
 
 // bit k = byte k of w equals the byte replicated in pat
 __device__ __forceinline__ uint32_t eq4(uint32_t w, uint32_t pat)
@@ -48,11 +59,11 @@ __device__ __forceinline__ uint32_t eq4(uint32_t w, uint32_t pat)
 }
 
 struct LaneMasks {
-    uint64_t nl, nl_real, cr, hc, pl;
+    uint64_t nl, nl_real, cr, hc, pl, at, valid;
     uint32_t w[16];
 };
 
-// the 64 bytes of this lane (absent ones -- behind the chunk's length -- read as '\n': dropped, harmless)
+// the 64 bytes of this lane (absent ones -- behind the chunk's length -- read as '\n' for the FASTA carry: dropped, harmless)
 __device__ __forceinline__ void lane_masks(const uint8_t *__restrict__ raw, uint64_t abs, uint32_t have, LaneMasks &m)
 {
     if (have) {
@@ -65,27 +76,31 @@ __device__ __forceinline__ void lane_masks(const uint8_t *__restrict__ raw, uint
 #pragma unroll
         for (int k = 0; k < 16; ++k) m.w[k] = 0;
     }
-    uint32_t nl[2] = {0, 0}, cr[2] = {0, 0}, hc[2] = {0, 0}, pl[2] = {0, 0};
+    uint32_t nl[2] = {0, 0}, cr[2] = {0, 0}, gt[2] = {0, 0}, at[2] = {0, 0}, pl[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int h = k >> 3, s = 4 * (k & 7);
         nl[h] |= eq4(m.w[k], 0x0A0A0A0Au) << s;
         cr[h] |= eq4(m.w[k], 0x0D0D0D0Du) << s;
-        hc[h] |= (eq4(m.w[k], 0x3E3E3E3Eu) | eq4(m.w[k], 0x40404040u)) << s;  // '>' '@' (the host parser takes both)
+        gt[h] |= eq4(m.w[k], 0x3E3E3E3Eu) << s;
+        at[h] |= eq4(m.w[k], 0x40404040u) << s;
         pl[h] |= eq4(m.w[k], 0x2B2B2B2Bu) << s;
     }
     const uint64_t valid = have >= 64 ? ~0ull : ((1ull << have) - 1);
+    m.valid = valid;
     m.nl_real = (((uint64_t)nl[1] << 32) | nl[0]) & valid;
     m.nl = m.nl_real | ~valid;
     m.cr = (((uint64_t)cr[1] << 32) | cr[0]) & valid;
-    m.hc = (((uint64_t)hc[1] << 32) | hc[0]) & valid;
+    m.at = (((uint64_t)at[1] << 32) | at[0]) & valid;
+    m.hc = ((((uint64_t)gt[1] << 32) | gt[0]) & valid) | m.at;  // '>' '@' (the host parser takes both for a FASTA header)
     m.pl = (((uint64_t)pl[1] << 32) | pl[0]) & valid;
 }
 
+// ---- FASTA ----------------------------------------------------------------------------------------------------------------
 // the lane's transfer function: with a newline inside, whatever came in is forgotten
 __device__ __forceinline__ uint32_t lane_fn(const LaneMasks &m)
 {
-    if (m.nl == 0) return FX_HDR | (FX_SEQ << 2) | (((m.hc & 1) ? FX_HDR : FX_SEQ) << 4);
+    if (m.nl == 0) return FX_HDR | (FX_SEQ << 2) | (((m.hc & 1) ? FX_HDR : FX_SEQ) << 4) | (3u << 6);
     const uint64_t x = ~m.nl, hs = (m.nl << 1) & m.hc;
     const bool open = x + hs < x;  // the last header line has no newline yet
     return fn_const(open ? FX_HDR : ((m.nl >> 63) ? FX_FRESH : FX_SEQ));
@@ -100,6 +115,32 @@ __device__ __forceinline__ uint64_t lane_out(const LaneMasks &m, uint32_t s, uin
     const uint64_t x = ~m.nl;
     const uint64_t span = (x + hsx) ^ x;  // from every header start to its newline, inclusive
     return (~span & ~m.nl & ~m.cr) | hdr_start;
+}
+
+// ---- FASTQ (strict four-line records) ---------------------------------------------------------------------------------------
+// A byte's line index modulo 4 = (carry + the newlines in front of it) mod 4, a newline counting to the line it ENDS: two
+// bit planes by prefix-xor (the low plane is the parity of the newlines so far, the high plane flips where a newline
+// arrives on odd parity).  q[j] = the bytes of this lane whose line index is j.
+__device__ __forceinline__ uint64_t prefix_xor(uint64_t x)
+{
+    x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+    return x;
+}
+__device__ __forceinline__ void lane_line_index(uint64_t nl, uint32_t carry, uint64_t q[4])
+{
+    const uint64_t lo = prefix_xor(nl << 1);          // parity of the newlines in front of each byte
+    const uint64_t hi = prefix_xor((nl & lo) << 1);   // ... of those that arrived on odd parity
+    const uint64_t c0 = (carry & 1u) ? ~0ull : 0ull, c1 = (carry & 2u) ? ~0ull : 0ull;
+    const uint64_t b0 = lo ^ c0, b1 = hi ^ c1 ^ (lo & c0);
+    q[0] = ~b0 & ~b1, q[1] = b0 & ~b1, q[2] = ~b0 & b1, q[3] = b0 & b1;
+}
+// emitted: the sequence lines' bytes, and ONE invalid byte per record -- the newline that ends its header line
+__device__ __forceinline__ uint64_t lane_out_fastq(const LaneMasks &m, uint32_t carry, uint64_t &as_n)
+{
+    uint64_t q[4];
+    lane_line_index(m.nl_real, carry, q);
+    as_n = m.nl_real & q[0];
+    return (q[1] & ~m.nl_real & ~m.cr & m.valid) | as_n;
 }
 
 // exclusive prefix composition of the lanes' functions over the workgroup (256 lanes): Hillis-Steele through LDS
@@ -122,110 +163,172 @@ __device__ __forceinline__ uint32_t wg_scan_fn(uint32_t f, uint8_t *sh, uint32_t
     return ex;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 }  // namespace
 
-// pass A: every chunk's transfer function and its emitted bytes for each of the three carries; the genome's status
+// pass A: every chunk's transfer function and what it emits under each possible carry.
+//   FASTA: a[s] = bytes emitted with carry s; the genome's status is raised here (its checks do not depend on the carry).
+//   FASTQ: relative to a carry of 0, a[j] = bytes (no newline, no '\r') on lines of index j, b[j] = newlines that end a line
+//   of index j, bad8 bit j / bit 4 + j = a line of index j is followed by a line that does not begin with '@' / '+'
+//   (k_fastx_offsets, which knows the carry, rotates them into place).
 __global__ __launch_bounds__(256) void k_fastx_scan(const uint8_t *__restrict__ raw, const FastxChunk *__restrict__ chunks,
-                                                     const FastxGenome *__restrict__ genomes, uint4 *__restrict__ summ,
+                                                     const FastxGenome *__restrict__ genomes, FastxSumm *__restrict__ summ,
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint8_t sh[256];
-    __shared__ uint32_t cnt[3];
+    __shared__ uint32_t acc[9];
     const FastxChunk ck = chunks[blockIdx.x];
+    const FastxGenome g = genomes[ck.genome];
     const int t = threadIdx.x;
-    if (t < 3) cnt[t] = 0;
+    if (t < 9) acc[t] = 0;
     const uint32_t at = (uint32_t)t * 64u;
     const uint32_t have = at < ck.len ? (ck.len - at < 64u ? ck.len - at : 64u) : 0u;
     LaneMasks m;
     lane_masks(raw, ck.begin + at, have, m);
-    // not plain FASTA: the genome does not begin with '>', or a line begins with '+' (the byte behind this lane's last
-    // newline may be the next lane's, or the next chunk's, first)
-    bool bad = false;
-    if (have) {
-        const FastxGenome g = genomes[ck.genome];
-        const uint64_t next = ck.begin + at + 64;
-        const uint32_t nb = next < g.off + g.rawlen ? raw[next] : 0u;
-        bad = (m.nl_real & ((m.pl >> 1) | ((uint64_t)(nb == '+') << 63))) != 0;
-        if (ck.begin + at == g.off) bad = bad || (m.w[0] & 0xFFu) != '>';
-    }
-    if (bad) atomicOr(&status[ck.genome], 1u);
+    const uint64_t next = ck.begin + at + 64;
+    const bool has_next = have && next < g.off + g.rawlen;
+    const uint32_t nb = has_next ? raw[next] : 0u;  // (the byte behind this lane: the next lane's, or the next chunk's, first)
     uint32_t total;
-    const uint32_t ex = wg_scan_fn(lane_fn(m), sh, total);
-    uint64_t hs;
-    const uint32_t c[3] = {(uint32_t)__popcll(lane_out(m, FX_HDR, hs)), (uint32_t)__popcll(lane_out(m, FX_SEQ, hs)),
-                           (uint32_t)__popcll(lane_out(m, FX_FRESH, hs))};
-#pragma unroll
-    for (uint32_t x = 0; x < 3; ++x) {
-        const uint32_t s = fn_apply(ex, x);
-        uint32_t v = s == FX_HDR ? c[0] : (s == FX_SEQ ? c[1] : c[2]);
-#pragma unroll
-        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-        if ((t & 63) == 0) atomicAdd(&cnt[x], v);
-    }
-    __syncthreads();
-    if (t == 0) summ[blockIdx.x] = make_uint4(total, cnt[0], cnt[1], cnt[2]);
-}
-
-// pass B: one workgroup per genome -- every chunk's carry and where its output starts; the decoded length
-__global__ __launch_bounds__(256) void k_fastx_offsets(const FastxGenome *__restrict__ genomes, const uint4 *__restrict__ summ,
-                                                        const uint32_t *__restrict__ status, uint2 *__restrict__ state,
-                                                        uint64_t *__restrict__ declen)
-{
-    __shared__ uint32_t sf[256];
-    __shared__ uint64_t sc[256][3];
-    const FastxGenome g = genomes[blockIdx.x];
-    const int t = threadIdx.x;
-    if (status[blockIdx.x]) {  // the host will parse this one: nothing is emitted
-        for (uint32_t c = t; c < g.nchunks; c += 256) state[g.chunk0 + c] = make_uint2(0xFFFFFFFFu, 0xFFu);
-        if (t == 0) declen[blockIdx.x] = 0;
-        return;
-    }
-    const uint32_t per = (g.nchunks + 255) / 256;
-    const uint32_t c0 = (uint32_t)t * per, c1 = c0 + per < g.nchunks ? c0 + per : g.nchunks;
-    // this lane's run of chunks as ONE element: function + emitted bytes per incoming carry
-    uint32_t f = kFnIdentity;
-    uint64_t n3[3] = {0, 0, 0};
-    for (uint32_t c = c0; c < c1; ++c) {
-        const uint4 s = summ[g.chunk0 + c];
-        const uint32_t cc[3] = {s.y, s.z, s.w};
+    if (g.fmt == 0) {
+        // not plain FASTA: the genome does not begin with '>', or a line begins with '+'
+        bool bad = false;
+        if (have) {
+            bad = (m.nl_real & ((m.pl >> 1) | ((uint64_t)(nb == '+') << 63))) != 0;
+            if (ck.begin + at == g.off) bad = bad || (m.w[0] & 0xFFu) != '>';
+        }
+        if (bad) atomicOr(&status[ck.genome], 1u);
+        const uint32_t ex = wg_scan_fn(lane_fn(m), sh, total);
+        uint64_t hs;
+        const uint32_t c[3] = {(uint32_t)__popcll(lane_out(m, FX_HDR, hs)), (uint32_t)__popcll(lane_out(m, FX_SEQ, hs)),
+                               (uint32_t)__popcll(lane_out(m, FX_FRESH, hs))};
 #pragma unroll
         for (uint32_t x = 0; x < 3; ++x) {
-            const uint32_t y = fn_apply(f, x);
-            n3[x] += y == 0 ? cc[0] : (y == 1 ? cc[1] : cc[2]);
+            const uint32_t s = fn_apply(ex, x);
+            const uint32_t v = wave_sum(s == FX_HDR ? c[0] : (s == FX_SEQ ? c[1] : c[2]));
+            if ((t & 63) == 0) atomicAdd(&acc[x], v);
         }
-        f = fn_then(f, s.x);
-    }
-    sf[t] = f;
-    sc[t][0] = n3[0], sc[t][1] = n3[1], sc[t][2] = n3[2];
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of (function, counts): (a then b)[x] = a.n[x] + b.n[a.f(x)]
-        uint32_t vf = sf[t];
-        uint64_t vn[3] = {sc[t][0], sc[t][1], sc[t][2]};
-        if (t >= d) {
-            const uint32_t af = sf[t - d];
+    } else {
+        if (have && ck.begin + at == g.off && (m.w[0] & 0xFFu) != '@') atomicOr(&status[ck.genome], 1u);
+        const uint32_t ex = wg_scan_fn(fn_add((uint32_t)__popcll(m.nl_real)), sh, total);
+        uint64_t q[4];
+        lane_line_index(m.nl_real, fn_apply(ex, 0), q);
+        const uint64_t body = ~m.nl_real & ~m.cr & m.valid;
+        // the first byte of the line behind a newline: the next bit, or the byte behind the lane; nothing behind the genome's end
+        const uint64_t nx_exists = (m.valid >> 1) | ((uint64_t)has_next << 63);
+        const uint64_t nx_at = (m.at >> 1) | ((uint64_t)(nb == '@') << 63), nx_pl = (m.pl >> 1) | ((uint64_t)(nb == '+') << 63);
+        uint32_t bad8 = 0;
 #pragma unroll
-            for (uint32_t x = 0; x < 3; ++x) {
-                const uint32_t y = fn_apply(af, x);
-                vn[x] = sc[t - d][x] + (y == 0 ? sc[t][0] : (y == 1 ? sc[t][1] : sc[t][2]));
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t n = wave_sum((uint32_t)__popcll(q[j] & body)), nn = wave_sum((uint32_t)__popcll(q[j] & m.nl_real));
+            if ((t & 63) == 0) {
+                atomicAdd(&acc[j], n);
+                atomicAdd(&acc[4 + j], nn);
             }
-            vf = fn_then(af, vf);
+            const uint64_t ends = m.nl_real & q[j] & nx_exists;
+            if (ends & ~nx_at) bad8 |= 1u << j;
+            if (ends & ~nx_pl) bad8 |= 16u << j;
         }
+        if (bad8) atomicOr(&acc[8], bad8);
+    }
+    __syncthreads();
+    if (t == 0) {
+        FastxSumm o;
+        o.fn = total;
+        o.bad8 = acc[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.a[j] = acc[j], o.b[j] = acc[4 + j];
+        summ[blockIdx.x] = o;
+    }
+}
+
+namespace {
+// a chunk's emitted bytes under the concrete carry c (FASTQ also: its sequence / quality bytes and whether it breaks the
+// four-line pattern)
+__device__ __forceinline__ uint32_t chunk_emits(const FastxSumm &s, uint32_t fmt, uint32_t c, uint64_t &seq, uint64_t &qual, bool &bad)
+{
+    if (fmt == 0) return s.a[c < 3 ? c : 2];
+    // a line of raw index r has the index (r + c) & 3: sequence lines r = 1 - c, quality 3 - c, header newlines 0 - c; the line
+    // behind one of index 3 must begin with '@', the one behind index 1 with '+'
+    seq += s.a[(1u - c) & 3u];
+    qual += s.a[(3u - c) & 3u];
+    bad = bad || ((s.bad8 >> ((3u - c) & 3u)) & 1u) || ((s.bad8 >> (4u + ((1u - c) & 3u))) & 1u);
+    return s.a[(1u - c) & 3u] + s.b[(0u - c) & 3u];
+}
+}  // namespace
+
+// pass B: one workgroup per genome -- every chunk's carry and where its output starts; the decoded length; the verdict
+__global__ __launch_bounds__(256) void k_fastx_offsets(const FastxGenome *__restrict__ genomes, const FastxSumm *__restrict__ summ,
+                                                        uint32_t *__restrict__ status, uint2 *__restrict__ state,
+                                                        uint64_t *__restrict__ declen)
+{
+    __shared__ uint8_t sf[256];
+    __shared__ uint64_t sn[256], sq[2];
+    __shared__ uint32_t sbad;
+    const FastxGenome g = genomes[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t == 0) sq[0] = sq[1] = 0, sbad = status[blockIdx.x];
+    const uint32_t per = (g.nchunks + 255) / 256;
+    const uint32_t c0 = (uint32_t)t * per, c1 = c0 + per < g.nchunks ? c0 + per : g.nchunks;
+    // 1. the carry in front of every lane's run of chunks: prefix composition of the chunks' functions
+    uint32_t f = kFnIdentity;
+    for (uint32_t c = c0; c < c1; ++c) f = fn_then(f, summ[g.chunk0 + c].fn);
+    sf[t] = (uint8_t)f;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint32_t v = sf[t];
+        if (t >= d) v = fn_then(sf[t - d], v);
         __syncthreads();
-        sf[t] = vf;
-        sc[t][0] = vn[0], sc[t][1] = vn[1], sc[t][2] = vn[2];
+        sf[t] = (uint8_t)v;
         __syncthreads();
     }
-    // the genome starts FRESH: this lane's carry and offset, then its chunks one after the other
-    uint32_t carry = t ? fn_apply(sf[t - 1], FX_FRESH) : FX_FRESH;
-    uint64_t off = t ? sc[t - 1][FX_FRESH] : 0;
+    const uint32_t start = g.fmt == 0 ? FX_FRESH : 0u;  // a genome begins with a fresh line / with line 0
+    const uint32_t carry0 = t ? fn_apply(sf[t - 1], start) : start;
+    // 2. with the carries known: what every chunk emits; prefix sum over the lanes' runs
+    uint64_t mine = 0, seq = 0, qual = 0;
+    bool bad = false;
+    uint32_t carry = carry0;
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint4 s = summ[g.chunk0 + c];
-        // (a chunk's output starts less than 4 GiB into its genome's region or the genome is refused below)
-        state[g.chunk0 + c] = make_uint2((uint32_t)off, carry | ((uint32_t)(off >> 32) << 8));
-        off += carry == 0 ? s.y : (carry == 1 ? s.z : s.w);
-        carry = fn_apply(s.x, carry);
+        const FastxSumm s = summ[g.chunk0 + c];
+        mine += chunk_emits(s, g.fmt, carry, seq, qual, bad);
+        carry = fn_apply(s.fn, carry);
     }
-    if (t == 255) declen[blockIdx.x] = sc[255][FX_FRESH];
+    sn[t] = mine;
+    if (bad) atomicOr(&sbad, 1u);
+    if (seq) atomicAdd((unsigned long long *)&sq[0], (unsigned long long)seq);
+    if (qual) atomicAdd((unsigned long long *)&sq[1], (unsigned long long)qual);
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint64_t v = sn[t];
+        if (t >= d) v += sn[t - d];
+        __syncthreads();
+        sn[t] = v;
+        __syncthreads();
+    }
+    // FASTQ: the quality lines must hold as many bytes as the sequence lines (a short or missing quality line would make
+    // the host parser swallow the following lines: refused here, parsed there)
+    const bool refused = sbad != 0 || (g.fmt != 0 && sq[0] != sq[1]);
+    if (refused) {  // the host will parse this one: nothing is emitted
+        for (uint32_t c = t; c < g.nchunks; c += 256) state[g.chunk0 + c] = make_uint2(0xFFFFFFFFu, 0xFFu);
+        if (t == 0) declen[blockIdx.x] = 0, status[blockIdx.x] = 1u;
+        return;
+    }
+    uint64_t off = t ? sn[t - 1] : 0;
+    carry = carry0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const FastxSumm s = summ[g.chunk0 + c];
+        state[g.chunk0 + c] = make_uint2((uint32_t)off, carry | ((uint32_t)(off >> 32) << 8));
+        uint64_t d0 = 0, d1 = 0;
+        bool db = false;
+        off += chunk_emits(s, g.fmt, carry, d0, d1, db);
+        carry = fn_apply(s.fn, carry);
+    }
+    if (t == 255) declen[blockIdx.x] = sn[255];
 }
 
 // pass C: the chunk's emitted bytes, compacted through LDS, to out + (genome offset + the chunk's offset)
@@ -239,16 +342,21 @@ __global__ __launch_bounds__(256) void k_fastx_compact(const uint8_t *__restrict
     const uint2 st = state[blockIdx.x];
     if ((st.y & 0xFFu) == 0xFFu) return;  // (a refused genome)
     const FastxChunk ck = chunks[blockIdx.x];
+    const FastxGenome g = genomes[ck.genome];
     const int t = threadIdx.x;
     const uint32_t at = (uint32_t)t * 64u;
     const uint32_t have = at < ck.len ? (ck.len - at < 64u ? ck.len - at : 64u) : 0u;
     LaneMasks m;
     lane_masks(raw, ck.begin + at, have, m);
     uint32_t total_fn;
-    const uint32_t ex = wg_scan_fn(lane_fn(m), sh, total_fn);
-    const uint32_t s = fn_apply(ex, st.y & 3u);
-    uint64_t hs;
-    const uint64_t keep = lane_out(m, s, hs);
+    uint64_t hs, keep;
+    if (g.fmt == 0) {
+        const uint32_t ex = wg_scan_fn(lane_fn(m), sh, total_fn);
+        keep = lane_out(m, fn_apply(ex, st.y & 3u), hs);
+    } else {
+        const uint32_t ex = wg_scan_fn(fn_add((uint32_t)__popcll(m.nl_real)), sh, total_fn);
+        keep = lane_out_fastq(m, fn_apply(ex, st.y & 3u), hs);
+    }
     const uint32_t mine = (uint32_t)__popcll(keep);
     // exclusive prefix sum of the lanes' byte counts: inside the wave by shuffles, across the four waves through LDS
     uint32_t inc = mine;
@@ -265,7 +373,7 @@ __global__ __launch_bounds__(256) void k_fastx_compact(const uint8_t *__restrict
         if (w < (t >> 6)) base += wsum[w];
         total += wsum[w];
     }
-    const uint64_t dst0 = genomes[ck.genome].off + (((uint64_t)(st.y >> 8) << 32) | st.x);
+    const uint64_t dst0 = g.off + (((uint64_t)(st.y >> 8) << 32) | st.x);
     const uint32_t A = (uint32_t)(dst0 & 15u);
     uint32_t pos = A + base + inc - mine;
 #pragma unroll
@@ -316,7 +424,7 @@ hipError_t preload_fastx_kernels()
 }
 
 hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
-                               const FastxGenome *genomes, uint32_t ngenomes, uint4 *summ, uint2 *state, uint64_t *declen,
+                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint2 *state, uint64_t *declen,
                                uint32_t *status, uint8_t *out)
 {
     if (ngenomes == 0) return hipSuccess;

@@ -118,14 +118,16 @@ int dsh_sketch_batch_device(dsh_ctx *ctx, const void *d_seq, const uint64_t *gen
  * (src/sketch_and_cmp.h:338-342): `raw` holds the bytes of plain FASTA files as they lie on disk -- genome g's at
  * raw[genome_off[g] .. genome_off[g] + raw_len[g]) (several files of one genome: back to back with a '\n' between them),
  * its region [genome_off[g], genome_off[g+1]) at least that long, every genome_off[g] a multiple of 32.  The library
- * copies the raw bytes to the device and decodes them there into what kseq would hand the encoder: header lines
- * ('>' or '@' first) end a record (one invalid byte: k-mers never span records), '\n' and '\r' vanish, everything else is
- * sequence (validated and case-folded by the sketch kernel as above) -- then sketches as dsh_sketch_batch_async does.
- * What is not plain FASTA is REFUSED per genome, never guessed at: a genome that does not begin with '>' or holds a line
- * that begins with '+' (FASTQ: quality lines need record state) gets status_out[g] != 0 and contributes NOTHING to its
- * slot; the host then parses that genome itself (dsh_sketch_batch).  status_out: n_genomes words of page-locked host
- * memory (or NULL), valid after dsh_wait.  `raw` must stay untouched until then.  Compressed inputs and pipes are the
- * host's business (inflate, then either entry point). */
+ * copies the raw bytes to the device and decodes them there into what kseq would hand the encoder, then sketches as
+ * dsh_sketch_batch_async does.  A genome that begins with '>' is FASTA: header lines ('>' or '@' first) end a record (one
+ * invalid byte: k-mers never span records), '\n' and '\r' vanish, everything else is sequence (validated and case-folded
+ * by the sketch kernel as above).  A genome that begins with '@' is FASTQ in four-line records: of every four lines the
+ * second is sequence.  What does not keep its format's promise is REFUSED per genome, never guessed at -- a first byte
+ * that is neither, a FASTA line that begins with '+', a FASTQ file whose lines 4r are not '@' headers or 4r + 2 not '+'
+ * lines or whose quality bytes do not number its sequence bytes (multi-line records, cut-off files: the record state of
+ * kseq decides those) -- : status_out[g] != 0, NOTHING goes into its slot, and the host parses that genome itself
+ * (dsh_sketch_batch).  status_out: n_genomes words of page-locked host memory (or NULL), valid after dsh_wait.  `raw` must
+ * stay untouched until then.  Compressed inputs and pipes are the host's business (inflate, then either entry point). */
 int dsh_sketch_fastx_batch_async(dsh_ctx *ctx, const uint8_t *raw_pinned, const uint64_t *genome_off,
                                  const uint64_t *raw_len, uint32_t n_genomes, uint64_t first_slot, int k, int canon,
                                  uint32_t *status_out_pinned);

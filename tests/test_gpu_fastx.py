@@ -1,4 +1,4 @@
-"""GPU parity of the device-side FASTA decode (dsh_sketch_fastx_batch_async, kernels_fastx.hip): the registers of raw file
+"""GPU parity of the device-side FASTA / FASTQ decode (dsh_sketch_fastx_batch_async, kernels_fastx.hip): the registers of raw file
 bytes decoded ON THE DEVICE equal, bit for bit, the CPU oracle's registers of the sequence the HOST parser
 (host/host.cpp FastxParser, through libdashing_host.so) extracts from the same file -- the reference's
 Encoder::for_each(func, path) includes the parse (src/sketch_and_cmp.h:338-342).  What is not plain FASTA is refused per
@@ -118,10 +118,9 @@ def test_headers_of_every_length_and_position(ctx, oracle, host, tmp_path):
 def test_what_is_not_plain_fasta_is_refused_not_guessed(ctx, oracle, host, tmp_path):
     rng = np.random.default_rng(3)
     gs = genomes(4, 20011, 7, decorate=False)
-    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, gs[0][i * 100 : (i + 1) * 100], b"I" * 100) for i in range(150))
     files = [
         fasta(rng, [(b"ok", gs[1])], 80),
-        fq,                                              # FASTQ: begins with '@'
+        b"ACGT" * 100 + b"\n",                            # begins with neither '>' nor '@'
         b"\n" + fasta(rng, [(b"blank first", gs[2])], 80),  # does not begin with '>'
         fasta(rng, [(b"plus line", gs[3])], 80) + b"+\nIIII\n",  # a '+' line inside a '>' file
         b"",                                             # an empty file: nothing to refuse, nothing to sketch
@@ -132,6 +131,64 @@ def test_what_is_not_plain_fasta_is_refused_not_guessed(ctx, oracle, host, tmp_p
     files.append(b">x\n" + body + b"\n+\nII\n")
     files.append(b">y\n" + gs[3][: 64 - 4] + b"\n+\n")
     check(ctx, oracle, host, tmp_path, files, expect_status=[0, 1, 1, 1, 0, 0, 1, 1])
+
+
+def fastq(rng, reads, eol=b"\n", final_eol=True, qual=None):
+    out = []
+    for i, r in enumerate(reads):
+        q = qual(i, len(r)) if qual else bytes(rng.integers(33, 75, len(r), dtype=np.uint8))
+        out.append(b"@read%d some text\n".replace(b"\n", eol) % i + bytes(r) + eol + b"+" + eol + q + eol)
+    data = b"".join(out)
+    if not final_eol and data.endswith(eol):
+        data = data[: -len(eol)]
+    return data
+
+
+def test_fastq_in_strict_four_line_records(ctx, oracle, host, tmp_path):
+    """FASTQ (a genome that begins with '@'): line index modulo 4 by counting newlines, the sequence lines kept, one invalid
+    byte per record.  Quality lines may hold any character -- '@', '+', '>' first included --, reads from 1 base to longer
+    than a chunk, CRLF, no newline at the end; registers equal the oracle's on the HOST parser's sequence."""
+    rng = np.random.default_rng(7)
+    g = genomes(1, 400_000, 13, decorate=True)[0]
+
+    def reads(lens):
+        out, at = [], 0
+        for L in lens:
+            out.append(g[at : at + L])
+            at = (at + L) % (len(g) - 40000)
+        return out
+
+    nasty = lambda i, L: (b"@+>@"[i % 4 : i % 4 + 1] + bytes(rng.integers(33, 75, max(L - 1, 0), dtype=np.uint8)))[:L]
+    files = [
+        fastq(rng, reads([150] * 400)),
+        fastq(rng, reads([int(x) for x in rng.integers(1, 400, 600)]), qual=nasty),
+        fastq(rng, reads([100] * 300), eol=b"\r\n"),
+        fastq(rng, reads([250] * 100), final_eol=False),
+        fastq(rng, reads([20000, 35000, 17, 16384, 16383, 63, 64, 65])),
+        fastq(rng, reads([59] * 2000)),   # "@readN some text\n" + 59 + "\n+\n" + 59 + "\n": newlines drift across the lanes
+        fastq(rng, reads([40])),
+        b"@only a header",
+    ]
+    check(ctx, oracle, host, tmp_path, files, k=31)
+    check(ctx, oracle, host, tmp_path, files[:3], k=16, p=12, canon=False)
+
+
+def test_fastq_that_is_not_four_line_is_refused(ctx, oracle, host, tmp_path):
+    """multi-line sequence or quality, a quality line shorter / longer than its sequence, a blank line between records,
+    a record cut off: the device refuses the whole genome (the host parser's record state decides those), a well-formed
+    neighbour in the same batch is not touched"""
+    rng = np.random.default_rng(8)
+    g = genomes(1, 100_000, 17, decorate=False)[0]
+    rd = [g[i * 200 : (i + 1) * 200] for i in range(50)]
+    good = fastq(rng, rd)
+    two_line_seq = b"".join(b"@r%d\n%s\n%s\n+\n%s\n" % (i, r[:100], r[100:], b"I" * 200) for i, r in enumerate(rd))
+    two_line_qual = b"".join(b"@r%d\n%s\n+\n%s\n%s\n" % (i, r, b"I" * 100, b"I" * 100) for i, r in enumerate(rd))
+    short_qual = fastq(rng, rd[:20]) + b"@x\n" + rd[20] + b"\n+\n" + b"I" * 150 + b"\n" + fastq(rng, rd[21:])
+    long_qual = fastq(rng, rd[:20]) + b"@x\n" + rd[20] + b"\n+\n" + b"I" * 250 + b"\n" + fastq(rng, rd[21:])
+    blank_between = fastq(rng, rd[:10]) + b"\n" + fastq(rng, rd[10:])
+    cut_off = fastq(rng, rd[:10]) + b"@x\n" + rd[10] + b"\n+\n"
+    files = [good, two_line_seq, two_line_qual, short_qual, long_qual, blank_between, cut_off, good]
+    check(ctx, oracle, host, tmp_path, files, expect_status=[0, 1, 1, 1, 1, 1, 1, 0])
 
 
 def test_many_genomes_random_shapes(ctx, oracle, host, tmp_path):
