@@ -445,7 +445,7 @@ def run(args, backend, world, rank, line, dist_on):
     regs_d = torch.from_numpy(regs_h).to(dev)    # resident in HBM before timing
     total_pairs = n * (n - 1) // 2
     ctx = dashing_amd.Context(local_rank)
-    for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # tuning sweeps, e.g. "kc=64,emax=32"
+    for kv in filter(None, os.environ.get("DSH_BENCH_OPTS", "").split(",")):  # option sweeps, e.g. "kc=16,emax=32,finalize_signal=0"
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
     ctx.attach_device(regs_d.data_ptr(), n, p)

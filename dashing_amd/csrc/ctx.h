@@ -117,6 +117,7 @@ struct dsh_ctx {
     uint32_t rl_stride = 0;             // entries of a compact list row (emax + elow)
     // column layout of the cached plane matrix (plan.h) and the plan of the last compare call
     dsh::plan::Layout lay;
+    bool lay_built = false;             // `lay` holds a layout (whatever happened to the planes since)
     dsh::plan::PairPlan pp;
     std::vector<hipEvent_t> ev_part;    // part q complete (recorded on the ctx stream by the last call with parts)
     uint32_t parts_done = 0;            // parts of the last dsh_dist_rows_parts_device_async call

@@ -101,32 +101,46 @@ int prepare(dsh_ctx *c, int estim, int want_sorted, bool card_only, uint64_t wan
         }
         return DSH_OK;
     }
+#ifdef DSH_EXPERIMENT_REUSE_LAYOUT
+    // EXPERIMENT (make EXPERIMENT=1; never in the product library): the upper bound of what ANY device-built layout could
+    // save.  The sketches of a re-attached matrix are the same bytes, so the layout of the previous call -- host tables AND
+    // the permutation on the device -- is still right: skip the host's part entirely (the wait for the keys, the radix sort,
+    // the block statistics, the uploads) and go straight from the per-sketch pass to the index build and the transform.
+    // Results stay correct only while every call sees the same registers (bench.py's timed loop).  DESIGN.md section 8.
+    const bool reuse_host_layout = !keep_layout && c->lay_built && c->lay.n == n && c->lay.sorted == want_sorted &&
+                                   (!want_sorted || (c->lay.rb == want_rb && c->lay.re == want_re && c->lay.rowsorted == rowsorted &&
+                                                     c->lay.extra == *extra && (rowsorted ? c->lay.part_w == rs_pos : c->lay.parts == parts)));
+#else
+    constexpr bool reuse_host_layout = false;
+#endif
     if (!keep_layout) {
         if (c->p > kMaxPCompare)
             return fail(c, DSH_EINVAL, "the compare path takes p <= %d (p=%d: sketching and cardinalities only)", kMaxPCompare, c->p);
         // the keys are downloaded once per per-sketch pass: a later layout (next row block) needs no
         // device round trip and so does not wait for the work still queued on the stream
         const auto t_h0 = std::chrono::steady_clock::now();
-        if (!c->hk32_valid) {
+        if (!c->hk32_valid && !reuse_host_layout) {
             HIPCHK(c, hipEventSynchronize(c->ev_keys));
             c->hk32_valid = true;
         }
         const auto t_h1 = std::chrono::steady_clock::now();
         c->host_keys_wait_us = std::chrono::duration<double, std::micro>(t_h1 - t_h0).count();
         const uint32_t *k32 = c->hk32;
-        for (uint64_t i = c->card_from; i < n; ++i)  // (the sketches the per-sketch pass covered)
+        for (uint64_t i = c->card_from; i < n && !reuse_host_layout; ++i)  // (the sketches the per-sketch pass covered)
             if (plan::key_bad(k32[i]))
                 return fail(c, DSH_EINVAL, "sketch %llu holds a register value above %d (= 64 - p + 1): not an HLL of precision %d (corrupt or foreign .hll?)",
                             (unsigned long long)i, 64 - c->p + 1, c->p);
         c->planes_valid = false;  // (the cached layout is overwritten from here on)
         plan::Layout &L = c->lay;
-        plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0,
-                           extra->empty() ? nullptr : extra);
+        if (!reuse_host_layout)
+            plan::build_layout(k32, n, want_sorted, want_rb, want_re, parts, L, rowsorted ? std::max<uint32_t>(nparts, 1) : 0,
+                               extra->empty() ? nullptr : extra);
+        c->lay_built = true;
         c->cum_bytes = c->p <= 15 ? 2 : 4;
         const uint64_t m = 1ull << c->p;
         c->W = (uint32_t)std::max<uint64_t>(1, m / 32);
         c->kc = c->kc_opt ? c->kc_opt : (c->W >= 32 ? 32 : 16);
-        if (want_sorted) {
+        if (want_sorted && !reuse_host_layout) {
             // perm, then (whole collection only) its inverse for the un-permute of the shard path
             const uint64_t nperm = L.perm.size();
             HIPCHK(c, c->perm.ensure(std::max<uint64_t>(nperm, 1) * sizeof(uint32_t)));

@@ -15,6 +15,7 @@
 #   mock<N>           bench.py --gpus N over the stand-in transport (N ranks on the one GPU) -> bench_gpus<N>_mock.json
 #   model[:ENV=..,..] tools/shard_model.py with the given environment (e.g. model:G=8,PARTITIONS=contiguous+rowsets)
 #   py:<script>[:ENV=..,..]  python tools/<script>.py > <script>.jsonl
+#   experiment        the layout-reuse experiment: EXPERIMENT=1 library vs product, quick bench + 8-rank model
 set -x
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
@@ -50,6 +51,22 @@ for step in "$@"; do
       grep "^{" $O/bench_gpus${N}_mock.out > $O/bench_gpus${N}_mock.json; tail -c 1500 $O/bench_gpus${N}_mock.json; tail -3 $O/bench_gpus${N}_mock.err ;;
     model) ( export $(envs "$arg"); timeout 900 python tools/shard_model.py >> $O/shard_model.jsonl 2> $O/shard_model.err ); tail -c 600 $O/shard_model.jsonl; tail -3 $O/shard_model.err ;;
     py) s=${arg%%:*}; e=""; [ "$s" != "$arg" ] && e=${arg#*:}; ( export $(envs "$e"); timeout 1200 python tools/$s.py >> $O/$s.jsonl 2> $O/$s.err ); tail -c 1200 $O/$s.jsonl; tail -3 $O/$s.err ;;
+    experiment)
+      # the layout-reuse experiment: the library rebuilt with EXPERIMENT=1 ON THE GPU BOX, the quick bench
+      # three times each way, the 8-rank model; the product library rebuilt afterwards
+      for mode in product reuse product reuse product reuse; do
+        touch dashing_amd/csrc/engine.hip
+        if [ $mode = reuse ]; then make -s -j8 -C dashing_amd/csrc EXPERIMENT=1 > $O/experiment_build.log 2>&1; else make -s -j8 -C dashing_amd/csrc > $O/experiment_build.log 2>&1; fi
+        timeout 600 python bench.py --no-secondary --no-pmc --no-cpu-baseline --steps 40 > $O/exp_bench.tmp 2>> $O/experiment.err
+        python - "$mode" $O/exp_bench.tmp >> $O/experiment.jsonl <<'PYEOF'
+import json, sys
+d = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+print(json.dumps({"library": sys.argv[1], "ms_per_step": d["ms_per_step"], "pairs_per_s": d["value"], "step_ms": d["roofline"]["step"]["ms"]}))
+PYEOF
+        if [ $mode = reuse ]; then ( export G=8 TAG=reuse; timeout 600 python tools/shard_model.py >> $O/experiment_model_reuse.jsonl 2>> $O/experiment.err ); else ( export G=8; timeout 600 python tools/shard_model.py >> $O/experiment_model_product.jsonl 2>> $O/experiment.err ); fi
+      done
+      touch dashing_amd/csrc/engine.hip; make -s -j8 -C dashing_amd/csrc >> $O/experiment_build.log 2>&1
+      cat $O/experiment.jsonl; tail -3 $O/experiment.err ;;
     *) echo "unknown step $step" ;;
   esac
 done
