@@ -46,3 +46,22 @@ def test_more_bandwidth_never_hurts_and_the_gate_delays_the_first_round():
     free, _ = pipeline_model(rows, 1e12, 10.0, nmsg=3, dst_gate=False)
     gated, _ = pipeline_model(rows, 1e12, 10.0, nmsg=3)  # as the library decides: one launch of 7 rounds -> behind the tile kernel (1.5 ms)
     assert gated >= free and gated == pytest.approx(1.5 + 3 * (0.8 + 0.02) + 8 * MB / 1e12 * 1e3 + 0.005)
+
+
+def test_measured_interference_lengthens_the_destinations_own_kernels():
+    """dst_interference (round 6: what waiting receive kernels cost the destination's kernels, measured on one GPU): k_finalize
+    always, the tile kernel only when the receives are not gated behind it; nothing changes for a single rank"""
+    from dashing_amd.multigpu import MEASURED_RECV_INTERFERENCE
+
+    dst = rank(0, 2.0, [(2.0, 10 * MB)], rowsorted=False, finalize_ms=0.5, pair_ms=1.2, bands=1, rounds_of_512=7)
+    src = rank(1, 1.0, [(0.5, 4 * MB), (1.0, 4 * MB)])
+    f = {"pair": 1.10, "finalize": 1.20}
+    base, _ = pipeline_model([dst, src], 1e12, 1e6, nmsg=2, dst_gate=False)
+    free, _ = pipeline_model([dst, src], 1e12, 1e6, nmsg=2, dst_gate=False, dst_interference=f)
+    gated, _ = pipeline_model([dst, src], 1e12, 1e6, nmsg=2, dst_gate=True, dst_interference=f)
+    assert base == pytest.approx(2.0)
+    assert free == pytest.approx(2.0 + 0.5 * 0.20 + 1.2 * 0.10)
+    assert gated == pytest.approx(max(2.0 + 0.5 * 0.20, 1.5 + 2 * 0.02 + 2 * 4 * MB / 1e15 * 1e3 + 0.005), abs=1e-3)
+    alone, _ = pipeline_model([dst], 1e12, 1e6, nmsg=2, dst_interference=f)
+    assert alone == pytest.approx(2.0)
+    assert set(MEASURED_RECV_INTERFERENCE) == {"lds_over_32k", "lds_4k"}

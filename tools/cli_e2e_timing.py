@@ -41,6 +41,22 @@ def main():
         cli = os.path.join(ROOT, "dashing_amd", "dashing-amd")
         out = os.path.join(d, "dist.bin")
         ref = None
+        if os.environ.get("ROCPROF_OUT"):
+            # the same command under rocprofv3 --kernel-trace --stats: what the device does with the 5 GB (decode kernels,
+            # k_sketch, the dist kernels), per kernel
+            import glob
+
+            td = tempfile.mkdtemp(prefix="kt_", dir="/tmp")
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", td, "-o", "p", "--output-format", "csv", "--", cli, "dist", "-k", "31", "-S", "10",
+                                "-p", "16", "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst], capture_output=True, cwd="/tmp", timeout=900)
+            stats = glob.glob(os.path.join(td, "**", "*kernel_stats.csv"), recursive=True)
+            if stats:
+                shutil.copy(stats[0], os.environ["ROCPROF_OUT"])
+            print(json.dumps({"what": "CLI under rocprofv3 --kernel-trace --stats", "rc": r.returncode, "stats_file": os.environ["ROCPROF_OUT"] if stats else None,
+                              "stderr_tail": r.stderr.decode(errors="replace")[-300:] if r.returncode else ""}), flush=True)
+            shutil.rmtree(td, ignore_errors=True)
+            if os.environ.get("ROCPROF_ONLY"):
+                return
         for _ in range(3):  # what a process that does nothing costs: exec + dynamic loading of the HIP runtime + exit
             t0 = time.perf_counter()
             subprocess.run([cli, "--help"], capture_output=True)
