@@ -48,7 +48,8 @@ def main():
 
             td = tempfile.mkdtemp(prefix="kt_", dir="/tmp")
             r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", td, "-o", "p", "--output-format", "csv", "--", cli, "dist", "-k", "31", "-S", "10",
-                                "-p", "16", "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst], capture_output=True, cwd="/tmp", timeout=900)
+                                "-p", "16", "-b", "--avoid-sorting", "-O", out, "-o", os.devnull, "-F", lst], capture_output=True, cwd="/tmp", timeout=900,
+                               env=dict(os.environ, DSH_FULL_TEARDOWN="1"))  # (the profiler writes its files at exit: no _Exit)
             stats = glob.glob(os.path.join(td, "**", "*kernel_stats.csv"), recursive=True)
             if stats:
                 shutil.copy(stats[0], os.environ["ROCPROF_OUT"])
