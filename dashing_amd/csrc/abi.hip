@@ -239,15 +239,11 @@ int dsh_clear_sketches(dsh_ctx *c, uint64_t first, uint64_t n)
 static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genome_off,
                          uint32_t n_genomes, uint64_t first_slot, int k, int canon)
 {
-    // work list: each workgroup walks up to kSubsPerWG sub-chunks (8 192 bases each) of one genome -- 16 for a large call
-    // (1 000 x 5 Mbp: 39 000 workgroups), fewer for a small one so that it still fills the chip (a 48 MB batch of the
-    // streaming loader is 5 570 sub-chunks: 350 workgroups of 16 left most CUs with one; profiles/rd6n/cli_kernel_stats.csv),
-    // never so few that a workgroup's start and end -- clearing and max-merging 2^p registers -- outweigh its k-mers
-    uint64_t total_subs = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g)
-        if (genome_off[g + 1] >= genome_off[g]) total_subs += (genome_off[g + 1] - (genome_off[g] & ~31ull) + kSketchSub - 1) / kSketchSub;
-    const uint32_t min_subs = c->p <= 12 ? 1u : (c->p <= 14 ? 4u : 8u);
-    const uint32_t kSubsPerWG = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(min_subs, (total_subs + 4095) / 4096));
+    // work list: each workgroup walks up to kSubsPerWG sub-chunks (8 192 bases each) of one genome.  (Fewer sub-chunks per
+    // workgroup for SMALL calls -- a 46 MB batch of the streaming loader is 350 workgroups of 16 -- were tried in round 6 and
+    // lost: 2 sub-chunks = 2 785 workgroups took 147 us instead of 102, every workgroup ends by max-merging its 2^p
+    // registers into the same few rows of the matrix; profiles/rd6n, rd6o cli_kernel_stats.csv.)
+    constexpr uint32_t kSubsPerWG = 16;
     std::vector<SketchWork> work;
     for (uint32_t g = 0; g < n_genomes; ++g) {
         const uint64_t gb = genome_off[g], ge = genome_off[g + 1];
