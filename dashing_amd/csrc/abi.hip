@@ -243,7 +243,11 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
     // workgroup for SMALL calls -- a 46 MB batch of the streaming loader is 350 workgroups of 16 -- were tried in round 6 and
     // lost: 2 sub-chunks = 2 785 workgroups took 147 us instead of 102, every workgroup ends by max-merging its 2^p
     // registers into the same few rows of the matrix; profiles/rd6n, rd6o cli_kernel_stats.csv.)
-    constexpr uint32_t kSubsPerWG = 16;
+    static const uint32_t kSubsPerWG = [] {  // (A/B only: DSH_SKETCH_SUBS)
+        const char *e = std::getenv("DSH_SKETCH_SUBS");
+        const int v = e ? std::atoi(e) : 16;
+        return (uint32_t)(v < 1 ? 1 : (v > 4096 ? 4096 : v));
+    }();
     std::vector<SketchWork> work;
     for (uint32_t g = 0; g < n_genomes; ++g) {
         const uint64_t gb = genome_off[g], ge = genome_off[g + 1];
