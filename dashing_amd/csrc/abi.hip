@@ -243,11 +243,9 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
     // workgroup for SMALL calls -- a 46 MB batch of the streaming loader is 350 workgroups of 16 -- were tried in round 6 and
     // lost: 2 sub-chunks = 2 785 workgroups took 147 us instead of 102, every workgroup ends by max-merging its 2^p
     // registers into the same few rows of the matrix; profiles/rd6n, rd6o cli_kernel_stats.csv.)
-    static const uint32_t kSubsPerWG = [] {  // (A/B only: DSH_SKETCH_SUBS)
-        const char *e = std::getenv("DSH_SKETCH_SUBS");
-        const int v = e ? std::atoi(e) : 16;
-        return (uint32_t)(v < 1 ? 1 : (v > 4096 ? 4096 : v));
-    }();
+    // At BASELINE configs[1] size 16 is the optimum: 8 -> 8.43e11, 16 -> 8.59e11, 32 -> 8.31e11, 64 -> 8.2e11, 128 -> 8.3e11 bases/s
+    // (profiles/rd6p/sketch_subs_ab.jsonl).
+    constexpr uint32_t kSubsPerWG = 16;
     std::vector<SketchWork> work;
     for (uint32_t g = 0; g < n_genomes; ++g) {
         const uint64_t gb = genome_off[g], ge = genome_off[g + 1];
