@@ -214,3 +214,73 @@ def test_a_genome_of_many_chunks_and_precision_above_lds(ctx, oracle, host, tmp_
     files = [fasta(rng, [(b"big", g)], 80), fasta(rng, [(b"big one line", g[:3_000_000])], 0)]
     check(ctx, oracle, host, tmp_path, files)
     check(ctx, oracle, host, tmp_path, [files[0][:400000]], p=18)
+
+
+_FZ_FIRST = int(os.environ.get("DSH_FASTX_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("case", range(_FZ_FIRST, _FZ_FIRST + int(os.environ.get("DSH_FASTX_FUZZ_CASES", "40"))))
+def test_fastx_fuzz_accepted_means_equal_to_the_host_parser(ctx, oracle, host, tmp_path, case):
+    """Random FASTA and FASTQ texts, well-formed and damaged (lines dropped, doubled, cut, swapped; '+', '@', '>' put at line
+    starts; blank lines; CRLF): whatever the device ACCEPTS (status 0) must give the registers of the host parser's
+    sequence -- the device may refuse more than strictly necessary, it may never differ silently -- and what is well-formed
+    must be accepted."""
+    rng = np.random.default_rng(0xFA57 + case)
+    g = genomes(1, 60_000, 1000 + case, decorate=bool(case & 1))[0]
+    files, must_accept = [], []
+    for f in range(6):
+        eol = b"\r\n" if rng.random() < 0.2 else b"\n"
+        if rng.random() < 0.5:  # FASTA
+            nrec = int(rng.integers(1, 6))
+            cuts = sorted(set([0, len(g)] + [int(x) for x in rng.integers(0, len(g), nrec - 1)]))
+            recs = [(bytes(rng.integers(33, 126, int(rng.integers(0, 90)), dtype=np.uint8)), g[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+            data = fasta(rng, recs, int(rng.choice([0, 1, 7, 60, 63, 64, 65, 80, 200, 5000])), eol=eol, final_eol=bool(rng.random() < 0.7),
+                         blank_every=int(rng.choice([0, 0, 3, 11])))
+            ok = True
+        else:  # FASTQ
+            lens = [int(x) for x in rng.integers(1, int(rng.choice([50, 300, 3000])), int(rng.integers(1, 120)))]
+            at, rds = 0, []
+            for L in lens:
+                rds.append(g[at : at + L])
+                at = (at + L) % (len(g) - 3000)
+            data = fastq(rng, rds, eol=eol, final_eol=bool(rng.random() < 0.7))
+            ok = True
+        if rng.random() < 0.5:  # damage it
+            lines = data.split(eol)
+            for _ in range(int(rng.integers(1, 4))):
+                if len(lines) < 2:
+                    break
+                i = int(rng.integers(0, len(lines)))
+                kind = int(rng.integers(0, 7))
+                if kind == 0:
+                    del lines[i]
+                elif kind == 1:
+                    lines.insert(i, lines[i])
+                elif kind == 2:
+                    lines[i] = lines[i][: len(lines[i]) // 2]
+                elif kind == 3:
+                    lines.insert(i, b"")
+                elif kind == 4:
+                    lines[i] = bytes([int(rng.choice(list(b"+@>")))]) + lines[i]
+                elif kind == 5 and i + 1 < len(lines):
+                    lines[i], lines[i + 1] = lines[i + 1], lines[i]
+                else:
+                    lines[i] = lines[i] + bytes(rng.integers(33, 126, 5, dtype=np.uint8))
+            data = eol.join(lines)
+            ok = False
+        files.append(data)
+        must_accept.append(ok)
+    p, k = int(rng.choice([8, 10, 12])), int(rng.choice([5, 21, 31, 32]))
+    ctx.alloc(len(files), p)
+    status = ctx.sketch_fastx_batch(files, 0, k, True)
+    got = ctx.download(0, len(files))
+    for gi, f in enumerate(files):
+        if must_accept[gi]:
+            assert status[gi] == 0, "case %d genome %d: a well-formed file was refused" % (case, gi)
+        if status[gi]:
+            assert not got[gi].any(), "a refused genome must contribute nothing"
+            continue
+        s = host_parse(host, tmp_path, "z%d.fa" % gi, f)
+        seq, off = synth.concat_for_device([s])
+        want = oracle.sketch_batch(seq, off, k, p, True)[0]
+        assert (got[gi] == want).all(), "case %d genome %d: accepted, but %d registers differ from the host parser's" % (case, gi, int((got[gi] != want).sum()))

@@ -444,6 +444,8 @@ def test_dist_collect_with_the_librarys_own_partition(tmp_path):
     """dsh_dist_collect(bounds = NULL): balanced row sets + the pipelined exchange pair, for a host without device pointers"""
     run_mock_world(tmp_path, 4, 2200, 10, 1, "collect-auto")
     run_mock_world(tmp_path, 3, 1500, 12, 1, "collect-auto", dst=2)
+    run_mock_world(tmp_path, 2, 1, 10, 1, "collect-auto")  # one genome over two devices: an empty matrix, not an error (ADVICE r5)
+    run_mock_world(tmp_path, 3, 2, 10, 1, "collect-auto", dst=1)  # one pair, more ranks than rows
 
 
 @pytest.mark.gpu
