@@ -123,11 +123,15 @@ void dsh_destroy(dsh_ctx *c)
 
 int dsh_preload(int device, unsigned what)
 {
-    if (hipSetDevice(device) != hipSuccess) return DSH_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();  // (the runtime keeps the last error per thread: a later launch's check must not find this one)
+        return DSH_ENODEV;
+    }
     hipError_t e = hipSuccess;
     if ((what & DSH_PRELOAD_SKETCH) && e == hipSuccess) e = preload_sketch_kernels();
     if ((what & DSH_PRELOAD_SKETCH) && e == hipSuccess) e = preload_fastx_kernels();
     if ((what & DSH_PRELOAD_COMPARE) && e == hipSuccess) e = preload_compare_kernels();
+    if (e != hipSuccess) (void)hipGetLastError();
     return e == hipSuccess ? DSH_OK : DSH_EIO;
 }
 

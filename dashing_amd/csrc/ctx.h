@@ -206,9 +206,11 @@ inline int fail(dsh_ctx *c, int code, const char *fmt, ...)
 #define HIPCHK(c, expr)                                                                        \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* reported here: a later launch's check must not find it again */ \
             return dsh::fail((c), e_ == hipErrorOutOfMemory ? DSH_ENOMEM : DSH_EIO, "%s: %s",  \
                              #expr, hipGetErrorString(e_));                                    \
+        }                                                                                      \
     } while (0)
 
 inline int bind(dsh_ctx *c)
