@@ -1121,6 +1121,28 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, args, G=1000, L=5_000_000, p
         binding.update({"valu_insts_per_kmer": round(per_base, 2), "cycles_per_valu_inst": round(cpi, 3), "frac": round(ceil_nominal / cpi, 4),
                         "frac_of_isolated_rates": round(ceil_measured / cpi, 4)})
     traffic = hbm_bytes(pm)
+    # the parse on the device (dsh_sketch_fastx_batch_async): the first 40 genomes as FASTA text (80-column lines) from host
+    # memory -- decode kernels timed by HIP events, registers compared with the ones sketched from the bases in HBM
+    fastx = None
+    try:
+        ng = min(G, 40)
+        nl = torch.full((ng * (L // 80), 1), 10, dtype=torch.uint8, device=dev)
+        fa = torch.cat([seq[: ng * L].view(-1, 80), nl], dim=1).view(ng, L // 80 * 81).cpu().numpy()
+        files = [b">genome%d\n" % g_ + fa[g_].tobytes() for g_ in range(ng)]
+        del fa, nl
+        ctx.clear(0, ng)
+        ctx.set_profiling(True)
+        status = ctx.sketch_fastx_batch(files, 0, K, True)
+        dec_us, sk_us = ctx.info("fastx_decode_us"), ctx.info("sketch_kernel_us")
+        ctx.set_profiling(False)
+        fbytes = sum(len(f_) for f_ in files)
+        fastx = {"what": "dsh_sketch_fastx_batch_async on %d of the genomes as FASTA text (80-column lines, %d bytes of file): header lines -> one invalid byte, newlines removed, on the device (k_fastx_scan / _offsets / _compact / _pad), then k_sketch" % (ng, fbytes),
+                 "decode_ms": round(dec_us / 1e3, 4), "decode_file_GBs": round(fbytes / max(dec_us, 1) / 1e3, 1), "bytes_moved_per_file_byte": 3,
+                 "k_sketch_ms": round(sk_us / 1e3, 4), "refused": int((status != 0).sum()),
+                 "registers_equal_those_sketched_from_hbm": bool((ctx.download(0, ng) == regs[:ng]).all())}
+        del files
+    except Exception as e:  # noqa: BLE001
+        fastx = {"error": "%s: %s" % (type(e).__name__, e)}
     e2e = None
     if not args.no_secondary and not os.environ.get("DSH_BENCH_NO_CLI"):
         try:
@@ -1145,7 +1167,7 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, args, G=1000, L=5_000_000, p
                              "sample": "%d of the same genomes (%d bases) in %.2f s; oracle/dsh_oracle.c dsho_sketch_batch, one genome per thread as src/sketch_and_cmp.h:314-360" % (nc, nc * L, tc)},
             "parity": {"registers_bit_exact": exact, "genomes_checked": len(sample), "dist_pairs_checked": int(ref.size), "dist_max_rel_diff": float(rel.max()),
                        "tolerance": 1e-6, "note": PARITY_NOTE},
-            "end_to_end_cli": e2e}
+            "fastx_decode_on_device": fastx, "end_to_end_cli": e2e}
 
 
 def config_c4(ctx, torch, dev, dashing_amd, regs, pmc, args, n=100_000, p=10):

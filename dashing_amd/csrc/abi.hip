@@ -416,10 +416,24 @@ int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t 
     HIPCHK(c, c->fx_declen.ensure(gen.size() * sizeof(uint64_t)));
     HIPCHK(c, c->fx_status.ensure(gen.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(c->fx_status.ptr, 0, gen.size() * sizeof(uint32_t), c->stream));
+    hipEvent_t fe0 = nullptr, fe1 = nullptr;  // (profiling: the decode kernels alone, dsh_get_info "fastx_decode_us")
+    if (c->profiling) {
+        c->ev_used = 0;
+        fe0 = next_event(c);
+        fe1 = next_event(c);
+        if (fe0) (void)hipEventRecord(fe0, c->stream);
+    }
     HIPCHK(c, launch_fastx_decode(c->stream, (const uint8_t *)c->rawbuf.ptr, (const FastxChunk *)((const uint8_t *)c->fx_tab.ptr + gbytes),
                                   (uint32_t)chunks.size(), (const FastxGenome *)c->fx_tab.ptr, n_genomes, (FastxSumm *)c->fx_summ.ptr,
                                   (uint2 *)c->fx_state.ptr, (uint64_t *)c->fx_declen.ptr, (uint32_t *)c->fx_status.ptr,
                                   (uint8_t *)c->seqbuf.ptr));
+    if (fe0 && fe1) {
+        (void)hipEventRecord(fe1, c->stream);
+        (void)hipEventSynchronize(fe1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, fe0, fe1);
+        c->fastx_ms = ms;
+    }
     if (status_out)
         HIPCHK(c, hipMemcpyAsync(status_out, c->fx_status.ptr, gen.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     std::vector<uint64_t> off(n_genomes + 1);
@@ -872,6 +886,7 @@ int dsh_get_info(dsh_ctx *c, const char *name, int64_t *out)
     else if (!std::strcmp(name, "parts_done")) *out = c->parts_done;
     else if (!std::strcmp(name, "parts_signalled")) *out = c->parts_signalled ? 1 : 0;
     else if (!std::strcmp(name, "sketch_kernel_us")) *out = (int64_t)(c->sketch_ms * 1000.0);
+    else if (!std::strcmp(name, "fastx_decode_us")) *out = (int64_t)(c->fastx_ms * 1000.0);
     else if (!std::strcmp(name, "xch_recv_gated")) *out = c->xch_recv_gated ? 1 : 0;
     else if (!std::strcmp(name, "place_kernel_us")) *out = (int64_t)(c->place_ms * 1000.0);
     else if (!std::strcmp(name, "whatif_mfma")) {

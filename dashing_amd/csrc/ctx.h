@@ -182,7 +182,7 @@ struct dsh_ctx {
     // profiling
     bool profiling = false;
     double place_ms = 0;  // (profiling) device time of the last dsh_exchange_place_device's placement kernel
-    double pair_ms = 0, fin_ms = 0, prep_ms = 0, sketch_ms = 0;
+    double pair_ms = 0, fin_ms = 0, prep_ms = 0, sketch_ms = 0, fastx_ms = 0;
     uint32_t pair_launches = 0;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

@@ -445,7 +445,8 @@ int dsh_set_option(dsh_ctx *ctx, const char *name, int64_t value);
 /* Derived state of the last prepared sketch matrix: "planes" (dense bit-planes used), "vlo",
  * "vhi", "pbase", "threshold", "emax", "elow", "kc", "tile", "npad", "kpad", "cum_bytes", "sorted", "ncols", "lockstep", "tiles", "bands", "items" (work items of the tile kernel),
  * "words_per_plane", "avg_tile_planes_x100" (of the last dist call), "frag_items", "parts_done", "parts_signalled",
- * "place_kernel_us" (with profiling on: device time of the last dsh_exchange_place_device's placement kernel). */
+ * "place_kernel_us" (with profiling on: device time of the last dsh_exchange_place_device's placement kernel),
+ * "sketch_kernel_us" / "fastx_decode_us" (with profiling on: k_sketch / the FASTA-FASTQ decode kernels of the last sketch call). */
 int dsh_get_info(dsh_ctx *ctx, const char *name, int64_t *out);
 /* HIP stream of the ctx as a void* (hipStream_t) so a host framework can order its own work.
  * Every *_device entry point runs on THIS stream and (except the *_async forms) returns after its work has
