@@ -54,7 +54,7 @@ PARITY_NOTE = ("vs the CPU restatement (oracle/dsh_oracle.c); upstream arithmeti
 DEVICE_SOURCES = ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
                   "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
                   "dashing_amd/csrc/plan.h", "dashing_amd/csrc/plan.cpp", "dashing_amd/csrc/engine.hip", "dashing_amd/csrc/abi.hip",
-                  "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip")
+                  "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip", "dashing_amd/csrc/kernels_fastx.hip")
 
 
 def source_hash():

@@ -49,7 +49,7 @@ def source_hash():
     for rel in ("dashing_amd/csrc/kernels_compare.hip", "dashing_amd/csrc/kernels_sketch.hip",
                 "dashing_amd/csrc/estimators.h", "dashing_amd/csrc/kernels.h", "dashing_amd/csrc/consts.h", "dashing_amd/csrc/ctx.h",
                 "dashing_amd/csrc/plan.h", "dashing_amd/csrc/plan.cpp", "dashing_amd/csrc/engine.hip", "dashing_amd/csrc/abi.hip",
-                "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip"):
+                "dashing_amd/csrc/knn.hip", "dashing_amd/csrc/exchange.hip", "dashing_amd/csrc/kernels_fastx.hip"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
