@@ -412,10 +412,12 @@ int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t 
     HIPCHK(c, hipEventRecord(c->ev_fx, c->stream));
     c->fx_in_flight = true;
     HIPCHK(c, c->fx_summ.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(FastxSumm)));
-    HIPCHK(c, c->fx_state.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint2)));
+    HIPCHK(c, c->fx_state.ensure(std::max<size_t>(chunks.size(), 1) * sizeof(uint4)));
     HIPCHK(c, c->fx_declen.ensure(gen.size() * sizeof(uint64_t)));
-    HIPCHK(c, c->fx_status.ensure(gen.size() * sizeof(uint32_t)));
-    HIPCHK(c, hipMemsetAsync(c->fx_status.ptr, 0, gen.size() * sizeof(uint32_t), c->stream));
+    // [status words | length fingerprints]: one buffer, cleared by one memset
+    const size_t st_bytes = (gen.size() * sizeof(uint32_t) + 7) & ~(size_t)7;
+    HIPCHK(c, c->fx_status.ensure(st_bytes + gen.size() * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->fx_status.ptr, 0, st_bytes + gen.size() * sizeof(unsigned long long), c->stream));
     hipEvent_t fe0 = nullptr, fe1 = nullptr;  // (profiling: the decode kernels alone, dsh_get_info "fastx_decode_us")
     if (c->profiling) {
         c->ev_used = 0;
@@ -425,8 +427,8 @@ int dsh_sketch_fastx_batch_async(dsh_ctx *c, const uint8_t *raw, const uint64_t 
     }
     HIPCHK(c, launch_fastx_decode(c->stream, (const uint8_t *)c->rawbuf.ptr, (const FastxChunk *)((const uint8_t *)c->fx_tab.ptr + gbytes),
                                   (uint32_t)chunks.size(), (const FastxGenome *)c->fx_tab.ptr, n_genomes, (FastxSumm *)c->fx_summ.ptr,
-                                  (uint2 *)c->fx_state.ptr, (uint64_t *)c->fx_declen.ptr, (uint32_t *)c->fx_status.ptr,
-                                  (uint8_t *)c->seqbuf.ptr));
+                                  (uint4 *)c->fx_state.ptr, (uint64_t *)c->fx_declen.ptr, (uint32_t *)c->fx_status.ptr,
+                                  (unsigned long long *)((uint8_t *)c->fx_status.ptr + st_bytes), (uint8_t *)c->seqbuf.ptr));
     if (fe0 && fe1) {
         (void)hipEventRecord(fe1, c->stream);
         (void)hipEventSynchronize(fe1);

@@ -169,11 +169,11 @@ struct FastxSumm {  // what a chunk tells the per-genome scan (kernels_fastx.hip
     uint32_t fn, bad8;
     uint32_t a[4], b[4];
 };
-// summ [nchunks], state [nchunks] uint2, declen [ngenomes], status [ngenomes] (zeroed by the caller; != 0 afterwards: not
-// what its format promises, nothing emitted)
+// summ [nchunks], state [nchunks] uint4, declen [ngenomes], status and fingerprint [ngenomes] (both zeroed by the caller;
+// status != 0 afterwards: not what its format promises, nothing emitted)
 hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
-                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint2 *state, uint64_t *declen,
-                               uint32_t *status, uint8_t *out);
+                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint4 *state, uint64_t *declen,
+                               uint32_t *status, unsigned long long *fingerprint, uint8_t *out);
 
 // dsh_preload: load the code objects of the kernel translation units now (else: at the first launch from each)
 hipError_t preload_compare_kernels();

@@ -175,8 +175,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // pass A: every chunk's transfer function and what it emits under each possible carry.
 //   FASTA: a[s] = bytes emitted with carry s; the genome's status is raised here (its checks do not depend on the carry).
 //   FASTQ: relative to a carry of 0, a[j] = bytes (no newline, no '\r') on lines of index j, b[j] = newlines that end a line
-//   of index j, bad8 bit j / bit 4 + j = a line of index j is followed by a line that does not begin with '@' / '+'
-//   (k_fastx_offsets, which knows the carry, rotates them into place).
+//   of index j, bad8 bit j / bit 4 + j = a line of index j is followed by a line that does not begin with '@' / '+', bit 8 + j
+//   = ... by a line that begins with '@', '>' or '+' (k_fastx_offsets, which knows the carry, rotates them into place).
 __global__ __launch_bounds__(256) void k_fastx_scan(const uint8_t *__restrict__ raw, const FastxChunk *__restrict__ chunks,
                                                      const FastxGenome *__restrict__ genomes, FastxSumm *__restrict__ summ,
                                                      uint32_t *__restrict__ status)
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void k_fastx_scan(const uint8_t *__restrict__ 
         // the first byte of the line behind a newline: the next bit, or the byte behind the lane; nothing behind the genome's end
         const uint64_t nx_exists = (m.valid >> 1) | ((uint64_t)has_next << 63);
         const uint64_t nx_at = (m.at >> 1) | ((uint64_t)(nb == '@') << 63), nx_pl = (m.pl >> 1) | ((uint64_t)(nb == '+') << 63);
+        const uint64_t nx_mark = (m.hc >> 1) | nx_pl | ((uint64_t)(nb == '@' || nb == '>') << 63);  // '@' '>' '+': what the host parser reads as structure
         uint32_t bad8 = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void k_fastx_scan(const uint8_t *__restrict__ 
             const uint64_t ends = m.nl_real & q[j] & nx_exists;
             if (ends & ~nx_at) bad8 |= 1u << j;
             if (ends & ~nx_pl) bad8 |= 16u << j;
+            if (ends & nx_mark) bad8 |= 256u << j;
         }
         if (bad8) atomicOr(&acc[8], bad8);
     }
@@ -248,31 +250,30 @@ __global__ __launch_bounds__(256) void k_fastx_scan(const uint8_t *__restrict__ 
 }
 
 namespace {
-// a chunk's emitted bytes under the concrete carry c (FASTQ also: its sequence / quality bytes and whether it breaks the
-// four-line pattern)
-__device__ __forceinline__ uint32_t chunk_emits(const FastxSumm &s, uint32_t fmt, uint32_t c, uint64_t &seq, uint64_t &qual, bool &bad)
+// a chunk's emitted bytes under the concrete carry c (FASTQ also: whether it breaks the four-line pattern)
+__device__ __forceinline__ uint32_t chunk_emits(const FastxSumm &s, uint32_t fmt, uint32_t c, bool &bad)
 {
     if (fmt == 0) return s.a[c < 3 ? c : 2];
-    // a line of raw index r has the index (r + c) & 3: sequence lines r = 1 - c, quality 3 - c, header newlines 0 - c; the line
-    // behind one of index 3 must begin with '@', the one behind index 1 with '+'
-    seq += s.a[(1u - c) & 3u];
-    qual += s.a[(3u - c) & 3u];
-    bad = bad || ((s.bad8 >> ((3u - c) & 3u)) & 1u) || ((s.bad8 >> (4u + ((1u - c) & 3u))) & 1u);
+    // a line of raw index r has the index (r + c) & 3: sequence lines r = 1 - c, header newlines 0 - c; the line behind one of
+    // index 3 must begin with '@', the one behind index 1 with '+', and the one behind index 0 -- the sequence line -- with
+    // none of '@' '>' '+' (the host parser, like kseq, would read those as structure: a header, the separator)
+    bad = bad || ((s.bad8 >> ((3u - c) & 3u)) & 1u) || ((s.bad8 >> (4u + ((1u - c) & 3u))) & 1u) || ((s.bad8 >> (8u + ((0u - c) & 3u))) & 1u);
     return s.a[(1u - c) & 3u] + s.b[(0u - c) & 3u];
 }
 }  // namespace
 
 // pass B: one workgroup per genome -- every chunk's carry and where its output starts; the decoded length; the verdict
 __global__ __launch_bounds__(256) void k_fastx_offsets(const FastxGenome *__restrict__ genomes, const FastxSumm *__restrict__ summ,
-                                                        uint32_t *__restrict__ status, uint2 *__restrict__ state,
+                                                        uint32_t *__restrict__ status, uint4 *__restrict__ state,
                                                         uint64_t *__restrict__ declen)
 {
     __shared__ uint8_t sf[256];
-    __shared__ uint64_t sn[256], sq[2];
+    __shared__ uint64_t sn[256];
+    __shared__ uint32_t sl[256];
     __shared__ uint32_t sbad;
     const FastxGenome g = genomes[blockIdx.x];
     const int t = threadIdx.x;
-    if (t == 0) sq[0] = sq[1] = 0, sbad = status[blockIdx.x];
+    if (t == 0) sbad = status[blockIdx.x];
     const uint32_t per = (g.nchunks + 255) / 256;
     const uint32_t c0 = (uint32_t)t * per, c1 = c0 + per < g.nchunks ? c0 + per : g.nchunks;
     // 1. the carry in front of every lane's run of chunks: prefix composition of the chunks' functions
@@ -290,42 +291,43 @@ __global__ __launch_bounds__(256) void k_fastx_offsets(const FastxGenome *__rest
     const uint32_t start = g.fmt == 0 ? FX_FRESH : 0u;  // a genome begins with a fresh line / with line 0
     const uint32_t carry0 = t ? fn_apply(sf[t - 1], start) : start;
     // 2. with the carries known: what every chunk emits; prefix sum over the lanes' runs
-    uint64_t mine = 0, seq = 0, qual = 0;
+    uint64_t mine = 0;
+    uint32_t lines = 0;  // newlines of this lane's chunks (FASTQ: the line number of a byte = the newlines in front of it)
     bool bad = false;
     uint32_t carry = carry0;
     for (uint32_t c = c0; c < c1; ++c) {
         const FastxSumm s = summ[g.chunk0 + c];
-        mine += chunk_emits(s, g.fmt, carry, seq, qual, bad);
+        mine += chunk_emits(s, g.fmt, carry, bad);
+        lines += s.b[0] + s.b[1] + s.b[2] + s.b[3];
         carry = fn_apply(s.fn, carry);
     }
     sn[t] = mine;
+    sl[t] = lines;
     if (bad) atomicOr(&sbad, 1u);
-    if (seq) atomicAdd((unsigned long long *)&sq[0], (unsigned long long)seq);
-    if (qual) atomicAdd((unsigned long long *)&sq[1], (unsigned long long)qual);
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
         uint64_t v = sn[t];
-        if (t >= d) v += sn[t - d];
+        uint32_t w = sl[t];
+        if (t >= d) v += sn[t - d], w += sl[t - d];
         __syncthreads();
         sn[t] = v;
+        sl[t] = w;
         __syncthreads();
     }
-    // FASTQ: the quality lines must hold as many bytes as the sequence lines (a short or missing quality line would make
-    // the host parser swallow the following lines: refused here, parsed there)
-    const bool refused = sbad != 0 || (g.fmt != 0 && sq[0] != sq[1]);
-    if (refused) {  // the host will parse this one: nothing is emitted
-        for (uint32_t c = t; c < g.nchunks; c += 256) state[g.chunk0 + c] = make_uint2(0xFFFFFFFFu, 0xFFu);
+    if (sbad != 0) {  // the host will parse this one: nothing is emitted
+        for (uint32_t c = t; c < g.nchunks; c += 256) state[g.chunk0 + c] = make_uint4(0xFFFFFFFFu, 0xFFu, 0u, 0u);
         if (t == 0) declen[blockIdx.x] = 0, status[blockIdx.x] = 1u;
         return;
     }
     uint64_t off = t ? sn[t - 1] : 0;
+    lines = t ? sl[t - 1] : 0;
     carry = carry0;
     for (uint32_t c = c0; c < c1; ++c) {
         const FastxSumm s = summ[g.chunk0 + c];
-        state[g.chunk0 + c] = make_uint2((uint32_t)off, carry | ((uint32_t)(off >> 32) << 8));
-        uint64_t d0 = 0, d1 = 0;
+        state[g.chunk0 + c] = make_uint4((uint32_t)off, carry | ((uint32_t)(off >> 32) << 8), lines, 0u);
         bool db = false;
-        off += chunk_emits(s, g.fmt, carry, d0, d1, db);
+        off += chunk_emits(s, g.fmt, carry, db);
+        lines += s.b[0] + s.b[1] + s.b[2] + s.b[3];
         carry = fn_apply(s.fn, carry);
     }
     if (t == 255) declen[blockIdx.x] = sn[255];
@@ -333,13 +335,13 @@ __global__ __launch_bounds__(256) void k_fastx_offsets(const FastxGenome *__rest
 
 // pass C: the chunk's emitted bytes, compacted through LDS, to out + (genome offset + the chunk's offset)
 __global__ __launch_bounds__(256) void k_fastx_compact(const uint8_t *__restrict__ raw, const FastxChunk *__restrict__ chunks,
-                                                        const FastxGenome *__restrict__ genomes, const uint2 *__restrict__ state,
-                                                        uint8_t *__restrict__ out)
+                                                        const FastxGenome *__restrict__ genomes, const uint4 *__restrict__ state,
+                                                        uint8_t *__restrict__ out, unsigned long long *__restrict__ fingerprint)
 {
     __shared__ uint8_t sh[256];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[4], lsum[4];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kFastxChunk + 32];
-    const uint2 st = state[blockIdx.x];
+    const uint4 st = state[blockIdx.x];
     if ((st.y & 0xFFu) == 0xFFu) return;  // (a refused genome)
     const FastxChunk ck = chunks[blockIdx.x];
     const FastxGenome g = genomes[ck.genome];
@@ -356,6 +358,49 @@ __global__ __launch_bounds__(256) void k_fastx_compact(const uint8_t *__restrict
     } else {
         const uint32_t ex = wg_scan_fn(fn_add((uint32_t)__popcll(m.nl_real)), sh, total_fn);
         keep = lane_out_fastq(m, fn_apply(ex, st.y & 3u), hs);
+        // The host parser ends a record's quality when it holds as many bytes as the sequence ('\r' not counted): a
+        // quality line of ANOTHER length would shift its reading of every later line.  Per record that is a comparison of two
+        // line lengths that may lie chunks apart; as ONE number per genome: F = sum over records r of H(r) x (sequence bytes -
+        // quality bytes) with H a 64-bit mix of the record's number, in wrapping arithmetic -- linear in the bytes, so every
+        // lane adds its own pieces of lines (line number = the newlines in front, known here) -- and F = 0 when every record
+        // matches; a file in which one does not passes with probability 2^-64.  Summed into fingerprint[genome]; k_fastx_pad
+        // refuses the genome AFTER the emission (and blanks it) if the sum is not zero.
+        uint32_t lcnt = (uint32_t)__popcll(m.nl_real), linc = lcnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(linc, o);
+            if ((t & 63) >= o) linc += v;
+        }
+        if ((t & 63) == 63) lsum[t >> 6] = linc;
+        __syncthreads();
+        uint32_t line = st.z + linc - lcnt;  // the number of the line this lane's first byte lies on
+        for (int w = 0; w < (t >> 6); ++w) line += lsum[w];
+        const uint64_t body = ~m.nl_real & ~m.cr & m.valid;
+        uint64_t nlb = m.nl_real, below = 0, F = 0;  // `below`: the bits in front of the current piece
+        for (;;) {
+            const uint64_t upto = nlb ? ((nlb & (0 - nlb)) - 1) : ~0ull;  // bits in front of the next newline (all: none left)
+            const uint32_t len = (uint32_t)__popcll(body & upto & ~below);
+            if (len && (line & 1u)) {  // a sequence line adds, a quality line takes away
+                uint64_t h = (uint64_t)(line >> 2) + 0x9E3779B97F4A7C15ull;
+                h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+                h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+                h = (h ^ (h >> 31)) | 1ull;
+                F += (line & 2u) ? (0 - h * len) : h * len;
+            }
+            if (!nlb) break;
+            below = upto | (upto + 1);  // ... and the newline itself
+            nlb &= nlb - 1;
+            ++line;
+        }
+        uint32_t flo = (uint32_t)F, fhi = (uint32_t)(F >> 32);
+        // (wrapping 64-bit sum over the wave: carries between the halves matter, so add whole words lane by lane)
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const uint64_t other = ((uint64_t)__shfl_xor(fhi, o) << 32) | __shfl_xor(flo, o);
+            F += other;
+            flo = (uint32_t)F, fhi = (uint32_t)(F >> 32);
+        }
+        if ((t & 63) == 0 && F) atomicAdd(&fingerprint[ck.genome], (unsigned long long)F);
     }
     const uint32_t mine = (uint32_t)__popcll(keep);
     // exclusive prefix sum of the lanes' byte counts: inside the wave by shuffles, across the four waves through LDS
@@ -400,11 +445,15 @@ __global__ __launch_bounds__(256) void k_fastx_compact(const uint8_t *__restrict
 }
 
 // what the decoded genome leaves of its region: 'N' (no k-mer starts there)
+// (FASTQ: a genome whose length fingerprint is not zero is refused here, after its emission, and blanked altogether)
 __global__ __launch_bounds__(256) void k_fastx_pad(const FastxGenome *__restrict__ genomes, const uint64_t *__restrict__ declen,
+                                                    const unsigned long long *__restrict__ fingerprint, uint32_t *__restrict__ status,
                                                     uint8_t *__restrict__ out)
 {
     const FastxGenome g = genomes[blockIdx.x];
-    const uint64_t b = g.off + declen[blockIdx.x], e = g.region_end;
+    const bool late = g.fmt != 0 && fingerprint[blockIdx.x] != 0;
+    if (late && blockIdx.y == 0 && threadIdx.x == 0) status[blockIdx.x] = 1u;
+    const uint64_t b = g.off + (late ? 0 : declen[blockIdx.x]), e = g.region_end;
     const uint64_t tid = (uint64_t)blockIdx.y * 256 + threadIdx.x, nthr = (uint64_t)gridDim.y * 256;
     const uint64_t b16 = (b + 15) & ~15ull, e16 = e & ~15ull;
     if (b16 >= e16) {
@@ -424,8 +473,8 @@ hipError_t preload_fastx_kernels()
 }
 
 hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxChunk *chunks, uint32_t nchunks,
-                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint2 *state, uint64_t *declen,
-                               uint32_t *status, uint8_t *out)
+                               const FastxGenome *genomes, uint32_t ngenomes, FastxSumm *summ, uint4 *state, uint64_t *declen,
+                               uint32_t *status, unsigned long long *fingerprint, uint8_t *out)
 {
     if (ngenomes == 0) return hipSuccess;
     if (nchunks) {
@@ -433,9 +482,9 @@ hipError_t launch_fastx_decode(hipStream_t st, const uint8_t *raw, const FastxCh
     }
     hipLaunchKernelGGL(k_fastx_offsets, dim3(ngenomes), dim3(256), 0, st, genomes, summ, status, state, declen);
     if (nchunks) {
-        hipLaunchKernelGGL(k_fastx_compact, dim3(nchunks), dim3(256), 0, st, raw, chunks, genomes, state, out);
+        hipLaunchKernelGGL(k_fastx_compact, dim3(nchunks), dim3(256), 0, st, raw, chunks, genomes, state, out, fingerprint);
     }
-    hipLaunchKernelGGL(k_fastx_pad, dim3(ngenomes, 16), dim3(256), 0, st, genomes, declen, out);
+    hipLaunchKernelGGL(k_fastx_pad, dim3(ngenomes, 16), dim3(256), 0, st, genomes, declen, fingerprint, status, out);
     return hipGetLastError();
 }
 

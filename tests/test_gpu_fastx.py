@@ -189,6 +189,14 @@ def test_fastq_that_is_not_four_line_is_refused(ctx, oracle, host, tmp_path):
     cut_off = fastq(rng, rd[:10]) + b"@x\n" + rd[10] + b"\n+\n"
     files = [good, two_line_seq, two_line_qual, short_qual, long_qual, blank_between, cut_off, good]
     check(ctx, oracle, host, tmp_path, files, expect_status=[0, 1, 1, 1, 1, 1, 1, 0])
+    # found by the fuzz soak of round 6 (case 1685): a SEQUENCE line that begins with '@', '>' or '+' -- kseq and the host
+    # parser read those as a header / the separator, a count of lines does not -- and quality lines whose lengths are wrong
+    # in ways that cancel in total (one 3 short, another 3 long): per record, not in sum
+    marked = [fastq(rng, rd[:7]) + b"@x\n" + c + rd[7] + b"\n+\n" + b"I" * 201 + b"\n" + fastq(rng, rd[8:]) for c in (b"@", b">", b"+")]
+    cancel = (fastq(rng, rd[:5]) + b"@s\n" + rd[5] + b"\n+\n" + b"I" * 197 + b"\n" + fastq(rng, rd[6:30]) +
+              b"@l\n" + rd[30] + b"\n+\n" + b"I" * 203 + b"\n" + fastq(rng, rd[31:]))
+    far = fastq(rng, [g[:20000]] + rd[:3]) + b"@s\n" + g[:40000] + b"\n+\n" + b"I" * 39999 + b"\n" + fastq(rng, rd[3:])  # (lines chunks apart)
+    check(ctx, oracle, host, tmp_path, marked + [cancel, far, good], expect_status=[1, 1, 1, 1, 1, 0])
 
 
 def test_many_genomes_random_shapes(ctx, oracle, host, tmp_path):
