@@ -20,8 +20,9 @@
 // the line index modulo 4, i.e. the newlines so far: additive -- and per-lane bit planes of that count; sequence lines
 // are kept, a header's newline becomes the record's invalid byte.
 // What does not keep its format's promise -- a first byte that is neither '>' nor '@', a FASTA line that begins with '+',
-// FASTQ lines 4r that are not '@' headers or 4r + 2 that are not '+' lines, quality bytes that do not number the
-// sequence bytes (multi-line or cut-off records: kseq's record state decides those) -- raises the genome's status word:
+// FASTQ lines 4r that are not '@' headers or 4r + 2 that are not '+' lines, a sequence line that begins with '@' '>' '+',
+// a record whose quality line is not as long as its sequence line (multi-line or cut-off records: kseq's record state
+// decides those) -- raises the genome's status word:
 // nothing of it is emitted (its region becomes all 'N': no k-mer) and the host parses that file itself.  HBM-bound
 // byte work: no MFMA.
 #include <hip/hip_runtime.h>

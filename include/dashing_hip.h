@@ -124,8 +124,10 @@ int dsh_sketch_batch_device(dsh_ctx *ctx, const void *d_seq, const uint64_t *gen
  * by the sketch kernel as above).  A genome that begins with '@' is FASTQ in four-line records: of every four lines the
  * second is sequence.  What does not keep its format's promise is REFUSED per genome, never guessed at -- a first byte
  * that is neither, a FASTA line that begins with '+', a FASTQ file whose lines 4r are not '@' headers or 4r + 2 not '+'
- * lines or whose quality bytes do not number its sequence bytes (multi-line records, cut-off files: the record state of
- * kseq decides those) -- : status_out[g] != 0, NOTHING goes into its slot, and the host parses that genome itself
+ * lines, in which a sequence line begins with '@', '>' or '+', or in which some record's quality line is not exactly as
+ * long as its sequence line (multi-line records, cut-off files: the record state of kseq decides those; the length rule
+ * is checked as a 64-bit fingerprint over all records) -- : status_out[g] != 0, NOTHING goes into its slot, and the host
+ * parses that genome itself
  * (dsh_sketch_batch).  status_out: n_genomes words of page-locked host memory (or NULL), valid after dsh_wait.  `raw` must
  * stay untouched until then.  Compressed inputs and pipes are the host's business (inflate, then either entry point). */
 int dsh_sketch_fastx_batch_async(dsh_ctx *ctx, const uint8_t *raw_pinned, const uint64_t *genome_off,
