@@ -275,6 +275,11 @@ def test_fastx_fuzz_accepted_means_equal_to_the_host_parser(ctx, oracle, host, t
                 else:
                     lines[i] = lines[i] + bytes(rng.integers(33, 126, 5, dtype=np.uint8))
             data = eol.join(lines)
+            if rng.random() < 0.5 and len(data) > 4:  # single bytes overwritten: structure characters, NUL, high bytes, lone '\r' / '\n'
+                buf = bytearray(data)
+                for _ in range(int(rng.integers(1, 6))):
+                    buf[int(rng.integers(1, len(buf)))] = int(rng.choice(list(b"\n\r>@+\x00\xff NacgtACGT")))
+                data = bytes(buf)
             ok = False
         files.append(data)
         must_accept.append(ok)
