@@ -294,7 +294,7 @@ struct CtxFuture {
 // Hot loop 1 (src/sketch_and_cmp.h:314-360, 484-528) as a stream: genomes are taken in batches of <= ~48 MB of
 // file bytes; a batch is staged by the host threads STRAIGHT INTO page-locked memory (every genome has its region
 // reserved from the file sizes) -- the raw bytes of plain FASTA files, which the device decodes
-// (dsh_sketch_fastx_batch_async), or the sequence the host parser extracts (compressed inputs, pipes, FASTQ; what is
+// (dsh_sketch_fastx_batch_async), or the sequence the host parser extracts (compressed inputs, pipes, multi-line FASTQ; what is
 // left of the region filled with 'N') -- and enqueued at once; the staging buffers take turns (see kStageBufs).  Cache
 // hits (-W / sketch -c) read the .hll instead; .hll files of a batch are written when its buffer's turn comes again.
 static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool skip_cached, bool load_cached = false)
@@ -333,7 +333,7 @@ static void fill_sketches(CtxFuture &cf, const Opts &o, bool write_files, bool s
         dsh_ctx *ctx = cf.get();
         DSH(ctx, dsh_event_wait(ctx, f.ticket));
         for (size_t t = 0; t < f.slots.size(); ++t)
-            if (f.raw[t] && status[x][t]) sketch_on_host(ctx, f.slots[t]);  // not plain FASTA after all (a '+' line: FASTQ-like)
+            if (f.raw[t] && status[x][t]) sketch_on_host(ctx, f.slots[t]);  // not what its first byte promised (a '+' line in FASTA, multi-line FASTQ ...)
         if (write_files && !f.slots.empty()) {
             std::vector<uint8_t> rows(f.slots.size() * m);
             size_t r0 = 0;
