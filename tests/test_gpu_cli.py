@@ -452,3 +452,23 @@ def test_device_parse_many_tiny_genomes_and_one_larger_than_a_batch(tmp_path):
     assert outs["device"] == outs["host"]
     n = len(inputs)
     assert len(outs["device"][0]) == 9 + 4 * (n * (n - 1) // 2)
+
+
+def test_full_teardown_and_timing_marks_change_nothing(genomes, tmp_path):
+    """the CLI leaves with _Exit once its outputs are closed; DSH_FULL_TEARDOWN=1 runs the destructors instead (leak checkers,
+    profilers that write at exit), DSH_TIMING / DSH_T0 print phase marks on stderr: same bytes either way, text output through
+    a pipe included (stdio is flushed before leaving)"""
+    import time
+
+    d, paths, seqs = genomes
+    outs = []
+    for env in ({}, {"DSH_FULL_TEARDOWN": "1"}, {"DSH_TIMING": "1", "DSH_T0": repr(time.time())}):
+        o = tmp_path / ("m%d.bin" % len(outs))
+        r = subprocess.run([CLI, "dist", "-b", "--avoid-sorting", "-O", str(o), *paths[:5]], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        r2 = subprocess.run([CLI, "dist", "--avoid-sorting", *paths[:5]], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r2.returncode == 0 and r2.stdout.count(b"\n") >= 6 + 5, r2.stderr.decode()  # sizes (header + 5) and the matrix (header + 5 rows) on stdout
+        outs.append((o.read_bytes(), r.stdout, r2.stdout))
+        if "DSH_TIMING" in env:
+            assert b"[timing] main() entered" in r.stderr and b"leaving" in r.stderr
+    assert outs[0] == outs[1] == outs[2]
