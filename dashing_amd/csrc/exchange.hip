@@ -874,12 +874,45 @@ int dsh_exchange_probe_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *rowse
         return fail(c, DSH_ESTATE, "dsh_exchange_rows_device_async of this rank's rows must come first (%u parts computed, %zu expected)",
                     c->parts_done, mine.nparts());
     // where the parts end in the rank's buffer (the destination computes relative to its first row, as one part)
-    uint64_t at = 0;
+    std::vector<uint64_t> part_end;
     for (size_t i = 0; i < mine.nparts(); ++i) {
         uint64_t end;
         if (rank == dst) end = dsh_tri_span(n, mine.rb, mine.extra.empty() ? mine.re : mine.extra.back());
         else if (mine.rowsorted) end = c->lay.rowoff_w[mine.cut[i + 1]];
         else end = dsh_tri_span(n, mine.rb, mine.cut[i + 1]);
+        part_end.push_back(std::max(end, part_end.empty() ? 0 : part_end.back()));
+    }
+    if (c->comm && c->comm_world == 1) {
+        // The reader is librccl itself: the rank's step as dsh_exchange_collect_async runs it for a source -- M = nparts
+        // rounds, message q of the buffer behind the gate of the part that holds its last value, one grouped call per round
+        // -- with the one peer a communicator of one rank has: ncclSend to itself paired with the ncclRecv into d_probe.
+        Rccl *rc_ = rccl();
+        const uint64_t total = part_end.empty() ? 0 : part_end.back();
+        const size_t M = nparts;
+        size_t next_wait = 0;
+        for (size_t q = 0; q < M && total; ++q) {
+            uint64_t first, cnt;
+            message_span(total, q, M, first, cnt);
+            if (!cnt) continue;
+            const size_t i = std::min((size_t)(std::lower_bound(part_end.begin(), part_end.end(), first + cnt) - part_end.begin()), mine.nparts() - 1);
+            for (; next_wait <= i; ++next_wait)
+                if ((rc = wait_part(c, next_wait))) return rc;
+            NCCLCHK(c, rc_->GroupStart());
+            ncclResult_t e = rc_->Send((const float *)d_local + first, cnt, ncclFloat32, 0, c->comm, c->copy_stream);
+            if (e == ncclSuccess) e = rc_->Recv((float *)d_probe + first, cnt, ncclFloat32, 0, c->comm, c->copy_stream);
+            if (e != ncclSuccess) {
+                (void)rc_->GroupEnd();
+                return fail(c, DSH_EIO, "ncclSend/ncclRecv to this rank itself: %s", rc_->GetErrorString(e));
+            }
+            NCCLCHK(c, rc_->GroupEnd());
+        }
+        for (; next_wait < mine.nparts(); ++next_wait)  // (every gate is joined, as in the kernel-reader path)
+            if ((rc = wait_part(c, next_wait))) return rc;
+        return DSH_OK;
+    }
+    uint64_t at = 0;
+    for (size_t i = 0; i < mine.nparts(); ++i) {
+        const uint64_t end = part_end[i];
         if ((rc = wait_part(c, i))) return rc;
         if (end > at) {
             const uint64_t cnt = end - at;
@@ -887,7 +920,7 @@ int dsh_exchange_probe_parts_async(dsh_ctx *c, uint64_t n, const uint64_t *rowse
             hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(256), 0, c->copy_stream, (const float *)d_local + at, (float *)d_probe + at, cnt);
             HIPCHK(c, hipGetLastError());
         }
-        at = std::max(at, end);
+        at = end;
     }
     return DSH_OK;
 }

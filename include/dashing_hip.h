@@ -345,13 +345,17 @@ int dsh_exchange_collect_async(dsh_ctx *ctx, uint64_t n, const uint64_t *rowsets
                                void *d_final, int dst);
 int dsh_exchange_place_device(dsh_ctx *ctx, const uint64_t *rowsets, int src, uint32_t nparts, int dst,
                               const void *d_src_local, void *d_final);
-/* Diagnostics of the exchange on ONE GPU (tests/test_gpu_multirank.py, tools/interference_probe.py; no communicator):
+/* Diagnostics of the exchange on ONE GPU (tests/test_gpu_multirank.py, tools/interference_probe.py):
  *   dsh_exchange_probe_parts_async  after dsh_exchange_rows_device_async with the same (table, rank, nparts, dst): enqueues
  *                        on the copy stream, for every part of the rank's call, the part's gate (the flag k_finalize
  *                        sets / the event) and behind it a copy KERNEL of the part's share of d_local into d_probe at the
  *                        same offsets -- plain loads through the L2s while k_finalize is still running, exactly what an
  *                        RCCL send kernel does with the part (the copy engine of a hipMemcpy reads memory instead).
  *                        dsh_wait / dsh_comm_wait completes it.  d_probe: as many floats as d_local.
+ *                        On a context that holds a communicator of ONE rank (dsh_comm_init(.., 0, 1)) the reader is
+ *                        librccl itself: the rank's buffer travels as dsh_exchange_collect_async would send it -- nparts
+ *                        messages, each behind the gate of the part that holds its last value, one grouped call per
+ *                        message -- by ncclSend to the rank itself paired with the ncclRecv into d_probe.
  *   dsh_diag_spin_start  occupies `nblocks` workgroups of `threads` lanes and `lds_bytes` of LDS each with a kernel that
  *                        polls a word of host memory -- what an RCCL receive kernel does while its peers have nothing to
  *                        send -- on a stream of its own, until dsh_diag_spin_stop or max_ms (<= 10 000) have passed:

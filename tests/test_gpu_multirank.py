@@ -585,6 +585,58 @@ def test_signalled_parts_are_visible_to_a_kernel_reader_with_inputs_changing_eve
                 assert torch.equal(local, want[which])
 
 
+@pytest.mark.parametrize("signal", [1, 0])
+def test_signalled_parts_travel_through_librccl_itself_on_a_communicator_of_one_rank(signal):
+    """The same property with librccl as the reader (the real library, not the stand-in): on a communicator of ONE rank
+    dsh_exchange_probe_parts_async runs the rank's step of the exchange the way dsh_exchange_collect_async does for a
+    source -- nparts messages, each behind the gate of the part that holds its last value, one grouped call per message --
+    with the only peer such a communicator has: ncclSend to itself, paired with the ncclRecv into the side buffer.  What
+    RCCL has never done here with more than one rank it does with one: take grouped send/recv calls on the library's copy
+    stream behind hipStreamWaitValue32 gates while k_finalize is still running, and deliver what the step computed --
+    register matrix changing every step, virtual ranks of an 8-rank plan, both completion schemes."""
+    import torch
+
+    import dashing_amd
+    from dashing_amd import synth
+
+    if os.environ.get("DSH_RCCL_LIB"):
+        pytest.skip("DSH_RCCL_LIB names a stand-in: this test is about librccl")
+    n, p, world, nparts, dst = 5200, 12, 8, 8, 0
+    mats = [torch.from_numpy(synth.survey_sketches(n, p, seed=s)[0]).cuda() for s in (41, 42)]
+    with dashing_amd.Context(0) as ctx:
+        ctx.set_option("finalize_signal", signal)
+        ctx.comm_init(dashing_amd.comm_unique_id(), 0, 1)
+        try:
+            path, version = dashing_amd.comm_library()
+            assert "rccl" in os.path.basename(path) and "mock" not in path and version > 0, (path, version)
+            rows = dashing_amd.balance_rowsets(n, world, -1, dst)
+            for rank in (1, 5, 7, dst):
+                rs, k, floats = dashing_amd.exchange_mode(n, rows, rank, nparts, dst, want_floats=True)
+                local = torch.empty(floats, dtype=torch.float32, device="cuda")
+                probe = torch.empty(floats, dtype=torch.float32, device="cuda")
+                want = []
+                for m in mats:
+                    ctx.attach_device(m.data_ptr(), n, p)
+                    ctx.exchange_rows_device_async(local.data_ptr(), rows, rank, nparts, dst)
+                    ctx.synchronize()
+                    want.append(local.clone())
+                assert not torch.equal(want[0], want[1])
+                for step in range(12):
+                    which = step & 1
+                    probe.fill_(-5.0)
+                    torch.cuda.synchronize()
+                    ctx.attach_device(mats[which].data_ptr(), n, p)
+                    ctx.exchange_rows_device_async(local.data_ptr(), rows, rank, nparts, dst)
+                    ctx.exchange_probe_parts_async(n, rows, rank, nparts, local.data_ptr(), probe.data_ptr(), dst)
+                    ctx.comm_wait()
+                    bad = int((probe != want[which]).sum().item())
+                    assert bad == 0, "rank %d step %d (finalize_signal=%d): %d of %d values that librccl delivered differ from the step's result (stale: %d)" % (
+                        rank, step, signal, bad, floats, int(((probe != want[which]) & (probe == want[1 - which])).sum().item()))
+                    assert torch.equal(local, want[which])
+        finally:
+            ctx.comm_destroy()
+
+
 def test_diag_spin_leaves_by_itself_and_results_do_not_change(ctx):
     """dsh_diag_spin_start: workgroups that wait like an RCCL receive kernel beside the library's kernels -- they leave on
     dsh_diag_spin_stop or when max_ms have passed (a host that never comes back cannot hang the GPU), a second start
