@@ -2,7 +2,9 @@
 LDS) cost the phase-locked tile kernel beside it?  The destination of an exchange posts its receives either at once or
 behind its first tile kernel (option xch_recv_gate); the choice was reasoned, not measured.  Here the destination's job of
 BASELINE configs[2] over 8 ranks (and the single-GPU job) is timed with HIP events alone and beside `nblocks` waiting
-workgroups of `threads` lanes and `lds` bytes (dsh_diag_spin_start), several shapes.  One JSON line per case; the ratio
+workgroups of `threads` lanes and `lds` bytes (dsh_diag_spin_start), several shapes (SHAPES=13x256x19968: the shape
+librccl 2.26.6 launches for a point-to-point message to the rank itself, profiles/rd6u/rccl_kernel_shape.csv; 7 peers
+with such a kernel each would be 91 workgroups).  One JSON line per case; the ratio
 feeds dashing_amd.multigpu.pipeline_model(dst_interference=...)."""
 import json
 import os
@@ -23,6 +25,8 @@ def main():
     regs = torch.from_numpy(synth.survey_sketches(n, p, seed=0x5EED0000)[0]).cuda()
     rows = dashing_amd.balance_rowsets(n, world, -1, 0)
     shapes = [(0, 0, 0)] + [(nb, th, lds) for nb in (7, 14, 28, 56) for th, lds in ((256, 4096), (256, 32768), (512, 65536))] + [(0, 0, 0)]
+    if os.environ.get("SHAPES"):  # e.g. SHAPES=13x256x19968+91x256x19968 (workgroups x lanes x LDS bytes; '+' between shapes)
+        shapes = [(0, 0, 0)] + [tuple(int(x) for x in sh.split("x")) for sh in os.environ["SHAPES"].replace(",", "+").split("+")] + [(0, 0, 0)]
     with dashing_amd.Context(0) as ctx:
         for job in ("dst_of_%d" % world, "single_gpu"):
             floats = dashing_amd.exchange_mode(n, rows, 0, 8, 0, want_floats=True)[2] if job != "single_gpu" else n * (n - 1) // 2
