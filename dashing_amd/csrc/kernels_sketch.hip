@@ -123,6 +123,13 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
 // and a compare-and-swap loop on the containing word: a wave walked that 13-instruction path whenever ONE of its 64
 // lanes raised a register (~5 of 57 VALU per k-mer at p = 10, profiles/rd5g/sketch_instr.json).  4 KiB of LDS at p = 10,
 // 64 KiB at p = 14; above that the packed bytes keep more than one workgroup per CU.
+// The word holds value - 1 = clz(t), signed, -1 = untouched (the merge adds the 1): clz(t) is the clz of t's HIGH word
+// unless that word is zero (32 zero hash bits behind the index: 2^-32 of all k-mers), so the common case is one
+// v_ffbh_u32 + ds_max_i32 -- v_ffbh_u32 gives -1 for 0, which a signed max ignores -- instead of two v_ffbh_u32, an add, a
+// min, the guard bit and the + 1; a lane remembers whether one of its high words was zero and applies the exact rule to
+// those k-mers behind the sub-chunk (idempotent max).  A/B in separate processes (profiles/rd6w/sk_ab.jsonl): p = 10
+// 8.72e11 -> 9.48e11 bases/s (+8.7 %), p = 14 +6 %; the path behind the zero word is exercised by k-mers made for it
+// (the hash is invertible: tests/test_gpu_sketch.py::test_kmers_whose_hash_has_32_zero_bits_behind_the_index).
 template <bool GLOBAL, bool CANON, bool REG32>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
@@ -138,11 +145,15 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     uint64_t *xF = reinterpret_cast<uint64_t *>(lds + ((mwords + 3) & ~3u));
     uint64_t *xR = xF + 260;
     uint32_t *xV = reinterpret_cast<uint32_t *>(xR + 260);
-    for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = 0;
+    // FAST (word registers): a register holds value - 1 = the count of leading zeros, as a signed word, -1 = untouched
+    constexpr bool FAST = REG32 && !GLOBAL;
+    for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = FAST ? 0xFFFFFFFFu : 0u;
 
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int fshift = 64 - 2 * k;
     const uint64_t guard = 1ull << (p - 1);  // ((h << 1) | 1) << (p - 1) == (h << p) | guard
+    uint32_t guard_v = (uint32_t)guard;  // (in a VGPR: a VOP3 instruction reads ONE scalar register, and the shift amount is one)
+    asm("" : "+v"(guard_v));
 
     // pack the 32 bases at absolute offset B (bases outside [gbeg,gend) are invalid)
     auto pack_at = [&](uint64_t B, uint64_t &F, uint64_t &R, uint32_t &V) {
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         const uint64_t F1 = xF[tid + 1], R1 = xR[tid + 1];
         const uint64_t V = (uint64_t)V0 | ((uint64_t)xV[tid + 1] << 32);
         const uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
+        uint32_t mn = 0xFFFFFFFFu;  // (FAST) the smallest high word of t among this lane's k-mers of the sub-chunk
         const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
         const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
         // the k-mer that starts at base B + j (j a constant after unrolling, so the word selection folds away): 64-bit
@@ -198,7 +210,19 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             const uint32_t hhi = (uint32_t)(h >> 32), hlo = (uint32_t)h;
             const uint32_t idx = hhi >> (32 - p);
             const uint32_t thi = __builtin_amdgcn_alignbit(hhi, hlo, 32 - p);
-            const uint32_t tlo = (hlo << p) | (uint32_t)guard;
+            if constexpr (FAST) {
+                // value - 1 = clz(t) is the clz of t's HIGH word unless that word is zero -- 32 zero hash bits behind the
+                // index: 2^-32 of all k-mers.  v_ffbh_u32 gives -1 for 0 and a signed max with -1 changes nothing, so
+                // the common case is one instruction + the LDS atomic; `mn` remembers whether a high word was zero and
+                // the exact rule is then applied to those k-mers behind the sub-chunk (max is idempotent).
+                int lzs;
+                asm("v_ffbh_u32 %0, %1" : "=v"(lzs) : "v"(thi));
+                atomicMax(reinterpret_cast<int *>(lregs) + idx, lzs);  // ds_max_i32
+                mn = thi < mn ? thi : mn;
+                return;
+            }
+            uint32_t tlo;  // (hlo << p) | guard in ONE instruction (hipcc emits two: both operands would be scalar registers)
+            asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(tlo) : "v"(hlo), "s"(p), "v"(guard_v));
             uint32_t zh, zl;
             asm("v_ffbh_u32 %0, %1" : "=v"(zh) : "v"(thi));
             asm("v_ffbh_u32 %0, %1" : "=v"(zl) : "v"(tlo));
@@ -231,6 +255,23 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             for (int j = 0; j < 32; ++j)
                 if (ok & (1u << j)) kmer_at(j);
         }
+        if constexpr (FAST) {
+            if (__any(mn == 0u)) {  // (never, in practice: once per 4e9 k-mers)
+                if (mn == 0u) {
+#pragma unroll 1
+                    for (int j = 0; j < 32; ++j) {
+                        if (!((ok >> j) & 1u)) continue;
+                        const uint64_t fh = j ? ((F0 << (2 * j)) | (F1 >> (64 - 2 * j))) : F0;
+                        const uint64_t rl = j ? ((R0 >> (2 * j)) | (R1 << (64 - 2 * j))) : R0;
+                        const uint64_t fw = fh >> fshift, rc = rl & kmask;
+                        const uint64_t h = wang64((CANON && rc < fw) ? rc : fw);
+                        const uint64_t t = (h << p) | guard;
+                        if ((uint32_t)(t >> 32) == 0u)
+                            atomicMax(reinterpret_cast<int *>(lregs) + (uint32_t)(h >> (64 - p)), 32 + __builtin_clz((uint32_t)t));
+                    }
+                }
+            }
+        }
         F0 = Fn; R0 = Rn; V0 = Vn;
     }
     if (GLOBAL) return;
@@ -241,7 +282,8 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         uint32_t mine;
         if constexpr (REG32) {
             const uint4 q = reinterpret_cast<const uint4 *>(lregs)[w];  // four registers -> their packed bytes
-            mine = q.x | (q.y << 8) | (q.z << 16) | (q.w << 24);
+            if constexpr (FAST) mine = (q.x + 1u) | ((q.y + 1u) << 8) | ((q.z + 1u) << 16) | ((q.w + 1u) << 24);
+            else mine = q.x | (q.y << 8) | (q.z << 16) | (q.w << 24);
         } else {
             mine = lregs[w];
         }

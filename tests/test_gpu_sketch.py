@@ -60,6 +60,73 @@ def test_large_precisions_hbm_registers(ctx, oracle, p):
     assert np.allclose(d, ref, rtol=1e-6, atol=1e-15)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _unwang(h):
+    """the inverse of Thomas Wang's 64-bit hash (every step is a bijection of 64-bit words)"""
+    h = (h * pow((1 << 31) + 1, -1, 1 << 64)) & _M64          # key += key << 31
+    h ^= h >> 28; h ^= h >> 56                                # key ^= key >> 28
+    h = (h * pow(21, -1, 1 << 64)) & _M64                     # key *= 21
+    h ^= (h >> 14) ^ (h >> 28) ^ (h >> 42) ^ (h >> 56)        # key ^= key >> 14
+    h = (h * pow(265, -1, 1 << 64)) & _M64                    # key *= 265
+    h ^= (h >> 24) ^ (h >> 48)                                # key ^= key >> 24
+    return ((h + 1) * pow((1 << 21) - 1, -1, 1 << 64)) & _M64  # key = ~key + (key << 21) = key * (2^21 - 1) - 1
+
+
+def _revcomp(x, k):
+    r = 0
+    for _ in range(k):
+        r = (r << 2) | (3 - (x & 3))
+        x >>= 2
+    return r
+
+
+@pytest.mark.parametrize("k,p,canon", [(31, 10, True), (31, 14, True), (31, 8, False), (32, 12, True), (27, 13, True), (31, 16, True)])
+def test_kmers_whose_hash_has_32_zero_bits_behind_the_index(ctx, oracle, k, p, canon):
+    """Up to p = 14 k_sketch takes the register value from the HIGH word of t = (h << p) | guard alone and handles a zero
+    high word -- 32 zero hash bits behind the index, 2^-32 of all k-mers: no random genome holds one -- behind the
+    sub-chunk with the exact rule.  The hash is invertible, so such k-mers can be MADE: hashes idx << (64 - p) | low with
+    low < 2^(32-p) are inverted until the preimage is a k-mer (below 4^k) and, with canonical k-mers, its own canonical
+    form; they are planted in random genomes at positions that fall on every lane offset, on the first and last lanes of
+    a workgroup's sub-chunk, beside an N, and twice in one genome.  Registers bit-exact against the oracle, and the
+    oracle's registers show the planted values (>= 33, which nothing else produces).  p = 16 runs the packed-byte kernel
+    over the same inputs."""
+    import oracle.oracle_py as opy
+
+    rng = np.random.default_rng(1000 * k + p)
+    made = []
+    while len(made) < 12:
+        idx, low = int(rng.integers(0, 1 << p)), int(rng.integers(0, 1 << (32 - p)))
+        h = (idx << (64 - p)) | low
+        x = _unwang(h)
+        assert opy.wang(x) == h
+        if k < 32 and x >> (2 * k):
+            continue
+        if canon and _revcomp(x, k) < x:
+            continue
+        made.append((x, idx, (64 - p) - max(low, 0).bit_length() + 1 if low else 64 - p + 1))
+    letters = np.frombuffer(b"ACGT", np.uint8)
+
+    def text(x):
+        return letters[[(x >> (2 * (k - 1 - t))) & 3 for t in range(k)]]
+
+    genomes = []
+    base = synth.synthetic_genomes(len(made), 70000, seed=p * 131 + k, decorate=False)
+    spots = [0, 1, 31, 32, 8191 - k, 8192 - 5, 8192, 8192 + 31, 16384 - k + 1, 40001, 65536 - 3, 70000 - k]
+    for g, ((x, idx, val), at) in enumerate(zip(made, spots)):
+        a = base[g].copy()
+        a[at:at + k] = text(x)
+        if g % 3 == 1 and at > 0:
+            a[at - 1] = ord("N")           # the k-mer begins right behind an invalid base
+        if g % 4 == 2:
+            a[300:300 + k] = text(made[(g + 1) % len(made)][0])  # a second one in the same genome
+        genomes.append(a)
+    got = run(ctx, oracle, genomes, k, p, canon)
+    for g, (x, idx, val) in enumerate(made):
+        assert val >= 33 and got[g][idx] == val, (g, idx, val, int(got[g][idx]))
+
+
 def test_ragged_and_edge_genomes(ctx, oracle):
     """empty genome, shorter than k, exactly k, all-N, N every 31 bases, separators between records,
     lengths that straddle the 32/8192/131072-base chunk boundaries, unaligned offsets."""
