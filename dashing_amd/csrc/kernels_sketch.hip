@@ -130,7 +130,7 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
 // those k-mers behind the sub-chunk (idempotent max).  A/B in separate processes (profiles/rd6w/sk_ab.jsonl): p = 10
 // 8.72e11 -> 9.48e11 bases/s (+8.7 %), p = 14 +6 %; the path behind the zero word is exercised by k-mers made for it
 // (the hash is invertible: tests/test_gpu_sketch.py::test_kmers_whose_hash_has_32_zero_bits_behind_the_index).
-template <bool GLOBAL, bool CANON, bool REG32>
+template <bool GLOBAL, bool CANON, bool REG32, int KC>
 __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, uint8_t *__restrict__ regs)
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     constexpr bool FAST = REG32 && !GLOBAL;
     for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = FAST ? 0xFFFFFFFFu : 0u;
 
+    if constexpr (KC != 0) k = KC;  // (KC: the k-mer length as a compile-time constant -- dashing's default 31 -- else the argument)
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const int fshift = 64 - 2 * k;
     const uint64_t guard = 1ull << (p - 1);  // ((h << 1) | 1) << (p - 1) == (h << p) | guard
@@ -194,14 +195,24 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         // windows of (F0:F1) << 2j and (R1:R0) >> 2j, one v_alignbit_b32 per 32-bit half
         auto kmer_at = [&](const int j) {
             const int q = (2 * j) >> 5, r = (2 * j) & 31;
-            const uint32_t fhi = r ? __builtin_amdgcn_alignbit(fwv[q], fwv[q + 1], 32 - r) : fwv[q];
-            const uint32_t flo = r ? __builtin_amdgcn_alignbit(fwv[q + 1], fwv[q + 2], 32 - r) : fwv[q + 1];
             const uint32_t rlo = __builtin_amdgcn_alignbit(rwv[q + 1], rwv[q], r);
             const uint32_t rhi = __builtin_amdgcn_alignbit(rwv[q + 2], rwv[q + 1], r);
-            const uint64_t fh = ((uint64_t)fhi << 32) | flo;
             const uint64_t rl = ((uint64_t)rhi << 32) | rlo;
-            const uint64_t fw = fh >> fshift;
             const uint64_t rc = rl & kmask;
+            uint64_t fw;
+            if constexpr (KC != 0) {
+                // with k known the forward window is taken where it ENDS: (F0:F1) >> s, s = 128 - 2j - 2k, one funnel
+                // shift per half and the mask on the high word -- no 64-bit shift by 64 - 2k behind the two funnel shifts
+                const int s = 128 - 2 * j - 2 * KC, qs = s >> 5, rs = s & 31;
+                auto L = [&](const int i) -> uint32_t { return i <= 3 ? fwv[3 - i] : 0u; };  // (F0:F1) as little-endian words
+                const uint32_t lo = rs ? __builtin_amdgcn_alignbit(L(qs + 1), L(qs), rs) : L(qs);
+                const uint32_t hi = (rs ? __builtin_amdgcn_alignbit(L(qs + 2), L(qs + 1), rs) : L(qs + 1)) & (uint32_t)(kmask >> 32);
+                fw = ((uint64_t)hi << 32) | lo;
+            } else {
+                const uint32_t fhi = r ? __builtin_amdgcn_alignbit(fwv[q], fwv[q + 1], 32 - r) : fwv[q];
+                const uint32_t flo = r ? __builtin_amdgcn_alignbit(fwv[q + 1], fwv[q + 2], 32 - r) : fwv[q + 1];
+                fw = (((uint64_t)fhi << 32) | flo) >> fshift;
+            }
             const uint64_t km = (CANON && rc < fw) ? rc : fw;
             const uint64_t h = wang64(km);
             // index and register value from the 32-bit halves of h (4 <= p <= 24 < 32): the index is the top of the high
@@ -339,24 +350,24 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
     return e;
 }
 
-template <bool GLOBAL, bool REG32>
+template <bool GLOBAL, bool REG32, int KC>
 static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
                                   uint8_t *regs, size_t lds)
 {
     if (lds > (48u << 10)) {
-        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, REG32>)
-                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, REG32>), lds);
+        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, REG32, KC>)
+                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, REG32, KC>), lds);
         if (e != hipSuccess) return e;
     }
-    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, REG32>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
-    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, REG32>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, REG32, KC>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, REG32, KC>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
 }
 
 hipError_t preload_sketch_kernels()
 {
     hipFuncAttributes fa;
-    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sketch<false, true, true>));
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sketch<false, true, true, 31>));
 }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
@@ -364,12 +375,17 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
 {
     if (nwork == 0) return hipSuccess;
     const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
-    if (p > kMaxPLds) return launch_sketch_v<true, false>(st, seq, work, nwork, k, p, canon, regs, xch);
+    if (p > kMaxPLds) return launch_sketch_v<true, false, 0>(st, seq, work, nwork, k, p, canon, regs, xch);
     // registers (a word each up to p = kMaxPReg32, packed bytes above; 16-byte aligned) + the exchange slots
     const bool reg32 = p <= sketch_reg32_maxp() && !sketch_force_bytes();
     const size_t lds = ((((size_t)(reg32 ? 4 : 1) << p) + 15) & ~(size_t)15) + xch;
-    if (reg32) return launch_sketch_v<false, true>(st, seq, work, nwork, k, p, canon, regs, lds);
-    return launch_sketch_v<false, false>(st, seq, work, nwork, k, p, canon, regs, lds);
+    // dashing's default k = 31 (src/distmain.cpp:29) has an instance of its own with the window arithmetic folded: p = 10
+    // 9.40e11 -> 9.67e11 bases/s (+2.9 %), p = 14 +2.3 % (A/B in separate processes, DSH_SKETCH_GENERIC_K=1 selects the
+    // generic instance: profiles/rd6y/sk_k31_ab.jsonl)
+    static const bool generic_k = std::getenv("DSH_SKETCH_GENERIC_K") != nullptr;
+    if (reg32 && k == 31 && !generic_k) return launch_sketch_v<false, true, 31>(st, seq, work, nwork, k, p, canon, regs, lds);
+    if (reg32) return launch_sketch_v<false, true, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
+    return launch_sketch_v<false, false, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
 }
 
 }  // namespace dsh

@@ -112,12 +112,17 @@ def analyse(lines, var):
 
 
 def analyse_reg32(lines):
-    """round 6: the instance with one 32-bit word per LDS register (p <= 13): a k-mer's straight-line code ends in ONE
-    ds_max_u32 -- no filter read, no branch, no CAS path.  VALU between consecutive ds_max_u32 (median over the start positions
-    of the all-valid copy and of the per-position-test copy of the unrolled loop), by phase where the anchors allow."""
-    body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb1EEE")
-    anchors = [i for i, l in enumerate(body) if l.startswith("ds_max_u32")]
-    blocks = [body[anchors[k] + 1: anchors[k + 1] + 1] for k in range(len(anchors) - 1)]
+    """round 6: the instance with one 32-bit word per LDS register (p <= 14) and k = 31 folded in: a k-mer's code ends in ONE
+    ds_max_i32 (the register holds value - 1 = the leading zeros of t's high word; no filter read, no branch, no CAS path).
+    The per-position-test copy of the unrolled loop keeps one k-mer per exec-masked block: VALU between consecutive
+    ds_max_i32 there, by phase where the anchors allow (median over the start positions).  In the all-valid copy hipcc
+    interleaves the k-mers, so that copy is counted as a whole: its VALU instructions / 32."""
+    prefix = next((pf for pf in ("_ZN3dsh8k_sketchILb0ELb1ELb1ELi31EEE", "_ZN3dsh8k_sketchILb0ELb1ELb1EEE") if any(l.startswith(pf) for l in lines)), None)
+    body = body_of(lines, prefix)
+    atom = "ds_max_i32" if any(l.startswith("ds_max_i32") for l in body) else "ds_max_u32"
+    anchors = [i for i, l in enumerate(body) if l.startswith(atom)]
+    tested = [any(l.startswith(("s_and_saveexec", "s_cbranch")) for l in body[anchors[k]: anchors[k + 1]]) for k in range(len(anchors) - 1)]
+    blocks = [body[anchors[k] + 1: anchors[k + 1] + 1] for k in range(len(anchors) - 1) if tested[k]]
     per = []
     for b in blocks:
         names = [l.split()[0] for l in b if l.startswith("v_")]
@@ -127,20 +132,39 @@ def analyse_reg32(lines):
             continue
         per.append({"window_and_validity": cmp64, "canonical": 3, "hash": last_mad + 1 - (cmp64 + 3), "register_rule": len(names) - (last_mad + 1), "total": len(names)})
     med = lambda key: statistics.median([p[key] for p in per]) if per else 0
+    # the all-valid copy: the longest run of anchors with no exec test between them
+    best, cur = (0, 0), None
+    for k, t in enumerate(tested + [True]):
+        if not t and cur is None:
+            cur = k
+        if t and cur is not None:
+            if k - cur > best[1] - best[0]:
+                best = (cur, k)
+            cur = None
+    all_valid = None
+    if best[1] > best[0]:
+        start = max(i for i in range(anchors[best[0]]) if body[i].startswith("s_cbranch"))
+        n_kmers = best[1] - best[0] + 1
+        seg = [l.split()[0] for l in body[start + 1: anchors[best[1]] + 1] if l.startswith("v_")]
+        full = sum(1 for o in seg if FULL.match(o))
+        all_valid = {"kmers": n_kmers, "valu": len(seg), "valu_per_kmer": round(len(seg) / n_kmers, 2),
+                     "full_rate_share": round(full / max(len(seg), 1), 4), "nominal_cycles_per_kmer": round((2.0 * full + 4.0 * (len(seg) - full)) / n_kmers, 1)}
     cnt = collections.Counter(l.split()[0] for b in blocks for l in b if l.startswith("v_"))
     full = sum(c for k, c in cnt.items() if FULL.match(k))
     tot = sum(cnt.values())
-    return {"instance": "REG32 (p <= 13): ds_max_u32", "static_valu_total": sum(1 for l in body if l.startswith("v_")), "ds_max_u32": len(anchors),
-            "ds_cmpst": sum(1 for l in body if l.startswith("ds_cmpst")), "per_kmer_median": {k: med(k) for k in ("window_and_validity", "canonical", "hash", "register_rule", "total")},
+    return {"instance": prefix, "static_valu_total": sum(1 for l in body if l.startswith("v_")), atom: len(anchors),
+            "ds_cmpst": sum(1 for l in body if l.startswith("ds_cmpst")),
+            "per_position_test_copy_per_kmer_median": {k: med(k) for k in ("window_and_validity", "canonical", "hash", "register_rule", "total")},
+            "all_valid_copy": all_valid,
             "pack_and_prologue_valu_before_first_kmer": sum(1 for l in body[:anchors[0]] if l.startswith("v_")) if anchors else None,
-            "issue_classes_of_the_unrolled_loop": {"full_rate_share": round(full / max(tot, 1), 4), "nominal_cycles_per_inst": round((2.0 * full + 4.0 * (tot - full)) / max(tot, 1), 3)}}
+            "issue_classes_of_the_per_position_copy": {"full_rate_share": round(full / max(tot, 1), 4), "nominal_cycles_per_inst": round((2.0 * full + 4.0 * (tot - full)) / max(tot, 1), 3)}}
 
 
 def main():
     lines = listing()
-    if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELb1EEE") for l in lines):  # round 6: <GLOBAL, CANON, REG32>
-        byte_body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb0EEE")
-        print(json.dumps({"kernel": "k_sketch<GLOBAL=false, CANON=true, REG32>", "reg32": analyse_reg32(lines),
+    if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELb1E") for l in lines):  # round 6: <GLOBAL, CANON, REG32[, KC]>
+        byte_body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb0E")
+        print(json.dumps({"kernel": "k_sketch<GLOBAL=false, CANON=true, REG32, KC=31>", "reg32": analyse_reg32(lines),
                           "bytes_instance_static": {"static_valu_total": sum(1 for l in byte_body if l.startswith("v_")),
                                                     "ds_read_u8": sum(1 for l in byte_body if l.startswith("ds_read_u8")),
                                                     "ds_cmpst": sum(1 for l in byte_body if l.startswith("ds_cmpst"))},
