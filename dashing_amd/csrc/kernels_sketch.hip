@@ -384,10 +384,9 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *w
     const bool reg32 = p <= sketch_reg32_maxp() && !sketch_force_bytes();
     const size_t lds = ((((size_t)(reg32 ? 4 : 1) << p) + 15) & ~(size_t)15) + xch;
     // dashing's default k = 31 (src/distmain.cpp:29) has an instance of its own with the window arithmetic folded: p = 10
-    // 9.40e11 -> 9.67e11 bases/s (+2.9 %), p = 14 +2.3 % (A/B in separate processes, DSH_SKETCH_GENERIC_K=1 selects the
-    // generic instance: profiles/rd6y/sk_k31_ab.jsonl)
-    static const bool generic_k = std::getenv("DSH_SKETCH_GENERIC_K") != nullptr;
-    if (reg32 && k == 31 && !generic_k) return launch_sketch_v<false, true, 31>(st, seq, work, nwork, k, p, canon, regs, lds);
+    // 9.40e11 -> 9.67e11 bases/s (+2.9 %), p = 14 +2.3 % (A/B in separate processes behind an environment switch, since
+    // removed: profiles/rd6y/sk_k31_ab.jsonl)
+    if (reg32 && k == 31) return launch_sketch_v<false, true, 31>(st, seq, work, nwork, k, p, canon, regs, lds);
     if (reg32) return launch_sketch_v<false, true, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
     return launch_sketch_v<false, false, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
 }
