@@ -526,19 +526,22 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
         }
         // when every part of the call was final (from the start of the call, prepare included) and how many floats of the
         // rank's buffer it holds: what a model of the pipelined exchange needs (dsh_last_part_info)
+        auto fill_part_floats = [&] {  // how many floats of the rank's buffer every part holds
+            for (size_t i = 0; i < c->part_floats.size(); ++i) {
+                if (L.rowsorted && i + 1 < L.part_w.size()) c->part_floats[i] = L.rowoff_w[L.part_w[i + 1]] - L.rowoff_w[L.part_w[i]];
+                else if (!L.rowsorted && L.extra.empty() && i + 1 < L.parts.size()) c->part_floats[i] = plan::tri_span(c->n, L.parts[i], L.parts[i + 1]);
+                else if (!L.rowsorted) c->part_floats[i] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
+            }
+        };
         if (signal && e_call0 && c->wall_clock_khz > 0) {
             std::vector<unsigned long long> st(kSigMaxParts + 1);
             HIPCHK(c, hipMemcpy(st.data(), (uint32_t *)c->sig.ptr + kSigPartTime, kSigMaxParts * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             HIPCHK(c, hipMemcpy(&st[kSigMaxParts], (uint32_t *)c->sig.ptr + kSigT0, sizeof(unsigned long long), hipMemcpyDeviceToHost));
             c->part_ready_ms.assign(c->parts_done, 0.0);
             c->part_floats.assign(c->parts_done, 0);
-            for (size_t q = 0; q < c->part_ready_ms.size(); ++q)
-                c->part_ready_ms[q] = (double)(long long)(st[q] - st[kSigMaxParts]) / (double)c->wall_clock_khz;
-            for (size_t q = 0; q < c->part_floats.size(); ++q) {
-                if (L.rowsorted && q + 1 < L.part_w.size()) c->part_floats[q] = L.rowoff_w[L.part_w[q + 1]] - L.rowoff_w[L.part_w[q]];
-                else if (!L.rowsorted && L.extra.empty() && q + 1 < L.parts.size()) c->part_floats[q] = plan::tri_span(c->n, L.parts[q], L.parts[q + 1]);
-                else if (!L.rowsorted) c->part_floats[q] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
-            }
+            for (size_t i = 0; i < c->part_ready_ms.size(); ++i)
+                c->part_ready_ms[i] = (double)(long long)(st[i] - st[kSigMaxParts]) / (double)c->wall_clock_khz;
+            fill_part_floats();
         } else if (e_call0 && !ev_part_t.empty()) {
             c->part_ready_ms.assign(c->parts_done, 0.0);
             c->part_floats.assign(c->parts_done, 0);
@@ -547,11 +550,7 @@ int run_pairs(dsh_ctx *c, const PairJob &job)
                 (void)hipEventElapsedTime(&ms, e_call0, pe.second);
                 if (pe.first < c->part_ready_ms.size()) c->part_ready_ms[pe.first] = ms;
             }
-            for (size_t q = 0; q < c->part_floats.size(); ++q) {
-                if (L.rowsorted && q + 1 < L.part_w.size()) c->part_floats[q] = L.rowoff_w[L.part_w[q + 1]] - L.rowoff_w[L.part_w[q]];
-                else if (!L.rowsorted && L.extra.empty() && q + 1 < L.parts.size()) c->part_floats[q] = plan::tri_span(c->n, L.parts[q], L.parts[q + 1]);
-                else if (!L.rowsorted) c->part_floats[q] = plan::rowset_span(c->n, L.rb, L.re, L.extra);
-            }
+            fill_part_floats();
         }
     }
     return DSH_OK;
