@@ -7,6 +7,7 @@ import pytest
 
 import dashing_amd
 from dashing_amd import synth
+from hashinv import revcomp as _revcomp, unwang as _unwang  # (tests/hashinv.py)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -58,28 +59,6 @@ def test_large_precisions_hbm_registers(ctx, oracle, p):
     d = ctx.dist_rows(0, len(gs))
     ref = oracle.dist_tri(regs)
     assert np.allclose(d, ref, rtol=1e-6, atol=1e-15)
-
-
-_M64 = (1 << 64) - 1
-
-
-def _unwang(h):
-    """the inverse of Thomas Wang's 64-bit hash (every step is a bijection of 64-bit words)"""
-    h = (h * pow((1 << 31) + 1, -1, 1 << 64)) & _M64          # key += key << 31
-    h ^= h >> 28; h ^= h >> 56                                # key ^= key >> 28
-    h = (h * pow(21, -1, 1 << 64)) & _M64                     # key *= 21
-    h ^= (h >> 14) ^ (h >> 28) ^ (h >> 42) ^ (h >> 56)        # key ^= key >> 14
-    h = (h * pow(265, -1, 1 << 64)) & _M64                    # key *= 265
-    h ^= (h >> 24) ^ (h >> 48)                                # key ^= key >> 24
-    return ((h + 1) * pow((1 << 21) - 1, -1, 1 << 64)) & _M64  # key = ~key + (key << 21) = key * (2^21 - 1) - 1
-
-
-def _revcomp(x, k):
-    r = 0
-    for _ in range(k):
-        r = (r << 2) | (3 - (x & 3))
-        x >>= 2
-    return r
 
 
 @pytest.mark.parametrize("k,p,canon", [(31, 10, True), (31, 14, True), (31, 8, False), (32, 12, True), (27, 13, True), (31, 16, True)])
