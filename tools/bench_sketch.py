@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-genomes", type=int, default=16)
+    ap.add_argument("--n-every", type=int, default=0, help="an invalid byte every R bases (R = 151: what 150-bp reads look like to the kernel: every wave meets windows that are not valid)")
     args = ap.parse_args()
     import torch
 
@@ -40,6 +41,8 @@ def main():
         b = g * gstride
         seq[b + L // 3 : b + L // 3 + 50] = ord("N")
         seq[b + L // 2 : b + L // 2 + 1000] |= 0x20
+    if args.n_every:
+        seq[:: args.n_every] = ord("N")
     torch.cuda.synchronize()  # torch's stream wrote the bases; the library reads them on its own stream
     off = np.array([g * gstride for g in range(G)] + [0], np.uint64)
     off_end = off[:-1] + np.uint64(L)
@@ -92,7 +95,7 @@ def main():
                      "note": "VALU-bound in practice: ~47 VALU instructions per k-mer (25 of them the Wang hash), ~4.3 cycles each per wave64"},
         "cpu_baseline": {"value": nc * gstride / tc, "unit": "bases/s", "cores": cores, "kind": "port",
                          "sample": "%d genomes, oracle/dsh_oracle.c dsho_sketch_batch (one genome per thread, like src/sketch_and_cmp.h:314-360)" % nc},
-        "registers_bit_exact": exact}))
+        "registers_bit_exact": exact, "n_every": args.n_every}))
     ctx.close()
 
 
