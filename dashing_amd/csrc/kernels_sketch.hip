@@ -126,7 +126,7 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
 // native LDS atomic -- ds_max_u32, nothing returned, nothing to wait for -- instead of a byte read that filters, a branch
 // and a compare-and-swap loop on the containing word: a wave walked that 13-instruction path whenever ONE of its 64
 // lanes raised a register (~5 of 57 VALU per k-mer at p = 10, profiles/rd5g/sketch_instr.json).  4 KiB of LDS at p = 10,
-// 64 KiB at p = 14; above that the packed bytes keep more than one workgroup per CU.
+// 64 KiB at p = 14, 128 KiB at p = 15 (workgroups of 512 and 1 024 lanes there: launch_sketch); packed bytes for p = 16, 17.
 // The word holds value - 1 = clz(t), signed, -1 = untouched (the merge adds the 1): clz(t) is the clz of t's HIGH word
 // unless that word is zero (32 zero hash bits behind the index: 2^-32 of all k-mers), so the common case is one
 // v_ffbh_u32 + ds_max_i32 -- v_ffbh_u32 gives -1 for 0, which a signed max ignores -- instead of two v_ffbh_u32, an add, a
@@ -134,8 +134,8 @@ __device__ __forceinline__ uint64_t valid_windows(uint64_t V, int k)
 // those k-mers behind the sub-chunk (idempotent max).  A/B in separate processes (profiles/rd6w/sk_ab.jsonl): p = 10
 // 8.72e11 -> 9.48e11 bases/s (+8.7 %), p = 14 +6 %; the path behind the zero word is exercised by k-mers made for it
 // (the hash is invertible: tests/test_gpu_sketch.py::test_kmers_whose_hash_has_32_zero_bits_behind_the_index).
-template <bool GLOBAL, bool CANON, bool REG32, int KC>
-__global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
+template <bool GLOBAL, bool CANON, bool REG32, int KC, int NT>
+__global__ __launch_bounds__(NT) void k_sketch(const uint8_t *__restrict__ seq,
                                                  const SketchWork *__restrict__ work, int k,
                                                  int p, uint8_t *__restrict__ regs)
 {
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     const SketchWork wk = work[blockIdx.x];
     uint32_t *lregs = GLOBAL ? reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p)) : lds;
     uint64_t *xF = reinterpret_cast<uint64_t *>(lds + ((mwords + 3) & ~3u));
-    uint64_t *xR = xF + 260;
-    uint32_t *xV = reinterpret_cast<uint32_t *>(xR + 260);
+    uint64_t *xR = xF + (NT + 4);
+    uint32_t *xV = reinterpret_cast<uint32_t *>(xR + (NT + 4));
     // FAST (word registers): a register holds value - 1 = the count of leading zeros, as a signed word, -1 = untouched
     constexpr bool FAST = REG32 && !GLOBAL;
-    for (uint32_t w = tid; w < mwords; w += 256) lregs[w] = FAST ? 0xFFFFFFFFu : 0u;
+    for (uint32_t w = tid; w < mwords; w += NT) lregs[w] = FAST ? 0xFFFFFFFFu : 0u;
 
     if constexpr (KC != 0) k = KC;  // (KC: the k-mer length as a compile-time constant -- dashing's default 31 -- else the argument)
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -173,25 +173,33 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
         V &= rmask;
     };
 
-    // Software pipeline over the sub-chunks: a lane packs the NEXT sub-chunk's 32 bases while this one's k-mers are
+    // Software pipeline over the work item's bases in steps of NT x 32 (NT = 256: one 8 192-base sub-chunk of the work list
+    // per step; the 512- and 1 024-lane workgroups of p = 14 and 15 -- whose registers leave room for two and one workgroup
+    // per CU -- take two and four): a lane packs the NEXT step's 32 bases while this one's k-mers are
     // processed (the global loads travel under the hash arithmetic), and lane 0's look-ahead IS the right neighbour of
-    // lane 255 -- no separate pack of the 32 bases behind the sub-chunk (round 4: wave 0 packed them on top of its own,
-    // 2.3 of 57.5 instructions per k-mer).  Behind the work item's last sub-chunk only wave 0 looks ahead.
+    // the last lane -- no separate pack of the 32 bases behind the step (round 4: wave 0 packed them on top of its own,
+    // 2.3 of 57.5 instructions per k-mer).  Behind the work item's last step only wave 0 looks ahead.  Lanes of the last
+    // step that lie behind the item's end start no k-mer (the next work item does), but their bases are the right
+    // neighbours of the lanes in front of them.
+    constexpr uint32_t kStep = (uint32_t)NT * 32u;
+    const uint64_t item_end = wk.start + (uint64_t)wk.nsub * kSketchSub;
+    const uint32_t nstep = (uint32_t)(((uint64_t)wk.nsub * kSketchSub + kStep - 1) / kStep);
     uint64_t F0, R0;
     uint32_t V0;
     pack_at(wk.start + (uint64_t)tid * 32, F0, R0, V0);
-    for (uint32_t s = 0; s < wk.nsub; ++s) {
-        const uint64_t Bn = wk.start + (uint64_t)(s + 1) * kSketchSub + (uint64_t)tid * 32;
+    for (uint32_t s = 0; s < nstep; ++s) {
+        const uint64_t Bn = wk.start + (uint64_t)(s + 1) * kStep + (uint64_t)tid * 32;
         uint64_t Fn = 0, Rn = 0;
         uint32_t Vn = 0;
-        if (s + 1 < wk.nsub || tid < 64) pack_at(Bn, Fn, Rn, Vn);  // (wave-uniform)
+        if (s + 1 < nstep || tid < 64) pack_at(Bn, Fn, Rn, Vn);  // (wave-uniform)
         __syncthreads();  // previous sub-chunk's neighbour reads (and the register clear) are done
         xF[tid] = F0; xR[tid] = R0; xV[tid] = V0;
-        if (tid == 0) { xF[256] = Fn; xR[256] = Rn; xV[256] = Vn; }
+        if (tid == 0) { xF[NT] = Fn; xR[NT] = Rn; xV[NT] = Vn; }
         __syncthreads();
         const uint64_t F1 = xF[tid + 1], R1 = xR[tid + 1];
         const uint64_t V = (uint64_t)V0 | ((uint64_t)xV[tid + 1] << 32);
-        const uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
+        uint32_t ok = (uint32_t)valid_windows(V, k);  // bit j: a k-mer starts at base B+j
+        if (NT != 256 && wk.start + (uint64_t)s * kStep + (uint64_t)tid * 32 >= item_end) ok = 0;  // (behind the item's end)
         uint32_t mn = 0xFFFFFFFFu;  // (FAST) the smallest high word of t among this lane's k-mers of the sub-chunk
         const uint32_t fwv[4] = {(uint32_t)(F0 >> 32), (uint32_t)F0, (uint32_t)(F1 >> 32), (uint32_t)F1};
         const uint32_t rwv[4] = {(uint32_t)R0, (uint32_t)(R0 >> 32), (uint32_t)R1, (uint32_t)(R1 >> 32)};
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
     __syncthreads();
     uint32_t *g = reinterpret_cast<uint32_t *>(regs + ((uint64_t)wk.slot << p));
     const uint32_t gwords = (1u << p) >> 2;
-    for (uint32_t w = tid; w < gwords; w += 256) {
+    for (uint32_t w = tid; w < gwords; w += NT) {
         uint32_t mine;
         if constexpr (REG32) {
             const uint4 q = reinterpret_cast<const uint4 *>(lregs)[w];  // four registers -> their packed bytes
@@ -312,23 +320,6 @@ __global__ __launch_bounds__(256) void k_sketch(const uint8_t *__restrict__ seq,
             old = prev;
         }
     }
-}
-
-// A/B of round 6 only (tools/bench_sketch.py, profiles/rd6*): DSH_SKETCH_BYTES=1 keeps the packed-byte registers at every p
-static bool sketch_force_bytes()
-{
-    static const bool v = std::getenv("DSH_SKETCH_BYTES") != nullptr;
-    return v;
-}
-
-static int sketch_reg32_maxp()  // (A/B: DSH_SKETCH_REG32_MAXP=14..15 tries the word-per-register layout above kMaxPReg32)
-{
-    static const int v = [] {
-        const char *e = std::getenv("DSH_SKETCH_REG32_MAXP");
-        const int x = e ? std::atoi(e) : kMaxPReg32;
-        return x < 4 ? 4 : (x > 15 ? 15 : x);  // (p = 15: 128 KiB of LDS, the most a workgroup can be given beside the exchange slots)
-    }();
-    return v;
 }
 
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
@@ -354,41 +345,62 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes)
     return e;
 }
 
-template <bool GLOBAL, bool REG32, int KC>
+template <bool GLOBAL, bool REG32, int KC, int NT>
 static hipError_t launch_sketch_v(hipStream_t st, const uint8_t *seq, const SketchWork *work, uint32_t nwork, int k, int p, int canon,
                                   uint8_t *regs, size_t lds)
 {
     if (lds > (48u << 10)) {
-        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, REG32, KC>)
-                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, REG32, KC>), lds);
+        hipError_t e = ensure_dynamic_lds(canon ? reinterpret_cast<const void *>(k_sketch<GLOBAL, true, REG32, KC, NT>)
+                                                : reinterpret_cast<const void *>(k_sketch<GLOBAL, false, REG32, KC, NT>), lds);
         if (e != hipSuccess) return e;
     }
-    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, REG32, KC>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
-    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, REG32, KC>), dim3(nwork), dim3(256), lds, st, seq, work, k, p, regs);
+    if (canon) hipLaunchKernelGGL((k_sketch<GLOBAL, true, REG32, KC, NT>), dim3(nwork), dim3(NT), lds, st, seq, work, k, p, regs);
+    else hipLaunchKernelGGL((k_sketch<GLOBAL, false, REG32, KC, NT>), dim3(nwork), dim3(NT), lds, st, seq, work, k, p, regs);
     return hipGetLastError();
 }
+
+// the LDS of a workgroup of NT lanes: its registers (16-byte aligned) + the exchange slots, (NT + 4) x (F, R, V)
+static size_t sketch_lds(size_t reg_bytes, int nt) { return ((reg_bytes + 15) & ~(size_t)15) + (size_t)(nt + 4) * 20 + 16; }
 
 hipError_t preload_sketch_kernels()
 {
     hipFuncAttributes fa;
-    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sketch<false, true, true, 31>));
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sketch<false, true, true, 31, 256>));
 }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t *seq, const SketchWork *work,
                          uint32_t nwork, int k, int p, int canon, uint8_t *regs)
 {
     if (nwork == 0) return hipSuccess;
-    const size_t xch = 260 * 16 + 260 * 4 + 16;  // 260 x (F, R) + 260 x V exchange slots
-    if (p > kMaxPLds) return launch_sketch_v<true, false, 0>(st, seq, work, nwork, k, p, canon, regs, xch);
-    // registers (a word each up to p = kMaxPReg32, packed bytes above; 16-byte aligned) + the exchange slots
-    const bool reg32 = p <= sketch_reg32_maxp() && !sketch_force_bytes();
-    const size_t lds = ((((size_t)(reg32 ? 4 : 1) << p) + 15) & ~(size_t)15) + xch;
+    if (p > kMaxPLds) return launch_sketch_v<true, false, 0, 256>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(0, 256));
+    // registers: a word each up to p = kMaxPReg32, packed bytes above
+    const bool reg32 = p <= kMaxPReg32;
+    // A workgroup's registers decide how many workgroups share a CU: 64 KiB (words at p = 14, bytes at p = 16) leave room
+    // for two, 128 KiB (p = 15, p = 17) for one -- with 256 lanes that is 2 and 1 wave per SIMD.  Those precisions run 512
+    // and 1 024 lanes per workgroup (4 waves per SIMD again; a step of the loop is then 2 or 4 sub-chunks of the work
+    // list).  A/B behind an environment switch, since removed, 300 x 5 Mbp, registers identical (profiles/rd6ab):
+    //   p = 14  6.85e11 -> 7.86e11 bases/s (+15 %)      p = 15  5.27e11 (packed bytes) -> 6.2e11 (words, 1 024 lanes; 256 lanes: 3.7e11)
+    //   p = 16  3.06e11 -> 4.61e11 (+51 %)              p = 17  1.33e11 -> 3.31e11 (x2.5)
+    if (!reg32) {  // packed bytes
+        const size_t rbb = (size_t)1 << p;
+        if (p >= 17) return launch_sketch_v<false, false, 0, 1024>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rbb, 1024));
+        if (p == 16) return launch_sketch_v<false, false, 0, 512>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rbb, 512));
+        return launch_sketch_v<false, false, 0, 256>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rbb, 256));
+    }
     // dashing's default k = 31 (src/distmain.cpp:29) has an instance of its own with the window arithmetic folded: p = 10
     // 9.40e11 -> 9.67e11 bases/s (+2.9 %), p = 14 +2.3 % (A/B in separate processes behind an environment switch, since
     // removed: profiles/rd6y/sk_k31_ab.jsonl)
-    if (reg32 && k == 31) return launch_sketch_v<false, true, 31>(st, seq, work, nwork, k, p, canon, regs, lds);
-    if (reg32) return launch_sketch_v<false, true, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
-    return launch_sketch_v<false, false, 0>(st, seq, work, nwork, k, p, canon, regs, lds);
+    const size_t rb = (size_t)4 << p;
+    if (p >= 15) {
+        if (k == 31) return launch_sketch_v<false, true, 31, 1024>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 1024));
+        return launch_sketch_v<false, true, 0, 1024>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 1024));
+    }
+    if (p == 14) {
+        if (k == 31) return launch_sketch_v<false, true, 31, 512>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 512));
+        return launch_sketch_v<false, true, 0, 512>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 512));
+    }
+    if (k == 31) return launch_sketch_v<false, true, 31, 256>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 256));
+    return launch_sketch_v<false, true, 0, 256>(st, seq, work, nwork, k, p, canon, regs, sketch_lds(rb, 256));
 }
 
 }  // namespace dsh

@@ -117,7 +117,7 @@ def analyse_reg32(lines):
     The per-position-test copy of the unrolled loop keeps one k-mer per exec-masked block: VALU between consecutive
     ds_max_i32 there, by phase where the anchors allow (median over the start positions).  In the all-valid copy hipcc
     interleaves the k-mers, so that copy is counted as a whole: its VALU instructions / 32."""
-    prefix = next((pf for pf in ("_ZN3dsh8k_sketchILb0ELb1ELb1ELi31EEE", "_ZN3dsh8k_sketchILb0ELb1ELb1EEE") if any(l.startswith(pf) for l in lines)), None)
+    prefix = next((pf for pf in ("_ZN3dsh8k_sketchILb0ELb1ELb1ELi31ELi256EEE", "_ZN3dsh8k_sketchILb0ELb1ELb1ELi31EEE", "_ZN3dsh8k_sketchILb0ELb1ELb1EEE") if any(l.startswith(pf) for l in lines)), None)
     body = body_of(lines, prefix)
     atom = "ds_max_i32" if any(l.startswith("ds_max_i32") for l in body) else "ds_max_u32"
     anchors = [i for i, l in enumerate(body) if l.startswith(atom)]
@@ -163,8 +163,8 @@ def analyse_reg32(lines):
 def main():
     lines = listing()
     if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELb1E") for l in lines):  # round 6: <GLOBAL, CANON, REG32[, KC]>
-        byte_body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb0E")
-        print(json.dumps({"kernel": "k_sketch<GLOBAL=false, CANON=true, REG32, KC=31>", "reg32": analyse_reg32(lines),
+        byte_body = body_of(lines, "_ZN3dsh8k_sketchILb0ELb1ELb0ELi0ELi256E" if any(l.startswith("_ZN3dsh8k_sketchILb0ELb1ELb0ELi0ELi256E") for l in lines) else "_ZN3dsh8k_sketchILb0ELb1ELb0E")
+        print(json.dumps({"kernel": "k_sketch<GLOBAL=false, CANON=true, REG32, KC=31, NT=256>", "reg32": analyse_reg32(lines),
                           "bytes_instance_static": {"static_valu_total": sum(1 for l in byte_body if l.startswith("v_")),
                                                     "ds_read_u8": sum(1 for l in byte_body if l.startswith("ds_read_u8")),
                                                     "ds_cmpst": sum(1 for l in byte_body if l.startswith("ds_cmpst"))},
