@@ -112,7 +112,7 @@ def analyse(lines, var):
 
 
 def analyse_reg32(lines):
-    """round 6: the instance with one 32-bit word per LDS register (p <= 14) and k = 31 folded in: a k-mer's code ends in ONE
+    """round 6: the instance with one 32-bit word per LDS register (p <= 15; the 256-lane instance of p <= 13) and k = 31 folded in: a k-mer's code ends in ONE
     ds_max_i32 (the register holds value - 1 = the leading zeros of t's high word; no filter read, no branch, no CAS path).
     The per-position-test copy of the unrolled loop keeps one k-mer per exec-masked block: VALU between consecutive
     ds_max_i32 there, by phase where the anchors allow (median over the start positions).  In the all-valid copy hipcc
