@@ -106,6 +106,25 @@ def test_kmers_whose_hash_has_32_zero_bits_behind_the_index(ctx, oracle, k, p, c
         assert val >= 33 and got[g][idx] == val, (g, idx, val, int(got[g][idx]))
 
 
+@pytest.mark.parametrize("p", [13, 14, 15, 16, 17])
+@pytest.mark.parametrize("k", [31, 21])
+def test_workgroup_sizes_and_work_item_ends(ctx, oracle, p, k):
+    """p = 14 / 16 run 512 lanes per workgroup and p = 15 / 17 run 1 024 (their registers leave room for two / one workgroup
+    per CU): one step of the kernel's loop then covers 2 or 4 sub-chunks of the work list, and the lanes of a work item's
+    last step that lie behind its end must start nothing (the next item does) while their bases remain the right
+    neighbours of the lanes in front.  Genomes whose work items end on every position of such a step: 1 ... 5 sub-chunks,
+    16 + 1, 17 whole ones, 33 and a ragged tail, several work items; a run of N across an item's end."""
+    base = synth.synthetic_genomes(1, 450000, seed=77 + p, decorate=False)[0]
+    sub = 8192
+    lens = [sub - 7, sub, sub + 1, 2 * sub + 31, 3 * sub + 1, 4 * sub, 5 * sub - 17, 16 * sub, 16 * sub + 5000, 17 * sub, 33 * sub + 123, 450000]
+    gs = [base[:n].copy() for n in lens]
+    edge = base[:20 * sub].copy()
+    edge[16 * sub - 40:16 * sub + 9] = ord("N")   # invalid windows on both sides of the first work item's end
+    gs.append(edge)
+    gs.append(base[13:13 + 16 * sub + 3].copy())   # unaligned start: the item grid is shifted against the genome
+    run(ctx, oracle, gs, k, p)
+
+
 def test_ragged_and_edge_genomes(ctx, oracle):
     """empty genome, shorter than k, exactly k, all-N, N every 31 bases, separators between records,
     lengths that straddle the 32/8192/131072-base chunk boundaries, unaligned offsets."""
@@ -165,7 +184,7 @@ def test_random_sketch_case(ctx, oracle, case):
     lengths (0 .. 70 000), random bytes from a dirty alphabet (N, lowercase, IUPAC, newline, NUL)."""
     rng = np.random.default_rng(7000 + case)
     k = int(rng.choice([1, 2, 7, 15, 16, 17, 21, 31, 32]))
-    p = int(rng.choice([4, 5, 9, 10, 12, 14, 16, 17, 18, 21]))
+    p = int(rng.choice([4, 5, 9, 10, 12, 13, 14, 15, 16, 17, 18, 21]))
     canon = bool(rng.integers(2))
     ng = int(rng.integers(1, 9))
     alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnRYKM\n\x00-", np.uint8)
