@@ -82,14 +82,31 @@ __device__ __forceinline__ void pack32_perm(const uint4 lo, const uint4 hi, uint
 {
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t fh = 0, fl = 0;
-    V = 0;
+    // Almost every wave sees 64 x 32 clean bases: the distance of every byte from the letter its index stands for, summed
+    // over the 32 bytes (v_sad_u8, one per word), is then zero in all lanes and the per-byte validity bits -- a zero-byte
+    // test, a gather multiply and a shift-or per word -- need not be formed at all: p = 10 9.80e11 -> 1.014e12 bases/s
+    // (+3.4 %), p = 14 +2.2 %; where every wave meets an invalid byte (reads: one every 151 bases) -1.3 % (profiles/rd6ae).
+    uint32_t dist = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        uint32_t be, v;
-        pack4_perm(w[k], be, v);
+        const uint32_t x = w[k];
+        const uint32_t idx = (x >> 1) & 0x07070707u;
+        const uint32_t expect = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x47544341u, idx);
+        const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, idx);
+        dist = __builtin_amdgcn_sad_u8(expect, x & 0xDFDFDFDFu, dist);
+        const uint32_t be = (code * 0x40100401u) >> 24;
         if (k < 4) fh |= be << (24 - 8 * k);
         else fl |= be << (56 - 8 * k);
-        V |= v << (4 * k);
+    }
+    V = 0xFFFFFFFFu;
+    if (__any(dist != 0u)) {
+        V = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t be, v;
+            pack4_perm(w[k], be, v);
+            V |= v << (4 * k);
+        }
     }
     F = ((uint64_t)fh << 32) | fl;
     // R: complement codes, little-endian (base 0 in the lowest two bits) = the pair-reversal of ~F
