@@ -249,7 +249,16 @@ static int sketch_common(dsh_ctx *c, const uint8_t *d_seq, const uint64_t *genom
     // registers into the same few rows of the matrix; profiles/rd6n, rd6o cli_kernel_stats.csv.)
     // At BASELINE configs[1] size 16 is the optimum: 8 -> 8.43e11, 16 -> 8.59e11, 32 -> 8.31e11, 64 -> 8.2e11, 128 -> 8.3e11 bases/s
     // (profiles/rd6p/sketch_subs_ab.jsonl).
-    constexpr uint32_t kSubsPerWG = 16;
+    // Large registers make the merge dear (a workgroup ends by max-merging its 2^p registers into the matrix) and leave few
+    // workgroups per CU: from p = 14 a workgroup walks more sub-chunks when the call is big enough to still give every CU
+    // several workgroups -- 300 x 5 Mbp, bases/s: p = 14 16 -> 64 sub-chunks 7.97e11 -> 8.17e11; p = 15 -> 128 6.38e11 ->
+    // 7.62e11 (256: 6.96e11); p = 16 4.63e11 -> 5.18e11; p = 17 3.35e11 -> 4.66e11; p = 13 stays at 16 (32: -3 %)
+    // (profiles/rd6af/sketch_subs_large_p.txt).
+    uint64_t total_subs = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g)
+        if (genome_off[g + 1] >= genome_off[g]) total_subs += (genome_off[g + 1] - (genome_off[g] & ~31ull) + kSketchSub - 1) / kSketchSub;
+    const uint32_t subs_cap = c->p <= 13 ? 16u : (c->p == 14 ? 64u : 128u);
+    const uint32_t kSubsPerWG = (uint32_t)std::min<uint64_t>(subs_cap, std::max<uint64_t>(16, total_subs / 1024));
     std::vector<SketchWork> work;
     for (uint32_t g = 0; g < n_genomes; ++g) {
         const uint64_t gb = genome_off[g], ge = genome_off[g + 1];
