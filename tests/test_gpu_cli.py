@@ -175,6 +175,32 @@ def test_cache_presketched_and_sketch_subcommand(genomes, oracle, tmp_path):
         assert gzip.open(str(sk / os.path.basename(h))).read() == gzip.open(h).read()
 
 
+@pytest.mark.parametrize("p", [14, 15, 16, 17])
+def test_sketch_subcommand_at_large_precisions(genomes, oracle, tmp_path, p):
+    """`sketch -S 14 ... 17` through the whole CLI path (device FASTA decode, 512- / 1 024-lane k_sketch workgroups, word and
+    packed-byte registers): every .hll payload equals the oracle's registers, and `dist --presketched` over the files gives
+    the matrix of a direct `dist -S p`."""
+    import glob
+    import gzip
+
+    d, paths, seqs = genomes
+    sk = tmp_path / "sk"
+    sk.mkdir()
+    run("sketch", "-k", 31, "-S", p, "-p", 4, "-P", sk, *paths)
+    regs = oracle_regs(oracle, seqs, 31, p)
+    hlls = []
+    for i, path in enumerate(paths):
+        found = glob.glob(str(sk / (os.path.basename(path) + ".*.hll")))
+        assert len(found) == 1, found
+        raw = gzip.open(found[0]).read()
+        assert raw[-(1 << p):] == regs[i].tobytes(), "registers of %s differ at p = %d" % (path, p)
+        hlls.append(found[0])
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    run("dist", "-k", 31, "-S", p, "-b", "--avoid-sorting", "-O", a, "-o", os.devnull, *paths)
+    run("dist", "--presketched", "-S", p, "-b", "--avoid-sorting", "-O", b, "-o", os.devnull, *hlls)
+    assert a.read_bytes() == b.read_bytes()
+
+
 def test_query_reference_and_containment(genomes, oracle, tmp_path):
     """-Q queries x -F references (partdist_loop format: name, then "\\t%g" per reference) and the
     containment family; an asymmetric measure without -Q switches to all-vs-all rectangle."""
