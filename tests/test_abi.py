@@ -150,3 +150,28 @@ def test_row_set_helpers_are_pure_host_functions():
     bad = dashing_amd.RowSets(n, np.array([2, 2, 0, 5000, 9999, 0, 1], np.uint64))  # does not reach n
     with pytest.raises(dashing_amd.DshError):
         bad.rows(0)
+
+
+def test_header_is_plain_c_and_a_cxx_client_links(tmp_path):
+    """include/dashing_hip.h is the drop-in boundary: it must compile as C11 (no C++ in the signatures) as well as C++17, and
+    a host written against it alone -- tools/cabi/overlap_cabi.cpp, a plain C++ client without Python or torch -- must
+    compile and LINK against libdashing_hip.so (nothing is run: no GPU here)."""
+    import shutil
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    hdr = os.path.join(inc, "dashing_hip.h")
+    c_src = tmp_path / "use.c"
+    c_src.write_text('#include "dashing_hip.h"\nint main(void) { dsh_ctx *c = 0; (void)c; return dsh_abi_version() == DSH_ABI_VERSION ? 0 : 1; }\n')
+    assert os.path.exists(hdr)
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(c_src)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(c_src)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    lib = os.path.join(ROOT, "dashing_amd", "libdashing_hip.so")
+    if not os.path.exists(lib) or not shutil.which("g++"):
+        pytest.skip("libdashing_hip.so not built")
+    exe = tmp_path / "overlap_cabi"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tools", "cabi", "overlap_cabi.cpp"), "-I", inc, "-L", os.path.dirname(lib),
+                        "-ldashing_hip", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
