@@ -1104,13 +1104,14 @@ def config_sketch(ctx, torch, dev, dashing_amd, pm, args, G=1000, L=5_000_000, p
     tc = time.perf_counter() - t0
     del h0
     ksec = kernel_ms * 1e-3
-    # the kernel's static mix (tools/sketch_instr.py / tools/isa_mix.py on k_sketch<false,true,1>): two thirds of the unrolled
-    # loop's VALU instructions are full-rate VOP1/VOP2 (2 issue cycles per wave64 instruction), the rest -- the 64-bit shifts
-    # and v_mad_u64_u32 of the Wang hash, the funnel shifts -- take 4; measured alone 2.5 / 4.4 (profiles/ubench)
-    full_share = 0.664
+    # the kernel's static mix (tools/sketch_instr.py on k_sketch<false, true, true, 31, 256>, the all-valid copy of the unrolled
+    # loop, final tree of round 6): 53.7 % of its VALU instructions are full-rate VOP1/VOP2 (2 issue cycles per wave64
+    # instruction), the rest -- the 64-bit shifts and v_mad_u64_u32 of the Wang hash, the funnel shifts -- take 4; measured
+    # alone 2.5 / 4.4 (profiles/ubench).  (Rounds 4-5 had 66.4 % here: the instructions round 6 removed were full-rate ones.)
+    full_share = 0.537
     ceil_nominal = 2.0 * full_share + 4.0 * (1 - full_share)
     ceil_measured = 2.5 * full_share + 4.4 * (1 - full_share)
-    binding = {"resource": "int VALU issue (24 of the ~43 instructions per k-mer are the 64-bit Wang hash, fixed by the bit-exactness contract)",
+    binding = {"resource": "int VALU issue (24 of the ~42 instructions per k-mer are the 64-bit Wang hash, fixed by the bit-exactness contract)",
                "frac": None, "valu_insts_per_kmer": None, "ceiling_cycles_per_valu_inst": round(ceil_nominal, 3),
                "ceiling_note": "mix-aware: %.1f %% full-rate (2 cycles per wave64 instruction) + %.1f %% half-rate (4); measured alone 2.5 / 4.4 -> %.2f" % (
                    100 * full_share, 100 * (1 - full_share), ceil_measured)}
